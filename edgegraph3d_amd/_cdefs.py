@@ -1,0 +1,98 @@
+"""ctypes mirrors of the POD structs in include/eg3d.h and include/eg3d_host.h (plumbing only)."""
+import ctypes as C
+
+import numpy as np
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+i32p = C.POINTER(C.c_int32)
+f32p = C.POINTER(C.c_float)
+f64p = C.POINTER(C.c_double)
+
+
+class Scene(C.Structure):
+    _fields_ = [("n_views", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+                ("cam_P", f32p), ("F", f64p), ("F_valid", u8p), ("view_pl_off", u32p),
+                ("pl_vtx_off", u32p), ("vtx_xy", f32p), ("pl_start", u32p), ("pl_end", u32p),
+                ("pl_valid", u8p)]
+
+
+class Seeds(C.Structure):
+    _fields_ = [("n_seeds", C.c_uint32), ("trk_off", u32p), ("trk_view", i32p), ("trk_xy", f32p)]
+
+
+class EdgePoints(C.Structure):
+    _fields_ = [("n_points", C.c_uint64), ("n_obs", C.c_uint64), ("X", f32p), ("obs_off", u32p),
+                ("obs_view", i32p), ("obs_pl", u32p), ("obs_seg", u32p), ("obs_xy", f32p), ("key", u32p),
+                ("n_tasks", C.c_uint64), ("n_hypotheses", C.c_uint64), ("n_chains", C.c_uint64),
+                ("flags", C.c_uint32), ("_owner", C.c_void_p)]
+
+
+class Candidates(C.Structure):
+    _fields_ = [("n_sv", C.c_uint32), ("cand_off", u32p), ("cand_pl", u32p), ("start_off", u32p),
+                ("start_pl", u32p), ("start_seg", u32p), ("start_xy", f32p), ("n_tasks", C.c_uint32),
+                ("task_sv", u32p), ("task_hit", u32p), ("task_list_off", u32p), ("list_off", u32p),
+                ("hit_pl", u32p), ("hit_seg", u32p), ("hit_xy", f32p), ("_owner", C.c_void_p)]
+
+
+class StageTimes(C.Structure):
+    _fields_ = [("ms_total", C.c_float), ("ms_candidates", C.c_float), ("ms_epipolar", C.c_float),
+                ("ms_hypotheses", C.c_float), ("ms_select", C.c_float), ("ms_expand", C.c_float),
+                ("ms_emit", C.c_float), ("bytes_algorithmic", C.c_uint64)]
+
+
+class SynthConfig(C.Structure):
+    _fields_ = [("n_views", C.c_int32), ("n_seeds", C.c_uint32), ("n_curves", C.c_int32),
+                ("rng_seed", C.c_uint64), ("max_track", C.c_int32), ("obs_noise_px", C.c_float),
+                ("vtx_noise_px", C.c_float), ("invalid_frac", C.c_float), ("seed_offset_px", C.c_float),
+                ("width", C.c_int32), ("height", C.c_int32), ("focal", C.c_float), ("ppx", C.c_float),
+                ("ppy", C.c_float)]
+
+
+def as_np(ptr, n, dtype):
+    """Copy n elements behind a ctypes pointer into a numpy array."""
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(int(n),)).astype(dtype, copy=True)
+
+
+def np_ptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def edgepoints_to_dict(e):
+    n, m = int(e.n_points), int(e.n_obs)
+    return {
+        "n_points": n, "n_obs": m,
+        "X": as_np(e.X, 3 * n, np.float32).reshape(n, 3),
+        "obs_off": as_np(e.obs_off, n + 1, np.uint32),
+        "obs_view": as_np(e.obs_view, m, np.int32),
+        "obs_pl": as_np(e.obs_pl, m, np.uint32),
+        "obs_seg": as_np(e.obs_seg, m, np.uint32),
+        "obs_xy": as_np(e.obs_xy, 2 * m, np.float32).reshape(m, 2),
+        "key": as_np(e.key, 4 * n, np.uint32).reshape(n, 4),
+        "n_tasks": int(e.n_tasks), "n_hypotheses": int(e.n_hypotheses), "n_chains": int(e.n_chains),
+        "flags": int(e.flags),
+    }
+
+
+def candidates_to_dict(c):
+    nsv, nt = int(c.n_sv), int(c.n_tasks)
+    cand_off = as_np(c.cand_off, nsv + 1, np.uint32)
+    start_off = as_np(c.start_off, nsv + 1, np.uint32)
+    task_list_off = as_np(c.task_list_off, nt + 1, np.uint32)
+    nl = int(task_list_off[-1]) if nt else 0
+    list_off = as_np(c.list_off, nl + 1, np.uint32)
+    nh = int(list_off[-1]) if nl else 0
+    ns = int(start_off[-1]) if nsv else 0
+    return {
+        "n_sv": nsv, "n_tasks": nt, "cand_off": cand_off,
+        "cand_pl": as_np(c.cand_pl, int(cand_off[-1]) if nsv else 0, np.uint32),
+        "start_off": start_off, "start_pl": as_np(c.start_pl, ns, np.uint32),
+        "start_seg": as_np(c.start_seg, ns, np.uint32),
+        "start_xy": as_np(c.start_xy, 2 * ns, np.float32).reshape(ns, 2),
+        "task_sv": as_np(c.task_sv, nt, np.uint32), "task_hit": as_np(c.task_hit, nt, np.uint32),
+        "task_list_off": task_list_off, "list_off": list_off,
+        "hit_pl": as_np(c.hit_pl, nh, np.uint32), "hit_seg": as_np(c.hit_seg, nh, np.uint32),
+        "hit_xy": as_np(c.hit_xy, 2 * nh, np.float32).reshape(nh, 2),
+    }

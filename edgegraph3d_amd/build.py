@@ -1,0 +1,84 @@
+"""Build recipes for the native parts of edgegraph3d_amd (in-tree, no pip).
+
+  libeg3d_host.so  g++    host-side utilities (synthetic workload, grid builder, JSON, post steps)
+  libeg3d.so       hipcc  the C-ABI library with the gfx950 kernels (include/eg3d.h)
+
+`python -m edgegraph3d_amd.build` builds both. hipcc cross-compiles gfx950 without a GPU.
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "edgegraph3d_amd")
+HOST_DIR = os.path.join(PKG, "host")
+CSRC_DIR = os.path.join(PKG, "csrc")
+INC_DIR = os.path.join(ROOT, "include")
+
+HOST_LIB = os.path.join(PKG, "libeg3d_host.so")
+HIP_LIB = os.path.join(PKG, "libeg3d.so")
+
+# -ffp-contract=off everywhere: decisions on the path are float threshold tests and the
+# arithmetic contract forbids FMA formation on host and device alike.
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-Wall"]
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+             "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-rdc",
+             "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
+
+
+def _all_sources(d, exts):
+    out = []
+    for base, _, files in os.walk(d):
+        for f in files:
+            if f.endswith(exts):
+                out.append(os.path.join(base, f))
+    return sorted(out)
+
+
+def _run(cmd):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
+def build_host(force=False):
+    srcs = _all_sources(HOST_DIR, (".cpp",))
+    deps = srcs + _all_sources(HOST_DIR, (".hpp", ".h")) + _all_sources(INC_DIR, (".h",)) + _all_sources(CSRC_DIR, (".h", ".hpp"))
+    if force or _newer(HOST_LIB, deps):
+        _run(["g++"] + HOST_FLAGS + ["-I", INC_DIR, "-I", CSRC_DIR, "-o", HOST_LIB] + srcs)
+    return HOST_LIB
+
+
+def build_hip(force=False):
+    srcs = _all_sources(CSRC_DIR, (".hip",))
+    host_srcs = [os.path.join(HOST_DIR, "grid_build.cpp")]
+    deps = srcs + host_srcs + _all_sources(CSRC_DIR, (".h", ".hpp")) + _all_sources(INC_DIR, (".h",))
+    if force or _newer(HIP_LIB, deps):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        _run([hipcc] + HIP_FLAGS + ["-I", INC_DIR, "-I", CSRC_DIR, "-I", HOST_DIR, "-o", HIP_LIB] + srcs + host_srcs)
+    return HIP_LIB
+
+
+def build_oracle(force=False):
+    """Builds the CPU oracle (test infrastructure). Building the checker is not using it."""
+    d = os.path.join(ROOT, "oracle")
+    if force:
+        _run(["make", "-C", d, "clean"])
+    _run(["make", "-C", d])
+    return os.path.join(d, "liboracle.so")
+
+
+def build_all(force=False):
+    build_host(force)
+    build_hip(force)
+    build_oracle(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

@@ -1,0 +1,390 @@
+// eg3d_dev_geom.h — 2-D geometry and polyline-walking primitives of the MI355X path.
+//
+// These are the per-lane building blocks of the gfx950 kernels in eg3d_kernels.hip. They are
+// written against flat device arrays (struct-of-arrays scene, CSR polylines) instead of the
+// reference's vector-of-struct graph. Each function names the reference behaviour it must
+// reproduce (file:line relative to the reference tree) — behaviour, not code: the layout,
+// control flow and data types here are this project's.
+//
+// Arithmetic contract: compiled with -ffp-contract=off; float/double mix and
+// evaluation order fixed so results are bit-identical to the CPU oracle.
+//
+// EG3D_HD expands to __host__ __device__ under hipcc. The host instantiation is used by the
+// grid builder (host/grid_build.cpp) and by the test-only host simulation of the kernels
+// (tests/hostsim); the product's compute path runs these on the GPU only.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define EG3D_HD __host__ __device__ inline
+#else
+#define EG3D_HD inline
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EG3D_SQRTF(x) __fsqrt_rn(x)
+#define EG3D_SQRT(x) __dsqrt_rn(x)
+#else
+#include <math.h>
+#define EG3D_SQRTF(x) sqrtf(x)
+#define EG3D_SQRT(x) sqrt(x)
+#endif
+
+namespace eg3d {
+
+struct f2 {
+  float x, y;
+};
+
+// A polyline as the kernels see it: a contiguous slice of the vertex array + its two node ids.
+struct PlRef {
+  const f2* v;
+  uint32_t n;      // vertex count
+  uint32_t start;  // node ids (reference polyline::start / ::end)
+  uint32_t end;
+};
+
+// A point on a polyline: segment index + coordinates (reference pl_point).
+struct PlPt {
+  uint32_t seg;
+  float x, y;
+};
+
+// walk status bits
+enum : uint32_t {
+  WALK_FOUND = 1u,
+  WALK_EXTREME = 2u,        // reached the polyline extreme
+  WALK_QUASIPARALLEL = 4u,  // stopped on a quasi-parallel segment
+  WALK_BOUND = 8u,          // hit found but outside [min,max] distance
+  WALK_BAD_DIR = 16u        // direction is neither end of this polyline (Q15)
+};
+
+// |a-b|^2: differences in float, squares and sum in double, one rounding to float
+// (geometric_utilities.cpp:555-557, Q5).
+EG3D_HD float dist2(float ax, float ay, float bx, float by) {
+  double dx = (double)(ax - bx);
+  double dy = (double)(ay - by);
+  return (float)(dx * dx + dy * dy);
+}
+EG3D_HD float dist(float ax, float ay, float bx, float by) { return EG3D_SQRTF(dist2(ax, ay, bx, by)); }
+
+EG3D_HD float dotf(float ax, float ay, float bx, float by) {
+  float p = ax * bx;
+  float q = ay * by;
+  return p + q;
+}
+
+// a + ratio*(b-a), per component (geometric_utilities.cpp:1370-1372)
+EG3D_HD void lerp_from(float ax, float ay, float bx, float by, float ratio, float& ox, float& oy) {
+  float dx = bx - ax, dy = by - ay;
+  float rx = ratio * dx, ry = ratio * dy;
+  ox = ax + rx;
+  oy = ay + ry;
+}
+
+// Closest point of segment vw to p; returns squared distance (geometric_utilities.cpp:940-954).
+EG3D_HD float seg_closest(float px, float py, float vx, float vy, float wx, float wy, float& qx, float& qy) {
+  const float l2 = dist2(vx, vy, wx, wy);
+  if (l2 == 0.0f) {
+    qx = vx;
+    qy = vy;
+    return dist2(px, py, vx, vy);
+  }
+  const float q = dotf(px - vx, py - vy, wx - vx, wy - vy) / l2;
+  const float m = (q < 1.0f) ? q : 1.0f;  // std::min(1,q): NaN -> 1
+  const float t = (0.0f < m) ? m : 0.0f;  // std::max(0,m)
+  float ex = wx - vx, ey = wy - vy;
+  float tx = t * ex, ty = t * ey;
+  qx = vx + tx;
+  qy = vy + ty;
+  return dist2(px, py, qx, qy);
+}
+
+// Segment (x1,y1)-(x2,y2) against line (a,b,c): returns true and the hit when 0<=t<=1
+// (geometric_utilities.cpp:272-312).
+EG3D_HD bool seg_line_hit(float x1, float y1, float x2, float y2, float la, float lb, float lc, float& hx,
+                          float& hy) {
+  float dx = x2 - x1, dy = y2 - y1;
+  float n0 = la * x1, n1 = lb * y1;
+  float num = (n0 + n1) + lc;
+  float d0 = la * dx, d1 = lb * dy;
+  float den = d0 + d1;
+  if (den != 0.0f) {
+    float t = -num / den;
+    if (t >= 0.0f && t <= 1.0f) {
+      float tx = t * dx, ty = t * dy;
+      hx = x1 + tx;
+      hy = y1 + ty;
+      return true;
+    }
+  }
+  return false;
+}
+
+EG3D_HD float point_line_dist(float px, float py, float la, float lb, float lc) {
+  float t0 = la * px, t1 = lb * py;
+  float den = (t0 + t1) + lc;
+  den *= den;
+  float a2 = la * la, b2 = lb * lb;
+  return EG3D_SQRTF(den / (a2 + b2));
+}
+
+// Signed cosine between the segment (walking order) and the line direction (1,-a/b) or (0,1)
+// (geometric_utilities.cpp:590-618, Q14).
+EG3D_HD float seg_line_cos(float x1, float y1, float x2, float y2, float la, float lb) {
+  float ax = x2 - x1, ay = y2 - y1;
+  float bx, by;
+  if (lb == 0.0f) {
+    bx = 0.0f;
+    by = 1.0f;
+  } else {
+    bx = 1.0f;
+    by = -la / lb;
+  }
+  float d = dotf(ax, ay, bx, by);
+  float aa = dotf(ax, ay, ax, ay);
+  float bb = dotf(bx, by, bx, by);
+  return d / EG3D_SQRTF(aa * bb);
+}
+
+// Segment/line test with the quasi-parallel guard (cos > 0.965 within 5 px),
+// geometric_utilities.cpp:365-430. Returns bit0 = hit found, bit1 = quasi-parallel within distance.
+EG3D_HD uint32_t seg_line_hit_guarded(float x1, float y1, float x2, float y2, float la, float lb, float lc,
+                                      float& hx, float& hy) {
+  const float QP_COS = (float)0.965;
+  const float QP_DIST = 5.0f;
+  uint32_t r = 0;
+  float dx = x2 - x1, dy = y2 - y1;
+  float n0 = la * x1, n1 = lb * y1;
+  float num = (n0 + n1) + lc;
+  float d0 = la * dx, d1 = lb * dy;
+  float den = d0 + d1;
+  if (den != 0.0f) {
+    float t = -num / den;
+    if (t >= 0.0f && t <= 1.0f) {
+      float tx = t * dx, ty = t * dy;
+      hx = x1 + tx;
+      hy = y1 + ty;
+      r |= 1u;
+    }
+    if (seg_line_cos(x1, y1, x2, y2, la, lb) > QP_COS) {
+      float distance;
+      if (t < 0.0f)
+        distance = point_line_dist(x1, y1, la, lb, lc);
+      else if (t > 1.0f)
+        distance = point_line_dist(x2, y2, la, lb, lc);
+      else
+        distance = 0.0f;
+      if (distance <= QP_DIST) r |= 2u;
+    }
+  } else {
+    float distance = point_line_dist(x1, y1, la, lb, lc);
+    if (distance <= QP_DIST) r |= 2u;
+  }
+  return r;
+}
+
+// ---------------------------------------------------------------- walking -----
+// Next point at `distance` (Euclidean from p, not arc length) towards node `direction`
+// (polyline_graph_2d.cpp:391-447). Returns WALK_FOUND, WALK_EXTREME or WALK_BAD_DIR.
+EG3D_HD uint32_t walk_by_distance(const PlRef& pl, const PlPt& p, uint32_t direction, float distance, PlPt& out) {
+  float prevdist = 0.0f, curdist, ratio;
+  if (direction == pl.start) {
+    curdist = dist(pl.v[p.seg].x, pl.v[p.seg].y, p.x, p.y);
+    if (curdist >= distance) {
+      ratio = distance / curdist;
+      out.seg = p.seg;
+      lerp_from(p.x, p.y, pl.v[p.seg].x, pl.v[p.seg].y, ratio, out.x, out.y);
+      return WALK_FOUND;
+    }
+    uint32_t i;
+    for (i = p.seg; i > 0; i--) {
+      prevdist = curdist;
+      curdist = dist(pl.v[i - 1].x, pl.v[i - 1].y, p.x, p.y);
+      if (curdist >= distance) break;
+    }
+    if (i == 0) {
+      out.seg = 0;
+      out.x = pl.v[0].x;
+      out.y = pl.v[0].y;
+      return WALK_EXTREME;
+    }
+    ratio = (distance - prevdist) / (curdist - prevdist);
+    out.seg = i - 1;
+    lerp_from(pl.v[i].x, pl.v[i].y, pl.v[i - 1].x, pl.v[i - 1].y, ratio, out.x, out.y);
+    return WALK_FOUND;
+  } else if (direction == pl.end) {
+    const uint32_t n = pl.n;
+    if (p.seg >= n - 1) {
+      out.seg = n - 2;
+      out.x = pl.v[n - 1].x;
+      out.y = pl.v[n - 1].y;
+      return WALK_EXTREME;
+    }
+    curdist = dist(pl.v[p.seg + 1].x, pl.v[p.seg + 1].y, p.x, p.y);
+    if (curdist >= distance) {
+      ratio = distance / curdist;
+      out.seg = p.seg;
+      lerp_from(p.x, p.y, pl.v[p.seg + 1].x, pl.v[p.seg + 1].y, ratio, out.x, out.y);
+      return WALK_FOUND;
+    }
+    uint32_t i;
+    for (i = p.seg + 1; i < n - 1; i++) {
+      prevdist = curdist;
+      curdist = dist(pl.v[i + 1].x, pl.v[i + 1].y, p.x, p.y);
+      if (curdist >= distance) break;
+    }
+    if (i == n - 1) {
+      out.seg = n - 2;
+      out.x = pl.v[n - 1].x;
+      out.y = pl.v[n - 1].y;
+      return WALK_EXTREME;
+    }
+    ratio = (distance - prevdist) / (curdist - prevdist);
+    out.seg = i;
+    lerp_from(pl.v[i].x, pl.v[i].y, pl.v[i + 1].x, pl.v[i + 1].y, ratio, out.x, out.y);
+    return WALK_FOUND;
+  }
+  out = p;
+  return WALK_EXTREME | WALK_BAD_DIR;  // Q15: undefined in the reference; the walk fails
+}
+
+// Next intersection with the line towards `direction`, stopping at quasi-parallel segments;
+// optional [min,max] distance window (polyline_graph_2d.cpp:579-655 and :657-780).
+EG3D_HD uint32_t walk_by_line(const PlRef& pl, const PlPt& p, uint32_t direction, float la, float lb, float lc,
+                              bool bounded, float min_d, float max_d, PlPt& out) {
+  float hx = 0.0f, hy = 0.0f;
+  uint32_t r;
+  uint32_t seg_found = 0;
+  bool got = false;
+  if (direction == pl.start) {
+    r = seg_line_hit_guarded(p.x, p.y, pl.v[p.seg].x, pl.v[p.seg].y, la, lb, lc, hx, hy);
+    if (r & 2u) return WALK_QUASIPARALLEL;
+    if (r & 1u) {
+      got = true;
+      seg_found = p.seg;
+    } else {
+      for (uint32_t i = p.seg; i > 0; i--) {
+        r = seg_line_hit_guarded(pl.v[i].x, pl.v[i].y, pl.v[i - 1].x, pl.v[i - 1].y, la, lb, lc, hx, hy);
+        if (r & 2u) return WALK_QUASIPARALLEL;
+        if (r & 1u) {
+          got = true;
+          seg_found = i - 1;
+          break;
+        }
+      }
+      if (!got) return WALK_EXTREME;
+    }
+  } else if (direction == pl.end) {
+    r = seg_line_hit_guarded(p.x, p.y, pl.v[p.seg + 1].x, pl.v[p.seg + 1].y, la, lb, lc, hx, hy);
+    if (r & 2u) return WALK_QUASIPARALLEL;
+    if (r & 1u) {
+      got = true;
+      seg_found = p.seg;
+    } else {
+      for (uint32_t i = p.seg + 1; i < pl.n - 1; i++) {
+        r = seg_line_hit_guarded(pl.v[i].x, pl.v[i].y, pl.v[i + 1].x, pl.v[i + 1].y, la, lb, lc, hx, hy);
+        if (r & 2u) return WALK_QUASIPARALLEL;
+        if (r & 1u) {
+          got = true;
+          seg_found = i;
+          break;
+        }
+      }
+      if (!got) return WALK_EXTREME;
+    }
+  } else {
+    return WALK_BAD_DIR;  // Q15: the reference leaves every flag false
+  }
+  out.seg = seg_found;
+  out.x = hx;
+  out.y = hy;
+  if (bounded) {
+    float dsq = dist2(hx, hy, p.x, p.y);
+    if (dsq < (min_d * min_d) || dsq > (max_d * max_d)) return WALK_BOUND;
+  }
+  return WALK_FOUND;
+}
+
+// Closest point of a whole polyline, first minimal segment wins (polyline_graph_2d.cpp:845-862).
+EG3D_HD float polyline_closest(const PlRef& pl, float px, float py, PlPt& out) {
+  float bx, by;
+  float best = seg_closest(px, py, pl.v[0].x, pl.v[0].y, pl.v[1].x, pl.v[1].y, bx, by);
+  uint32_t bseg = 0;
+  for (uint32_t i = 2; i < pl.n; i++) {
+    float cx, cy;
+    float d = seg_closest(px, py, pl.v[i - 1].x, pl.v[i - 1].y, pl.v[i].x, pl.v[i].y, cx, cy);
+    if (d < best) {
+      best = d;
+      bx = cx;
+      by = cy;
+      bseg = i - 1;
+    }
+  }
+  out.seg = bseg;
+  out.x = bx;
+  out.y = by;
+  return best;
+}
+
+// ---------------------------------------------------------------- grid cells ---
+#if defined(__HIP_DEVICE_COMPILE__)
+#define EG3D_CEILF(x) __builtin_ceilf(x)
+#define EG3D_FLOORF(x) __builtin_floorf(x)
+#define EG3D_FABSF(x) __builtin_fabsf(x)
+#else
+#define EG3D_CEILF(x) ceilf(x)
+#define EG3D_FLOORF(x) floorf(x)
+#define EG3D_FABSF(x) fabsf(x)
+#endif
+
+// edge_graph_3d_utilities.cpp:600-629: floor, or ceil when within 1e-3 below an integer
+EG3D_HD float cell_round(float v) {
+  float c = EG3D_CEILF(v);
+  if ((double)(c - v) < 0.001) return c;
+  return EG3D_FLOORF(v);
+}
+EG3D_HD bool on_cell_boundary(float m, float n) {
+  float div = m / n;
+  float mul = cell_round(div) * n;
+  return (double)EG3D_FABSF(m - mul) < 0.001;
+}
+struct CellCoord {
+  int32_t col, row;
+  bool bx, by;  // x (resp. y) is a multiple of the cell size
+};
+EG3D_HD CellCoord cell_of(float cell_dim, float x, float y) {
+  CellCoord c;
+  c.bx = on_cell_boundary(x, cell_dim);
+  c.by = on_cell_boundary(y, cell_dim);
+  c.col = (int32_t)cell_round(x / cell_dim);
+  c.row = (int32_t)cell_round(y / cell_dim);
+  return c;
+}
+
+// Window of grid cells to visit around a point (polyLine_2d_map_search.cpp:46-77, Q7):
+// empty for points on/outside the image border; shrunk on cell boundaries.
+struct CellWindow {
+  int32_t c0, c1, r0, r1;  // inclusive; empty if c1 < c0
+};
+EG3D_HD CellWindow cell_window(float cell_dim, int img_w, int img_h, int map_w, int map_h, float x, float y) {
+  CellWindow w;
+  w.c0 = 0;
+  w.c1 = -1;
+  w.r0 = 0;
+  w.r1 = -1;
+  if (x <= 0.0f || x >= (float)img_w || y <= 0.0f || y >= (float)img_h) return w;
+  CellCoord cc = cell_of(cell_dim, x, y);
+  int32_t cx = cc.col, cy = cc.row;
+  if (cx < 0 || cx >= map_w) cx = map_w - 1;  // the reference compares as unsigned
+  if (cy < 0 || cy >= map_h) cy = map_h - 1;
+  w.r0 = cy + (cy > 0 ? -1 : 0);
+  w.c0 = cx + (cx > 0 ? -1 : 0);
+  // the x-boundary flag limits rows, the y-boundary flag limits columns (reference naming)
+  w.r1 = cc.bx ? cy : cy + (cy < map_h - 1 ? 1 : 0);
+  w.c1 = cc.by ? cx : cx + (cx < map_w - 1 ? 1 : 0);
+  return w;
+}
+
+}  // namespace eg3d

@@ -1,0 +1,473 @@
+// eg3d_dev_tri.h — epipolar lines, projection, 2-view DLT initialisation and FP64
+// Gauss-Newton triangulation for the MI355X path (per-lane device functions).
+//
+// Reproduces the behaviour of the reference's em_estimate3Dpositions / em_GaussNewton /
+// em_add_new_observation_to_3Dpositions (src/edgegraph3d/utils/geometry/triangulation.cpp:
+// 105-323, 347-466) and of the OpenCV routines they call, under the evaluation order fixed
+// in DESIGN.md "Arithmetic contract". Design differences from the reference: no matrices are
+// materialised — the normal equations are accumulated in registers while streaming the
+// observations twice per iteration (residual+Jacobian pass, update pass), so a solve over n
+// views needs O(1) storage; observations come through a cursor so the same solver runs on
+// register arrays (3-view hypotheses) and on the chain pools in HBM (expand-all-views).
+#pragma once
+#include "eg3d_dev_geom.h"
+
+namespace eg3d {
+
+struct Obs {
+  int32_t view;
+  uint32_t pl;
+  uint32_t seg;
+  float x, y;
+};
+
+// l = F_ij * (x,y,1), normalised so a^2+b^2 = 1; double accumulate, float result
+// (geometric_utilities.cpp:824-843 -> cv::computeCorrespondEpilines).
+EG3D_HD bool epiline(const double* F, const uint8_t* F_valid, int n_views, int from, int to, float x, float y,
+                     float& la, float& lb, float& lc) {
+  size_t idx = (size_t)from * n_views + to;
+  if (!F_valid[idx]) return false;
+  const double* f = F + idx * 9;
+  double t0 = x, t1 = y;
+  double a = (f[0] * t0 + f[1] * t1) + f[2];
+  double b = (f[3] * t0 + f[4] * t1) + f[5];
+  double c = (f[6] * t0 + f[7] * t1) + f[8];
+  double nu = a * a + b * b;
+  nu = (nu != 0.0) ? 1. / EG3D_SQRT(nu) : 1.;
+  a *= nu;
+  b *= nu;
+  c *= nu;
+  la = (float)a;
+  lb = (float)b;
+  lc = (float)c;
+  return true;
+}
+
+// float projection (geometric_utilities.cpp:973-977 with glm's vec4*mat4 order)
+EG3D_HD void project_f32(const float* P, float X, float Y, float Z, float& u, float& v) {
+  float u0 = ((P[0] * X + P[1] * Y) + P[2] * Z) + P[3] * 1.0f;
+  float u1 = ((P[4] * X + P[5] * Y) + P[6] * Z) + P[7] * 1.0f;
+  float u2 = ((P[8] * X + P[9] * Y) + P[10] * Z) + P[11] * 1.0f;
+  u = u0 / u2;
+  v = u1 / u2;
+}
+
+EG3D_HD double absd(double v) { return v < 0.0 ? -v : v; }
+
+// Smallest right singular vector of a 4x4 double matrix by one-sided Jacobi (the algorithm
+// OpenCV's SVD uses inside cv::triangulatePoints); rotation order (i<j ascending), the
+// 30-sweep cap and the 10*DBL_EPSILON skip test are part of the arithmetic contract.
+EG3D_HD void svd4_smallest_v(const double A[4][4], double out[4]) {
+  double At[4][4], Vt[4][4], W[4];
+  for (int i = 0; i < 4; i++)
+    for (int k = 0; k < 4; k++) {
+      At[i][k] = A[k][i];
+      Vt[i][k] = (i == k) ? 1.0 : 0.0;
+    }
+  const double eps = 2.2204460492503131e-16 * 10;
+  for (int i = 0; i < 4; i++) {
+    double sd = 0;
+    for (int k = 0; k < 4; k++) sd += At[i][k] * At[i][k];
+    W[i] = sd;
+  }
+  for (int iter = 0; iter < 30; iter++) {
+    bool changed = false;
+    for (int i = 0; i < 3; i++)
+      for (int j = i + 1; j < 4; j++) {
+        double a = W[i], p = 0, b = W[j];
+        for (int k = 0; k < 4; k++) p += At[i][k] * At[j][k];
+        if (absd(p) <= eps * EG3D_SQRT(a * b)) continue;
+        p *= 2;
+        double beta = a - b, gamma = EG3D_SQRT(p * p + beta * beta);
+        double c, s;
+        if (beta < 0) {
+          double delta = (gamma - beta) * 0.5;
+          s = EG3D_SQRT(delta / gamma);
+          c = p / (gamma * s * 2);
+        } else {
+          c = EG3D_SQRT((gamma + beta) / (gamma * 2));
+          s = p / (gamma * c * 2);
+        }
+        a = 0;
+        b = 0;
+        for (int k = 0; k < 4; k++) {
+          double t0 = c * At[i][k] + s * At[j][k];
+          double t1 = c * At[j][k] - s * At[i][k];
+          At[i][k] = t0;
+          At[j][k] = t1;
+          a += t0 * t0;
+          b += t1 * t1;
+        }
+        W[i] = a;
+        W[j] = b;
+        changed = true;
+        for (int k = 0; k < 4; k++) {
+          double t0 = c * Vt[i][k] + s * Vt[j][k];
+          double t1 = c * Vt[j][k] - s * Vt[i][k];
+          Vt[i][k] = t0;
+          Vt[j][k] = t1;
+        }
+      }
+    if (!changed) break;
+  }
+  for (int i = 0; i < 4; i++) {
+    double sd = 0;
+    for (int k = 0; k < 4; k++) sd += At[i][k] * At[i][k];
+    W[i] = EG3D_SQRT(sd);
+  }
+  // descending selection sort; track which row ends up last
+  int order[4] = {0, 1, 2, 3};
+  for (int i = 0; i < 3; i++) {
+    int j = i;
+    for (int k = i + 1; k < 4; k++)
+      if (W[j] < W[k]) j = k;
+    if (i != j) {
+      double tw = W[i];
+      W[i] = W[j];
+      W[j] = tw;
+      int to = order[i];
+      order[i] = order[j];
+      order[j] = to;
+    }
+  }
+  const int last = order[3];
+  for (int k = 0; k < 4; k++) out[k] = Vt[last][k];
+}
+
+// 2-view DLT: rows x*P(2,:)-P(0,:), y*P(2,:)-P(1,:) per view in double; the homogeneous
+// solution is rounded to float before the float division by w (triangulation.cpp:216-224).
+EG3D_HD void dlt2(const float* P1, float x1, float y1, const float* P2, float x2, float y2, double X0[3]) {
+  double A[4][4];
+  {
+    double x = x1, y = y1;
+    for (int k = 0; k < 4; k++) {
+      A[0][k] = x * (double)P1[8 + k] - (double)P1[k];
+      A[1][k] = y * (double)P1[8 + k] - (double)P1[4 + k];
+    }
+  }
+  {
+    double x = x2, y = y2;
+    for (int k = 0; k < 4; k++) {
+      A[2][k] = x * (double)P2[8 + k] - (double)P2[k];
+      A[3][k] = y * (double)P2[8 + k] - (double)P2[4 + k];
+    }
+  }
+  double v[4];
+  svd4_smallest_v(A, v);
+  float h0 = (float)v[0], h1 = (float)v[1], h2 = (float)v[2], h3 = (float)v[3];
+  X0[0] = (double)(h0 / h3);
+  X0[1] = (double)(h1 / h3);
+  X0[2] = (double)(h2 / h3);
+}
+
+// --- observation cursors -------------------------------------------------------
+// A cursor enumerates (view, x, y) in list order and can be rewound.
+struct ArrayCursor {
+  const Obs* a;
+  int n;          // observations in the array
+  const Obs* extra;  // optional trailing observation (ADD), may be null
+  int i;
+  EG3D_HD void rewind() { i = 0; }
+  EG3D_HD int count() const { return n + (extra ? 1 : 0); }
+  EG3D_HD bool next(int32_t& view, float& x, float& y) {
+    if (i < n) {
+      view = a[i].view;
+      x = a[i].x;
+      y = a[i].y;
+      i++;
+      return true;
+    }
+    if (extra && i == n) {
+      view = extra->view;
+      x = extra->x;
+      y = extra->y;
+      i++;
+      return true;
+    }
+    return false;
+  }
+};
+
+// FP64 Gauss-Newton over the cursor's observations from X0 (triangulation.cpp:105-176):
+// <=30 iterations; stop when |mse/(2n) - last| < 5e-7; fail when det(H) < 1e-5; accept iff
+// last mse < 9. H and the update are accumulated in observation order (rows 2m, 2m+1).
+template <class Cursor>
+EG3D_HD bool gauss_newton_f64(const float* cam_P, Cursor& cur, const double X0[3], float Xout[3]) {
+  const int n = cur.count();
+  double X[3] = {X0[0], X0[1], X0[2]};
+  double last_mse = 0;
+  const double two_n = (double)(n * 2);
+  for (int it = 0; it < 30; it++) {
+    double mse = 0;
+    double H00 = 0, H01 = 0, H02 = 0, H11 = 0, H12 = 0, H22 = 0;
+    cur.rewind();
+    int32_t view;
+    float ox, oy;
+    while (cur.next(view, ox, oy)) {
+      const float* P = cam_P + (size_t)view * 16;
+      double p00 = P[0], p01 = P[1], p02 = P[2], p03 = P[3];
+      double p10 = P[4], p11 = P[5], p12 = P[6], p13 = P[7];
+      double p20 = P[8], p21 = P[9], p22 = P[10], p23 = P[11];
+      double xH = ((p00 * X[0] + p01 * X[1]) + p02 * X[2]) + p03 * 1.0;
+      double yH = ((p10 * X[0] + p11 * X[1]) + p12 * X[2]) + p13 * 1.0;
+      double zH = ((p20 * X[0] + p21 * X[1]) + p22 * X[2]) + p23 * 1.0;
+      double r0 = (double)ox - xH / zH;
+      mse += r0 * r0;
+      double r1 = (double)oy - yH / zH;
+      mse += r1 * r1;
+      double zz = zH * zH;
+      double j00 = (p00 * zH - p20 * xH) / zz;
+      double j10 = (p10 * zH - p20 * yH) / zz;
+      double j01 = (p01 * zH - p21 * xH) / zz;
+      double j11 = (p11 * zH - p21 * yH) / zz;
+      double j02 = (p02 * zH - p22 * xH) / zz;
+      double j12 = (p12 * zH - p22 * yH) / zz;
+      H00 += j00 * j00;
+      H00 += j10 * j10;
+      H01 += j00 * j01;
+      H01 += j10 * j11;
+      H02 += j00 * j02;
+      H02 += j10 * j12;
+      H11 += j01 * j01;
+      H11 += j11 * j11;
+      H12 += j01 * j02;
+      H12 += j11 * j12;
+      H22 += j02 * j02;
+      H22 += j12 * j12;
+    }
+    if (absd(mse / two_n - last_mse) < 0.0000005) break;
+    last_mse = mse / two_n;
+    const double H10 = H01, H20 = H02, H21 = H12;
+    double d = H00 * (H11 * H22 - H12 * H21) - H01 * (H10 * H22 - H12 * H20) + H02 * (H10 * H21 - H11 * H20);
+    if (d < 0.00001) return false;
+    double id = 1. / d;
+    double I00 = (H11 * H22 - H12 * H21) * id;
+    double I01 = (H02 * H21 - H01 * H22) * id;
+    double I02 = (H01 * H12 - H02 * H11) * id;
+    double I10 = (H12 * H20 - H10 * H22) * id;
+    double I11 = (H00 * H22 - H02 * H20) * id;
+    double I12 = (H02 * H10 - H00 * H12) * id;
+    double I20 = (H10 * H21 - H11 * H20) * id;
+    double I21 = (H01 * H20 - H00 * H21) * id;
+    double I22 = (H00 * H11 - H01 * H10) * id;
+    double d0 = 0, d1 = 0, d2 = 0;
+    cur.rewind();
+    while (cur.next(view, ox, oy)) {
+      const float* P = cam_P + (size_t)view * 16;
+      double p00 = P[0], p01 = P[1], p02 = P[2], p03 = P[3];
+      double p10 = P[4], p11 = P[5], p12 = P[6], p13 = P[7];
+      double p20 = P[8], p21 = P[9], p22 = P[10], p23 = P[11];
+      double xH = ((p00 * X[0] + p01 * X[1]) + p02 * X[2]) + p03 * 1.0;
+      double yH = ((p10 * X[0] + p11 * X[1]) + p12 * X[2]) + p13 * 1.0;
+      double zH = ((p20 * X[0] + p21 * X[1]) + p22 * X[2]) + p23 * 1.0;
+      double r0 = (double)ox - xH / zH;
+      double r1 = (double)oy - yH / zH;
+      double zz = zH * zH;
+      double j00 = (p00 * zH - p20 * xH) / zz;
+      double j10 = (p10 * zH - p20 * yH) / zz;
+      double j01 = (p01 * zH - p21 * xH) / zz;
+      double j11 = (p11 * zH - p21 * yH) / zz;
+      double j02 = (p02 * zH - p22 * xH) / zz;
+      double j12 = (p12 * zH - p22 * yH) / zz;
+      d0 += ((I00 * j00 + I01 * j01) + I02 * j02) * r0;
+      d0 += ((I00 * j10 + I01 * j11) + I02 * j12) * r1;
+      d1 += ((I10 * j00 + I11 * j01) + I12 * j02) * r0;
+      d1 += ((I10 * j10 + I11 * j11) + I12 * j12) * r1;
+      d2 += ((I20 * j00 + I21 * j01) + I22 * j02) * r0;
+      d2 += ((I20 * j10 + I21 * j11) + I22 * j12) * r1;
+    }
+    X[0] += d0;
+    X[1] += d1;
+    X[2] += d2;
+  }
+  if (last_mse < 9) {
+    Xout[0] = (float)X[0];
+    Xout[1] = (float)X[1];
+    Xout[2] = (float)X[2];
+    return true;
+  }
+  return false;
+}
+
+// TRI on an observation array: DLT on (first minimal view id, LAST entry) — Q1/Q11 — then GN.
+// flags gets EG3D_FLAG_DEGENERATE_DLT (16) when both DLT views coincide.
+EG3D_HD bool triangulate_array(const float* cam_P, const Obs* a, int n, float Xout[3], uint32_t& flags) {
+  int mi = 0;
+  int32_t mv = a[0].view;
+  for (int i = 0; i < n; i++)
+    if (a[i].view < mv) {
+      mv = a[i].view;
+      mi = i;
+    }
+  const int la = n - 1;
+  if (a[mi].view == a[la].view) flags |= 16u;
+  double X0[3];
+  dlt2(cam_P + (size_t)a[mi].view * 16, a[mi].x, a[mi].y, cam_P + (size_t)a[la].view * 16, a[la].x, a[la].y, X0);
+  ArrayCursor c;
+  c.a = a;
+  c.n = n;
+  c.extra = nullptr;
+  c.i = 0;
+  return gauss_newton_f64(cam_P, c, X0, Xout);
+}
+
+// First 3-subset (std::prev_permutation order of the selection mask) that triangulates, then
+// greedy ADD of the remaining observations in list order (triangulation.cpp:1105-1158).
+// `sel` receives the final mask; `tmp` must hold n observations.
+EG3D_HD bool triangulate_combinations(const float* cam_P, const Obs* a, int n, Obs* tmp, uint8_t* sel,
+                                      float Xout[3], uint32_t& flags) {
+  // enumerate 3-subsets i<j<k in the order prev_permutation visits {1,1,1,0,...}:
+  // lexicographically descending masks == ascending (i,j,k) with k fastest
+  bool valid = false;
+  int bi = 0, bj = 0, bk = 0;
+  for (int i = 0; i < n - 2 && !valid; i++)
+    for (int j = i + 1; j < n - 1 && !valid; j++)
+      for (int k = j + 1; k < n && !valid; k++) {
+        tmp[0] = a[i];
+        tmp[1] = a[j];
+        tmp[2] = a[k];
+        if (triangulate_array(cam_P, tmp, 3, Xout, flags)) {
+          valid = true;
+          bi = i;
+          bj = j;
+          bk = k;
+        }
+      }
+  if (!valid) return false;
+  for (int i = 0; i < n; i++) sel[i] = (i == bi || i == bj || i == bk) ? 1 : 0;
+  tmp[0] = a[bi];
+  tmp[1] = a[bj];
+  tmp[2] = a[bk];
+  int m = 3;
+  for (int i = 0; i < n; i++) {
+    if (!sel[i]) {
+      ArrayCursor c;
+      c.a = tmp;
+      c.n = m;
+      c.extra = &a[i];
+      c.i = 0;
+      double X0[3] = {(double)Xout[0], (double)Xout[1], (double)Xout[2]};
+      float Xn[3];
+      if (gauss_newton_f64(cam_P, c, X0, Xn)) {
+        sel[i] = 1;
+        Xout[0] = Xn[0];
+        Xout[1] = Xn[1];
+        Xout[2] = Xn[2];
+        tmp[m++] = a[i];
+      }
+    }
+  }
+  return true;
+}
+
+// ------------------------------------------------------------ config 5 (FP32) ---
+// One point of gaussNewtonFiltering (src/edgegraph3d/filtering/gauss_newton.cpp:83-134):
+// FP32 state, products of the normal equations accumulated in double and rounded to float
+// per element (OpenCV float GEMM), determinant/inverse of the 3x3 in double.
+EG3D_HD bool gauss_newton_f32(const float* cam_P, const int32_t* views, const float* xy, int n, const float X0[3],
+                              float gn_max_mse, bool legacy_abs, float Xout[3]) {
+  float X[3] = {X0[0], X0[1], X0[2]};
+  float last_mse = 0;
+  for (int it = 0; it < 30; it++) {
+    float mse = 0;
+    double H00 = 0, H01 = 0, H02 = 0, H11 = 0, H12 = 0, H22 = 0;
+    for (int m = 0; m < n; m++) {
+      const float* P = cam_P + (size_t)views[m] * 16;
+      float xH = ((P[0] * X[0] + P[1] * X[1]) + P[2] * X[2]) + P[3] * 1.0f;
+      float yH = ((P[4] * X[0] + P[5] * X[1]) + P[6] * X[2]) + P[7] * 1.0f;
+      float zH = ((P[8] * X[0] + P[9] * X[1]) + P[10] * X[2]) + P[11] * 1.0f;
+      float r0 = xy[2 * m] - xH / zH;
+      mse += r0 * r0;
+      float r1 = xy[2 * m + 1] - yH / zH;
+      mse += r1 * r1;
+      float zz = zH * zH;
+      float j00 = (P[0] * zH - P[8] * xH) / zz;
+      float j10 = (P[4] * zH - P[8] * yH) / zz;
+      float j01 = (P[1] * zH - P[9] * xH) / zz;
+      float j11 = (P[5] * zH - P[9] * yH) / zz;
+      float j02 = (P[2] * zH - P[10] * xH) / zz;
+      float j12 = (P[6] * zH - P[10] * yH) / zz;
+      H00 += (double)j00 * (double)j00;
+      H00 += (double)j10 * (double)j10;
+      H01 += (double)j00 * (double)j01;
+      H01 += (double)j10 * (double)j11;
+      H02 += (double)j00 * (double)j02;
+      H02 += (double)j10 * (double)j12;
+      H11 += (double)j01 * (double)j01;
+      H11 += (double)j11 * (double)j11;
+      H12 += (double)j01 * (double)j02;
+      H12 += (double)j11 * (double)j12;
+      H22 += (double)j02 * (double)j02;
+      H22 += (double)j12 * (double)j12;
+    }
+    float diff = mse / (float)(n * 2) - last_mse;
+    bool conv;
+    if (legacy_abs) {
+      int di = (int)diff;
+      conv = (double)(di < 0 ? -di : di) < 0.0000000005;  // Q9
+    } else {
+      conv = (double)EG3D_FABSF(diff) < 0.0000000005;
+    }
+    if (conv) break;
+    last_mse = mse / (float)(n * 2);
+    float h00 = (float)H00, h01 = (float)H01, h02 = (float)H02, h11 = (float)H11, h12 = (float)H12, h22 = (float)H22;
+    float h10 = h01, h20 = h02, h21 = h12;
+    double dd = h00 * ((double)h11 * h22 - (double)h12 * h21) - h01 * ((double)h10 * h22 - (double)h12 * h20) +
+                h02 * ((double)h10 * h21 - (double)h11 * h20);
+    float d = (float)dd;
+    if ((double)d < 0.0000000001) return false;
+    float I00 = 0, I01 = 0, I02 = 0, I10 = 0, I11 = 0, I12 = 0, I20 = 0, I21 = 0, I22 = 0;
+    if (dd != 0.) {
+      double id = 1. / dd;
+      I00 = (float)(((double)h11 * h22 - (double)h12 * h21) * id);
+      I01 = (float)(((double)h02 * h21 - (double)h01 * h22) * id);
+      I02 = (float)(((double)h01 * h12 - (double)h02 * h11) * id);
+      I10 = (float)(((double)h12 * h20 - (double)h10 * h22) * id);
+      I11 = (float)(((double)h00 * h22 - (double)h02 * h20) * id);
+      I12 = (float)(((double)h02 * h10 - (double)h00 * h12) * id);
+      I20 = (float)(((double)h10 * h21 - (double)h11 * h20) * id);
+      I21 = (float)(((double)h01 * h20 - (double)h00 * h21) * id);
+      I22 = (float)(((double)h00 * h11 - (double)h01 * h10) * id);
+    }
+    double d0 = 0, d1 = 0, d2 = 0;
+    for (int m = 0; m < n; m++) {
+      const float* P = cam_P + (size_t)views[m] * 16;
+      float xH = ((P[0] * X[0] + P[1] * X[1]) + P[2] * X[2]) + P[3] * 1.0f;
+      float yH = ((P[4] * X[0] + P[5] * X[1]) + P[6] * X[2]) + P[7] * 1.0f;
+      float zH = ((P[8] * X[0] + P[9] * X[1]) + P[10] * X[2]) + P[11] * 1.0f;
+      float r0 = xy[2 * m] - xH / zH;
+      float r1 = xy[2 * m + 1] - yH / zH;
+      float zz = zH * zH;
+      float j00 = (P[0] * zH - P[8] * xH) / zz;
+      float j10 = (P[4] * zH - P[8] * yH) / zz;
+      float j01 = (P[1] * zH - P[9] * xH) / zz;
+      float j11 = (P[5] * zH - P[9] * yH) / zz;
+      float j02 = (P[2] * zH - P[10] * xH) / zz;
+      float j12 = (P[6] * zH - P[10] * yH) / zz;
+      float m00 = (float)(((double)I00 * j00 + (double)I01 * j01) + (double)I02 * j02);
+      float m01 = (float)(((double)I00 * j10 + (double)I01 * j11) + (double)I02 * j12);
+      float m10 = (float)(((double)I10 * j00 + (double)I11 * j01) + (double)I12 * j02);
+      float m11 = (float)(((double)I10 * j10 + (double)I11 * j11) + (double)I12 * j12);
+      float m20 = (float)(((double)I20 * j00 + (double)I21 * j01) + (double)I22 * j02);
+      float m21 = (float)(((double)I20 * j10 + (double)I21 * j11) + (double)I22 * j12);
+      d0 += (double)m00 * (double)r0;
+      d0 += (double)m01 * (double)r1;
+      d1 += (double)m10 * (double)r0;
+      d1 += (double)m11 * (double)r1;
+      d2 += (double)m20 * (double)r0;
+      d2 += (double)m21 * (double)r1;
+    }
+    X[0] += (float)d0;
+    X[1] += (float)d1;
+    X[2] += (float)d2;
+  }
+  if (last_mse < gn_max_mse) {
+    Xout[0] = X[0];
+    Xout[1] = X[1];
+    Xout[2] = X[2];
+    return true;
+  }
+  return false;
+}
+
+}  // namespace eg3d

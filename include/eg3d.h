@@ -1,0 +1,179 @@
+/*
+ * eg3d.h — C ABI of the MI355X-native EdgeGraph3D hot path
+ * (refpoint -> epipolar polyline match -> multi-view edge-point triangulation,
+ *  plus the batched Gauss-Newton outlier filter).
+ *
+ * The reference (abignoli/EdgeGraph3D) has no FFI layer: its seams are C++ free
+ * functions and virtual classes. Each entry point below names the reference seam
+ * it replaces (paths relative to the reference tree):
+ *
+ *   eg3d_create / eg3d_destroy
+ *       context construction in edge_matching(): PolyLine2DMapSearch per view at
+ *       4 px (src/edgegraph3d/edge_matcher.cpp:101-103), PLGEdgeManager ctor with
+ *       the 30 px maps (edge_managers/plg_edge_manager.cpp:46-75),
+ *       PLGPCM3ViewsPLGFollowing ctor (edge_matcher.cpp:115).
+ *   eg3d_candidates
+ *       PLGEdgeManager::detect_nearby_intersections_and_correspondences_plgp(int)
+ *       (include/.../plg_edge_manager.hpp:74, plg_edge_manager.cpp:261-300).
+ *   eg3d_match_refpoints
+ *       plg_matching_from_refpoints[_parallel](sfmd, em, cm, plgmm)
+ *       (include/.../plg_matching_from_refpoints.hpp:53,55;
+ *        src/.../plg_matching_from_refpoints.cpp:64-116).
+ *   eg3d_gn_filter
+ *       gaussNewtonFiltering(SfMData&, vector<bool>&, float)
+ *       (include/edgegraph3d/filtering/gauss_newton.hpp:20; gauss_newton.cpp:136-178).
+ *   eg3d_get_grid
+ *       read-back of PolyLine2DMap::pls_id_maps (matching/plg_matching/polyLine_2d_map.cpp:40-58)
+ *       so the grid membership can be checked against the CPU oracle.
+ *
+ * Conventions: plain C, POD structs, caller-owned input buffers that must stay
+ * valid for the duration of the call only (eg3d_create copies the scene to HBM).
+ * Status: 0 = ok, <0 = error (eg3d_last_error() gives text). One context per GPU;
+ * a context is thread-compatible (one caller thread at a time), like the reference.
+ * Ids that are `ulong` in the reference are uint32_t here (documented narrowing).
+ */
+#ifndef EG3D_H_
+#define EG3D_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EG3D_OK 0
+#define EG3D_ERR_ARG -1
+#define EG3D_ERR_HIP -2
+#define EG3D_ERR_CAPACITY -3 /* a device-side fixed capacity was exceeded; flags say which */
+#define EG3D_ERR_NODEVICE -4
+
+/* ---------------------------------------------------------------- scene ---- */
+/* Flat, read-only description of everything the path reads besides the seeds.
+ * Replaces SfMData::camerasList_[v].cameraMatrix, `Mat** F` and
+ * vector<PolyLineGraph2DHMapImpl> (reference: SfMData.h:16-30,
+ * types_reconstructor.hpp:68-82, polyline_graph_2d.hpp:85-119,278-294). */
+typedef struct eg3d_scene {
+  int32_t n_views;
+  int32_t width, height;      /* image size, identical for all views (imgs[0].size()) */
+  const float* cam_P;         /* [V][16] cameraMatrix[r][c], row-major 4x4, last row 0 (Q6) */
+  const double* F;            /* [V][V][9] row-major; F[i][j] maps a point of view i to its line in view j */
+  const uint8_t* F_valid;     /* [V][V] 0 => "1x1 Mat" => epiline fails (geometric_utilities.cpp:826,840) */
+  const uint32_t* view_pl_off;/* [V+1] polyline index range of each view in the arrays below */
+  const uint32_t* pl_vtx_off; /* [NP+1] vertex range of each polyline (global indices into vtx_xy) */
+  const float* vtx_xy;        /* [NV][2] polyline_coords */
+  const uint32_t* pl_start;   /* [NP] node id `start` */
+  const uint32_t* pl_end;     /* [NP] node id `end`   */
+  const uint8_t* pl_valid;    /* [NP] PolyLineGraph2D::is_valid_polyline (polyline_graph_2d.cpp:1141-1147) */
+} eg3d_scene;
+
+/* Seeds = SfM reference points: camViewingPointN_ + point2DoncamViewingPoint_ as CSR. */
+typedef struct eg3d_seeds {
+  uint32_t n_seeds;
+  const uint32_t* trk_off;    /* [N+1] */
+  const int32_t* trk_view;    /* [trk_off[N]] view ids, in the order stored in the SfM file */
+  const float* trk_xy;        /* [trk_off[N]][2] */
+} eg3d_seeds;
+
+/* ------------------------------------------------------------- outputs ----- */
+/* Edge-points = vector<tuple<vec3, vector<plg_point>, vector<int>>> of the reference,
+ * flattened. Library-owned; release with eg3d_free_edgepoints. Order is the
+ * reference's emission order (seed, start view in track order, start hit in
+ * ascending polyline id, chain order). */
+typedef struct eg3d_edgepoints {
+  uint64_t n_points;
+  uint64_t n_obs;
+  float* X;            /* [n_points][3] */
+  uint32_t* obs_off;   /* [n_points+1] */
+  int32_t* obs_view;   /* [n_obs] */
+  uint32_t* obs_pl;    /* [n_obs] polyline id inside its view */
+  uint32_t* obs_seg;   /* [n_obs] segment index */
+  float* obs_xy;       /* [n_obs][2] */
+  uint32_t* key;       /* [n_points][4] seed, start-view index in track, start-hit index, index in chain */
+  uint64_t n_tasks;        /* (seed, start view, start hit) tasks examined */
+  uint64_t n_hypotheses;   /* 3-view hypotheses evaluated */
+  uint64_t n_chains;       /* chains emitted */
+  uint32_t flags;          /* EG3D_FLAG_* capacity / quirk indicators */
+  void* _owner;            /* internal */
+} eg3d_edgepoints;
+
+#define EG3D_FLAG_CHAIN_OVERFLOW   1u  /* a chain exceeded the device chain capacity */
+#define EG3D_FLAG_OBS_OVERFLOW     2u  /* a chain's observation pool was exhausted   */
+#define EG3D_FLAG_HYP_OVERFLOW     4u  /* a following direction exceeded its capacity */
+#define EG3D_FLAG_DIR_MISMATCH     8u  /* Q15: a walk was asked to follow a node id that is neither end of its polyline */
+#define EG3D_FLAG_DEGENERATE_DLT  16u  /* Q11: a DLT initialisation used the same camera twice */
+
+/* Stage A result for one seed range (testable alone). Library-owned. */
+typedef struct eg3d_candidates {
+  uint32_t n_sv;            /* number of (seed, track entry) pairs = trk_off[end]-trk_off[begin] */
+  uint32_t* cand_off;       /* [n_sv+1] candidate polylines (<= 30 px), ascending id */
+  uint32_t* cand_pl;
+  uint32_t* start_off;      /* [n_sv+1] starting intersections (<= 10 px) */
+  uint32_t* start_pl;
+  uint32_t* start_seg;
+  float* start_xy;          /* [..][2] */
+  /* per starting intersection (task), per track entry of the seed: epipolar hits */
+  uint32_t n_tasks;
+  uint32_t* task_sv;        /* [n_tasks] index of the (seed,view) pair the task starts from */
+  uint32_t* task_hit;       /* [n_tasks] index of the start hit inside that pair */
+  uint32_t* task_list_off;  /* [n_tasks+1] offset into list_off: one list per track entry */
+  uint32_t* list_off;       /* [n_lists+1] */
+  uint32_t* hit_pl;
+  uint32_t* hit_seg;
+  float* hit_xy;
+  void* _owner;
+} eg3d_candidates;
+
+typedef struct eg3d_ctx eg3d_ctx;
+
+/* Per-call timing of the device stages, filled by eg3d_match_refpoints (ms, HIP events
+ * on the context's stream). */
+typedef struct eg3d_stage_times {
+  float ms_total;
+  float ms_candidates;   /* K1 seed_candidates (count+fill) */
+  float ms_epipolar;     /* K2 epipolar_hits (count+fill)   */
+  float ms_hypotheses;   /* K3a consensus hypotheses        */
+  float ms_select;       /* K3s uniqueness / chain assembly */
+  float ms_expand;       /* K3b expand-all-views            */
+  float ms_emit;         /* K4 compaction                   */
+  uint64_t bytes_algorithmic; /* SURVEY 8(d) algorithmic bytes of this call */
+} eg3d_stage_times;
+
+const char* eg3d_last_error(void);
+int eg3d_device_count(void);
+
+int eg3d_create(const eg3d_scene* scene, int device, eg3d_ctx** out);
+void eg3d_destroy(eg3d_ctx* ctx);
+
+/* which: 0 = 30 px candidate grid, 1 = 4 px expand-all-views grid. Pointers stay
+ * valid until eg3d_destroy. cell index = row*ncols + col. */
+int eg3d_get_grid(eg3d_ctx* ctx, int view, int which, uint32_t* ncols, uint32_t* nrows,
+                  const uint32_t** cell_off, const uint32_t** ids);
+
+int eg3d_candidates_run(eg3d_ctx* ctx, const eg3d_seeds* seeds, uint32_t seed_begin,
+                        uint32_t seed_end, eg3d_candidates* out);
+void eg3d_free_candidates(eg3d_candidates* c);
+
+/* Full path on seeds [seed_begin, seed_end). With device_only != 0 the result stays
+ * in HBM (out->X etc. are NULL, counts are filled) — used for kernel-only timing. */
+int eg3d_match_refpoints(eg3d_ctx* ctx, const eg3d_seeds* seeds, uint32_t seed_begin,
+                         uint32_t seed_end, int device_only, eg3d_edgepoints* out,
+                         eg3d_stage_times* times /* may be NULL */);
+void eg3d_free_edgepoints(eg3d_edgepoints* e);
+
+/* Resident-seed variant: upload once, run many times (bench: inputs in HBM before the
+ * timed region). */
+int eg3d_upload_seeds(eg3d_ctx* ctx, const eg3d_seeds* seeds);
+int eg3d_match_resident(eg3d_ctx* ctx, uint32_t seed_begin, uint32_t seed_end, int device_only,
+                        eg3d_edgepoints* out, eg3d_stage_times* times);
+
+/* Config 5: batched FP32 Gauss-Newton filter. view ids index ctx's cameras.
+ * X_out may alias X. legacy_abs != 0 selects the Q9 integer-abs behaviour. */
+int eg3d_gn_filter(eg3d_ctx* ctx, const float* X, const uint32_t* obs_off, const int32_t* obs_view,
+                   const float* obs_xy, uint64_t n_points, float gn_max_mse, int legacy_abs,
+                   float* X_out, uint8_t* inlier, float* ms_kernel /* may be NULL */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EG3D_H_ */

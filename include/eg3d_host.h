@@ -1,0 +1,88 @@
+/*
+ * eg3d_host.h — host-side (no GPU) utilities of the MI355X-native EdgeGraph3D path:
+ * the seeded synthetic workload generator of SURVEY.md 8(d), the grid-map builder used by
+ * eg3d_create (row a3), the OpenMVG-JSON reader/writer (row a-IO), and the host steps
+ * either side of the path (N3: dedup + observation filter). Plain C ABI, POD only.
+ */
+#ifndef EG3D_HOST_H_
+#define EG3D_HOST_H_
+#include "eg3d.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------ synthetic workload ---- */
+typedef struct eg3d_synth_config {
+  int32_t n_views;
+  uint32_t n_seeds;
+  int32_t n_curves;       /* 3-D curves in the 400 mm cube */
+  uint64_t rng_seed;      /* master seed; SURVEY 8(d): 0xE63D2018 + config index stream */
+  int32_t max_track;      /* k ~ U[3, min(V, max_track)] */
+  float obs_noise_px;     /* seed observation noise sigma (0.4) */
+  float vtx_noise_px;     /* polyline vertex noise sigma (0.15) */
+  float invalid_frac;     /* fraction of polylines emitted invalid/empty (0.01) */
+  float seed_offset_px;   /* seeds lie within this many projected px of a curve (6) */
+  int32_t width, height;  /* 1600 x 1200 */
+  float focal, ppx, ppy;  /* 2890, 823, 619 */
+} eg3d_synth_config;
+
+typedef struct eg3d_synth eg3d_synth;
+
+void eg3d_synth_default_config(eg3d_synth_config* c, int config_index /* 2,3,4: SURVEY C2,C3',C4; 0: tiny */);
+eg3d_synth* eg3d_synth_create(const eg3d_synth_config* c);
+const eg3d_scene* eg3d_synth_scene(const eg3d_synth* s);
+const eg3d_seeds* eg3d_synth_seeds(const eg3d_synth* s);
+/* true 3-D position of each seed's curve point ([n_seeds][3]) — for sanity checks only */
+const float* eg3d_synth_seed_truth(const eg3d_synth* s);
+uint64_t eg3d_synth_total_segments(const eg3d_synth* s);
+void eg3d_synth_destroy(eg3d_synth* s);
+
+/* Config 5 workload: n points with k~U[3,10] observations, X = truth + N(0, 2 mm),
+ * obs = projection + N(0, 0.5 px), 5 % gross outliers (20-50 px). Arrays are malloc'd;
+ * free with eg3d_host_free. */
+int eg3d_synth_points(const eg3d_synth* s, uint64_t n_points, uint64_t rng_seed, float** X, uint32_t** obs_off,
+                      int32_t** obs_view, float** obs_xy);
+void eg3d_host_free(void* p);
+
+/* --------------------------------------------------------------- grid maps ---- */
+/* Uniform grid of one view (reference PolyLine2DMap ctor, polyLine_2d_map.cpp:40-58).
+ * Outputs malloc'd CSR arrays (cell = row*ncols+col), free with eg3d_host_free. */
+int eg3d_host_build_grid(const eg3d_scene* scene, int view, float cell_dim, uint32_t* ncols, uint32_t* nrows,
+                         uint32_t** cell_off, uint32_t** ids, uint32_t* dropped);
+
+/* ------------------------------------------------------------ host post steps -- */
+/* filter_3d_points_close_2d_array (filtering_close_plgps.cpp:99-124): keep[i] = 1 if kept. */
+int eg3d_host_filter_close_2d(int n_views, int width, int height, const eg3d_edgepoints* pts, uint8_t* keep);
+/* compute_inliers tail (outliers_filtering.cpp:37-64); returns the threshold used. */
+int eg3d_host_observation_filter(int n_cameras, const uint32_t* obs_off, uint64_t n_points, uint64_t first_edgepoint,
+                                 int forced_min_filter, uint8_t* inlier_inout);
+
+/* -------------------------------------------------------------- OpenMVG JSON --- */
+typedef struct eg3d_sfm eg3d_sfm; /* host mirror of SfMData (SfMData.h:16-30) */
+eg3d_sfm* eg3d_sfm_read_json(const char* path);          /* OpenMvgParser::parse, OpenMvgParser.cpp:39-301 */
+int eg3d_sfm_write_json(const eg3d_sfm* s, const char* in_path_for_passthrough, const char* out_path); /* output_sfm_data.cpp:186-229 */
+eg3d_sfm* eg3d_sfm_create(int n_views, int width, int height);
+void eg3d_sfm_destroy(eg3d_sfm* s);
+int eg3d_sfm_n_views(const eg3d_sfm* s);
+uint64_t eg3d_sfm_n_points(const eg3d_sfm* s);
+const float* eg3d_sfm_cam_P(const eg3d_sfm* s);           /* [V][16] */
+int eg3d_sfm_set_camera(eg3d_sfm* s, int view, float focal, float ppx, float ppy, const float* R9_rowmajor,
+                        const float* center3, const char* image_path);
+/* seeds view of the points (pointers valid until the next mutation) */
+int eg3d_sfm_seeds(const eg3d_sfm* s, eg3d_seeds* out);
+const float* eg3d_sfm_points(const eg3d_sfm* s);          /* [N][3] */
+int eg3d_sfm_add_point(eg3d_sfm* s, const float* X3, int n_obs, const int32_t* views, const float* xy);
+/* add_3dpoints_to_sfmd (output_utilities.cpp:96-111) */
+int eg3d_sfm_add_edgepoints(eg3d_sfm* s, const eg3d_edgepoints* pts, const uint8_t* keep /* may be NULL */);
+/* removeOutliers (outliers_filtering.cpp:66-92) */
+int eg3d_sfm_remove_outliers(eg3d_sfm* s, const uint8_t* inlier);
+int eg3d_sfm_set_point_coords(eg3d_sfm* s, const float* X /* [N][3] */);
+/* analytic fundamental matrices from the cameras (replaces generate_all_fundamental_matrices,
+ * geometric_utilities.cpp:818-820, whose LMedS estimate is not reproducible without OpenCV) */
+int eg3d_sfm_analytic_F(const eg3d_sfm* s, double* F /* [V][V][9] */, uint8_t* F_valid /* [V][V] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,506 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY. PARITY UNPINNED.
+// The reference (abignoli/EdgeGraph3D) has no tests, no golden vectors and cannot be
+// compiled here (OpenCV, CGAL, Boost absent: SURVEY.md F3/F4), so this restatement is pinned
+// only by hand-derived known-answer tests (tests/test_oracle_kat.py) and by the quirk tests
+// Q1-Q15. It is the checker for the HIP path; the product never links or calls it.
+//
+// Drivers restated here:
+//   plg_matching_from_refpoints[_parallel]  src/edgegraph3d/matching/plg_matching/plg_matching_from_refpoints.cpp:83-116
+//   gaussNewtonFiltering                    src/edgegraph3d/filtering/gauss_newton.cpp:136-178
+//   filter_3d_points_close_2d_array         src/edgegraph3d/filtering/filtering_close_plgps.cpp:99-124
+//   compute_inliers (observation filter)    src/edgegraph3d/filtering/outliers_filtering.cpp:37-64
+#include "eg3d_oracle.h"
+
+#include <omp.h>
+
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "oracle_plg.hpp"
+
+using namespace orc;
+
+struct orc_ctx {
+  Scene sc;
+  std::vector<float> P;
+  std::vector<double> F;
+  std::vector<uint8_t> Fv;
+  // flattened grids for export
+  std::vector<std::vector<uint32_t>> g_off[2], g_ids[2];
+};
+
+static void flatten_grid(const PolyLine2DMapSearch& g, std::vector<uint32_t>& off, std::vector<uint32_t>& ids) {
+  off.assign(g.cells.size() + 1, 0);
+  ids.clear();
+  for (size_t c = 0; c < g.cells.size(); c++) {
+    off[c] = (uint32_t)ids.size();
+    for (auto v : g.cells[c]) ids.push_back((uint32_t)v);
+  }
+  off[g.cells.size()] = (uint32_t)ids.size();
+}
+
+extern "C" orc_ctx* orc_create(const eg3d_scene* s) {
+  orc_ctx* c = new orc_ctx();
+  const int V = s->n_views;
+  c->P.assign(s->cam_P, s->cam_P + (size_t)V * 16);
+  c->F.assign(s->F, s->F + (size_t)V * V * 9);
+  c->Fv.assign(s->F_valid, s->F_valid + (size_t)V * V);
+  c->sc.cams.n_views = V;
+  c->sc.cams.P = c->P.data();
+  c->sc.cams.F = c->F.data();
+  c->sc.cams.F_valid = c->Fv.data();
+  c->sc.width = s->width;
+  c->sc.height = s->height;
+  c->sc.dir_mismatch = 0;
+  c->sc.plgs.resize(V);
+  for (int v = 0; v < V; v++) {
+    PLG& g = c->sc.plgs[v];
+    uint32_t p0 = s->view_pl_off[v], p1 = s->view_pl_off[v + 1];
+    g.polylines.resize(p1 - p0);
+    for (uint32_t p = p0; p < p1; p++) {
+      polyline& pl = g.polylines[p - p0];
+      pl.start = s->pl_start[p];
+      pl.end = s->pl_end[p];
+      pl.valid = s->pl_valid[p] != 0;
+      pl.dir_mismatch_counter = &c->sc.dir_mismatch;
+      uint32_t a = s->pl_vtx_off[p], b = s->pl_vtx_off[p + 1];
+      pl.polyline_coords.resize(b - a);
+      for (uint32_t i = a; i < b; i++) pl.polyline_coords[i - a] = vec2(s->vtx_xy[2 * i], s->vtx_xy[2 * i + 1]);
+    }
+  }
+  c->sc.grid30.resize(V);
+  c->sc.grid4.resize(V);
+  for (int w = 0; w < 2; w++) {
+    c->g_off[w].resize(V);
+    c->g_ids[w].resize(V);
+  }
+#pragma omp parallel for schedule(dynamic)
+  for (int v = 0; v < V; v++) {
+    // 30 px: starting_detection_dist*factor (plg_edge_manager.cpp:46,74); 4 px: edge_matcher.cpp:103
+    c->sc.grid30[v].build(c->sc.plgs[v], s->width, s->height, 10.0f * 3.0f);
+    c->sc.grid4[v].build(c->sc.plgs[v], s->width, s->height, 4.0f);
+    flatten_grid(c->sc.grid30[v], c->g_off[0][v], c->g_ids[0][v]);
+    flatten_grid(c->sc.grid4[v], c->g_off[1][v], c->g_ids[1][v]);
+  }
+  return c;
+}
+
+extern "C" void orc_destroy(orc_ctx* c) { delete c; }
+
+extern "C" int orc_get_grid(orc_ctx* c, int view, int which, uint32_t* ncols, uint32_t* nrows,
+                            const uint32_t** cell_off, const uint32_t** ids) {
+  if (!c || view < 0 || view >= c->sc.cams.n_views || which < 0 || which > 1) return -1;
+  const PolyLine2DMapSearch& g = which == 0 ? c->sc.grid30[view] : c->sc.grid4[view];
+  *ncols = g.map_w;
+  *nrows = g.map_h;
+  *cell_off = c->g_off[which][view].data();
+  *ids = c->g_ids[which][view].data();
+  return 0;
+}
+
+static SeedView seed_view(const eg3d_seeds* s, uint32_t i) {
+  SeedView sv;
+  sv.views = s->trk_view + s->trk_off[i];
+  sv.xy = reinterpret_cast<const vec2*>(s->trk_xy + 2 * (size_t)s->trk_off[i]);
+  sv.k = (int)(s->trk_off[i + 1] - s->trk_off[i]);
+  return sv;
+}
+
+extern "C" int orc_match_refpoints(orc_ctx* c, const eg3d_seeds* seeds, uint32_t b, uint32_t e, int nthreads,
+                                   eg3d_edgepoints* out, orc_stats* stats) {
+  if (!c || !seeds || e > seeds->n_seeds || b > e) return -1;
+  memset(out, 0, sizeof(*out));
+  const uint32_t n = e - b;
+  std::vector<std::vector<EdgePoint>> per_seed(n);
+  if (nthreads < 1) nthreads = 1;
+  std::vector<Stats> tstats(nthreads);
+  c->sc.dir_mismatch = 0;
+  auto t0 = std::chrono::steady_clock::now();
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+  for (uint32_t i = 0; i < n; i++) {
+    int t = omp_get_thread_num();
+    SeedView sv = seed_view(seeds, b + i);
+    plg_matching_from_refpoint(c->sc, sv, b + i, per_seed[i], &tstats[t]);
+  }
+  auto t1 = std::chrono::steady_clock::now();
+  uint64_t np = 0, no = 0;
+  for (auto& v : per_seed)
+    for (auto& ep : v) {
+      np++;
+      no += ep.p.obs.size();
+    }
+  out->n_points = np;
+  out->n_obs = no;
+  out->X = (float*)malloc(sizeof(float) * 3 * (np ? np : 1));
+  out->obs_off = (uint32_t*)malloc(sizeof(uint32_t) * (np + 1));
+  out->obs_view = (int32_t*)malloc(sizeof(int32_t) * (no ? no : 1));
+  out->obs_pl = (uint32_t*)malloc(sizeof(uint32_t) * (no ? no : 1));
+  out->obs_seg = (uint32_t*)malloc(sizeof(uint32_t) * (no ? no : 1));
+  out->obs_xy = (float*)malloc(sizeof(float) * 2 * (no ? no : 1));
+  out->key = (uint32_t*)malloc(sizeof(uint32_t) * 4 * (np ? np : 1));
+  uint64_t pi = 0, oi = 0;
+  for (auto& v : per_seed)
+    for (auto& ep : v) {
+      out->X[3 * pi] = ep.p.X.x;
+      out->X[3 * pi + 1] = ep.p.X.y;
+      out->X[3 * pi + 2] = ep.p.X.z;
+      out->obs_off[pi] = (uint32_t)oi;
+      for (int k = 0; k < 4; k++) out->key[4 * pi + k] = ep.key[k];
+      for (size_t j = 0; j < ep.p.obs.size(); j++) {
+        out->obs_view[oi] = ep.p.views[j];
+        out->obs_pl[oi] = (uint32_t)ep.p.obs[j].polyline_id;
+        out->obs_seg[oi] = (uint32_t)ep.p.obs[j].plp.segment_index;
+        out->obs_xy[2 * oi] = ep.p.obs[j].plp.coords.x;
+        out->obs_xy[2 * oi + 1] = ep.p.obs[j].plp.coords.y;
+        oi++;
+      }
+      pi++;
+    }
+  out->obs_off[np] = (uint32_t)oi;
+  Stats tot;
+  for (auto& s : tstats) {
+    tot.n_tasks += s.n_tasks;
+    tot.n_hyp += s.n_hyp;
+    tot.n_chains += s.n_chains;
+    tot.bytes_algorithmic += s.bytes_algorithmic;
+    tot.tri.n_tri += s.tri.n_tri;
+    tot.tri.n_add += s.tri.n_add;
+    tot.tri.n_degenerate_dlt += s.tri.n_degenerate_dlt;
+    tot.tri.n_combos += s.tri.n_combos;
+  }
+  out->n_tasks = tot.n_tasks;
+  out->n_hypotheses = tot.n_hyp;
+  out->n_chains = tot.n_chains;
+  out->flags = 0;
+  if (c->sc.dir_mismatch) out->flags |= EG3D_FLAG_DIR_MISMATCH;
+  if (tot.tri.n_degenerate_dlt) out->flags |= EG3D_FLAG_DEGENERATE_DLT;
+  if (stats) {
+    stats->n_tasks = tot.n_tasks;
+    stats->n_hyp = tot.n_hyp;
+    stats->n_chains = tot.n_chains;
+    stats->n_tri = tot.tri.n_tri;
+    stats->n_add = tot.tri.n_add;
+    stats->n_degenerate_dlt = tot.tri.n_degenerate_dlt;
+    stats->n_combos = tot.tri.n_combos;
+    stats->bytes_algorithmic = tot.bytes_algorithmic;
+    stats->dir_mismatch = c->sc.dir_mismatch;
+    uint32_t gd = 0;
+    for (auto& g : c->sc.grid30) gd += g.dropped_out_of_range;
+    for (auto& g : c->sc.grid4) gd += g.dropped_out_of_range;
+    stats->grid_dropped = gd;
+    stats->seconds = std::chrono::duration<double>(t1 - t0).count();
+  }
+  return 0;
+}
+
+extern "C" void orc_free_edgepoints(eg3d_edgepoints* e) {
+  if (!e) return;
+  free(e->X);
+  free(e->obs_off);
+  free(e->obs_view);
+  free(e->obs_pl);
+  free(e->obs_seg);
+  free(e->obs_xy);
+  free(e->key);
+  memset(e, 0, sizeof(*e));
+}
+
+template <typename T>
+static T* dup_vec(const std::vector<T>& v) {
+  T* p = (T*)malloc(sizeof(T) * (v.size() ? v.size() : 1));
+  if (!v.empty()) memcpy(p, v.data(), sizeof(T) * v.size());
+  return p;
+}
+
+extern "C" int orc_candidates(orc_ctx* c, const eg3d_seeds* seeds, uint32_t b, uint32_t e, eg3d_candidates* out) {
+  if (!c || !seeds || e > seeds->n_seeds || b > e) return -1;
+  memset(out, 0, sizeof(*out));
+  std::vector<uint32_t> cand_off(1, 0), cand_pl, start_off(1, 0), start_pl, start_seg, task_sv, task_hit,
+      task_list_off(1, 0), list_off(1, 0), hit_pl, hit_seg;
+  std::vector<float> start_xy, hit_xy;
+  uint32_t sv_base = 0;
+  for (uint32_t s = b; s < e; s++) {
+    SeedView sv = seed_view(seeds, s);
+    StageA sa = detect_nearby_intersections_and_correspondences_plgp(c->sc, sv, nullptr);
+    for (int a = 0; a < sv.k; a++) {
+      for (auto id : sa.cand[a]) cand_pl.push_back((uint32_t)id);
+      cand_off.push_back((uint32_t)cand_pl.size());
+      for (auto& h : sa.start_hits[a]) {
+        start_pl.push_back((uint32_t)h.polyline_id);
+        start_seg.push_back((uint32_t)h.plp.segment_index);
+        start_xy.push_back(h.plp.coords.x);
+        start_xy.push_back(h.plp.coords.y);
+      }
+      start_off.push_back((uint32_t)start_pl.size());
+    }
+    for (int a = 0; a < sv.k; a++)
+      for (size_t h = 0; h < sa.start_hits[a].size(); h++) {
+        task_sv.push_back(sv_base + a);
+        task_hit.push_back((uint32_t)h);
+        for (int i = 0; i < sv.k; i++) {
+          for (auto& p : sa.corr[a][h][i]) {
+            hit_pl.push_back((uint32_t)p.polyline_id);
+            hit_seg.push_back((uint32_t)p.plp.segment_index);
+            hit_xy.push_back(p.plp.coords.x);
+            hit_xy.push_back(p.plp.coords.y);
+          }
+          list_off.push_back((uint32_t)hit_pl.size());
+        }
+        task_list_off.push_back((uint32_t)list_off.size() - 1);
+      }
+    sv_base += sv.k;
+  }
+  out->n_sv = sv_base;
+  out->cand_off = dup_vec(cand_off);
+  out->cand_pl = dup_vec(cand_pl);
+  out->start_off = dup_vec(start_off);
+  out->start_pl = dup_vec(start_pl);
+  out->start_seg = dup_vec(start_seg);
+  out->start_xy = dup_vec(start_xy);
+  out->n_tasks = (uint32_t)task_sv.size();
+  out->task_sv = dup_vec(task_sv);
+  out->task_hit = dup_vec(task_hit);
+  out->task_list_off = dup_vec(task_list_off);
+  out->list_off = dup_vec(list_off);
+  out->hit_pl = dup_vec(hit_pl);
+  out->hit_seg = dup_vec(hit_seg);
+  out->hit_xy = dup_vec(hit_xy);
+  return 0;
+}
+
+extern "C" void orc_free_candidates(eg3d_candidates* c) {
+  if (!c) return;
+  free(c->cand_off);
+  free(c->cand_pl);
+  free(c->start_off);
+  free(c->start_pl);
+  free(c->start_seg);
+  free(c->start_xy);
+  free(c->task_sv);
+  free(c->task_hit);
+  free(c->task_list_off);
+  free(c->list_off);
+  free(c->hit_pl);
+  free(c->hit_seg);
+  free(c->hit_xy);
+  memset(c, 0, sizeof(*c));
+}
+
+// gaussNewtonFiltering, gauss_newton.cpp:136-178
+extern "C" int orc_gn_filter(orc_ctx* c, const float* X, const uint32_t* obs_off, const int32_t* obs_view,
+                             const float* obs_xy, uint64_t n_points, float gn_max_mse, int legacy_abs, int nthreads,
+                             float* X_out, uint8_t* inlier) {
+  if (!c) return -1;
+  if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+  for (uint64_t i = 0; i < n_points; i++) {
+    uint32_t a = obs_off[i], b = obs_off[i + 1];
+    std::vector<GNObs> obs(b - a);
+    for (uint32_t j = a; j < b; j++) {
+      obs[j - a].P = c->P.data() + (size_t)obs_view[j] * 16;
+      obs[j - a].x = obs_xy[2 * j];
+      obs[j - a].y = obs_xy[2 * j + 1];
+    }
+    float init[3] = {X[3 * i], X[3 * i + 1], X[3 * i + 2]}, opt[3];
+    if (GaussNewton_f32(obs, init, opt, gn_max_mse, legacy_abs != 0) != -1) {
+      X_out[3 * i] = opt[0];
+      X_out[3 * i + 1] = opt[1];
+      X_out[3 * i + 2] = opt[2];
+      inlier[i] = 1;
+    } else {
+      X_out[3 * i] = init[0];
+      X_out[3 * i + 1] = init[1];
+      X_out[3 * i + 2] = init[2];
+      inlier[i] = 0;
+    }
+  }
+  return 0;
+}
+
+// filter_3d_points_close_2d_array, filtering_close_plgps.cpp:75-124 (CELLSIZE 3)
+extern "C" int orc_filter_close_2d(orc_ctx* c, const eg3d_edgepoints* pts, uint8_t* keep) {
+  if (!c) return -1;
+  const int CELL = 3;
+  const int w = int(std::ceil((float)c->sc.width / CELL)), h = int(std::ceil((float)c->sc.height / CELL));
+  const int V = c->sc.cams.n_views;
+  std::vector<std::vector<uint8_t>> bmaps(V, std::vector<uint8_t>((size_t)w * h, 0));
+  for (uint64_t i = 0; i < pts->n_points; i++) {
+    bool is_new = false;
+    for (uint32_t j = pts->obs_off[i]; j < pts->obs_off[i + 1]; j++) {
+      int cx = int(pts->obs_xy[2 * j] / CELL), cy = int(pts->obs_xy[2 * j + 1] / CELL);
+      if (!bmaps[pts->obs_view[j]][(size_t)cy * w + cx]) {
+        is_new = true;
+        break;
+      }
+    }
+    keep[i] = is_new ? 1 : 0;
+    if (is_new)
+      for (uint32_t j = pts->obs_off[i]; j < pts->obs_off[i + 1]; j++) {
+        int cx = int(pts->obs_xy[2 * j] / CELL), cy = int(pts->obs_xy[2 * j + 1] / CELL);
+        bmaps[pts->obs_view[j]][(size_t)cy * w + cx] = 1;
+      }
+  }
+  return 0;
+}
+
+// compute_ray_stats + compute_inliers tail, outliers_filtering.cpp:14-35,37-64
+extern "C" int orc_observation_filter(int n_cameras, const uint32_t* obs_off, uint64_t n_points,
+                                      uint64_t first_edgepoint, int forced_min_filter, uint8_t* inlier) {
+  std::vector<int> dist(n_cameras, 0);
+  int count = 0;
+  for (uint64_t i = 0; i < n_points; i++)
+    if (inlier[i]) {
+      count++;
+      int k = (int)(obs_off[i + 1] - obs_off[i]);
+      if (k >= 1 && k <= n_cameras) dist[k - 1]++;
+    }
+  int m_amount = 0, median = 0;
+  for (median = 0; median < n_cameras; median++) {
+    m_amount += dist[median];
+    if (m_amount >= count / 2) break;
+  }
+  int intended = (3 >= median / 2 - 1) ? 3 : (median / 2 - 1);
+  if (forced_min_filter > -1) intended = forced_min_filter;
+  for (uint64_t i = first_edgepoint; i < n_points; i++)
+    inlier[i] = inlier[i] && ((int)(obs_off[i + 1] - obs_off[i]) > intended);
+  return intended;
+}
+
+// ------------------------------------------------------------- primitive probes ----
+extern "C" float orc_squared_2d_distance(float ax, float ay, float bx, float by) {
+  return squared_2d_distance(vec2(ax, ay), vec2(bx, by));
+}
+extern "C" float orc_minimum_distancesq(float px, float py, float vx, float vy, float wx, float wy, float* proj) {
+  vec2 pr;
+  float d = minimum_distancesq(vec2(px, py), vec2(vx, vy), vec2(wx, wy), pr);
+  proj[0] = pr.x;
+  proj[1] = pr.y;
+  return d;
+}
+extern "C" int orc_intersect_segment_line(float x1, float y1, float x2, float y2, const float* line, float* inter,
+                                          int* parallel, int* overlapped) {
+  bool p, o, f;
+  vec2 i;
+  intersect_segment_line(x1, y1, x2, y2, line, p, o, f, i);
+  inter[0] = i.x;
+  inter[1] = i.y;
+  *parallel = p;
+  *overlapped = o;
+  return f;
+}
+extern "C" int orc_intersect_segment_line_nqp(float x1, float y1, float x2, float y2, const float* line, float* inter,
+                                              int* quasiparallel, float* distance) {
+  bool p, o, f, q, v;
+  vec2 i;
+  float d = -1;
+  intersect_segment_line_no_quasiparallel(x1, y1, x2, y2, line, QP_COS, QP_DIST, p, o, f, q, v, d, i);
+  inter[0] = i.x;
+  inter[1] = i.y;
+  *quasiparallel = q;
+  *distance = d;
+  return f;
+}
+extern "C" int orc_cell_from_coords(float cell, float x, float y, int* col, int* row, int* b_row, int* b_col) {
+  bool br, bc;
+  auto c = get_2dmap_cell_from_coords(cell, vec2(x, y), br, bc);
+  *col = (int)c.first;
+  *row = (int)c.second;
+  *b_row = br;
+  *b_col = bc;
+  return 0;
+}
+extern "C" int orc_epiline(const double* F9, float x, float y, float* line) {
+  Cameras cm;
+  uint8_t one = 1;
+  cm.n_views = 1;
+  cm.F = F9;
+  cm.F_valid = &one;
+  cm.P = nullptr;
+  return computeCorrespondEpilineSinglePoint(cm, 0, 0, vec2(x, y), line);
+}
+extern "C" void orc_project(const float* P16, const float* X, float* xy) {
+  vec2 r = compute_projection(P16, vec3(X[0], X[1], X[2]));
+  xy[0] = r.x;
+  xy[1] = r.y;
+}
+extern "C" int orc_triangulate(const float* P, const int* view_ids, const float* xy, int n, float* X,
+                               int* degenerate) {
+  Cameras cm;
+  cm.P = P;
+  cm.F = nullptr;
+  cm.F_valid = nullptr;
+  cm.n_views = 0;
+  std::vector<vec2> coords(n);
+  std::vector<int> ids(view_ids, view_ids + n);
+  for (int i = 0; i < n; i++) coords[i] = vec2(xy[2 * i], xy[2 * i + 1]);
+  vec3 out;
+  bool valid;
+  TriStats st;
+  em_estimate3Dpositions(cm, coords, ids, out, valid, &st);
+  if (degenerate) *degenerate = (int)st.n_degenerate_dlt;
+  if (valid) {
+    X[0] = out.x;
+    X[1] = out.y;
+    X[2] = out.z;
+  }
+  return valid;
+}
+extern "C" int orc_gn_add(const float* P, const int* view_ids, const float* xy, int n, const float* X0, float* X) {
+  Cameras cm;
+  cm.P = P;
+  cm.F = nullptr;
+  cm.F_valid = nullptr;
+  cm.n_views = 0;
+  std::vector<vec2> coords(n - 1);
+  std::vector<int> ids(view_ids, view_ids + n - 1);
+  for (int i = 0; i < n - 1; i++) coords[i] = vec2(xy[2 * i], xy[2 * i + 1]);
+  vec3 out;
+  bool valid;
+  em_add_new_observation_to_3Dpositions(cm, vec3(X0[0], X0[1], X0[2]), coords, ids,
+                                        vec2(xy[2 * (n - 1)], xy[2 * (n - 1) + 1]), view_ids[n - 1], out, valid,
+                                        nullptr);
+  if (valid) {
+    X[0] = out.x;
+    X[1] = out.y;
+    X[2] = out.z;
+  }
+  return valid;
+}
+extern "C" void orc_dlt(const float* P1, const float* xy1, const float* P2, const float* xy2, double* X0) {
+  dlt2_init(P1, vec2(xy1[0], xy1[1]), P2, vec2(xy2[0], xy2[1]), X0);
+}
+static polyline make_pl(const float* vtx, int n, uint32_t start, uint32_t end) {
+  polyline pl;
+  pl.start = start;
+  pl.end = end;
+  pl.valid = true;
+  pl.polyline_coords.resize(n);
+  for (int i = 0; i < n; i++) pl.polyline_coords[i] = vec2(vtx[2 * i], vtx[2 * i + 1]);
+  return pl;
+}
+extern "C" int orc_next_by_distance(const float* vtx, int n, uint32_t start, uint32_t end, uint32_t seg, float x,
+                                    float y, uint32_t direction, float distance, uint32_t* out_seg, float* out_xy) {
+  polyline pl = make_pl(vtx, n, start, end);
+  bool reached;
+  pl_point r = pl.next_pl_point_by_distance(pl_point(seg, vec2(x, y)), direction, distance, reached);
+  *out_seg = (uint32_t)r.segment_index;
+  out_xy[0] = r.coords.x;
+  out_xy[1] = r.coords.y;
+  return reached;
+}
+extern "C" int orc_next_by_line(const float* vtx, int n, uint32_t start, uint32_t end, uint32_t seg, float x, float y,
+                                uint32_t direction, const float* line, int bounded, float mind, float maxd,
+                                uint32_t* out_seg, float* out_xy, int* flags) {
+  polyline pl = make_pl(vtx, n, start, end);
+  pl_point next, nbq;
+  bool fqp, reached, bdv, found;
+  pl.next_pl_point_by_line_intersection_impl(pl_point(seg, vec2(x, y)), direction, line, bounded != 0, mind, maxd,
+                                             next, fqp, nbq, reached, bdv, found);
+  *out_seg = (uint32_t)next.segment_index;
+  out_xy[0] = next.coords.x;
+  out_xy[1] = next.coords.y;
+  *flags = (fqp ? 1 : 0) | (reached ? 2 : 0) | (bdv ? 4 : 0);
+  return found;
+}

@@ -1,0 +1,65 @@
+/* ORACLE — TEST INFRASTRUCTURE ONLY. PARITY UNPINNED (no reference tests / golden vectors
+ * exist, and the reference cannot be built here — SURVEY.md F3/F4).
+ * C interface of the CPU restatement, consumed through ctypes by tests/, by
+ * __graft_entry__.smoke() and by bench.py's cpu_baseline leg. Never linked into the product. */
+#ifndef EG3D_ORACLE_H_
+#define EG3D_ORACLE_H_
+#include "../include/eg3d.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_ctx orc_ctx;
+
+typedef struct orc_stats {
+  uint64_t n_tasks, n_hyp, n_chains;
+  uint64_t n_tri, n_add, n_degenerate_dlt, n_combos;
+  uint64_t bytes_algorithmic;
+  uint32_t dir_mismatch;
+  uint32_t grid_dropped;
+  double seconds; /* wall time of the call, scene/grid construction excluded */
+} orc_stats;
+
+orc_ctx* orc_create(const eg3d_scene* scene);
+void orc_destroy(orc_ctx*);
+int orc_get_grid(orc_ctx*, int view, int which, uint32_t* ncols, uint32_t* nrows, const uint32_t** cell_off,
+                 const uint32_t** ids);
+/* out uses the eg3d_edgepoints layout; release with orc_free_edgepoints. nthreads<=1: serial. */
+int orc_match_refpoints(orc_ctx*, const eg3d_seeds* seeds, uint32_t seed_begin, uint32_t seed_end, int nthreads,
+                        eg3d_edgepoints* out, orc_stats* stats);
+void orc_free_edgepoints(eg3d_edgepoints* e);
+int orc_candidates(orc_ctx*, const eg3d_seeds* seeds, uint32_t seed_begin, uint32_t seed_end, eg3d_candidates* out);
+void orc_free_candidates(eg3d_candidates* c);
+int orc_gn_filter(orc_ctx*, const float* X, const uint32_t* obs_off, const int32_t* obs_view, const float* obs_xy,
+                  uint64_t n_points, float gn_max_mse, int legacy_abs, int nthreads, float* X_out, uint8_t* inlier);
+/* filter_3d_points_close_2d_array (filtering_close_plgps.cpp:99-124): keep[i]=1 for kept points */
+int orc_filter_close_2d(orc_ctx*, const eg3d_edgepoints* pts, uint8_t* keep);
+/* compute_inliers tail (outliers_filtering.cpp:37-64) given GN inliers: returns threshold used */
+int orc_observation_filter(int n_cameras, const uint32_t* obs_off, uint64_t n_points, uint64_t first_edgepoint,
+                           int forced_min_filter, uint8_t* inlier_inout);
+
+/* primitive probes for known-answer tests */
+float orc_squared_2d_distance(float ax, float ay, float bx, float by);
+float orc_minimum_distancesq(float px, float py, float vx, float vy, float wx, float wy, float* proj);
+int orc_intersect_segment_line(float x1, float y1, float x2, float y2, const float* line, float* inter,
+                               int* parallel, int* overlapped);
+int orc_intersect_segment_line_nqp(float x1, float y1, float x2, float y2, const float* line, float* inter,
+                                   int* quasiparallel, float* distance);
+int orc_cell_from_coords(float cell, float x, float y, int* col, int* row, int* b_row, int* b_col);
+int orc_epiline(const double* F9, float x, float y, float* line);
+void orc_project(const float* P16, const float* X, float* xy);
+int orc_triangulate(const float* P /*[n][16]*/, const int* view_ids, const float* xy, int n, float* X, int* degenerate);
+int orc_gn_add(const float* P, const int* view_ids, const float* xy, int n, const float* X0, float* X);
+void orc_dlt(const float* P1, const float* xy1, const float* P2, const float* xy2, double* X0);
+/* polyline walking probes: vtx = [n][2], start/end node ids */
+int orc_next_by_distance(const float* vtx, int n, uint32_t start, uint32_t end, uint32_t seg, float x, float y,
+                         uint32_t direction, float distance, uint32_t* out_seg, float* out_xy);
+int orc_next_by_line(const float* vtx, int n, uint32_t start, uint32_t end, uint32_t seg, float x, float y,
+                     uint32_t direction, const float* line, int bounded, float mind, float maxd, uint32_t* out_seg,
+                     float* out_xy, int* flags /*1 qp,2 extreme,4 bound*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,742 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY. PARITY UNPINNED (see oracle_geom.hpp header).
+// CPU restatement of the consensus / polyline-following / expand-all-views logic of
+// abignoli/EdgeGraph3D:
+//   plg_matching.cpp  = src/edgegraph3d/matching/plg_matching/plg_matching.cpp
+//   triangulation.cpp = src/edgegraph3d/utils/geometry/triangulation.cpp
+//   plg_edge_manager.cpp = src/edgegraph3d/edge_managers/plg_edge_manager.cpp
+// Active switches: GLOBAL_SWITCH_USEEXPANDALLVIEWSVECTOR, SWITCH_PLG_MATCHING_ADDPOINT_BOTHDIR_ONE,
+// SWITCH_DISABLE_INTERVAL (global_switches.hpp:35, plg_matching.hpp:60, triangulation.cpp:740).
+#pragma once
+#include <algorithm>
+#include <tuple>
+#include <vector>
+
+#include "oracle_geom.hpp"
+#include "oracle_tri.hpp"
+
+namespace orc {
+
+// new_3dpoint_plgp_matches (polyline_graph_2d.hpp:451)
+struct P3 {
+  vec3 X;
+  std::vector<plg_point> obs;
+  std::vector<int> views;
+};
+
+struct Scene {
+  Cameras cams;
+  int width, height;
+  std::vector<PLG> plgs;
+  std::vector<PolyLine2DMapSearch> grid30;  // PLGEdgeManager::correspondence_plmaps (plg_edge_manager.cpp:73-74)
+  std::vector<PolyLine2DMapSearch> grid4;   // plmaps, 4 px (edge_matcher.cpp:101-103)
+  mutable uint32_t dir_mismatch;
+};
+
+struct Stats {
+  TriStats tri;
+  uint64_t n_tasks = 0, n_hyp = 0, n_chains = 0;
+  uint64_t bytes_algorithmic = 0;
+};
+
+// plg_matching.hpp:39-41,62 ; triangulation.hpp:46
+static const float PLG_FOLLOW_FIRST_IMAGE_DISTANCE = (float)10.0;
+static const float PLG_FOLLOW_CORR_MIN = (float)(10.0 / 2);
+static const float PLG_FOLLOW_CORR_MAX = (float)(10.0 * 2);
+static const size_t PLG_MIN_TRI_POINTS = 3;
+static const float MAX_3DPOINT_PROJECTIONDISTSQ_EXPANDALLVIEWS = (float)16.0;
+
+static inline std::vector<vec2> coords_of(const std::vector<plg_point>& v) {
+  std::vector<vec2> r;
+  for (const auto& p : v) r.push_back(p.plp.coords);
+  return r;
+}
+
+// ---- 3-view step: compatible(), plg_matching.cpp:51-132 (unbounded walk on B and C) ----
+struct Step3Result {
+  plg_point a, b, c;
+  vec3 X;
+};
+static inline bool compatible3(const Scene& sc, const int ids[3], const plg_point cur[3], const ulong_t dirs[3],
+                               Step3Result& out, Stats* st) {
+  const polyline& pl_a = sc.plgs[ids[0]].polylines[cur[0].polyline_id];
+  const polyline& pl_b = sc.plgs[ids[1]].polylines[cur[1].polyline_id];
+  const polyline& pl_c = sc.plgs[ids[2]].polylines[cur[2].polyline_id];
+  bool reached;
+  const pl_point next_a =
+      pl_a.next_pl_point_by_distance(cur[0].plp, dirs[0], PLG_FOLLOW_FIRST_IMAGE_DISTANCE, reached);
+  if (reached) return false;
+  float epi[3];
+  bool found, fqp;
+  pl_point nbq, next_b, next_c;
+  if (!computeCorrespondEpilineSinglePoint(sc.cams, ids[0], ids[1], next_a.coords, epi)) return false;
+  pl_b.next_pl_point_by_line_intersection(cur[1].plp, dirs[1], epi, next_b, fqp, nbq, reached, found);
+  if (!found) return false;
+  if (!computeCorrespondEpilineSinglePoint(sc.cams, ids[0], ids[2], next_a.coords, epi)) return false;
+  pl_c.next_pl_point_by_line_intersection(cur[2].plp, dirs[2], epi, next_c, fqp, nbq, reached, found);
+  if (!found) return false;
+  bool valid;
+  std::vector<vec2> coords = {next_a.coords, next_b.coords, next_c.coords};
+  std::vector<int> vids = {ids[0], ids[1], ids[2]};
+  vec3 X;
+  compute_3d_point_coords(sc.cams, coords, vids, X, valid, st ? &st->tri : nullptr);  // compute_3d_point :1160-1176
+  if (!valid) return false;
+  out.a = plg_point(cur[0].polyline_id, next_a);
+  out.b = plg_point(cur[1].polyline_id, next_b);
+  out.c = plg_point(cur[2].polyline_id, next_c);
+  out.X = X;
+  return true;
+}
+
+// find_direction_given_first_extreme, plg_matching.cpp:142-203
+static inline bool find_direction_given_first_extreme(const Scene& sc, const int ids[3], const plg_point cur[3],
+                                                      const ulong_t first_direction, ulong_t valid_direction[3],
+                                                      std::vector<Step3Result>& valid_points, Stats* st) {
+  const polyline& pl_b = sc.plgs[ids[1]].polylines[cur[1].polyline_id];
+  const polyline& pl_c = sc.plgs[ids[2]].polylines[cur[2].polyline_id];
+  ulong_t pd[4][3] = {{first_direction, pl_b.start, pl_c.start},
+                      {first_direction, pl_b.start, pl_c.end},
+                      {first_direction, pl_b.end, pl_c.start},
+                      {first_direction, pl_b.end, pl_c.end}};
+  bool valid_dir[4] = {true, true, true, true};
+  std::vector<Step3Result> tri_pts[4];
+  plg_point last[4][3];
+  for (int i = 0; i < 4; i++)
+    for (int k = 0; k < 3; k++) last[i][k] = cur[k];
+  int amount_of_valid = 4;
+  while (amount_of_valid > 1) {
+    for (int i = 0; i < 4; i++) {
+      if (valid_dir[i]) {
+        Step3Result r;
+        if (compatible3(sc, ids, last[i], pd[i], r, st)) {
+          last[i][0] = r.a;
+          last[i][1] = r.b;
+          last[i][2] = r.c;
+          tri_pts[i].push_back(r);
+        } else {
+          valid_dir[i] = false;
+          amount_of_valid--;
+        }
+      }
+    }
+  }
+  if (amount_of_valid == 0) return false;
+  for (int i = 0; i < 4; i++)
+    if (valid_dir[i]) {
+      for (int k = 0; k < 3; k++) valid_direction[k] = pd[i][k];
+      valid_points = tri_pts[i];
+    }
+  return true;
+}
+
+// find_directions (tuple form), plg_matching.cpp:205-265
+static inline void find_directions3(const Scene& sc, const int ids[3], const plg_point cur[3], ulong_t direction1[3],
+                                    bool& direction1_valid, std::vector<Step3Result>& pts1, ulong_t direction2[3],
+                                    bool& direction2_valid, std::vector<Step3Result>& pts2, Stats* st) {
+  direction1_valid = false;
+  direction2_valid = false;
+  const polyline& pl_a = sc.plgs[ids[0]].polylines[cur[0].polyline_id];
+  const polyline& pl_b = sc.plgs[ids[1]].polylines[cur[1].polyline_id];
+  const polyline& pl_c = sc.plgs[ids[2]].polylines[cur[2].polyline_id];
+  std::vector<Step3Result> towards_start;
+  bool valid_towards_start = find_direction_given_first_extreme(sc, ids, cur, pl_a.start, direction1, towards_start, st);
+  if (valid_towards_start) {
+    direction1_valid = true;
+    pts1 = towards_start;
+    direction2[0] = pl_a.start == direction1[0] ? pl_a.end : pl_a.start;
+    direction2[1] = pl_b.start == direction1[1] ? pl_b.end : pl_b.start;
+    direction2[2] = pl_c.start == direction1[2] ? pl_c.end : pl_c.start;
+    Step3Result r;
+    if (compatible3(sc, ids, cur, direction2, r, st)) {
+      direction2_valid = true;
+      pts2.clear();
+      pts2.push_back(r);
+    }
+  } else {
+    std::vector<Step3Result> towards_end;
+    bool valid_towards_end = find_direction_given_first_extreme(sc, ids, cur, pl_a.end, direction1, towards_end, st);
+    if (valid_towards_end) {
+      direction1_valid = true;
+      pts1 = towards_end;
+      direction2[0] = pl_a.start == direction1[0] ? pl_a.end : pl_a.start;
+      direction2[1] = pl_b.start == direction1[1] ? pl_b.end : pl_b.start;
+      direction2[2] = pl_c.start == direction1[2] ? pl_c.end : pl_c.start;
+    }
+  }
+}
+
+// ---- N-view step: compatible() vector form, plg_matching.cpp:633-759 (bounded walk) ----
+static inline bool compatibleN(const Scene& sc, const std::vector<ulong_t>& directions, const P3& current,
+                               P3& new_point_data, Stats* st) {
+  for (int s = 0; s < (int)current.views.size(); s++) {
+    const std::vector<plg_point>& cur_plgps = current.obs;
+    const std::vector<int>& cur_ids = current.views;
+    const int starting_plg_id = cur_ids[s];
+    std::vector<int> sel_ids;
+    std::vector<vec2> sel_coords;
+    std::vector<plg_point> sel_plgps;
+    bool reached;
+    const plg_point& plgp_starting = cur_plgps[s];
+    const polyline& pl_starting = sc.plgs[starting_plg_id].polylines[plgp_starting.polyline_id];
+    const pl_point next_start = pl_starting.next_pl_point_by_distance(
+        plgp_starting.plp, directions[starting_plg_id], PLG_FOLLOW_FIRST_IMAGE_DISTANCE, reached);
+    if (reached) continue;
+    sel_plgps.push_back(plg_point(plgp_starting.polyline_id, next_start));
+    sel_ids.push_back(starting_plg_id);
+    sel_coords.push_back(next_start.coords);
+    float epi[3];
+    bool found, bdv, fqp;
+    pl_point nbq;
+    for (int i = 0; i < (int)cur_ids.size(); i++)
+      if (i != s) {
+        const int cur_plg_id = cur_ids[i];
+        const plg_point& cur_plgp = cur_plgps[i];
+        const polyline& cur_pl = sc.plgs[cur_plg_id].polylines[cur_plgp.polyline_id];
+        if (!computeCorrespondEpilineSinglePoint(sc.cams, starting_plg_id, cur_plg_id, next_start.coords, epi))
+          continue;
+        pl_point next_plp;
+        cur_pl.next_pl_point_by_line_intersection_bounded_distance(cur_plgp.plp, directions[cur_plg_id], epi,
+                                                                   PLG_FOLLOW_CORR_MIN, PLG_FOLLOW_CORR_MAX, next_plp,
+                                                                   fqp, nbq, reached, bdv, found);
+        if (found) {
+          sel_plgps.push_back(plg_point(cur_plgp.polyline_id, next_plp));
+          sel_ids.push_back(cur_plg_id);
+          sel_coords.push_back(next_plp.coords);
+        }
+      }
+    bool valid;
+    vec3 new_X;
+    if (sel_ids.size() < PLG_MIN_TRI_POINTS) continue;
+    compute_3d_point_coords(sc.cams, sel_coords, sel_ids, new_X, valid, st ? &st->tri : nullptr);
+    if (!valid) {
+      std::vector<bool> selected;
+      compute_3d_point_coords_combinations(sc.cams, sel_coords, sel_ids, (int)PLG_MIN_TRI_POINTS, selected, new_X,
+                                           valid, st ? &st->tri : nullptr);
+      if (valid) {
+        std::vector<plg_point> a_plgps;
+        std::vector<int> a_ids;
+        for (size_t i = 0; i < sel_plgps.size(); i++)
+          if (selected[i]) {
+            a_plgps.push_back(sel_plgps[i]);
+            a_ids.push_back(sel_ids[i]);
+          }
+        sel_plgps = a_plgps;
+        sel_ids = a_ids;
+      }
+    }
+    if (valid) {
+      new_point_data.X = new_X;
+      new_point_data.obs = sel_plgps;
+      new_point_data.views = sel_ids;
+      return true;
+    }
+  }
+  return false;
+}
+
+// follow_direction / follow_direction_vector_end, plg_matching.cpp:765-769, 791-795
+static inline void follow_direction(const Scene& sc, const std::vector<ulong_t>& directions,
+                                    std::vector<P3>& valid_points, Stats* st) {
+  P3 np;
+  while (compatibleN(sc, directions, valid_points[valid_points.size() - 1], np, st)) valid_points.push_back(np);
+}
+// follow_direction_vector_start, plg_matching.cpp:771-789
+static inline void follow_direction_vector_start(const Scene& sc, const std::vector<ulong_t>& directions,
+                                                 std::vector<P3>& valid_points, Stats* st) {
+  P3 np;
+  std::vector<P3> new_valid;
+  if (compatibleN(sc, directions, valid_points[0], np, st)) {
+    new_valid.push_back(np);
+    while (compatibleN(sc, directions, new_valid[new_valid.size() - 1], np, st)) new_valid.push_back(np);
+    std::vector<P3> res;
+    for (int i = (int)new_valid.size() - 1; i >= 0; i--) res.push_back(new_valid[i]);
+    for (size_t i = 0; i < valid_points.size(); i++) res.push_back(valid_points[i]);
+    valid_points = res;
+  }
+}
+
+// ---- hypothesis: compatible_new_plg_point -> follow_plgs_from_match4 -> find_directions_all_views
+// -> find_directions_3view_firstlast (vector form), plg_matching.cpp:1276-1287, 1249-1270, 1060-1076, 325-370.
+// The out vectors keep their previous content when the corresponding direction is not
+// valid (Q12): callers declare them once per start hit (triangulation.cpp:559-561).
+static inline bool compatible_new_plg_point(const Scene& sc, const P3& matches, std::vector<ulong_t>& directions1,
+                                            bool& direction1_valid, std::vector<P3>& pts1,
+                                            std::vector<ulong_t>& directions2, bool& direction2_valid,
+                                            std::vector<P3>& pts2, Stats* st) {
+  direction1_valid = false;
+  direction2_valid = false;
+  const int amount = (int)matches.views.size();
+  if (amount >= 3) {
+    int sel[3] = {0, amount / 2, amount - 1};
+    int ids[3] = {matches.views[sel[0]], matches.views[sel[1]], matches.views[sel[2]]};
+    plg_point cur[3] = {matches.obs[sel[0]], matches.obs[sel[1]], matches.obs[sel[2]]};
+    ulong_t d1[3], d2[3];
+    std::vector<Step3Result> p1t, p2t;
+    find_directions3(sc, ids, cur, d1, direction1_valid, p1t, d2, direction2_valid, p2t, st);
+    if (direction1_valid) {
+      directions1 = std::vector<ulong_t>(sc.plgs.size());
+      for (int k = 0; k < 3; k++) directions1[ids[k]] = d1[k];
+      pts1.clear();
+      for (auto& v : p1t) {
+        P3 p;
+        p.X = v.X;
+        p.obs = {v.a, v.b, v.c};
+        p.views = {ids[0], ids[1], ids[2]};
+        pts1.push_back(p);
+      }
+      directions2 = std::vector<ulong_t>(sc.plgs.size());
+      for (int k = 0; k < 3; k++) directions2[ids[k]] = d2[k];
+      if (direction2_valid) {
+        pts2.clear();
+        for (auto& v : p2t) {
+          P3 p;
+          p.X = v.X;
+          p.obs = {v.a, v.b, v.c};
+          p.views = {ids[0], ids[1], ids[2]};
+          pts2.push_back(p);
+        }
+      }
+    }
+    // find_directions_all_views :1064-1074: the extra loops are empty for 3 matches.
+    if (direction1_valid) follow_direction(sc, directions1, pts1, st);
+    if (direction2_valid) follow_direction(sc, directions2, pts2, st);
+  }
+  if (direction1_valid && pts1.size() >= 2) return true;
+  if (direction2_valid && pts2.size() >= 2) return true;
+  return false;
+}
+
+// compute_unique_potential_3d_points_3views_plg_following_newpoint_compatibility, triangulation.cpp:550-601
+struct Sides {
+  std::vector<P3> pts1;
+  std::vector<ulong_t> dirs1;
+  P3 central;
+  std::vector<P3> pts2;
+  std::vector<ulong_t> dirs2;
+};
+static inline void compute_unique_potential_3d_points_3views(const Scene& sc,
+                                                             const std::vector<plg_point> lists[3],
+                                                             const int view_ids[3], Sides& new_point, bool& valid,
+                                                             Stats* st) {
+  valid = true;
+  bool found = false;
+  bool d1v, d2v;
+  std::vector<P3> pts2, pts1;                // declared once: Q12
+  std::vector<ulong_t> directions1, directions2;
+  std::vector<int> views = {view_ids[0], view_ids[1], view_ids[2]};
+  for (const auto& p0 : lists[0])
+    for (const auto& p1 : lists[1])
+      for (const auto& p2 : lists[2]) {
+        vec3 X;
+        bool tvalid;
+        std::vector<plg_point> new_plgps = {p0, p1, p2};
+        if (st) st->n_hyp++;
+        em_estimate3Dpositions(sc.cams, coords_of(new_plgps), views, X, tvalid, st ? &st->tri : nullptr);
+        if (tvalid) {
+          P3 potential;
+          potential.X = X;
+          potential.obs = new_plgps;
+          potential.views = views;
+          if (compatible_new_plg_point(sc, potential, directions1, d1v, pts1, directions2, d2v, pts2, st)) {
+            if (found) {
+              valid = false;  // Q3
+              return;
+            } else {
+              found = true;
+              new_point.pts1 = pts1;
+              new_point.dirs1 = directions1;
+              new_point.central = potential;
+              new_point.pts2 = pts2;
+              new_point.dirs2 = directions2;
+            }
+          }
+        }
+      }
+  if (!found) valid = false;
+}
+
+// ---- attach a view to a chain ----
+// get_plgp_by_epipolar_intersection_from_known_point, plg_matching.cpp:797-819
+static inline void get_plgp_by_epipolar_intersection_from_known_point(const Scene& sc, const int current_plg_id,
+                                                                      const plg_point& current_plgp,
+                                                                      const ulong_t direction, const P3& known_point,
+                                                                      pl_point& next_plp, bool& valid) {
+  const int starting_plg_id = known_point.views[0];
+  const vec2 starting_coords = known_point.obs[0].plp.coords;
+  float epi[3];
+  if (!computeCorrespondEpilineSinglePoint(sc.cams, starting_plg_id, current_plg_id, starting_coords, epi)) {
+    valid = false;
+    return;
+  }
+  bool fqp, reached;
+  pl_point nbq;
+  sc.plgs[current_plg_id].polylines[current_plgp.polyline_id].next_pl_point_by_line_intersection(
+      current_plgp.plp, direction, epi, next_plp, fqp, nbq, reached, valid);
+}
+
+// compatible_direction_noupdate_vector, plg_matching.cpp:866-914
+static inline bool compatible_direction_noupdate_vector(const Scene& sc, const int current_plg_id,
+                                                        const plg_point& current_plgp, const ulong_t direction,
+                                                        const std::vector<P3>& valid_points,
+                                                        std::vector<std::pair<vec3, plg_point>>& to_add,
+                                                        const int start_interval_index, const int cur_point_index,
+                                                        int end_interval_index, const bool towards_start, Stats* st) {
+  to_add.clear();
+  const int sz = (int)valid_points.size();
+  if (sz == 0) return false;
+  bool valid;
+  plg_point actual = current_plgp;
+  int i = towards_start ? cur_point_index - 1 : cur_point_index + 1;
+  while ((towards_start && i >= start_interval_index) || (!towards_start && i < end_interval_index)) {
+    const P3& cur_pt = valid_points[i];
+    pl_point next_plp;
+    get_plgp_by_epipolar_intersection_from_known_point(sc, current_plg_id, actual, direction, cur_pt, next_plp, valid);
+    if (!valid) break;
+    vec3 tp;
+    em_add_new_observation_to_3Dpositions(sc.cams, cur_pt.X, coords_of(cur_pt.obs), cur_pt.views, next_plp.coords,
+                                          current_plg_id, tp, valid, st ? &st->tri : nullptr);
+    if (valid) {
+      to_add.push_back(std::make_pair(tp, plg_point(current_plgp.polyline_id, next_plp)));
+      actual = plg_point(actual.polyline_id, next_plp);
+    } else
+      break;
+    if (towards_start)
+      i--;
+    else
+      i++;
+  }
+  return to_add.size() > 0;
+}
+
+// update_new_3dpoint_plgp_matches, polyline_graph_2d.cpp:1604-1608
+static inline void update_p3(P3& pt, const int new_view, const plg_point& new_obs, const vec3& new_X) {
+  pt.X = new_X;
+  pt.obs.push_back(new_obs);
+  pt.views.push_back(new_view);
+}
+
+// add_view_to_3dpoint_and_sides_plgp_matches_vector, plg_matching.cpp:1345-1412 with
+// find_directions_on_plg_known_3D_point_no_update_vector (:1011-1058) inlined (Q13).
+static inline std::pair<int, int> add_view_vector(const Scene& sc, std::vector<P3>& cur_pts,
+                                                  std::vector<ulong_t>& start_dirs, std::vector<ulong_t>& end_dirs,
+                                                  const int current_plg_id, const plg_point& current_plgp,
+                                                  int start_interval_index, int cur_point_index,
+                                                  int end_interval_index, bool& success, Stats* st) {
+  success = false;
+  vec3 new_central;
+  {
+    bool v;
+    const P3& c = cur_pts[cur_point_index];
+    em_add_new_observation_to_3Dpositions(sc.cams, c.X, coords_of(c.obs), c.views, current_plgp.plp.coords,
+                                          current_plg_id, new_central, v, st ? &st->tri : nullptr);
+    if (!v) return std::make_pair(0, 0);
+  }
+  ulong_t new_direction1 = 0, new_direction2 = 0;
+  std::vector<std::pair<vec3, plg_point>> nd1, nd2;
+  {
+    const polyline& pl = sc.plgs[current_plg_id].polylines[current_plgp.polyline_id];
+    const ulong_t start = pl.start, end = pl.end;
+    if (cur_point_index > start_interval_index) {
+      if (compatible_direction_noupdate_vector(sc, current_plg_id, current_plgp, start, cur_pts, nd1,
+                                               start_interval_index, cur_point_index, end_interval_index, true, st)) {
+        new_direction1 = start;
+        new_direction2 = end;
+        if (cur_point_index < end_interval_index)
+          compatible_direction_noupdate_vector(sc, current_plg_id, current_plgp, end, cur_pts, nd2,
+                                               start_interval_index, cur_point_index, end_interval_index, false, st);
+      } else if (compatible_direction_noupdate_vector(sc, current_plg_id, current_plgp, end, cur_pts, nd1,
+                                                      start_interval_index, cur_point_index, end_interval_index, true,
+                                                      st)) {
+        new_direction1 = end;
+        new_direction2 = start;
+        if (cur_point_index < end_interval_index)
+          compatible_direction_noupdate_vector(sc, current_plg_id, current_plgp, start, cur_pts, nd2,
+                                               start_interval_index, cur_point_index, end_interval_index, false, st);
+      } else {
+        if (cur_point_index < end_interval_index) {
+          if (compatible_direction_noupdate_vector(sc, current_plg_id, current_plgp, end, cur_pts, nd2,
+                                                   start_interval_index, cur_point_index, end_interval_index, false,
+                                                   st)) {
+            new_direction2 = end;
+            new_direction1 = start;
+          } else if (compatible_direction_noupdate_vector(sc, current_plg_id, current_plgp, start, cur_pts, nd2,
+                                                          start_interval_index, cur_point_index, end_interval_index,
+                                                          false, st)) {
+            new_direction2 = start;
+            new_direction1 = end;
+          }
+        }
+      }
+    }
+  }
+  if (cur_point_index > 0 && nd1.size() == 0) return std::make_pair(0, 0);
+  if (cur_point_index < (int)cur_pts.size() - 1 && nd2.size() == 0) return std::make_pair(0, 0);
+
+  success = true;
+  int amount_start = (int)nd1.size();
+  int amount_end = (int)nd2.size();
+  update_p3(cur_pts[cur_point_index], current_plg_id, current_plgp, new_central);
+  for (int i = 0; i < (int)nd1.size(); i++)
+    update_p3(cur_pts[cur_point_index - 1 - i], current_plg_id, nd1[i].second, nd1[i].first);
+  for (int i = 0; i < (int)nd2.size(); i++)
+    update_p3(cur_pts[cur_point_index + 1 + i], current_plg_id, nd2[i].second, nd2[i].first);
+  int starting_sz;
+  int new_start = 0;
+  if (nd1.size() > 0 && (int)nd1.size() == cur_point_index) {
+    starting_sz = (int)cur_pts.size();
+    start_dirs[current_plg_id] = new_direction1;
+    follow_direction_vector_start(sc, start_dirs, cur_pts, st);
+    new_start = ((int)cur_pts.size() - starting_sz);
+    amount_start += new_start;
+    cur_point_index += new_start;
+  }
+  if (nd2.size() > 0 && (int)nd2.size() == ((int)cur_pts.size() - cur_point_index - 1)) {
+    starting_sz = (int)cur_pts.size();
+    end_dirs[current_plg_id] = new_direction2;
+    follow_direction(sc, end_dirs, cur_pts, st);  // follow_direction_vector_end
+    amount_end += ((int)cur_pts.size() - starting_sz);
+  }
+  return std::make_pair(amount_start, amount_end);
+}
+
+// expand_allpoints_to_other_view_using_plmap, triangulation.cpp:742-833 (SWITCH_DISABLE_INTERVAL branch) — Q4
+static inline void expand_allpoints_to_other_view_using_plmap(const Scene& sc, const int other_plg_id,
+                                                              const std::vector<plg_point>& epipolar_correspondences,
+                                                              const PolyLine2DMapSearch& plmap,
+                                                              std::vector<P3>& cur_p3ds,
+                                                              std::vector<ulong_t>& start_dirs,
+                                                              std::vector<ulong_t>& end_dirs,
+                                                              int& original_central_point_index, Stats* st) {
+  bool success;
+  std::pair<int, int> epc_matches;
+  std::pair<int, int> epc_idx(0, 0);
+  bool epc_matched = false;
+  for (auto& epc : epipolar_correspondences) {
+    epc_matches = add_view_vector(sc, cur_p3ds, start_dirs, end_dirs, other_plg_id, epc, 0,
+                                  original_central_point_index, (int)cur_p3ds.size(), epc_matched, st);
+    if (epc_matched) {
+      if (epc_matches.first > original_central_point_index) {
+        original_central_point_index = epc_matches.first;
+        epc_idx.first = 0;
+        epc_idx.second = epc_matches.first + epc_matches.second;
+      } else {
+        epc_idx.first = original_central_point_index - epc_matches.first;
+        epc_idx.second = original_central_point_index + epc_matches.second;
+      }
+      break;
+    }
+  }
+  ulong_t cur_pl_id = 0;
+  bool valid;
+  std::pair<int, int> added;
+  int central_point;
+  int cur_interval_end;
+  int last_matched = -1;
+  for (int cur_point = 0; cur_point < (int)cur_p3ds.size(); cur_point++) {
+    if (epc_matched && cur_point == epc_idx.first) {
+      cur_point = epc_idx.second;
+      last_matched = epc_idx.second;
+      continue;
+    }
+    vec2 start_coords = compute_projection(sc.cams.P + (size_t)other_plg_id * 16, cur_p3ds[cur_point].X);
+    plmap.find_unique_polyline_potentially_within_search_dist(start_coords, cur_pl_id, valid);
+    if (valid) {
+      central_point = cur_point;
+      const polyline& pl = sc.plgs[other_plg_id].polylines[cur_pl_id];
+      if (st) st->bytes_algorithmic += 8 * pl.polyline_coords.size();
+      pl_point init_ppl;
+      if (pl.compute_distancesq(start_coords, init_ppl.segment_index, init_ppl.coords) >
+          MAX_3DPOINT_PROJECTIONDISTSQ_EXPANDALLVIEWS)
+        return;  // "return false" in a void function: abandons this view (Q4)
+      plg_point init_plgp(cur_pl_id, init_ppl);
+      if (epc_matched)
+        cur_interval_end = central_point <= epc_idx.first ? epc_idx.first : (int)cur_p3ds.size();
+      else
+        cur_interval_end = (int)cur_p3ds.size();
+      added = add_view_vector(sc, cur_p3ds, start_dirs, end_dirs, other_plg_id, init_plgp, last_matched + 1,
+                              central_point, cur_interval_end, success, st);
+      if (success) {
+        if (added.first > central_point) {
+          original_central_point_index = added.first;
+          cur_point = (added.first + added.second);
+        } else {
+          cur_point = central_point + (added.second);
+        }
+        last_matched = cur_point;
+      }
+    }
+  }
+}
+
+// compute_3D_point_multiple_views_plg_following_expandallviews_vector, triangulation.cpp:1027-1088
+// epipolar_correspondences is indexed by view id (size = number of views) — a9,
+// plgpcm_3views_plg_following.cpp:40-50.
+static inline std::vector<P3> compute_3D_point_multiple_views(const Scene& sc, const int starting_plg_id,
+                                                              const std::vector<std::vector<plg_point>>& epc,
+                                                              Stats* st) {
+  std::vector<P3> res;
+  Sides sides;
+  bool valid = false;
+  int amount_non_empty = 0, min_index = -1, max_index = -1;
+  for (int i = 0; i < (int)epc.size(); i++)
+    if (epc[i].size() > 0) {
+      amount_non_empty++;
+      min_index = min_index != -1 ? min_index : i;
+      max_index = i;
+    }
+  if (amount_non_empty < 3) return res;
+  int cur_rel = 0, rel_mid = amount_non_empty / 2, mid_index = 0;
+  for (int i = 0; i < (int)epc.size(); i++)
+    if (epc[i].size() > 0) {
+      if (cur_rel == rel_mid) {
+        mid_index = i;
+        break;
+      } else
+        cur_rel++;
+    }
+  int sel[3] = {min_index, (starting_plg_id == min_index || starting_plg_id == max_index) ? mid_index : starting_plg_id,
+                max_index};
+  std::vector<plg_point> lists[3] = {epc[sel[0]], epc[sel[1]], epc[sel[2]]};
+  compute_unique_potential_3d_points_3views(sc, lists, sel, sides, valid, st);
+  if (!valid) return res;
+  // new_3dpoint_and_sides_plgp_matches_to_vector, polyline_graph_2d.cpp:1298-1306
+  for (int i = (int)sides.pts1.size() - 1; i >= 0; i--) res.push_back(sides.pts1[i]);
+  res.push_back(sides.central);
+  for (size_t i = 0; i < sides.pts2.size(); i++) res.push_back(sides.pts2[i]);
+  int central_point = (int)sides.pts1.size();
+  // expand_point_to_other_views_expandallviews_vector, triangulation.cpp:960-973: every view
+  // except the three selected, ascending
+  for (int i = 0; i < sc.cams.n_views; i++) {
+    if (i == sel[0] || i == sel[1] || i == sel[2]) continue;
+    expand_allpoints_to_other_view_using_plmap(sc, i, epc[i], sc.grid4[i], res, sides.dirs1, sides.dirs2,
+                                               central_point, st);
+  }
+  return res;
+}
+
+// ---- stage A: PLGEdgeManager::detect_nearby_intersections_and_correspondences_plgp(int),
+// plg_edge_manager.cpp:261-300 with :246-259, :208-243 (potentially_correspondent_polylines
+// overloads) and :191-205 ----
+struct SeedView {
+  const int* views;  // camViewingPointN_[seed]
+  const vec2* xy;    // point2DoncamViewingPoint_[seed]
+  int k;
+};
+// get_2d_coordinates_of_point_on_image, edge_graph_3d_utilities.cpp:395-403 — last match wins (Q2)
+static inline bool get_2d_coordinates_of_point_on_image(const SeedView& sv, int img_id, vec2& point) {
+  bool found = false;
+  for (int i = 0; i < sv.k; i++)
+    if (sv.views[i] == img_id) {
+      point = sv.xy[i];
+      found = true;
+    }
+  return found;
+}
+
+struct StageA {
+  std::vector<std::vector<ulong_t>> cand;                      // [k] candidate polylines per track entry
+  std::vector<std::vector<plg_point>> start_hits;              // [k]
+  // [k start view][start hit][k lists]
+  std::vector<std::vector<std::vector<std::vector<plg_point>>>> corr;
+};
+
+static const float STARTING_DETECTION_DIST = 10.0f;     // global_defines.hpp:35
+static const float CORR_DETECTION_FACTOR = 3.0f;        // global_defines.hpp:36
+static inline StageA detect_nearby_intersections_and_correspondences_plgp(const Scene& sc, const SeedView& sv,
+                                                                          Stats* st) {
+  StageA out;
+  const float starting_distsq = STARTING_DETECTION_DIST * STARTING_DETECTION_DIST;
+  const float corr_dist = STARTING_DETECTION_DIST * CORR_DETECTION_FACTOR;
+  const float corr_distsq = corr_dist * corr_dist;
+  for (int a = 0; a < sv.k; a++) {
+    const int img = sv.views[a];
+    vec2 sp;
+    get_2d_coordinates_of_point_on_image(sv, img, sp);
+    std::set<ulong_t> tmp = sc.grid30[img].find_polylines_potentially_within_search_dist(sp);
+    std::vector<ulong_t> pcps;
+    std::vector<plg_point> sni;
+    for (const auto pl_id : tmp) {
+      ulong_t closest_segm;
+      vec2 projection;
+      const polyline& pl = sc.plgs[img].polylines[pl_id];
+      if (st) st->bytes_algorithmic += 8 * pl.polyline_coords.size();
+      float d = pl.compute_distancesq(sp, closest_segm, projection);
+      if (d <= starting_distsq) {
+        pcps.push_back(pl_id);
+        sni.push_back(plg_point(pl_id, closest_segm, projection));
+      } else if (d <= corr_distsq)
+        pcps.push_back(pl_id);
+    }
+    out.cand.push_back(pcps);
+    out.start_hits.push_back(sni);
+  }
+  out.corr.resize(sv.k);
+  for (int a = 0; a < sv.k; a++) {
+    const int starting_img = sv.views[a];
+    vec2 init_coords;
+    get_2d_coordinates_of_point_on_image(sv, starting_img, init_coords);
+    for (const auto& hit : out.start_hits[a]) {
+      float radius = compute_2d_distance(init_coords, hit.plp.coords) * CORR_DETECTION_FACTOR;
+      std::vector<std::vector<plg_point>> all;
+      for (int i = 0; i < sv.k; i++) {
+        const int cur_img = sv.views[i];
+        if (cur_img != starting_img) {
+          const vec2 sp_cur = sv.xy[i];
+          float epi[3];
+          if (!computeCorrespondEpilineSinglePoint(sc.cams, starting_img, cur_img, hit.plp.coords, epi)) {
+            all.push_back(std::vector<plg_point>());
+            continue;
+          }
+          std::vector<plg_point> inters;
+          float detsq = radius * radius;
+          for (const auto pl_id : out.cand[i]) {
+            std::vector<pl_point> pis = sc.plgs[cur_img].polylines[pl_id].intersect_line(epi);
+            for (auto& plp : pis)
+              if (squared_2d_distance(sp_cur, plp.coords) <= detsq) inters.push_back(plg_point(pl_id, plp));
+          }
+          all.push_back(inters);
+        } else {
+          all.push_back(std::vector<plg_point>(1, hit));
+        }
+      }
+      out.corr[a].push_back(all);
+    }
+  }
+  return out;
+}
+
+// plg_matching_from_refpoint, plg_matching_from_refpoints.cpp:64-81 (the PLGMatchesManager
+// update at :75 is write-only on this path and is replayed on the host from the output).
+struct EdgePoint {
+  P3 p;
+  uint32_t key[4];
+};
+static inline void plg_matching_from_refpoint(const Scene& sc, const SeedView& sv, uint32_t seed_id,
+                                              std::vector<EdgePoint>& res, Stats* st) {
+  StageA sa = detect_nearby_intersections_and_correspondences_plgp(sc, sv, st);
+  if (st) {
+    st->bytes_algorithmic += 12 + (uint64_t)sv.k * 12 + (uint64_t)sv.k * 64 + (uint64_t)sv.k * (sv.k - 1) * 72;
+  }
+  for (int a = 0; a < sv.k; a++) {
+    const int starting_img = sv.views[a];
+    for (size_t h = 0; h < sa.start_hits[a].size(); h++) {
+      if (st) st->n_tasks++;
+      // consensus_strategy_single_point_single_intersection, plgpcm_3views_plg_following.cpp:40-50
+      std::vector<std::vector<plg_point>> all(sc.plgs.size());
+      for (int i = 0; i < sv.k; i++) all[sv.views[i]] = sa.corr[a][h][i];
+      std::vector<P3> chain = compute_3D_point_multiple_views(sc, starting_img, all, st);
+      if (!chain.empty() && st) st->n_chains++;
+      for (size_t c = 0; c < chain.size(); c++) {
+        EdgePoint e;
+        e.p = chain[c];
+        e.key[0] = seed_id;
+        e.key[1] = (uint32_t)a;
+        e.key[2] = (uint32_t)h;
+        e.key[3] = (uint32_t)c;
+        if (st) st->bytes_algorithmic += 12 + (uint64_t)chain[c].obs.size() * 20;
+        res.push_back(e);
+      }
+    }
+  }
+}
+
+}  // namespace orc

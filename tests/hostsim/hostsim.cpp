@@ -1,0 +1,277 @@
+// TEST-ONLY host simulation of the stage-B kernels (not part of the product, never linked
+// into libeg3d.so). It compiles the per-lane device bodies of edgegraph3d_amd/csrc/*.h with
+// g++ and runs them serially, one "lane" at a time, in the same order of phases as the GPU
+// pipeline (task_setup -> hypotheses -> select -> expand -> emit). Purpose: debug the kernel
+// logic against the CPU oracle on machines without a GPU. Stage A (K1/K2) is wave-cooperative
+// HIP code and cannot run here; the harness takes stage-A results as input.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/eg3d.h"
+#include "../../include/eg3d_host.h"
+#include "eg3d_dev_pipeline.h"
+
+using namespace eg3d;
+
+struct HostScene {
+  DevScene ds;
+  std::vector<uint32_t> g30_off, g30_ids, g4_off, g4_ids;
+};
+
+static int build_dev_scene(const eg3d_scene* sc, HostScene& hs) {
+  DevScene& d = hs.ds;
+  d.n_views = sc->n_views;
+  d.width = sc->width;
+  d.height = sc->height;
+  d.cam_P = sc->cam_P;
+  d.F = sc->F;
+  d.F_valid = sc->F_valid;
+  d.view_pl_off = sc->view_pl_off;
+  d.pl_vtx_off = sc->pl_vtx_off;
+  d.vtx = reinterpret_cast<const f2*>(sc->vtx_xy);
+  d.pl_start = sc->pl_start;
+  d.pl_end = sc->pl_end;
+  for (int which = 0; which < 2; which++) {
+    std::vector<uint32_t>& off = which == 0 ? hs.g30_off : hs.g4_off;
+    std::vector<uint32_t>& ids = which == 0 ? hs.g30_ids : hs.g4_ids;
+    off.assign(1, 0);
+    uint32_t w = 0, h = 0;
+    for (int v = 0; v < sc->n_views; v++) {
+      uint32_t *o, *i, dropped;
+      if (eg3d_host_build_grid(sc, v, which == 0 ? 30.0f : 4.0f, &w, &h, &o, &i, &dropped) != 0) return -1;
+      uint32_t base = (uint32_t)ids.size();
+      for (uint32_t c = 0; c < w * h; c++) off.push_back(base + o[c + 1]);
+      ids.insert(ids.end(), i, i + o[w * h]);
+      free(o);
+      free(i);
+    }
+    if (which == 0) {
+      d.g30_w = (int)w;
+      d.g30_h = (int)h;
+    } else {
+      d.g4_w = (int)w;
+      d.g4_h = (int)h;
+    }
+  }
+  d.g30_off = hs.g30_off.data();
+  d.g30_ids = hs.g30_ids.data();
+  d.g4_off = hs.g4_off.data();
+  d.g4_ids = hs.g4_ids.data();
+  return 0;
+}
+
+extern "C" int hostsim_match(const eg3d_scene* sc, const eg3d_seeds* seeds, uint32_t b, uint32_t e,
+                             const eg3d_candidates* ca, uint32_t hyp_cap, uint32_t chain_cap, uint32_t pool_cap,
+                             eg3d_edgepoints* out) {
+  memset(out, 0, sizeof(*out));
+  HostScene hs;
+  if (build_dev_scene(sc, hs) != 0) return -1;
+  const DevScene& ds = hs.ds;
+  const uint32_t sv_base = seeds->trk_off[b];
+  const uint32_t n_sv = seeds->trk_off[e] - sv_base;
+  if (ca->n_sv != n_sv) return -2;
+  // sv -> (seed, entry)
+  std::vector<uint32_t> sv_seed(n_sv), sv_entry(n_sv);
+  for (uint32_t s = b; s < e; s++)
+    for (uint32_t i = seeds->trk_off[s]; i < seeds->trk_off[s + 1]; i++) {
+      sv_seed[i - sv_base] = s;
+      sv_entry[i - sv_base] = i - seeds->trk_off[s];
+    }
+  const uint32_t nt = ca->n_tasks;
+  std::vector<uint32_t> task_seed(nt), task_entry(nt), list_ptr, list_cnt;
+  std::vector<Obs> hits;
+  const uint32_t n_lists = nt ? ca->task_list_off[nt] : 0;
+  list_ptr.resize(n_lists);
+  list_cnt.resize(n_lists);
+  for (uint32_t t = 0; t < nt; t++) {
+    task_seed[t] = sv_seed[ca->task_sv[t]];
+    task_entry[t] = sv_entry[ca->task_sv[t]];
+    const uint32_t l0 = ca->task_list_off[t], l1 = ca->task_list_off[t + 1];
+    for (uint32_t l = l0; l < l1; l++) {
+      const int32_t view = seeds->trk_view[seeds->trk_off[task_seed[t]] + (l - l0)];
+      list_ptr[l] = (uint32_t)hits.size();
+      list_cnt[l] = ca->list_off[l + 1] - ca->list_off[l];
+      for (uint32_t h = ca->list_off[l]; h < ca->list_off[l + 1]; h++) {
+        Obs o;
+        o.view = view;
+        o.pl = ca->hit_pl[h];
+        o.seg = ca->hit_seg[h];
+        o.x = ca->hit_xy[2 * h];
+        o.y = ca->hit_xy[2 * h + 1];
+        hits.push_back(o);
+      }
+    }
+  }
+  StageAView a;
+  a.trk_off = seeds->trk_off;
+  a.trk_view = seeds->trk_view;
+  a.trk_xy = seeds->trk_xy;
+  a.seed_begin = b;
+  a.sv_base = sv_base;
+  a.n_tasks = nt;
+  a.task_seed = task_seed.data();
+  a.task_entry = task_entry.data();
+  a.task_hit = ca->task_hit;
+  a.task_list_off = ca->task_list_off;
+  a.list_ptr = list_ptr.data();
+  a.list_cnt = list_cnt.data();
+  a.hits = hits.data();
+  // seed view maps
+  std::vector<int32_t> map_view(n_sv ? n_sv : 1);
+  std::vector<uint32_t> map_entry(n_sv ? n_sv : 1), map_n(e - b ? e - b : 1);
+  for (uint32_t s = b; s < e; s++) {
+    uint32_t base = seeds->trk_off[s] - sv_base;
+    map_n[s - b] = build_seed_view_map(seeds->trk_view + seeds->trk_off[s], seeds->trk_off[s + 1] - seeds->trk_off[s],
+                                       map_view.data() + base, map_entry.data() + base);
+  }
+  // task setup + hypothesis offsets
+  std::vector<TaskDesc> tasks(nt ? nt : 1);
+  std::vector<uint32_t> hyp_off(nt + 1, 0);
+  for (uint32_t t = 0; t < nt; t++) {
+    task_setup(a, t, map_view.data(), map_entry.data(), map_n.data(), tasks[t]);
+    hyp_off[t + 1] = hyp_off[t] + tasks[t].n_hyp;
+  }
+  const uint32_t n_hyp = hyp_off[nt];
+  // K3a
+  std::vector<HypResult> res(n_hyp ? n_hyp : 1);
+  std::vector<HPoint> arena;
+  std::vector<HPoint> s1(hyp_cap), s2(hyp_cap);
+  uint32_t flags = 0;
+  for (uint32_t t = 0; t < nt; t++)
+    for (uint32_t h = hyp_off[t]; h < hyp_off[t + 1]; h++) {
+      Obs c[3];
+      hypothesis_hits(a, tasks[t], t, h - hyp_off[t], c);
+      evaluate_hypothesis(ds, c, s1.data(), s2.data(), hyp_cap, res[h]);
+      flags |= res[h].flags;
+      if (res[h].status & HYP_COMPAT) {
+        res[h].pts1_off = (uint32_t)arena.size();
+        arena.insert(arena.end(), s1.begin(), s1.begin() + res[h].n1);
+      }
+      if (res[h].status & HYP_D2) {
+        res[h].pts2_off = (uint32_t)arena.size();
+        arena.insert(arena.end(), s2.begin(), s2.begin() + res[h].n2);
+      }
+    }
+  // K3s
+  std::vector<ChainSeed> chains;
+  for (uint32_t t = 0; t < nt; t++) {
+    ChainSeed cs;
+    cs.task = t;
+    if (hyp_off[t + 1] > hyp_off[t] && select_task(res.data(), hyp_off[t], hyp_off[t + 1], cs)) chains.push_back(cs);
+  }
+  // K3b
+  ChainLayout L = chain_layout(chain_cap, pool_cap, (uint32_t)ds.n_views);
+  std::vector<unsigned char> scratch(L.total * (chains.size() ? chains.size() : 1));
+  std::vector<ChainOut> couts(chains.size() ? chains.size() : 1);
+  uint64_t np = 0, no = 0;
+  for (size_t j = 0; j < chains.size(); j++) {
+    const ChainSeed& cs = chains[j];
+    expand_chain(ds, a, tasks[cs.task], cs, hyp_off[cs.task], res.data(), arena.data(), map_view.data(),
+                 map_entry.data(), map_n.data(), L, scratch.data() + L.total * j, couts[j]);
+    flags |= couts[j].flags;
+    np += couts[j].n_points;
+    no += couts[j].n_obs;
+  }
+  // K4
+  out->n_points = np;
+  out->n_obs = no;
+  out->X = (float*)malloc(sizeof(float) * 3 * (np ? np : 1));
+  out->obs_off = (uint32_t*)malloc(sizeof(uint32_t) * (np + 1));
+  out->obs_view = (int32_t*)malloc(sizeof(int32_t) * (no ? no : 1));
+  out->obs_pl = (uint32_t*)malloc(sizeof(uint32_t) * (no ? no : 1));
+  out->obs_seg = (uint32_t*)malloc(sizeof(uint32_t) * (no ? no : 1));
+  out->obs_xy = (float*)malloc(sizeof(float) * 2 * (no ? no : 1));
+  out->key = (uint32_t*)malloc(sizeof(uint32_t) * 4 * (np ? np : 1));
+  uint64_t pb = 0, ob = 0;
+  for (size_t j = 0; j < chains.size(); j++) {
+    emit_chain(L, scratch.data() + L.total * j, couts[j], tasks[chains[j].task], pb, ob, out->X, out->obs_off,
+               out->obs_view, out->obs_pl, out->obs_seg, out->obs_xy, out->key);
+    pb += couts[j].n_points;
+    ob += couts[j].n_obs;
+  }
+  out->obs_off[np] = (uint32_t)no;
+  out->n_tasks = nt;
+  out->n_hypotheses = n_hyp;
+  out->n_chains = chains.size();
+  out->flags = flags;
+  return 0;
+}
+
+extern "C" void hostsim_free_edgepoints(eg3d_edgepoints* e) {
+  free(e->X);
+  free(e->obs_off);
+  free(e->obs_view);
+  free(e->obs_pl);
+  free(e->obs_seg);
+  free(e->obs_xy);
+  free(e->key);
+  memset(e, 0, sizeof(*e));
+}
+
+// ---- primitive probes so the device bodies can be KAT-tested on CPU too ----
+extern "C" float hostsim_dist2(float ax, float ay, float bx, float by) { return dist2(ax, ay, bx, by); }
+extern "C" float hostsim_seg_closest(float px, float py, float vx, float vy, float wx, float wy, float* q) {
+  return seg_closest(px, py, vx, vy, wx, wy, q[0], q[1]);
+}
+extern "C" int hostsim_walk_by_distance(const float* vtx, int n, uint32_t start, uint32_t end, uint32_t seg, float x,
+                                        float y, uint32_t direction, float distance, uint32_t* oseg, float* oxy) {
+  PlRef pl;
+  pl.v = reinterpret_cast<const f2*>(vtx);
+  pl.n = (uint32_t)n;
+  pl.start = start;
+  pl.end = end;
+  PlPt p, o;
+  p.seg = seg;
+  p.x = x;
+  p.y = y;
+  uint32_t w = walk_by_distance(pl, p, direction, distance, o);
+  *oseg = o.seg;
+  oxy[0] = o.x;
+  oxy[1] = o.y;
+  return (int)w;
+}
+extern "C" int hostsim_walk_by_line(const float* vtx, int n, uint32_t start, uint32_t end, uint32_t seg, float x,
+                                    float y, uint32_t direction, const float* line, int bounded, float mind,
+                                    float maxd, uint32_t* oseg, float* oxy) {
+  PlRef pl;
+  pl.v = reinterpret_cast<const f2*>(vtx);
+  pl.n = (uint32_t)n;
+  pl.start = start;
+  pl.end = end;
+  PlPt p, o;
+  p.seg = seg;
+  p.x = x;
+  p.y = y;
+  o = p;
+  uint32_t w = walk_by_line(pl, p, direction, line[0], line[1], line[2], bounded != 0, mind, maxd, o);
+  *oseg = o.seg;
+  oxy[0] = o.x;
+  oxy[1] = o.y;
+  return (int)w;
+}
+extern "C" int hostsim_triangulate(const float* cam_P, const int32_t* views, const float* xy, int n, float* X) {
+  std::vector<Obs> a(n);
+  for (int i = 0; i < n; i++) {
+    a[i].view = views[i];
+    a[i].pl = 0;
+    a[i].seg = 0;
+    a[i].x = xy[2 * i];
+    a[i].y = xy[2 * i + 1];
+  }
+  uint32_t flags = 0;
+  return triangulate_array(cam_P, a.data(), n, X, flags) ? 1 : 0;
+}
+extern "C" int hostsim_gn_filter(const float* cam_P, const float* X, const uint32_t* obs_off, const int32_t* obs_view,
+                                 const float* obs_xy, uint64_t n, float gn_max_mse, int legacy_abs, float* Xo,
+                                 uint8_t* inl) {
+  for (uint64_t i = 0; i < n; i++) {
+    uint32_t a = obs_off[i], b = obs_off[i + 1];
+    float o[3];
+    bool ok = gauss_newton_f32(cam_P, obs_view + a, obs_xy + 2 * a, (int)(b - a), X + 3 * i, gn_max_mse,
+                               legacy_abs != 0, o);
+    inl[i] = ok;
+    for (int k = 0; k < 3; k++) Xo[3 * i + k] = ok ? o[k] : X[3 * i + k];
+  }
+  return 0;
+}
