@@ -1,0 +1,139 @@
+"""Python view of the C ABI (include/eg3d.h) in libeg3d.so — plumbing over ctypes.
+
+There is no CPU fallback: constructing a Context without the built HIP library or without a
+GPU raises. The class mirrors the reference call surface for the path:
+  Context(scene)                     ~ PLGEdgeManager / PLGPCM3ViewsPLGFollowing construction
+  Context.match_refpoints(seeds)     ~ plg_matching_from_refpoints_parallel(sfmd, em, cm, plgmm)
+  Context.candidates(seeds)          ~ PLGEdgeManager::detect_nearby_intersections_and_correspondences_plgp
+  Context.gn_filter(...)             ~ gaussNewtonFiltering(sfmd, inliers, gn_max_mse)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _cdefs as D
+
+_LIB = None
+
+
+class Eg3dError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libeg3d.so")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise Eg3dError("libeg3d.so (HIP extension) is missing: run `python -m edgegraph3d_amd.build`. "
+                            "There is no CPU fallback.")
+        L = C.CDLL(path)
+        L.eg3d_last_error.restype = C.c_char_p
+        L.eg3d_device_count.restype = C.c_int
+        L.eg3d_create.argtypes = [C.POINTER(D.Scene), C.c_int, C.POINTER(C.c_void_p)]
+        L.eg3d_destroy.argtypes = [C.c_void_p]
+        L.eg3d_get_grid.argtypes = [C.c_void_p, C.c_int, C.c_int, D.u32p, D.u32p, C.POINTER(D.u32p), C.POINTER(D.u32p)]
+        L.eg3d_candidates_run.argtypes = [C.c_void_p, C.POINTER(D.Seeds), C.c_uint32, C.c_uint32, C.POINTER(D.Candidates)]
+        L.eg3d_free_candidates.argtypes = [C.POINTER(D.Candidates)]
+        L.eg3d_match_refpoints.argtypes = [C.c_void_p, C.POINTER(D.Seeds), C.c_uint32, C.c_uint32, C.c_int,
+                                           C.POINTER(D.EdgePoints), C.POINTER(D.StageTimes)]
+        L.eg3d_free_edgepoints.argtypes = [C.POINTER(D.EdgePoints)]
+        L.eg3d_upload_seeds.argtypes = [C.c_void_p, C.POINTER(D.Seeds)]
+        L.eg3d_match_resident.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(D.EdgePoints),
+                                          C.POINTER(D.StageTimes)]
+        L.eg3d_gn_filter.argtypes = [C.c_void_p, D.f32p, D.u32p, D.i32p, D.f32p, C.c_uint64, C.c_float, C.c_int,
+                                     D.f32p, D.u8p, D.f32p]
+        _LIB = L
+    return _LIB
+
+
+# every symbol include/eg3d.h declares (checked by tests/test_abi.py without a GPU)
+EXPORTED_SYMBOLS = [
+    "eg3d_last_error", "eg3d_device_count", "eg3d_create", "eg3d_destroy", "eg3d_get_grid", "eg3d_candidates_run",
+    "eg3d_free_candidates", "eg3d_match_refpoints", "eg3d_free_edgepoints", "eg3d_upload_seeds",
+    "eg3d_match_resident", "eg3d_gn_filter",
+]
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise Eg3dError("%s failed (rc=%d): %s" % (what, rc, lib().eg3d_last_error().decode()))
+
+
+def device_count():
+    return int(lib().eg3d_device_count())
+
+
+class Context:
+    def __init__(self, scene_ptr, device=0):
+        self._h = C.c_void_p()
+        _check(lib().eg3d_create(scene_ptr, device, C.byref(self._h)), "eg3d_create")
+
+    def close(self):
+        if self._h:
+            lib().eg3d_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def grid(self, view, which):
+        ncols, nrows = C.c_uint32(), C.c_uint32()
+        off, ids = D.u32p(), D.u32p()
+        _check(lib().eg3d_get_grid(self._h, view, which, C.byref(ncols), C.byref(nrows), C.byref(off), C.byref(ids)),
+               "eg3d_get_grid")
+        n = ncols.value * nrows.value
+        o = D.as_np(off, n + 1, np.uint32)
+        return ncols.value, nrows.value, o, D.as_np(ids, int(o[-1]), np.uint32)
+
+    def upload_seeds(self, seeds_ptr):
+        _check(lib().eg3d_upload_seeds(self._h, seeds_ptr), "eg3d_upload_seeds")
+
+    def match_resident(self, begin, end, device_only=False):
+        e, tm = D.EdgePoints(), D.StageTimes()
+        rc = lib().eg3d_match_resident(self._h, begin, end, 1 if device_only else 0, C.byref(e), C.byref(tm))
+        _check(rc, "eg3d_match_resident")
+        if device_only:
+            d = {"n_points": int(e.n_points), "n_obs": int(e.n_obs), "n_tasks": int(e.n_tasks),
+                 "n_hypotheses": int(e.n_hypotheses), "n_chains": int(e.n_chains), "flags": int(e.flags)}
+        else:
+            d = D.edgepoints_to_dict(e)
+        lib().eg3d_free_edgepoints(C.byref(e))
+        d["times"] = {f[0]: getattr(tm, f[0]) for f in D.StageTimes._fields_}
+        return d
+
+    def match_refpoints(self, seeds_ptr, begin=0, end=None, device_only=False):
+        if end is None:
+            end = int(seeds_ptr.contents.n_seeds) if hasattr(seeds_ptr, "contents") else int(seeds_ptr.n_seeds)
+        self.upload_seeds(seeds_ptr)
+        return self.match_resident(begin, end, device_only)
+
+    def candidates(self, seeds_ptr, begin, end):
+        c = D.Candidates()
+        _check(lib().eg3d_candidates_run(self._h, seeds_ptr, begin, end, C.byref(c)), "eg3d_candidates_run")
+        d = D.candidates_to_dict(c)
+        lib().eg3d_free_candidates(C.byref(c))
+        return d
+
+    def gn_filter(self, X, obs_off, obs_view, obs_xy, gn_max_mse=2.25, legacy_abs=False):
+        X = np.ascontiguousarray(X, np.float32)
+        obs_off = np.ascontiguousarray(obs_off, np.uint32)
+        obs_view = np.ascontiguousarray(obs_view, np.int32)
+        obs_xy = np.ascontiguousarray(obs_xy, np.float32)
+        n = len(obs_off) - 1
+        Xo = np.zeros((n, 3), np.float32)
+        inl = np.zeros(n, np.uint8)
+        ms = C.c_float(0)
+        _check(lib().eg3d_gn_filter(self._h, D.np_ptr(X, C.c_float), D.np_ptr(obs_off, C.c_uint32),
+                                    D.np_ptr(obs_view, C.c_int32), D.np_ptr(obs_xy, C.c_float), n, gn_max_mse,
+                                    1 if legacy_abs else 0, D.np_ptr(Xo, C.c_float), D.np_ptr(inl, C.c_uint8),
+                                    C.byref(ms)), "eg3d_gn_filter")
+        return Xo, inl, ms.value

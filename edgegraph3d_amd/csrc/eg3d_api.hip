@@ -1,0 +1,735 @@
+// eg3d_api.hip — implementation of the C ABI declared in include/eg3d.h.
+//
+// Host orchestration of the phase pipeline: HBM-resident scene (cameras, F, polyline CSR, the
+// two uniform grids), resident seeds, grow-only device work buffers, rocPRIM/hipCUB exclusive
+// scans between phases, HIP events for per-stage timing. No CPU fallback exists: every entry
+// point fails with EG3D_ERR_NODEVICE / EG3D_ERR_HIP when no gfx950 device is usable.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/eg3d.h"
+#include "../../include/eg3d_host.h"
+#include "eg3d_kernels.h"
+
+using namespace eg3d;
+
+static thread_local std::string g_err;
+extern "C" const char* eg3d_last_error(void) { return g_err.c_str(); }
+
+#define HIP_TRY(expr)                                                                               \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess) {                                                                         \
+      g_err = std::string(#expr) + ": " + hipGetErrorString(_e);                                    \
+      return EG3D_ERR_HIP;                                                                          \
+    }                                                                                               \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap && p) return EG3D_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    size_t want = std::max<size_t>(bytes + bytes / 4, 256);
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      cap = 0;
+      g_err = std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e);
+      return EG3D_ERR_HIP;
+    }
+    cap = want;
+    return EG3D_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+#define BUF_TRY(expr)          \
+  do {                         \
+    int _r = (expr);           \
+    if (_r != EG3D_OK) return _r; \
+  } while (0)
+
+struct eg3d_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int V = 0, W = 0, H = 0;
+  DevScene ds;
+  DevBuf b_camP, b_F, b_Fv, b_vpo, b_pvo, b_vtx, b_pls, b_ple, b_g30o, b_g30i, b_g4o, b_g4i;
+  // host copies of the grids for eg3d_get_grid (per view CSR with view-local offsets)
+  std::vector<std::vector<uint32_t>> h_off[2], h_ids[2];
+  uint32_t gw[2] = {0, 0}, gh[2] = {0, 0};
+  uint32_t grid_dropped = 0;
+  std::vector<uint32_t> h_pl_nvtx_dummy;
+  // resident seeds
+  uint32_t n_seeds = 0;
+  std::vector<uint32_t> h_trk_off;
+  DevBuf b_toff, b_tview, b_txy;
+  // work buffers
+  DevBuf b_sv_seed, b_map_view, b_map_entry, b_map_n, b_raw_cnt, b_raw_off, b_cand_pl, b_start_hits, b_cand_cnt,
+      b_start_cnt, b_task_off, b_task_seed, b_task_entry, b_task_hit, b_task_k, b_task_list_off, b_list_cnt, b_list_ptr,
+      b_hits, b_tasks, b_nhyp, b_hyp_off, b_res, b_hscratch, b_arena, b_ctr, b_cs_task, b_valid, b_chain_off, b_chains,
+      b_cscratch, b_couts, b_cpts, b_cobs, b_cpoff, b_cooff, b_scan_tmp;
+  DevBuf o_X, o_off, o_view, o_pl, o_seg, o_xy, o_key;
+  DevBuf f_X, f_off, f_view, f_xy, f_Xo, f_inl;
+  hipEvent_t ev[8];
+  uint32_t chain_cap = 384, pool_cap = 0, hyp_cap = 160;
+  uint32_t k3a_blocks = 0;
+};
+
+template <typename T>
+static int upload(DevBuf& b, const T* src, size_t n, hipStream_t st) {
+  BUF_TRY(b.ensure(sizeof(T) * std::max<size_t>(n, 1)));
+  if (n) HIP_TRY(hipMemcpyAsync(b.p, src, sizeof(T) * n, hipMemcpyHostToDevice, st));
+  return EG3D_OK;
+}
+
+static int scan_exclusive_u32(eg3d_ctx* c, const uint32_t* in, uint32_t* out, size_t n_plus_one) {
+  // in[n] must be 0 (or ignored): out[n] = total
+  size_t tmp_bytes = 0;
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, in, out, (int)n_plus_one, c->stream));
+  BUF_TRY(c->b_scan_tmp.ensure(tmp_bytes));
+  HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->b_scan_tmp.p, tmp_bytes, in, out, (int)n_plus_one, c->stream));
+  return EG3D_OK;
+}
+static int read_u32(eg3d_ctx* c, const uint32_t* dptr, uint32_t& v) {
+  HIP_TRY(hipMemcpyAsync(&v, dptr, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return EG3D_OK;
+}
+
+extern "C" int eg3d_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
+  if (!sc || !out || sc->n_views < 1) {
+    g_err = "eg3d_create: bad arguments";
+    return EG3D_ERR_ARG;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_err = "eg3d_create: no HIP device available (this library has no CPU fallback)";
+    return EG3D_ERR_NODEVICE;
+  }
+  if (device < 0 || device >= ndev) {
+    g_err = "eg3d_create: device index out of range";
+    return EG3D_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(device));
+  eg3d_ctx* c = new eg3d_ctx();
+  c->device = device;
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  for (int i = 0; i < 8; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
+  const int V = sc->n_views;
+  c->V = V;
+  c->W = sc->width;
+  c->H = sc->height;
+  const uint32_t NP = sc->view_pl_off[V];
+  const uint32_t NV = sc->pl_vtx_off[NP];
+  int rc;
+#define UP(buf, ptr, n)                                        \
+  if ((rc = upload(c->buf, ptr, (size_t)(n), c->stream)) != EG3D_OK) { \
+    eg3d_destroy(c);                                           \
+    return rc;                                                 \
+  }
+  UP(b_camP, sc->cam_P, (size_t)V * 16);
+  UP(b_F, sc->F, (size_t)V * V * 9);
+  UP(b_Fv, sc->F_valid, (size_t)V * V);
+  UP(b_vpo, sc->view_pl_off, V + 1);
+  UP(b_pvo, sc->pl_vtx_off, NP + 1);
+  UP(b_vtx, sc->vtx_xy, (size_t)NV * 2);
+  UP(b_pls, sc->pl_start, NP);
+  UP(b_ple, sc->pl_end, NP);
+  // grids: built on the host (row a3), one CSR over (view, cell) per cell size
+  for (int which = 0; which < 2; which++) {
+    std::vector<uint32_t> off(1, 0), ids;
+    c->h_off[which].resize(V);
+    c->h_ids[which].resize(V);
+    for (int v = 0; v < V; v++) {
+      uint32_t w = 0, h = 0, *o = nullptr, *i = nullptr, dropped = 0;
+      if (eg3d_host_build_grid(sc, v, which == 0 ? 30.0f : 4.0f, &w, &h, &o, &i, &dropped) != 0) {
+        g_err = "eg3d_create: grid construction failed";
+        eg3d_destroy(c);
+        return EG3D_ERR_ARG;
+      }
+      c->gw[which] = w;
+      c->gh[which] = h;
+      c->grid_dropped += dropped;
+      const uint32_t base = (uint32_t)ids.size();
+      for (uint32_t cc = 0; cc < w * h; cc++) off.push_back(base + o[cc + 1]);
+      ids.insert(ids.end(), i, i + o[w * h]);
+      c->h_off[which][v].assign(o, o + w * h + 1);
+      c->h_ids[which][v].assign(i, i + o[w * h]);
+      free(o);
+      free(i);
+    }
+    if (which == 0) {
+      UP(b_g30o, off.data(), off.size());
+      UP(b_g30i, ids.data(), ids.size());
+    } else {
+      UP(b_g4o, off.data(), off.size());
+      UP(b_g4i, ids.data(), ids.size());
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));  // `off`/`ids` go out of scope
+  }
+#undef UP
+  DevScene& d = c->ds;
+  d.n_views = V;
+  d.width = sc->width;
+  d.height = sc->height;
+  d.cam_P = c->b_camP.as<float>();
+  d.F = c->b_F.as<double>();
+  d.F_valid = c->b_Fv.as<uint8_t>();
+  d.view_pl_off = c->b_vpo.as<uint32_t>();
+  d.pl_vtx_off = c->b_pvo.as<uint32_t>();
+  d.vtx = c->b_vtx.as<f2>();
+  d.pl_start = c->b_pls.as<uint32_t>();
+  d.pl_end = c->b_ple.as<uint32_t>();
+  d.g30_w = (int)c->gw[0];
+  d.g30_h = (int)c->gh[0];
+  d.g4_w = (int)c->gw[1];
+  d.g4_h = (int)c->gh[1];
+  d.g30_off = c->b_g30o.as<uint32_t>();
+  d.g30_ids = c->b_g30i.as<uint32_t>();
+  d.g4_off = c->b_g4o.as<uint32_t>();
+  d.g4_ids = c->b_g4i.as<uint32_t>();
+  c->pool_cap = std::min<uint32_t>(8192, 256u * (uint32_t)std::min(V, 32));
+  if (c->pool_cap < 1536) c->pool_cap = 1536;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  c->k3a_blocks = (uint32_t)prop.multiProcessorCount * 2;  // 2 blocks x 4 waves per CU
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *out = c;
+  return EG3D_OK;
+}
+
+extern "C" void eg3d_destroy(eg3d_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  DevBuf* all[] = {&c->b_camP, &c->b_F, &c->b_Fv, &c->b_vpo, &c->b_pvo, &c->b_vtx, &c->b_pls, &c->b_ple, &c->b_g30o,
+                   &c->b_g30i, &c->b_g4o, &c->b_g4i, &c->b_toff, &c->b_tview, &c->b_txy, &c->b_sv_seed, &c->b_map_view,
+                   &c->b_map_entry, &c->b_map_n, &c->b_raw_cnt, &c->b_raw_off, &c->b_cand_pl, &c->b_start_hits,
+                   &c->b_cand_cnt, &c->b_start_cnt, &c->b_task_off, &c->b_task_seed, &c->b_task_entry, &c->b_task_hit,
+                   &c->b_task_k, &c->b_task_list_off, &c->b_list_cnt, &c->b_list_ptr, &c->b_hits, &c->b_tasks,
+                   &c->b_nhyp, &c->b_hyp_off, &c->b_res, &c->b_hscratch, &c->b_arena, &c->b_ctr, &c->b_cs_task,
+                   &c->b_valid, &c->b_chain_off, &c->b_chains, &c->b_cscratch, &c->b_couts, &c->b_cpts, &c->b_cobs,
+                   &c->b_cpoff, &c->b_cooff, &c->b_scan_tmp, &c->o_X, &c->o_off, &c->o_view, &c->o_pl, &c->o_seg,
+                   &c->o_xy, &c->o_key, &c->f_X, &c->f_off, &c->f_view, &c->f_xy, &c->f_Xo, &c->f_inl};
+  for (DevBuf* b : all) b->release();
+  for (int i = 0; i < 8; i++)
+    if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int eg3d_get_grid(eg3d_ctx* c, int view, int which, uint32_t* ncols, uint32_t* nrows,
+                             const uint32_t** cell_off, const uint32_t** ids) {
+  if (!c || view < 0 || view >= c->V || which < 0 || which > 1) {
+    g_err = "eg3d_get_grid: bad arguments";
+    return EG3D_ERR_ARG;
+  }
+  *ncols = c->gw[which];
+  *nrows = c->gh[which];
+  *cell_off = c->h_off[which][view].data();
+  *ids = c->h_ids[which][view].data();
+  return EG3D_OK;
+}
+
+extern "C" int eg3d_upload_seeds(eg3d_ctx* c, const eg3d_seeds* s) {
+  if (!c || !s) {
+    g_err = "eg3d_upload_seeds: bad arguments";
+    return EG3D_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  const uint32_t n = s->n_seeds;
+  const uint32_t m = s->trk_off[n];
+  for (uint32_t i = 0; i < m; i++)
+    if (s->trk_view[i] < 0 || s->trk_view[i] >= c->V) {
+      g_err = "eg3d_upload_seeds: view id out of range";
+      return EG3D_ERR_ARG;
+    }
+  c->n_seeds = n;
+  c->h_trk_off.assign(s->trk_off, s->trk_off + n + 1);
+  BUF_TRY(upload(c->b_toff, s->trk_off, n + 1, c->stream));
+  BUF_TRY(upload(c->b_tview, s->trk_view, m, c->stream));
+  BUF_TRY(upload(c->b_txy, s->trk_xy, (size_t)m * 2, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return EG3D_OK;
+}
+
+namespace {
+
+struct BatchState {
+  uint32_t b, e, n_seeds, sv_base, n_sv, n_tasks, n_lists, n_hits, n_hyp, n_chains, total_raw;
+  StageAView a;
+  SeedsDev sd;
+};
+
+// Stage A: K1 + task enumeration + K2. Leaves everything on the device.
+int run_stage_a(eg3d_ctx* c, BatchState& B, eg3d_stage_times* tm) {
+  hipStream_t st = c->stream;
+  B.n_seeds = B.e - B.b;
+  B.sv_base = c->h_trk_off[B.b];
+  B.n_sv = c->h_trk_off[B.e] - B.sv_base;
+  B.sd.trk_off = c->b_toff.as<uint32_t>();
+  B.sd.trk_view = c->b_tview.as<int32_t>();
+  B.sd.trk_xy = c->b_txy.as<float>();
+  const uint32_t n_sv = B.n_sv;
+  BUF_TRY(c->b_sv_seed.ensure(sizeof(uint32_t) * (n_sv + 1)));
+  BUF_TRY(c->b_map_view.ensure(sizeof(int32_t) * (n_sv + 1)));
+  BUF_TRY(c->b_map_entry.ensure(sizeof(uint32_t) * (n_sv + 1)));
+  BUF_TRY(c->b_map_n.ensure(sizeof(uint32_t) * (B.n_seeds + 1)));
+  BUF_TRY(c->b_raw_cnt.ensure(sizeof(uint32_t) * (n_sv + 1)));
+  BUF_TRY(c->b_raw_off.ensure(sizeof(uint32_t) * (n_sv + 1)));
+  BUF_TRY(c->b_cand_cnt.ensure(sizeof(uint32_t) * (n_sv + 1)));
+  BUF_TRY(c->b_start_cnt.ensure(sizeof(uint32_t) * (n_sv + 1)));
+  BUF_TRY(c->b_task_off.ensure(sizeof(uint32_t) * (n_sv + 1)));
+  HIP_TRY(hipEventRecord(c->ev[0], st));
+  launch_seed_prep(st, B.sd, B.b, B.n_seeds, B.sv_base, c->b_sv_seed.as<uint32_t>(), c->b_map_view.as<int32_t>(),
+                   c->b_map_entry.as<uint32_t>(), c->b_map_n.as<uint32_t>());
+  HIP_TRY(hipMemsetAsync(c->b_raw_cnt.as<uint32_t>() + n_sv, 0, sizeof(uint32_t), st));
+  launch_k1_count_raw(st, c->ds, B.sd, B.sv_base, n_sv, c->b_sv_seed.as<uint32_t>(), c->b_raw_cnt.as<uint32_t>());
+  BUF_TRY(scan_exclusive_u32(c, c->b_raw_cnt.as<uint32_t>(), c->b_raw_off.as<uint32_t>(), n_sv + 1));
+  BUF_TRY(read_u32(c, c->b_raw_off.as<uint32_t>() + n_sv, B.total_raw));
+  BUF_TRY(c->b_cand_pl.ensure(sizeof(uint32_t) * (B.total_raw + 1)));
+  BUF_TRY(c->b_start_hits.ensure(sizeof(Obs) * (B.total_raw + 1)));
+  HIP_TRY(hipMemsetAsync(c->b_start_cnt.as<uint32_t>() + n_sv, 0, sizeof(uint32_t), st));
+  launch_k1(st, c->ds, B.sd, B.sv_base, n_sv, c->b_sv_seed.as<uint32_t>(), c->b_raw_off.as<uint32_t>(),
+            c->b_cand_pl.as<uint32_t>(), c->b_start_hits.as<Obs>(), c->b_cand_cnt.as<uint32_t>(),
+            c->b_start_cnt.as<uint32_t>());
+  HIP_TRY(hipEventRecord(c->ev[1], st));
+  BUF_TRY(scan_exclusive_u32(c, c->b_start_cnt.as<uint32_t>(), c->b_task_off.as<uint32_t>(), n_sv + 1));
+  BUF_TRY(read_u32(c, c->b_task_off.as<uint32_t>() + n_sv, B.n_tasks));
+  const uint32_t nt = B.n_tasks;
+  BUF_TRY(c->b_task_seed.ensure(sizeof(uint32_t) * (nt + 1)));
+  BUF_TRY(c->b_task_entry.ensure(sizeof(uint32_t) * (nt + 1)));
+  BUF_TRY(c->b_task_hit.ensure(sizeof(uint32_t) * (nt + 1)));
+  BUF_TRY(c->b_task_k.ensure(sizeof(uint32_t) * (nt + 1)));
+  BUF_TRY(c->b_task_list_off.ensure(sizeof(uint32_t) * (nt + 1)));
+  HIP_TRY(hipMemsetAsync(c->b_task_k.as<uint32_t>() + nt, 0, sizeof(uint32_t), st));
+  launch_task_fill(st, B.sd, B.sv_base, n_sv, c->b_sv_seed.as<uint32_t>(), c->b_start_cnt.as<uint32_t>(),
+                   c->b_task_off.as<uint32_t>(), c->b_task_seed.as<uint32_t>(), c->b_task_entry.as<uint32_t>(),
+                   c->b_task_hit.as<uint32_t>(), c->b_task_k.as<uint32_t>());
+  BUF_TRY(scan_exclusive_u32(c, c->b_task_k.as<uint32_t>(), c->b_task_list_off.as<uint32_t>(), nt + 1));
+  BUF_TRY(read_u32(c, c->b_task_list_off.as<uint32_t>() + nt, B.n_lists));
+  BUF_TRY(c->b_list_cnt.ensure(sizeof(uint32_t) * (B.n_lists + 1)));
+  BUF_TRY(c->b_list_ptr.ensure(sizeof(uint32_t) * (B.n_lists + 1)));
+  HIP_TRY(hipMemsetAsync(c->b_list_cnt.as<uint32_t>() + B.n_lists, 0, sizeof(uint32_t), st));
+  launch_k2(st, false, c->ds, B.sd, B.sv_base, nt, c->b_task_seed.as<uint32_t>(), c->b_task_entry.as<uint32_t>(),
+            c->b_task_hit.as<uint32_t>(), c->b_task_list_off.as<uint32_t>(), c->b_raw_off.as<uint32_t>(),
+            c->b_cand_pl.as<uint32_t>(), c->b_cand_cnt.as<uint32_t>(), c->b_start_hits.as<Obs>(),
+            c->b_list_cnt.as<uint32_t>(), nullptr, nullptr);
+  BUF_TRY(scan_exclusive_u32(c, c->b_list_cnt.as<uint32_t>(), c->b_list_ptr.as<uint32_t>(), B.n_lists + 1));
+  BUF_TRY(read_u32(c, c->b_list_ptr.as<uint32_t>() + B.n_lists, B.n_hits));
+  BUF_TRY(c->b_hits.ensure(sizeof(Obs) * (B.n_hits + 1)));
+  launch_k2(st, true, c->ds, B.sd, B.sv_base, nt, c->b_task_seed.as<uint32_t>(), c->b_task_entry.as<uint32_t>(),
+            c->b_task_hit.as<uint32_t>(), c->b_task_list_off.as<uint32_t>(), c->b_raw_off.as<uint32_t>(),
+            c->b_cand_pl.as<uint32_t>(), c->b_cand_cnt.as<uint32_t>(), c->b_start_hits.as<Obs>(),
+            c->b_list_cnt.as<uint32_t>(), c->b_list_ptr.as<uint32_t>(), c->b_hits.as<Obs>());
+  HIP_TRY(hipEventRecord(c->ev[2], st));
+  StageAView& a = B.a;
+  a.trk_off = B.sd.trk_off;
+  a.trk_view = B.sd.trk_view;
+  a.trk_xy = B.sd.trk_xy;
+  a.seed_begin = B.b;
+  a.sv_base = B.sv_base;
+  a.n_tasks = nt;
+  a.task_seed = c->b_task_seed.as<uint32_t>();
+  a.task_entry = c->b_task_entry.as<uint32_t>();
+  a.task_hit = c->b_task_hit.as<uint32_t>();
+  a.task_list_off = c->b_task_list_off.as<uint32_t>();
+  a.list_ptr = c->b_list_ptr.as<uint32_t>();
+  a.list_cnt = c->b_list_cnt.as<uint32_t>();
+  a.hits = c->b_hits.as<Obs>();
+  (void)tm;
+  return EG3D_OK;
+}
+
+struct HostOut {
+  std::vector<float> X, xy;
+  std::vector<uint32_t> off, pl, seg, key;
+  std::vector<int32_t> view;
+  uint64_t n_points = 0, n_obs = 0, n_tasks = 0, n_hyp = 0, n_chains = 0;
+  uint32_t flags = 0;
+  uint64_t bytes_algorithmic = 0;
+  float ms[7] = {0, 0, 0, 0, 0, 0, 0};
+};
+
+int run_batch(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, HostOut& H) {
+  hipStream_t st = c->stream;
+  BatchState B;
+  memset(&B, 0, sizeof(B));
+  B.b = b;
+  B.e = e;
+  BUF_TRY(run_stage_a(c, B, nullptr));
+  const uint32_t nt = B.n_tasks;
+  // ---- task setup + hypothesis offsets
+  BUF_TRY(c->b_tasks.ensure(sizeof(TaskDesc) * (nt + 1)));
+  BUF_TRY(c->b_nhyp.ensure(sizeof(uint32_t) * (nt + 1)));
+  BUF_TRY(c->b_hyp_off.ensure(sizeof(uint32_t) * (nt + 1)));
+  HIP_TRY(hipMemsetAsync(c->b_nhyp.as<uint32_t>() + nt, 0, sizeof(uint32_t), st));
+  launch_task_setup(st, B.a, c->b_map_view.as<int32_t>(), c->b_map_entry.as<uint32_t>(), c->b_map_n.as<uint32_t>(),
+                    c->b_tasks.as<TaskDesc>(), c->b_nhyp.as<uint32_t>());
+  BUF_TRY(scan_exclusive_u32(c, c->b_nhyp.as<uint32_t>(), c->b_hyp_off.as<uint32_t>(), nt + 1));
+  BUF_TRY(read_u32(c, c->b_hyp_off.as<uint32_t>() + nt, B.n_hyp));
+  // ---- K3a
+  BUF_TRY(c->b_res.ensure(sizeof(HypResult) * (B.n_hyp + 1)));
+  BUF_TRY(c->b_ctr.ensure(sizeof(Counters)));
+  const uint32_t k3a_blocks =
+      std::max<uint32_t>(1, std::min<uint32_t>(c->k3a_blocks, (B.n_hyp + 255) / 256));
+  BUF_TRY(c->b_hscratch.ensure(sizeof(HPoint) * 2 * c->hyp_cap * (size_t)k3a_blocks * 256));
+  uint32_t arena_cap = std::max<uint32_t>(1u << 16, std::min<uint64_t>((uint64_t)B.n_hyp * 24, 1ull << 26));
+  Counters hc;
+  for (int attempt = 0;; attempt++) {
+    BUF_TRY(c->b_arena.ensure(sizeof(HPoint) * (size_t)arena_cap));
+    HIP_TRY(hipMemsetAsync(c->b_ctr.p, 0, sizeof(Counters), st));
+    launch_k3a(st, k3a_blocks, c->ds, B.a, c->b_tasks.as<TaskDesc>(), c->b_hyp_off.as<uint32_t>(), B.n_hyp,
+               c->b_res.as<HypResult>(), c->b_hscratch.as<HPoint>(), c->hyp_cap, c->b_arena.as<HPoint>(), arena_cap,
+               c->b_ctr.as<Counters>());
+    HIP_TRY(hipMemcpyAsync(&hc, c->b_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (!(hc.flags & CTR_ARENA_OVERFLOW)) break;
+    if (attempt >= 6) {
+      g_err = "eg3d: hypothesis arena overflow";
+      return EG3D_ERR_CAPACITY;
+    }
+    arena_cap = std::max<uint32_t>(arena_cap * 2, hc.arena_used + (hc.arena_used >> 2));
+  }
+  H.flags |= (hc.flags & 0xffu);
+  HIP_TRY(hipEventRecord(c->ev[3], st));
+  // ---- K3s
+  BUF_TRY(c->b_cs_task.ensure(sizeof(ChainSeed) * (nt + 1)));
+  BUF_TRY(c->b_valid.ensure(sizeof(uint32_t) * (nt + 1)));
+  BUF_TRY(c->b_chain_off.ensure(sizeof(uint32_t) * (nt + 1)));
+  HIP_TRY(hipMemsetAsync(c->b_valid.as<uint32_t>() + nt, 0, sizeof(uint32_t), st));
+  launch_k3s(st, nt, c->b_hyp_off.as<uint32_t>(), c->b_res.as<HypResult>(), c->b_cs_task.as<ChainSeed>(),
+             c->b_valid.as<uint32_t>());
+  BUF_TRY(scan_exclusive_u32(c, c->b_valid.as<uint32_t>(), c->b_chain_off.as<uint32_t>(), nt + 1));
+  BUF_TRY(read_u32(c, c->b_chain_off.as<uint32_t>() + nt, B.n_chains));
+  BUF_TRY(c->b_chains.ensure(sizeof(ChainSeed) * (B.n_chains + 1)));
+  launch_compact_chains(st, nt, c->b_cs_task.as<ChainSeed>(), c->b_valid.as<uint32_t>(), c->b_chain_off.as<uint32_t>(),
+                        c->b_chains.as<ChainSeed>());
+  HIP_TRY(hipEventRecord(c->ev[4], st));
+  // ---- K3b + K4 in chunks bounded by scratch size
+  const ChainLayout L = chain_layout(c->chain_cap, c->pool_cap, (uint32_t)c->V);
+  const size_t max_scratch = (size_t)24 << 30;
+  const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(B.n_chains ? B.n_chains : 1, max_scratch / L.total));
+  float ms_expand = 0, ms_emit = 0;
+  for (uint32_t c0 = 0; c0 < B.n_chains; c0 += chunk) {
+    const uint32_t nc = std::min(chunk, B.n_chains - c0);
+    BUF_TRY(c->b_cscratch.ensure(L.total * (size_t)nc));
+    BUF_TRY(c->b_couts.ensure(sizeof(ChainOut) * (nc + 1)));
+    BUF_TRY(c->b_cpts.ensure(sizeof(uint32_t) * (nc + 1)));
+    BUF_TRY(c->b_cobs.ensure(sizeof(uint32_t) * (nc + 1)));
+    BUF_TRY(c->b_cpoff.ensure(sizeof(uint32_t) * (nc + 1)));
+    BUF_TRY(c->b_cooff.ensure(sizeof(uint32_t) * (nc + 1)));
+    HIP_TRY(hipMemsetAsync(c->b_cpts.as<uint32_t>() + nc, 0, sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(c->b_cobs.as<uint32_t>() + nc, 0, sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(c->b_ctr.p, 0, sizeof(Counters), st));
+    HIP_TRY(hipEventRecord(c->ev[5], st));
+    launch_k3b(st, c->ds, B.a, c->b_tasks.as<TaskDesc>(), c->b_chains.as<ChainSeed>() + c0, nc,
+               c->b_hyp_off.as<uint32_t>(), c->b_res.as<HypResult>(), c->b_arena.as<HPoint>(),
+               c->b_map_view.as<int32_t>(), c->b_map_entry.as<uint32_t>(), c->b_map_n.as<uint32_t>(), L,
+               c->b_cscratch.as<unsigned char>(), c->b_couts.as<ChainOut>(), c->b_cpts.as<uint32_t>(),
+               c->b_cobs.as<uint32_t>(), c->b_ctr.as<Counters>());
+    HIP_TRY(hipEventRecord(c->ev[6], st));
+    BUF_TRY(scan_exclusive_u32(c, c->b_cpts.as<uint32_t>(), c->b_cpoff.as<uint32_t>(), nc + 1));
+    BUF_TRY(scan_exclusive_u32(c, c->b_cobs.as<uint32_t>(), c->b_cooff.as<uint32_t>(), nc + 1));
+    uint32_t np = 0, no = 0;
+    BUF_TRY(read_u32(c, c->b_cpoff.as<uint32_t>() + nc, np));
+    BUF_TRY(read_u32(c, c->b_cooff.as<uint32_t>() + nc, no));
+    HIP_TRY(hipMemcpyAsync(&hc, c->b_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
+    BUF_TRY(c->o_X.ensure(sizeof(float) * 3 * ((size_t)np + 1)));
+    BUF_TRY(c->o_off.ensure(sizeof(uint32_t) * ((size_t)np + 1)));
+    BUF_TRY(c->o_key.ensure(sizeof(uint32_t) * 4 * ((size_t)np + 1)));
+    BUF_TRY(c->o_view.ensure(sizeof(int32_t) * ((size_t)no + 1)));
+    BUF_TRY(c->o_pl.ensure(sizeof(uint32_t) * ((size_t)no + 1)));
+    BUF_TRY(c->o_seg.ensure(sizeof(uint32_t) * ((size_t)no + 1)));
+    BUF_TRY(c->o_xy.ensure(sizeof(float) * 2 * ((size_t)no + 1)));
+    // chunk-local indices on the device; the global observation base is added on the host
+    launch_k4(st, c->b_tasks.as<TaskDesc>(), c->b_chains.as<ChainSeed>() + c0, nc, L, c->b_cscratch.as<unsigned char>(),
+              c->b_couts.as<ChainOut>(), c->b_cpoff.as<uint32_t>(), c->b_cooff.as<uint32_t>(), 0, 0, c->o_X.as<float>(),
+              c->o_off.as<uint32_t>(), c->o_view.as<int32_t>(), c->o_pl.as<uint32_t>(), c->o_seg.as<uint32_t>(),
+              c->o_xy.as<float>(), c->o_key.as<uint32_t>());
+    HIP_TRY(hipEventRecord(c->ev[7], st));
+    HIP_TRY(hipStreamSynchronize(st));
+    H.flags |= (hc.flags & 0xffu);
+    float t = 0;
+    HIP_TRY(hipEventElapsedTime(&t, c->ev[5], c->ev[6]));
+    ms_expand += t;
+    HIP_TRY(hipEventElapsedTime(&t, c->ev[6], c->ev[7]));
+    ms_emit += t;
+    if (!device_only && np) {
+      const size_t p0 = H.X.size() / 3, o0 = H.view.size();
+      H.X.resize((p0 + np) * 3);
+      H.off.resize(p0 + np);
+      H.key.resize((p0 + np) * 4);
+      H.view.resize(o0 + no);
+      H.pl.resize(o0 + no);
+      H.seg.resize(o0 + no);
+      H.xy.resize((o0 + no) * 2);
+      HIP_TRY(hipMemcpy(H.X.data() + p0 * 3, c->o_X.p, sizeof(float) * 3 * np, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(H.off.data() + p0, c->o_off.p, sizeof(uint32_t) * np, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(H.key.data() + p0 * 4, c->o_key.p, sizeof(uint32_t) * 4 * np, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(H.view.data() + o0, c->o_view.p, sizeof(int32_t) * no, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(H.pl.data() + o0, c->o_pl.p, sizeof(uint32_t) * no, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(H.seg.data() + o0, c->o_seg.p, sizeof(uint32_t) * no, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(H.xy.data() + o0 * 2, c->o_xy.p, sizeof(float) * 2 * no, hipMemcpyDeviceToHost));
+      for (size_t i = p0; i < p0 + np; i++) H.off[i] += (uint32_t)o0;
+    }
+    H.n_points += np;
+    H.n_obs += no;
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  float t = 0;
+  HIP_TRY(hipEventElapsedTime(&t, c->ev[0], c->ev[1]));
+  H.ms[1] += t;
+  HIP_TRY(hipEventElapsedTime(&t, c->ev[1], c->ev[2]));
+  H.ms[2] += t;
+  HIP_TRY(hipEventElapsedTime(&t, c->ev[2], c->ev[3]));
+  H.ms[3] += t;
+  HIP_TRY(hipEventElapsedTime(&t, c->ev[3], c->ev[4]));
+  H.ms[4] += t;
+  H.ms[5] += ms_expand;
+  H.ms[6] += ms_emit;
+  H.n_tasks += B.n_tasks;
+  H.n_hyp += B.n_hyp;
+  H.n_chains += B.n_chains;
+  return EG3D_OK;
+}
+
+template <typename T>
+T* dup_to_malloc(const std::vector<T>& v, size_t extra = 0) {
+  T* p = (T*)malloc(sizeof(T) * std::max<size_t>(1, v.size() + extra));
+  if (!v.empty()) memcpy(p, v.data(), sizeof(T) * v.size());
+  return p;
+}
+
+}  // namespace
+
+extern "C" int eg3d_match_resident(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, eg3d_edgepoints* out,
+                                   eg3d_stage_times* times) {
+  if (!c || !out || b > e || e > c->n_seeds) {
+    g_err = "eg3d_match_resident: bad arguments (seeds uploaded?)";
+    return EG3D_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  memset(out, 0, sizeof(*out));
+  HostOut H;
+  const uint32_t SEED_BATCH = 16384;
+  hipEvent_t t0, t1;
+  HIP_TRY(hipEventCreate(&t0));
+  HIP_TRY(hipEventCreate(&t1));
+  HIP_TRY(hipEventRecord(t0, c->stream));
+  for (uint32_t s = b; s < e; s += SEED_BATCH) {
+    int rc = run_batch(c, s, std::min(e, s + SEED_BATCH), device_only, H);
+    if (rc != EG3D_OK) return rc;
+  }
+  HIP_TRY(hipEventRecord(t1, c->stream));
+  HIP_TRY(hipEventSynchronize(t1));
+  float total = 0;
+  HIP_TRY(hipEventElapsedTime(&total, t0, t1));
+  (void)hipEventDestroy(t0);
+  (void)hipEventDestroy(t1);
+  out->n_points = H.n_points;
+  out->n_obs = H.n_obs;
+  out->n_tasks = H.n_tasks;
+  out->n_hypotheses = H.n_hyp;
+  out->n_chains = H.n_chains;
+  out->flags = H.flags;
+  if (!device_only) {
+    H.off.push_back((uint32_t)H.n_obs);
+    out->X = dup_to_malloc(H.X);
+    out->obs_off = dup_to_malloc(H.off);
+    out->obs_view = dup_to_malloc(H.view);
+    out->obs_pl = dup_to_malloc(H.pl);
+    out->obs_seg = dup_to_malloc(H.seg);
+    out->obs_xy = dup_to_malloc(H.xy);
+    out->key = dup_to_malloc(H.key);
+    out->_owner = (void*)1;
+  }
+  if (times) {
+    times->ms_total = total;
+    times->ms_candidates = H.ms[1];
+    times->ms_epipolar = H.ms[2];
+    times->ms_hypotheses = H.ms[3];
+    times->ms_select = H.ms[4];
+    times->ms_expand = H.ms[5];
+    times->ms_emit = H.ms[6];
+    times->bytes_algorithmic = 0;
+  }
+  if (H.flags & (EG3D_FLAG_CHAIN_OVERFLOW | EG3D_FLAG_OBS_OVERFLOW | EG3D_FLAG_HYP_OVERFLOW)) {
+    g_err = "eg3d: a device-side capacity was exceeded (flags in out->flags)";
+    return EG3D_ERR_CAPACITY;
+  }
+  return EG3D_OK;
+}
+
+extern "C" int eg3d_match_refpoints(eg3d_ctx* c, const eg3d_seeds* seeds, uint32_t b, uint32_t e, int device_only,
+                                    eg3d_edgepoints* out, eg3d_stage_times* times) {
+  int rc = eg3d_upload_seeds(c, seeds);
+  if (rc != EG3D_OK) return rc;
+  return eg3d_match_resident(c, b, e, device_only, out, times);
+}
+
+extern "C" void eg3d_free_edgepoints(eg3d_edgepoints* e) {
+  if (!e) return;
+  free(e->X);
+  free(e->obs_off);
+  free(e->obs_view);
+  free(e->obs_pl);
+  free(e->obs_seg);
+  free(e->obs_xy);
+  free(e->key);
+  memset(e, 0, sizeof(*e));
+}
+
+extern "C" int eg3d_candidates_run(eg3d_ctx* c, const eg3d_seeds* seeds, uint32_t b, uint32_t e, eg3d_candidates* out) {
+  if (!c || !seeds || !out || b > e || e > seeds->n_seeds) {
+    g_err = "eg3d_candidates_run: bad arguments";
+    return EG3D_ERR_ARG;
+  }
+  int rc = eg3d_upload_seeds(c, seeds);
+  if (rc != EG3D_OK) return rc;
+  memset(out, 0, sizeof(*out));
+  BatchState B;
+  memset(&B, 0, sizeof(B));
+  B.b = b;
+  B.e = e;
+  BUF_TRY(run_stage_a(c, B, nullptr));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const uint32_t n_sv = B.n_sv, nt = B.n_tasks;
+  std::vector<uint32_t> raw_off(n_sv + 1), cand_cnt(n_sv + 1), start_cnt(n_sv + 1), cand_pl(B.total_raw + 1),
+      task_seed(nt + 1), task_entry(nt + 1), task_hit(nt + 1), task_list_off(nt + 1), list_cnt(B.n_lists + 1),
+      list_ptr(B.n_lists + 1);
+  std::vector<Obs> start_hits(B.total_raw + 1), hits(B.n_hits + 1);
+#define DL(vec, buf, n) \
+  if (n) HIP_TRY(hipMemcpy(vec.data(), c->buf.p, sizeof(vec[0]) * (n), hipMemcpyDeviceToHost))
+  DL(raw_off, b_raw_off, n_sv + 1);
+  DL(cand_cnt, b_cand_cnt, n_sv);
+  DL(start_cnt, b_start_cnt, n_sv);
+  DL(cand_pl, b_cand_pl, B.total_raw);
+  DL(start_hits, b_start_hits, B.total_raw);
+  DL(task_seed, b_task_seed, nt);
+  DL(task_entry, b_task_entry, nt);
+  DL(task_hit, b_task_hit, nt);
+  DL(task_list_off, b_task_list_off, nt + 1);
+  DL(list_cnt, b_list_cnt, B.n_lists);
+  DL(list_ptr, b_list_ptr, B.n_lists + 1);
+  DL(hits, b_hits, B.n_hits);
+#undef DL
+  std::vector<uint32_t> o_cand_off(1, 0), o_cand_pl, o_start_off(1, 0), o_start_pl, o_start_seg, o_task_sv(nt),
+      o_hit_pl(B.n_hits), o_hit_seg(B.n_hits);
+  std::vector<float> o_start_xy, o_hit_xy((size_t)B.n_hits * 2);
+  for (uint32_t sv = 0; sv < n_sv; sv++) {
+    for (uint32_t i = 0; i < cand_cnt[sv]; i++) o_cand_pl.push_back(cand_pl[raw_off[sv] + i]);
+    o_cand_off.push_back((uint32_t)o_cand_pl.size());
+    for (uint32_t i = 0; i < start_cnt[sv]; i++) {
+      const Obs& o = start_hits[raw_off[sv] + i];
+      o_start_pl.push_back(o.pl);
+      o_start_seg.push_back(o.seg);
+      o_start_xy.push_back(o.x);
+      o_start_xy.push_back(o.y);
+    }
+    o_start_off.push_back((uint32_t)o_start_pl.size());
+  }
+  for (uint32_t t = 0; t < nt; t++) o_task_sv[t] = c->h_trk_off[task_seed[t]] - B.sv_base + task_entry[t];
+  for (uint32_t h = 0; h < B.n_hits; h++) {
+    o_hit_pl[h] = hits[h].pl;
+    o_hit_seg[h] = hits[h].seg;
+    o_hit_xy[2 * h] = hits[h].x;
+    o_hit_xy[2 * h + 1] = hits[h].y;
+  }
+  task_hit.resize(nt);
+  list_ptr.resize(B.n_lists + 1);
+  task_list_off.resize(nt + 1);
+  out->n_sv = n_sv;
+  out->cand_off = dup_to_malloc(o_cand_off);
+  out->cand_pl = dup_to_malloc(o_cand_pl);
+  out->start_off = dup_to_malloc(o_start_off);
+  out->start_pl = dup_to_malloc(o_start_pl);
+  out->start_seg = dup_to_malloc(o_start_seg);
+  out->start_xy = dup_to_malloc(o_start_xy);
+  out->n_tasks = nt;
+  out->task_sv = dup_to_malloc(o_task_sv);
+  out->task_hit = dup_to_malloc(task_hit);
+  out->task_list_off = dup_to_malloc(task_list_off);
+  out->list_off = dup_to_malloc(list_ptr);  // the exclusive scan of the counts is the CSR
+  out->hit_pl = dup_to_malloc(o_hit_pl);
+  out->hit_seg = dup_to_malloc(o_hit_seg);
+  out->hit_xy = dup_to_malloc(o_hit_xy);
+  out->_owner = (void*)1;
+  return EG3D_OK;
+}
+
+extern "C" void eg3d_free_candidates(eg3d_candidates* c) {
+  if (!c) return;
+  free(c->cand_off);
+  free(c->cand_pl);
+  free(c->start_off);
+  free(c->start_pl);
+  free(c->start_seg);
+  free(c->start_xy);
+  free(c->task_sv);
+  free(c->task_hit);
+  free(c->task_list_off);
+  free(c->list_off);
+  free(c->hit_pl);
+  free(c->hit_seg);
+  free(c->hit_xy);
+  memset(c, 0, sizeof(*c));
+}
+
+extern "C" int eg3d_gn_filter(eg3d_ctx* c, const float* X, const uint32_t* obs_off, const int32_t* obs_view,
+                              const float* obs_xy, uint64_t n, float gn_max_mse, int legacy_abs, float* X_out,
+                              uint8_t* inlier, float* ms_kernel) {
+  if (!c || !X || !obs_off || !X_out || !inlier) {
+    g_err = "eg3d_gn_filter: bad arguments";
+    return EG3D_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  const uint64_t m = n ? obs_off[n] : 0;
+  for (uint64_t i = 0; i < m; i++)
+    if (obs_view[i] < 0 || obs_view[i] >= c->V) {
+      g_err = "eg3d_gn_filter: view id out of range";
+      return EG3D_ERR_ARG;
+    }
+  hipStream_t st = c->stream;
+  BUF_TRY(upload(c->f_X, X, n * 3, st));
+  BUF_TRY(upload(c->f_off, obs_off, n + 1, st));
+  BUF_TRY(upload(c->f_view, obs_view, m, st));
+  BUF_TRY(upload(c->f_xy, obs_xy, m * 2, st));
+  BUF_TRY(c->f_Xo.ensure(sizeof(float) * 3 * (n + 1)));
+  BUF_TRY(c->f_inl.ensure(n + 1));
+  HIP_TRY(hipEventRecord(c->ev[0], st));
+  launch_k5(st, c->ds.cam_P, c->f_X.as<float>(), c->f_off.as<uint32_t>(), c->f_view.as<int32_t>(), c->f_xy.as<float>(),
+            n, gn_max_mse, legacy_abs, c->f_Xo.as<float>(), c->f_inl.as<uint8_t>());
+  HIP_TRY(hipEventRecord(c->ev[1], st));
+  if (n) {
+    HIP_TRY(hipMemcpyAsync(X_out, c->f_Xo.p, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(inlier, c->f_inl.p, n, hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  if (ms_kernel) HIP_TRY(hipEventElapsedTime(ms_kernel, c->ev[0], c->ev[1]));
+  return EG3D_OK;
+}

@@ -1,0 +1,55 @@
+// Host-visible declarations of the kernel launch wrappers (eg3d_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "eg3d_dev_pipeline.h"
+
+namespace eg3d {
+
+struct SeedsDev {
+  const uint32_t* trk_off;
+  const int32_t* trk_view;
+  const float* trk_xy;
+};
+
+enum : uint32_t { CTR_ARENA_OVERFLOW = 0x100u };
+struct Counters {
+  uint32_t arena_used;
+  uint32_t flags;  // EG3D_FLAG_* bits | CTR_ARENA_OVERFLOW
+};
+
+void launch_seed_prep(hipStream_t st, SeedsDev sd, uint32_t seed_begin, uint32_t n_seeds, uint32_t sv_base,
+                      uint32_t* sv_seed, int32_t* map_view, uint32_t* map_entry, uint32_t* map_n);
+void launch_k1_count_raw(hipStream_t st, DevScene s, SeedsDev sd, uint32_t sv_base, uint32_t n_sv, const uint32_t* sv_seed,
+                         uint32_t* raw_cnt);
+void launch_k1(hipStream_t st, DevScene s, SeedsDev sd, uint32_t sv_base, uint32_t n_sv, const uint32_t* sv_seed,
+               const uint32_t* raw_off, uint32_t* cand_pl, Obs* start_hits, uint32_t* cand_cnt, uint32_t* start_cnt);
+void launch_task_fill(hipStream_t st, SeedsDev sd, uint32_t sv_base, uint32_t n_sv, const uint32_t* sv_seed,
+                      const uint32_t* start_cnt, const uint32_t* task_off, uint32_t* task_seed, uint32_t* task_entry,
+                      uint32_t* task_hit, uint32_t* task_k);
+void launch_k2(hipStream_t st, bool fill, DevScene s, SeedsDev sd, uint32_t sv_base, uint32_t n_tasks,
+               const uint32_t* task_seed, const uint32_t* task_entry, const uint32_t* task_hit,
+               const uint32_t* task_list_off, const uint32_t* raw_off, const uint32_t* cand_pl, const uint32_t* cand_cnt,
+               const Obs* start_hits, uint32_t* list_cnt, const uint32_t* list_ptr, Obs* hits);
+void launch_task_setup(hipStream_t st, StageAView a, const int32_t* map_view, const uint32_t* map_entry,
+                       const uint32_t* map_n, TaskDesc* tasks, uint32_t* n_hyp);
+void launch_k3a(hipStream_t st, uint32_t n_blocks, DevScene s, StageAView a, const TaskDesc* tasks,
+                const uint32_t* hyp_off, uint32_t n_hyp, HypResult* res, HPoint* scratch, uint32_t hyp_cap, HPoint* arena,
+                uint32_t arena_cap, Counters* ctr);
+void launch_k3s(hipStream_t st, uint32_t n_tasks, const uint32_t* hyp_off, const HypResult* res, ChainSeed* per_task,
+                uint32_t* valid);
+void launch_compact_chains(hipStream_t st, uint32_t n_tasks, const ChainSeed* per_task, const uint32_t* valid,
+                           const uint32_t* chain_off, ChainSeed* chains);
+void launch_k3b(hipStream_t st, DevScene s, StageAView a, const TaskDesc* tasks, const ChainSeed* chains,
+                uint32_t n_chains, const uint32_t* hyp_off, const HypResult* res, const HPoint* arena,
+                const int32_t* map_view, const uint32_t* map_entry, const uint32_t* map_n, ChainLayout L,
+                unsigned char* scratch, ChainOut* outs, uint32_t* out_points, uint32_t* out_obs, Counters* ctr);
+void launch_k4(hipStream_t st, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains, ChainLayout L,
+               const unsigned char* scratch, const ChainOut* outs, const uint32_t* point_off, const uint32_t* obs_off_in,
+               uint64_t point_base, uint64_t obs_base, float* X, uint32_t* obs_off, int32_t* obs_view, uint32_t* obs_pl,
+               uint32_t* obs_seg, float* obs_xy, uint32_t* key);
+void launch_k5(hipStream_t st, const float* cam_P, const float* X, const uint32_t* obs_off, const int32_t* obs_view,
+               const float* obs_xy, uint64_t n, float gn_max_mse, int legacy_abs, float* X_out, uint8_t* inlier);
+
+}  // namespace eg3d

@@ -1,0 +1,476 @@
+// eg3d_kernels.hip — gfx950 kernels of the refpoint -> epipolar match -> triangulate path.
+//
+// Phase pipeline (DESIGN.md "Kernels"):
+//   k_seed_prep       1 lane / seed       view map of the track, (seed,entry) of every track entry
+//   k1_count_raw      1 lane / (seed,entry)  upper bound of candidate polylines (sizes the slots)
+//   k1_seed_candidates 1 WAVE / (seed,entry) k-way merge of the 30 px grid cells + cooperative
+//                                           closest-point scan of each candidate polyline
+//   k_task_fill       1 lane / (seed,entry)  enumerates (seed, start view, start hit) tasks
+//   k2_epipolar_hits  1 WAVE / task         epiline x candidate polylines, ballot/popcount
+//                                           ordered compaction (count pass + fill pass)
+//   k_task_setup      1 lane / task         3-view selection, hypothesis count
+//   k3a_hypotheses    1 lane / hypothesis   orientation + following (wave-synchronous batches)
+//   k3s_select        1 lane / task         uniqueness rule -> chain seeds
+//   k3b_expand        1 lane / chain        expand-all-views
+//   k4_emit           1 lane / chain        ordered SoA output
+//   k5_gn_filter      1 lane / point        config 5, FP32 Gauss-Newton outlier filter
+// All arithmetic follows the contract in DESIGN.md (no FMA contraction: -ffp-contract=off).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "eg3d_dev_pipeline.h"
+#include "eg3d_kernels.h"
+
+namespace eg3d {
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_min_f32(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float t = __shfl_xor(v, o, 64);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+
+// ------------------------------------------------------------------ prep -------
+__global__ void k_seed_prep(SeedsDev sd, uint32_t seed_begin, uint32_t n_seeds, uint32_t sv_base, uint32_t* sv_seed,
+                            int32_t* map_view, uint32_t* map_entry, uint32_t* map_n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_seeds) return;
+  uint32_t seed = seed_begin + i;
+  uint32_t t0 = sd.trk_off[seed], t1 = sd.trk_off[seed + 1];
+  for (uint32_t e = t0; e < t1; e++) sv_seed[e - sv_base] = seed;
+  map_n[i] = build_seed_view_map(sd.trk_view + t0, t1 - t0, map_view + (t0 - sv_base), map_entry + (t0 - sv_base));
+}
+
+// Observation of `seed` in view `view`: the LAST track entry with that view id (Q2).
+__device__ __forceinline__ void seed_obs_in_view(const SeedsDev& sd, uint32_t t0, uint32_t k, int32_t view, float& x,
+                                                 float& y) {
+  x = 0.f;
+  y = 0.f;
+  for (uint32_t i = 0; i < k; i++)
+    if (sd.trk_view[t0 + i] == view) {
+      x = sd.trk_xy[2 * (t0 + i)];
+      y = sd.trk_xy[2 * (t0 + i) + 1];
+    }
+}
+
+__global__ void k1_count_raw(DevScene s, SeedsDev sd, uint32_t sv_base, uint32_t n_sv, const uint32_t* sv_seed,
+                             uint32_t* raw_cnt) {
+  uint32_t sv = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sv >= n_sv) return;
+  uint32_t seed = sv_seed[sv];
+  uint32_t t0 = sd.trk_off[seed], k = sd.trk_off[seed + 1] - t0;
+  int32_t view = sd.trk_view[sv_base + sv];
+  float px, py;
+  seed_obs_in_view(sd, t0, k, view, px, py);
+  CellWindow w = cell_window(30.0f, s.width, s.height, s.g30_w, s.g30_h, px, py);
+  uint32_t n = 0;
+  if (w.c1 >= w.c0) {
+    const size_t base = (size_t)view * (size_t)(s.g30_w * s.g30_h);
+    for (int r = w.r0; r <= w.r1; r++)
+      n += s.g30_off[base + (size_t)r * s.g30_w + w.c1 + 1] - s.g30_off[base + (size_t)r * s.g30_w + w.c0];
+  }
+  raw_cnt[sv] = n;
+}
+
+// ------------------------------------------------------------------ K1 ---------
+// One wavefront per (seed, track entry). Lanes 0..8 each own one grid cell of the (shrunk)
+// 3x3 window and k-way-merge the ascending id lists (wave-min of the heads) so candidates
+// come out ascending and unique with no LDS cap; for every candidate all 64 lanes scan its
+// segments (coalesced 8-byte vertex loads) and an argmin reduction picks the first closest
+// segment. Outputs go to the slot [raw_off[sv], raw_off[sv+1]) sized by k1_count_raw.
+__global__ void __launch_bounds__(256) k1_seed_candidates(DevScene s, SeedsDev sd, uint32_t sv_base, uint32_t n_sv,
+                                                         const uint32_t* sv_seed, const uint32_t* raw_off,
+                                                         uint32_t* cand_pl, Obs* start_hits, uint32_t* cand_cnt,
+                                                         uint32_t* start_cnt) {
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63;
+  if (wave >= n_sv) return;
+  const uint32_t sv = wave;
+  const uint32_t seed = sv_seed[sv];
+  const uint32_t t0 = sd.trk_off[seed], k = sd.trk_off[seed + 1] - t0;
+  const int32_t view = sd.trk_view[sv_base + sv];
+  float px, py;
+  seed_obs_in_view(sd, t0, k, view, px, py);
+  CellWindow w = cell_window(30.0f, s.width, s.height, s.g30_w, s.g30_h, px, py);
+  uint32_t a = 0, b = 0;
+  if (w.c1 >= w.c0) {
+    const int ncols = w.c1 - w.c0 + 1, nrows = w.r1 - w.r0 + 1;
+    if ((int)lane < ncols * nrows) {
+      const int r = w.r0 + (int)lane / ncols, c = w.c0 + (int)lane % ncols;
+      const size_t cell = (size_t)view * (size_t)(s.g30_w * s.g30_h) + (size_t)r * s.g30_w + c;
+      a = s.g30_off[cell];
+      b = s.g30_off[cell + 1];
+    }
+  }
+  const uint32_t out_base = raw_off[sv];
+  uint32_t nc = 0, ns = 0;
+  for (;;) {
+    const uint32_t head = (a < b) ? s.g30_ids[a] : 0xffffffffu;
+    const uint32_t m = wave_min_u32(head);
+    if (m == 0xffffffffu) break;
+    if (head == m) a++;
+    const PlRef pl = polyline_of(s, view, m);
+    float best = __builtin_huge_valf();
+    uint32_t bj = 0xffffffffu;
+    float bx = 0.f, by = 0.f;
+    for (uint32_t j = lane; j + 1 < pl.n; j += 64) {
+      const f2 v0 = pl.v[j], v1 = pl.v[j + 1];
+      float qx, qy;
+      const float d = seg_closest(px, py, v0.x, v0.y, v1.x, v1.y, qx, qy);
+      if (d < best) {
+        best = d;
+        bj = j;
+        bx = qx;
+        by = qy;
+      }
+    }
+    const float dmin = wave_min_f32(best);
+    const uint32_t jmin = wave_min_u32(best == dmin ? bj : 0xffffffffu);
+    const unsigned long long win = __ballot(best == dmin && bj == jmin);
+    if (win == 0ull) continue;  // degenerate (NaN) polyline: never a candidate
+    const int wl = __ffsll((long long)win) - 1;
+    const float hx = __shfl(bx, wl, 64), hy = __shfl(by, wl, 64);
+    if (dmin <= 100.0f) {
+      if (lane == 0) {
+        cand_pl[out_base + nc] = m;
+        Obs o;
+        o.view = view;
+        o.pl = m;
+        o.seg = jmin;
+        o.x = hx;
+        o.y = hy;
+        start_hits[out_base + ns] = o;
+      }
+      nc++;
+      ns++;
+    } else if (dmin <= 900.0f) {
+      if (lane == 0) cand_pl[out_base + nc] = m;
+      nc++;
+    }
+  }
+  if (lane == 0) {
+    cand_cnt[sv] = nc;
+    start_cnt[sv] = ns;
+  }
+}
+
+__global__ void k_task_fill(SeedsDev sd, uint32_t sv_base, uint32_t n_sv, const uint32_t* sv_seed,
+                            const uint32_t* start_cnt, const uint32_t* task_off, uint32_t* task_seed,
+                            uint32_t* task_entry, uint32_t* task_hit, uint32_t* task_k) {
+  uint32_t sv = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sv >= n_sv) return;
+  const uint32_t seed = sv_seed[sv];
+  const uint32_t t0 = sd.trk_off[seed], k = sd.trk_off[seed + 1] - t0;
+  const uint32_t entry = sv_base + sv - t0;
+  const uint32_t n = start_cnt[sv], base = task_off[sv];
+  for (uint32_t h = 0; h < n; h++) {
+    task_seed[base + h] = seed;
+    task_entry[base + h] = entry;
+    task_hit[base + h] = h;
+    task_k[base + h] = k;
+  }
+}
+
+// ------------------------------------------------------------------ K2 ---------
+// One wavefront per task. For every other track entry: epipolar line of the start hit, then
+// all 64 lanes test consecutive segments of each candidate polyline; hits inside the
+// detection radius are compacted in segment order with __ballot + popcount. FILL=false
+// counts, FILL=true writes to the offsets produced by the scan of the counts.
+template <bool FILL>
+__global__ void __launch_bounds__(256) k2_epipolar_hits(DevScene s, SeedsDev sd, uint32_t sv_base, uint32_t n_tasks,
+                                                       const uint32_t* task_seed, const uint32_t* task_entry,
+                                                       const uint32_t* task_hit, const uint32_t* task_list_off,
+                                                       const uint32_t* raw_off, const uint32_t* cand_pl,
+                                                       const uint32_t* cand_cnt, const Obs* start_hits,
+                                                       uint32_t* list_cnt, const uint32_t* list_ptr, Obs* hits) {
+  const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63;
+  if (t >= n_tasks) return;
+  const uint32_t seed = task_seed[t], ea = task_entry[t], h = task_hit[t];
+  const uint32_t t0 = sd.trk_off[seed], k = sd.trk_off[seed + 1] - t0;
+  const uint32_t sv0 = t0 - sv_base;
+  const Obs hit = start_hits[raw_off[sv0 + ea] + h];
+  const int32_t start_view = sd.trk_view[t0 + ea];
+  float ix, iy;
+  seed_obs_in_view(sd, t0, k, start_view, ix, iy);
+  const float radius = dist(ix, iy, hit.x, hit.y) * 3.0f;
+  const float detsq = radius * radius;
+  const uint32_t lo = task_list_off[t];
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (uint32_t i = 0; i < k; i++) {
+    const int32_t cur_view = sd.trk_view[t0 + i];
+    uint32_t cnt = 0;
+    if (cur_view == start_view) {
+      cnt = 1;
+      if (FILL && lane == 0) {
+        Obs o = hit;
+        o.view = cur_view;
+        hits[list_ptr[lo + i]] = o;
+      }
+    } else {
+      float la, lb, lc;
+      if (epiline(s.F, s.F_valid, s.n_views, start_view, cur_view, hit.x, hit.y, la, lb, lc)) {
+        const float sx = sd.trk_xy[2 * (t0 + i)], sy = sd.trk_xy[2 * (t0 + i) + 1];
+        const uint32_t cbase = raw_off[sv0 + i], ncand = cand_cnt[sv0 + i];
+        const uint32_t wbase = FILL ? list_ptr[lo + i] : 0;
+        for (uint32_t c = 0; c < ncand; c++) {
+          const uint32_t pl_id = cand_pl[cbase + c];
+          const PlRef pl = polyline_of(s, cur_view, pl_id);
+          for (uint32_t base = 1; base < pl.n; base += 64) {
+            const uint32_t ii = base + lane;
+            bool ok = false;
+            float hx = 0.f, hy = 0.f;
+            if (ii < pl.n) {
+              const f2 v1 = pl.v[ii], v0 = pl.v[ii - 1];
+              if (seg_line_hit(v1.x, v1.y, v0.x, v0.y, la, lb, lc, hx, hy)) ok = dist2(sx, sy, hx, hy) <= detsq;
+            }
+            const unsigned long long mask = __ballot(ok);
+            if (FILL && ok) {
+              Obs o;
+              o.view = cur_view;
+              o.pl = pl_id;
+              o.seg = ii - 1;
+              o.x = hx;
+              o.y = hy;
+              hits[wbase + cnt + __popcll(mask & lt_mask)] = o;
+            }
+            cnt += __popcll(mask);
+          }
+        }
+      }
+    }
+    if (!FILL && lane == 0) list_cnt[lo + i] = cnt;
+  }
+}
+
+// ------------------------------------------------------------------ tasks ------
+__global__ void k_task_setup(StageAView a, const int32_t* map_view, const uint32_t* map_entry, const uint32_t* map_n,
+                             TaskDesc* tasks, uint32_t* n_hyp) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.n_tasks) return;
+  TaskDesc d;
+  task_setup(a, t, map_view, map_entry, map_n, d);
+  tasks[t] = d;
+  n_hyp[t] = d.n_hyp;
+}
+
+__device__ __forceinline__ uint32_t find_owner(const uint32_t* off, uint32_t n, uint32_t x) {
+  // largest t in [0,n) with off[t] <= x (off ascending, off[n] > x)
+  uint32_t lo = 0, hi = n;
+  while (hi - lo > 1) {
+    uint32_t mid = (lo + hi) >> 1;
+    if (off[mid] <= x)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// ------------------------------------------------------------------ K3a --------
+// One lane per hypothesis, wave-synchronous batches of 64 so every lane of a wave starts the
+// same routine together (divergence then comes only from data-dependent trip counts). Each
+// lane owns two HPoint lists in the scratch arena; finished lists that later stages need are
+// copied to a bump-allocated result arena.
+__global__ void __launch_bounds__(256) k3a_hypotheses(DevScene s, StageAView a, const TaskDesc* tasks,
+                                                     const uint32_t* hyp_off, uint32_t n_hyp, HypResult* res,
+                                                     HPoint* scratch, uint32_t hyp_cap, HPoint* arena,
+                                                     uint32_t arena_cap, Counters* ctr) {
+  const uint32_t lane_global = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n_lanes = gridDim.x * blockDim.x;
+  HPoint* pts1 = scratch + (size_t)lane_global * 2 * hyp_cap;
+  HPoint* pts2 = pts1 + hyp_cap;
+  for (uint32_t h = lane_global; h < n_hyp; h += n_lanes) {
+    const uint32_t t = find_owner(hyp_off, a.n_tasks, h);
+    const TaskDesc d = tasks[t];
+    Obs c[3];
+    hypothesis_hits(a, d, t, h - hyp_off[t], c);
+    HypResult r;
+    evaluate_hypothesis(s, c, pts1, pts2, hyp_cap, r);
+    uint32_t need1 = (r.status & HYP_COMPAT) ? r.n1 : 0;
+    uint32_t need2 = (r.status & HYP_D2) ? r.n2 : 0;
+    if (need1 + need2) {
+      uint32_t base = atomicAdd(&ctr->arena_used, need1 + need2);
+      if (base + need1 + need2 <= arena_cap) {
+        r.pts1_off = base;
+        r.pts2_off = base + need1;
+        for (uint32_t i = 0; i < need1; i++) arena[base + i] = pts1[i];
+        for (uint32_t i = 0; i < need2; i++) arena[base + need1 + i] = pts2[i];
+      } else {
+        atomicOr(&ctr->flags, CTR_ARENA_OVERFLOW);
+      }
+    }
+    if (r.flags) atomicOr(&ctr->flags, r.flags);
+    res[h] = r;
+  }
+}
+
+// ------------------------------------------------------------------ K3s --------
+__global__ void k3s_select(uint32_t n_tasks, const uint32_t* hyp_off, const HypResult* res, ChainSeed* seeds_out,
+                           uint32_t* valid) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tasks) return;
+  ChainSeed cs;
+  cs.task = t;
+  cs.winner = 0;
+  cs.pts2_src = 0xffffffffu;
+  cs.n1 = 0;
+  cs.n2 = 0;
+  bool ok = false;
+  if (hyp_off[t + 1] > hyp_off[t]) ok = select_task(res, hyp_off[t], hyp_off[t + 1], cs);
+  seeds_out[t] = cs;
+  valid[t] = ok ? 1u : 0u;
+}
+__global__ void k_compact_chains(uint32_t n_tasks, const ChainSeed* per_task, const uint32_t* valid,
+                                 const uint32_t* chain_off, ChainSeed* chains) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tasks) return;
+  if (valid[t]) chains[chain_off[t]] = per_task[t];
+}
+
+// ------------------------------------------------------------------ K3b --------
+__global__ void __launch_bounds__(64) k3b_expand(DevScene s, StageAView a, const TaskDesc* tasks,
+                                                 const ChainSeed* chains, uint32_t n_chains, const uint32_t* hyp_off,
+                                                 const HypResult* res, const HPoint* arena, const int32_t* map_view,
+                                                 const uint32_t* map_entry, const uint32_t* map_n, ChainLayout L,
+                                                 unsigned char* scratch, ChainOut* outs, uint32_t* out_points,
+                                                 uint32_t* out_obs, Counters* ctr) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_chains) return;
+  const ChainSeed cs = chains[j];
+  const TaskDesc d = tasks[cs.task];
+  ChainOut co;
+  expand_chain(s, a, d, cs, hyp_off[cs.task], res, arena, map_view, map_entry, map_n, L, scratch + L.total * (size_t)j,
+               co);
+  outs[j] = co;
+  out_points[j] = co.n_points;
+  out_obs[j] = co.n_obs;
+  if (co.flags) atomicOr(&ctr->flags, co.flags);
+}
+
+// ------------------------------------------------------------------ K4 ---------
+__global__ void k4_emit(const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains, ChainLayout L,
+                        const unsigned char* scratch, const ChainOut* outs, const uint32_t* point_off,
+                        const uint32_t* obs_off_in, uint64_t point_base, uint64_t obs_base, float* X, uint32_t* obs_off,
+                        int32_t* obs_view, uint32_t* obs_pl, uint32_t* obs_seg, float* obs_xy, uint32_t* key) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_chains) return;
+  emit_chain(L, scratch + L.total * (size_t)j, outs[j], tasks[chains[j].task], point_base + point_off[j],
+             obs_base + obs_off_in[j], X, obs_off, obs_view, obs_pl, obs_seg, obs_xy, key);
+}
+
+// ------------------------------------------------------------------ K5 ---------
+__global__ void __launch_bounds__(256) k5_gn_filter(const float* cam_P, const float* X, const uint32_t* obs_off,
+                                                   const int32_t* obs_view, const float* obs_xy, uint64_t n,
+                                                   float gn_max_mse, int legacy_abs, float* X_out, uint8_t* inlier) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t a = obs_off[i], b = obs_off[i + 1];
+  float x0[3] = {X[3 * i], X[3 * i + 1], X[3 * i + 2]}, o[3];
+  const bool ok = gauss_newton_f32(cam_P, obs_view + a, obs_xy + 2 * (size_t)a, (int)(b - a), x0, gn_max_mse,
+                                   legacy_abs != 0, o);
+  inlier[i] = ok ? 1 : 0;
+  X_out[3 * i] = ok ? o[0] : x0[0];
+  X_out[3 * i + 1] = ok ? o[1] : x0[1];
+  X_out[3 * i + 2] = ok ? o[2] : x0[2];
+}
+
+// ------------------------------------------------------------ launch wrappers --
+static inline dim3 blocks_for(uint64_t n, uint32_t per_block) { return dim3((unsigned)((n + per_block - 1) / per_block)); }
+
+void launch_seed_prep(hipStream_t st, SeedsDev sd, uint32_t seed_begin, uint32_t n_seeds, uint32_t sv_base,
+                      uint32_t* sv_seed, int32_t* map_view, uint32_t* map_entry, uint32_t* map_n) {
+  if (!n_seeds) return;
+  hipLaunchKernelGGL(k_seed_prep, blocks_for(n_seeds, 256), dim3(256), 0, st, sd, seed_begin, n_seeds, sv_base, sv_seed,
+                     map_view, map_entry, map_n);
+}
+void launch_k1_count_raw(hipStream_t st, DevScene s, SeedsDev sd, uint32_t sv_base, uint32_t n_sv, const uint32_t* sv_seed,
+                         uint32_t* raw_cnt) {
+  if (!n_sv) return;
+  hipLaunchKernelGGL(k1_count_raw, blocks_for(n_sv, 256), dim3(256), 0, st, s, sd, sv_base, n_sv, sv_seed, raw_cnt);
+}
+void launch_k1(hipStream_t st, DevScene s, SeedsDev sd, uint32_t sv_base, uint32_t n_sv, const uint32_t* sv_seed,
+               const uint32_t* raw_off, uint32_t* cand_pl, Obs* start_hits, uint32_t* cand_cnt, uint32_t* start_cnt) {
+  if (!n_sv) return;
+  hipLaunchKernelGGL(k1_seed_candidates, blocks_for((uint64_t)n_sv * 64, 256), dim3(256), 0, st, s, sd, sv_base, n_sv,
+                     sv_seed, raw_off, cand_pl, start_hits, cand_cnt, start_cnt);
+}
+void launch_task_fill(hipStream_t st, SeedsDev sd, uint32_t sv_base, uint32_t n_sv, const uint32_t* sv_seed,
+                      const uint32_t* start_cnt, const uint32_t* task_off, uint32_t* task_seed, uint32_t* task_entry,
+                      uint32_t* task_hit, uint32_t* task_k) {
+  if (!n_sv) return;
+  hipLaunchKernelGGL(k_task_fill, blocks_for(n_sv, 256), dim3(256), 0, st, sd, sv_base, n_sv, sv_seed, start_cnt,
+                     task_off, task_seed, task_entry, task_hit, task_k);
+}
+void launch_k2(hipStream_t st, bool fill, DevScene s, SeedsDev sd, uint32_t sv_base, uint32_t n_tasks,
+               const uint32_t* task_seed, const uint32_t* task_entry, const uint32_t* task_hit,
+               const uint32_t* task_list_off, const uint32_t* raw_off, const uint32_t* cand_pl, const uint32_t* cand_cnt,
+               const Obs* start_hits, uint32_t* list_cnt, const uint32_t* list_ptr, Obs* hits) {
+  if (!n_tasks) return;
+  if (fill)
+    hipLaunchKernelGGL(k2_epipolar_hits<true>, blocks_for((uint64_t)n_tasks * 64, 256), dim3(256), 0, st, s, sd, sv_base,
+                       n_tasks, task_seed, task_entry, task_hit, task_list_off, raw_off, cand_pl, cand_cnt, start_hits,
+                       list_cnt, list_ptr, hits);
+  else
+    hipLaunchKernelGGL(k2_epipolar_hits<false>, blocks_for((uint64_t)n_tasks * 64, 256), dim3(256), 0, st, s, sd,
+                       sv_base, n_tasks, task_seed, task_entry, task_hit, task_list_off, raw_off, cand_pl, cand_cnt,
+                       start_hits, list_cnt, list_ptr, hits);
+}
+void launch_task_setup(hipStream_t st, StageAView a, const int32_t* map_view, const uint32_t* map_entry,
+                       const uint32_t* map_n, TaskDesc* tasks, uint32_t* n_hyp) {
+  if (!a.n_tasks) return;
+  hipLaunchKernelGGL(k_task_setup, blocks_for(a.n_tasks, 256), dim3(256), 0, st, a, map_view, map_entry, map_n, tasks,
+                     n_hyp);
+}
+void launch_k3a(hipStream_t st, uint32_t n_blocks, DevScene s, StageAView a, const TaskDesc* tasks,
+                const uint32_t* hyp_off, uint32_t n_hyp, HypResult* res, HPoint* scratch, uint32_t hyp_cap, HPoint* arena,
+                uint32_t arena_cap, Counters* ctr) {
+  if (!n_hyp) return;
+  hipLaunchKernelGGL(k3a_hypotheses, dim3(n_blocks), dim3(256), 0, st, s, a, tasks, hyp_off, n_hyp, res, scratch,
+                     hyp_cap, arena, arena_cap, ctr);
+}
+void launch_k3s(hipStream_t st, uint32_t n_tasks, const uint32_t* hyp_off, const HypResult* res, ChainSeed* per_task,
+                uint32_t* valid) {
+  if (!n_tasks) return;
+  hipLaunchKernelGGL(k3s_select, blocks_for(n_tasks, 256), dim3(256), 0, st, n_tasks, hyp_off, res, per_task, valid);
+}
+void launch_compact_chains(hipStream_t st, uint32_t n_tasks, const ChainSeed* per_task, const uint32_t* valid,
+                           const uint32_t* chain_off, ChainSeed* chains) {
+  if (!n_tasks) return;
+  hipLaunchKernelGGL(k_compact_chains, blocks_for(n_tasks, 256), dim3(256), 0, st, n_tasks, per_task, valid, chain_off,
+                     chains);
+}
+void launch_k3b(hipStream_t st, DevScene s, StageAView a, const TaskDesc* tasks, const ChainSeed* chains,
+                uint32_t n_chains, const uint32_t* hyp_off, const HypResult* res, const HPoint* arena,
+                const int32_t* map_view, const uint32_t* map_entry, const uint32_t* map_n, ChainLayout L,
+                unsigned char* scratch, ChainOut* outs, uint32_t* out_points, uint32_t* out_obs, Counters* ctr) {
+  if (!n_chains) return;
+  hipLaunchKernelGGL(k3b_expand, blocks_for(n_chains, 64), dim3(64), 0, st, s, a, tasks, chains, n_chains, hyp_off, res,
+                     arena, map_view, map_entry, map_n, L, scratch, outs, out_points, out_obs, ctr);
+}
+void launch_k4(hipStream_t st, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains, ChainLayout L,
+               const unsigned char* scratch, const ChainOut* outs, const uint32_t* point_off, const uint32_t* obs_off_in,
+               uint64_t point_base, uint64_t obs_base, float* X, uint32_t* obs_off, int32_t* obs_view, uint32_t* obs_pl,
+               uint32_t* obs_seg, float* obs_xy, uint32_t* key) {
+  if (!n_chains) return;
+  hipLaunchKernelGGL(k4_emit, blocks_for(n_chains, 64), dim3(64), 0, st, tasks, chains, n_chains, L, scratch, outs,
+                     point_off, obs_off_in, point_base, obs_base, X, obs_off, obs_view, obs_pl, obs_seg, obs_xy, key);
+}
+void launch_k5(hipStream_t st, const float* cam_P, const float* X, const uint32_t* obs_off, const int32_t* obs_view,
+               const float* obs_xy, uint64_t n, float gn_max_mse, int legacy_abs, float* X_out, uint8_t* inlier) {
+  if (!n) return;
+  hipLaunchKernelGGL(k5_gn_filter, blocks_for(n, 256), dim3(256), 0, st, cam_P, X, obs_off, obs_view, obs_xy, n,
+                     gn_max_mse, legacy_abs, X_out, inlier);
+}
+
+}  // namespace eg3d

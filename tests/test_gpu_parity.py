@@ -1,0 +1,90 @@
+"""-m gpu: the parity tests proper. The HIP path is called through the C ABI and compared with
+the CPU oracle on the same seeded inputs (exact structure; X within 1e-4 relative as
+BASELINE.json's north_star states — in practice the arithmetic contract makes it bit-exact)."""
+import numpy as np
+import pytest
+
+from edgegraph3d_amd import api, host
+from parity_util import compare_edgepoints
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(scene):
+    from oracle import binding as ob
+    return ob.Oracle(scene)
+
+
+@pytest.fixture(scope="module")
+def have_gpu():
+    assert api.device_count() >= 1, "no HIP device: the product path has no CPU fallback"
+
+
+@pytest.mark.parametrize("cfg", [0, 1])
+def test_grids_match_oracle(have_gpu, cfg):
+    s = host.Synth(cfg)
+    ctx = api.Context(s.scene)
+    o = _oracle(s.scene)
+    for v in range(s.n_views):
+        for which in (0, 1):
+            a, b = ctx.grid(v, which), o.grid(v, which)
+            assert a[0] == b[0] and a[1] == b[1]
+            assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    ctx.close()
+
+
+@pytest.mark.parametrize("cfg", [0, 1])
+def test_stage_a_candidates_exact(have_gpu, cfg):
+    s = host.Synth(cfg)
+    ctx = api.Context(s.scene)
+    got = ctx.candidates(s.seeds, 0, s.n_seeds)
+    ref = _oracle(s.scene).candidates(s.seeds, 0, s.n_seeds)
+    for k in ("n_sv", "n_tasks"):
+        assert got[k] == ref[k], k
+    for k in ("cand_off", "cand_pl", "start_off", "start_pl", "start_seg", "task_sv", "task_hit", "task_list_off",
+              "list_off", "hit_pl", "hit_seg"):
+        assert np.array_equal(got[k], ref[k]), k
+    for k in ("start_xy", "hit_xy"):
+        assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), k + " not bit-exact"
+    ctx.close()
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+def test_full_path_parity(have_gpu, cfg):
+    s = host.Synth(cfg)
+    ctx = api.Context(s.scene)
+    got = ctx.match_refpoints(s.seeds)
+    ref = _oracle(s.scene).match(s.seeds, 0, s.n_seeds, nthreads=8)
+    rep = compare_edgepoints(ref, got, rel_tol=1e-4)
+    assert rep["ok"], rep["msgs"]
+    assert got["n_chains"] == ref["stats"]["n_chains"]
+    assert got["n_tasks"] == ref["stats"]["n_tasks"]
+    assert (got["flags"] & 7) == 0, "device capacity flag raised"
+    ctx.close()
+
+
+def test_seed_range_concatenation(have_gpu):
+    """Ranges are independent: [0,n/2) + [n/2,n) == [0,n) (the multi-GPU sharding property)."""
+    s = host.Synth(1)
+    ctx = api.Context(s.scene)
+    ctx.upload_seeds(s.seeds)
+    n = s.n_seeds
+    full = ctx.match_resident(0, n)
+    a = ctx.match_resident(0, n // 2)
+    b = ctx.match_resident(n // 2, n)
+    assert a["n_points"] + b["n_points"] == full["n_points"]
+    assert np.array_equal(np.concatenate([a["X"], b["X"]]).view(np.uint32), full["X"].view(np.uint32))
+    assert np.array_equal(np.concatenate([a["key"], b["key"]]), full["key"])
+    ctx.close()
+
+
+def test_gn_filter_parity(have_gpu):
+    s = host.Synth(1)
+    X, off, view, xy = s.points(20000)
+    ctx = api.Context(s.scene)
+    Xo, inl, ms = ctx.gn_filter(X, off, view, xy, 3.0)
+    Xr, ir = _oracle(s.scene).gn_filter(X, off, view, xy, 3.0, nthreads=8)
+    assert np.array_equal(inl, ir)
+    assert np.array_equal(Xo.view(np.uint32), Xr.view(np.uint32))
+    assert 0.5 < inl.mean() < 1.0
+    ctx.close()
