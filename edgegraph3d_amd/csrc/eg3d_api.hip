@@ -733,3 +733,7 @@ extern "C" int eg3d_gn_filter(eg3d_ctx* c, const float* X, const uint32_t* obs_o
   if (ms_kernel) HIP_TRY(hipEventElapsedTime(ms_kernel, c->ev[0], c->ev[1]));
   return EG3D_OK;
 }
+
+// accessors for the diagnostic probes (eg3d_probe.hip)
+extern "C" const float* eg3d_internal_cam_P(eg3d_ctx* c) { return c->ds.cam_P; }
+extern "C" hipStream_t eg3d_internal_stream(eg3d_ctx* c) { return c->stream; }

@@ -1,0 +1,130 @@
+// Diagnostic probes (include/eg3d_probe.h): run device primitives in isolation so tests can
+// verify the arithmetic contract bit-for-bit on the GPU.
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/eg3d_probe.h"
+#include "eg3d_dev_pipeline.h"
+
+using namespace eg3d;
+
+__global__ void k_probe_arith(uint64_t n, const double* a, const double* b, const double* c, double* od, const float* fa,
+                              const float* fb, const float* fc, float* of) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  od[0 * n + i] = a[i] / b[i];
+  od[1 * n + i] = EG3D_SQRT(absd(a[i]));
+  double p = a[i] * b[i];
+  od[2 * n + i] = p + c[i];
+  od[3 * n + i] = (double)(float)a[i];
+  od[4 * n + i] = 1. / EG3D_SQRT(absd(b[i]));
+  of[0 * n + i] = fa[i] / fb[i];
+  of[1 * n + i] = EG3D_SQRTF(EG3D_FABSF(fa[i]));
+  float q = fa[i] * fb[i];
+  of[2 * n + i] = q + fc[i];
+  of[3 * n + i] = dist2(fa[i], fb[i], fc[i], fa[i]);
+  of[4 * n + i] = __builtin_sqrtf(EG3D_FABSF(fa[i]));
+}
+
+__global__ void k_probe_tri(const float* cam_P, uint64_t n, int k, const int32_t* views, const float* xy, float* X,
+                            uint8_t* valid, double* dlt) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Obs a[16];
+  for (int j = 0; j < k && j < 16; j++) {
+    a[j].view = views[i * k + j];
+    a[j].pl = 0;
+    a[j].seg = 0;
+    a[j].x = xy[2 * (i * k + j)];
+    a[j].y = xy[2 * (i * k + j) + 1];
+  }
+  uint32_t flags = 0;
+  float Xo[3] = {0, 0, 0};
+  bool ok = triangulate_array(cam_P, a, k, Xo, flags);
+  valid[i] = ok;
+  X[3 * i] = Xo[0];
+  X[3 * i + 1] = Xo[1];
+  X[3 * i + 2] = Xo[2];
+  int mi = 0;
+  for (int j = 0; j < k; j++)
+    if (a[j].view < a[mi].view) mi = j;
+  double X0[3];
+  dlt2(cam_P + (size_t)a[mi].view * 16, a[mi].x, a[mi].y, cam_P + (size_t)a[k - 1].view * 16, a[k - 1].x, a[k - 1].y, X0);
+  dlt[3 * i] = X0[0];
+  dlt[3 * i + 1] = X0[1];
+  dlt[3 * i + 2] = X0[2];
+}
+
+// the context layout is private to eg3d_api.hip; probes only need the camera table, fetched
+// through this accessor
+extern "C" const float* eg3d_internal_cam_P(eg3d_ctx* c);
+extern "C" hipStream_t eg3d_internal_stream(eg3d_ctx* c);
+
+#define PT(expr)                         \
+  do {                                   \
+    if ((expr) != hipSuccess) return -2; \
+  } while (0)
+
+extern "C" int eg3d_probe_arith(eg3d_ctx* ctx, uint64_t n, const double* a, const double* b, const double* c, double* od,
+                                const float* fa, const float* fb, const float* fc, float* of) {
+  if (!ctx) return -1;
+  double *da, *db, *dc, *dod;
+  float *dfa, *dfb, *dfc, *dof;
+  PT(hipMalloc(&da, n * 8));
+  PT(hipMalloc(&db, n * 8));
+  PT(hipMalloc(&dc, n * 8));
+  PT(hipMalloc(&dod, n * 8 * 5));
+  PT(hipMalloc(&dfa, n * 4));
+  PT(hipMalloc(&dfb, n * 4));
+  PT(hipMalloc(&dfc, n * 4));
+  PT(hipMalloc(&dof, n * 4 * 5));
+  PT(hipMemcpy(da, a, n * 8, hipMemcpyHostToDevice));
+  PT(hipMemcpy(db, b, n * 8, hipMemcpyHostToDevice));
+  PT(hipMemcpy(dc, c, n * 8, hipMemcpyHostToDevice));
+  PT(hipMemcpy(dfa, fa, n * 4, hipMemcpyHostToDevice));
+  PT(hipMemcpy(dfb, fb, n * 4, hipMemcpyHostToDevice));
+  PT(hipMemcpy(dfc, fc, n * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_probe_arith, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, n, da, db, dc, dod, dfa, dfb, dfc,
+                     dof);
+  PT(hipDeviceSynchronize());
+  PT(hipMemcpy(od, dod, n * 8 * 5, hipMemcpyDeviceToHost));
+  PT(hipMemcpy(of, dof, n * 4 * 5, hipMemcpyDeviceToHost));
+  (void)hipFree(da);
+  (void)hipFree(db);
+  (void)hipFree(dc);
+  (void)hipFree(dod);
+  (void)hipFree(dfa);
+  (void)hipFree(dfb);
+  (void)hipFree(dfc);
+  (void)hipFree(dof);
+  return 0;
+}
+
+extern "C" int eg3d_probe_triangulate(eg3d_ctx* ctx, uint64_t n, int k, const int32_t* views, const float* xy, float* X,
+                                      uint8_t* valid, double* dlt) {
+  if (!ctx || k < 2 || k > 16) return -1;
+  int32_t* dv;
+  float *dxy, *dX;
+  uint8_t* dval;
+  double* ddlt;
+  PT(hipMalloc(&dv, n * k * 4));
+  PT(hipMalloc(&dxy, n * k * 8));
+  PT(hipMalloc(&dX, n * 12));
+  PT(hipMalloc(&dval, n));
+  PT(hipMalloc(&ddlt, n * 24));
+  PT(hipMemcpy(dv, views, n * k * 4, hipMemcpyHostToDevice));
+  PT(hipMemcpy(dxy, xy, n * k * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_probe_tri, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, eg3d_internal_cam_P(ctx), n, k, dv, dxy,
+                     dX, dval, ddlt);
+  PT(hipDeviceSynchronize());
+  PT(hipMemcpy(X, dX, n * 12, hipMemcpyDeviceToHost));
+  PT(hipMemcpy(valid, dval, n, hipMemcpyDeviceToHost));
+  PT(hipMemcpy(dlt, ddlt, n * 24, hipMemcpyDeviceToHost));
+  (void)hipFree(dv);
+  (void)hipFree(dxy);
+  (void)hipFree(dX);
+  (void)hipFree(dval);
+  (void)hipFree(ddlt);
+  return 0;
+}

@@ -1,0 +1,21 @@
+/*
+ * eg3d_probe.h — diagnostic entry points of libeg3d.so: they run single device primitives
+ * (IEEE arithmetic, triangulation, polyline walks) on the GPU so the tests can check the
+ * arithmetic contract bit-for-bit against the CPU oracle. Not part of the drop-in surface.
+ */
+#ifndef EG3D_PROBE_H_
+#define EG3D_PROBE_H_
+#include "eg3d.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* out_d[5][n]: a/b, sqrt(|a|), a*b+c (two roundings), (double)(float)a, 1/sqrt; out_f likewise in float */
+int eg3d_probe_arith(eg3d_ctx* ctx, uint64_t n, const double* a, const double* b, const double* c, double* out_d,
+                     const float* fa, const float* fb, const float* fc, float* out_f);
+/* n_cases triangulations of k observations each (views index ctx's cameras) */
+int eg3d_probe_triangulate(eg3d_ctx* ctx, uint64_t n_cases, int k, const int32_t* views, const float* xy, float* X,
+                           uint8_t* valid, double* dlt_X0);
+#ifdef __cplusplus
+}
+#endif
+#endif
