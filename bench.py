@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the refpoint -> epipolar match -> triangulate hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path (eg3d_match_resident: K1..K4) over one batch of synthetic
+seeds whose scene and tracks are already resident in HBM. N=1 runs BASELINE.json configs[1]
+(C2: 8 views / 2000 seeds / ~5k polyline segments per view). For N>1 (launched by
+torch.distributed.run, one rank per GPU) every rank owns its own 2000-seed shard of the same
+scene (weak scaling) and the step ends with an RCCL all-gather of the edge-point cloud over xGMI.
+Rank 0 prints ONE JSON line. value = whole-job edge-points per second.
+
+Besides the contract fields the line carries `roofline` (dominant kernel, HBM bound, algorithmic
+bytes of SURVEY 8(d) / that kernel's HIP-event duration) and `cpu_baseline` (the CPU oracle,
+1 thread, timed on this box on the same workload; N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+SEEDS_PER_GPU = 2000
+STAGES = [("k1_seed_candidates", "ms_candidates"), ("k2_epipolar_hits", "ms_epipolar"),
+          ("k3a_hypotheses", "ms_hypotheses"), ("k3s_select", "ms_select"), ("k3b_expand", "ms_expand"),
+          ("k4_emit", "ms_emit")]
+
+
+class _DevArr:
+    """Expose a raw HBM pointer to torch through __cuda_array_interface__ (no copy)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
+                                         "version": 2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, help="synthetic config index (2 = C2, BASELINE configs[1])")
+    ap.add_argument("--seeds-per-gpu", type=int, default=0, help="override the per-GPU seed count")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-runs", type=int, default=5)
+    args = ap.parse_args()
+
+    import torch
+    from edgegraph3d_amd import api, host
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, args.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if api.device_count() < 1 or not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfg = host.default_config(args.config)
+    per_gpu = args.seeds_per_gpu or cfg.n_seeds
+    if args.config == 2 and not args.seeds_per_gpu:
+        per_gpu = SEEDS_PER_GPU
+    cfg.n_seeds = per_gpu * world  # same scene on every rank; rank r owns seeds [r*per_gpu, (r+1)*per_gpu)
+    synth = host.Synth(cfg)
+    ctx = api.Context(synth.scene, local_rank)
+    ctx.upload_seeds(synth.seeds)   # inputs resident in HBM before the timed region
+    b, e = rank * per_gpu, (rank + 1) * per_gpu
+
+    staging = {}
+
+    def allgather_cloud():
+        """RCCL all-gather of the variable-length edge-point cloud: counts, then one padded
+        all_gather_into_tensor of [X | obs_off | key | obs_view | obs_pl | obs_seg | obs_xy]."""
+        d = ctx.last_device_output()
+        if not d.complete:
+            raise RuntimeError("bench: output spans several chunks; shrink the per-GPU batch")
+        np_, no_ = int(d.n_points), int(d.n_obs)
+        cnt = torch.tensor([np_, no_], dtype=torch.int64, device=dev)
+        allc = torch.empty(2 * world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allc, cnt)
+        allc = allc.view(world, 2).cpu()
+        mp, mo = int(allc[:, 0].max()), int(allc[:, 1].max())
+        nbytes = mp * (12 + 4 + 16) + mo * (4 + 4 + 4 + 8)
+        if staging.get("n", 0) < nbytes:
+            staging["n"] = int(nbytes * 1.25) + 256
+            staging["send"] = torch.empty(staging["n"], dtype=torch.uint8, device=dev)
+            staging["recv"] = torch.empty(staging["n"] * world, dtype=torch.uint8, device=dev)
+        send = staging["send"][:nbytes]
+        o = 0
+        # (device pointer, bytes per element, elements this rank has, padded element count)
+        for ptr, per, have, cap in ((d.X, 12, np_, mp), (d.obs_off, 4, np_, mp), (d.key, 16, np_, mp),
+                                    (d.obs_view, 4, no_, mo), (d.obs_pl, 4, no_, mo), (d.obs_seg, 4, no_, mo),
+                                    (d.obs_xy, 8, no_, mo)):
+            if have:
+                src = torch.as_tensor(_DevArr(ptr, have * per), device=dev)
+                send[o:o + have * per].copy_(src)
+            o += cap * per
+        recv = staging["recv"][:nbytes * world]
+        dist.all_gather_into_tensor(recv, send)
+        return int(allc[:, 0].sum())
+
+    def step():
+        r = ctx.match_resident(b, e, device_only=True)
+        total = r["n_points"]
+        if world > 1:
+            total = allgather_cloud()
+        return r, total
+
+    for _ in range(args.warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stage_ms = {k: [] for _, k in STAGES}
+    bytes_alg = 0
+    last = None
+    total_points = 0
+    for _ in range(args.steps):
+        last, total_points = step()
+        for _, k in STAGES:
+            stage_ms[k].append(last["times"][k])
+        bytes_alg = last["times"]["bytes_algorithmic"]
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = total_points * args.steps / elapsed
+        avg = {k: (sum(v) / len(v) if v else 0.0) for k, v in stage_ms.items()}
+        dom_name, dom_key = max(STAGES, key=lambda s: avg[s[1]])
+        dom_ms = avg[dom_key]
+        achieved = (bytes_alg / (dom_ms * 1e-3)) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(dom_name, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "triangulated edge-points/sec", "value": value, "unit": "edge-points/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": "C%d synthetic: %d views / %d seeds per GPU / %.0f polyline segments per view"
+                            % (args.config, synth.n_views, per_gpu, synth.total_segments / synth.n_views),
+                "edge_points_per_step": int(total_points), "observations_per_step_rank0": int(last["n_obs"]),
+                "tasks": int(last["n_tasks"]), "hypotheses": int(last["n_hypotheses"]), "chains": int(last["n_chains"]),
+                "parallelism": "seed-shard x%d%s" % (world, " + RCCL all-gather of the cloud" if world > 1 else ""),
+                "arithmetic": "2-D geometry f32, DLT+Gauss-Newton f64 (as the reference)",
+            },
+            "stage_ms": {n: round(avg[k], 4) for n, k in STAGES},
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(bytes_alg), "kernel_ms": dom_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import binding as ob   # cpu_baseline leg: the checker timed as the CPU port
+            orc = ob.Oracle(synth.scene)
+            orc.match(synth.seeds, b, min(e, b + 200), 1)  # warm-up
+            secs, pts = [], 0
+            for _ in range(max(1, args.cpu_runs)):
+                r = orc.match(synth.seeds, b, e, 1)
+                secs.append(r["stats"]["seconds"])
+                pts = r["n_points"]
+            med = statistics.median(secs)
+            ncores = os.cpu_count() or 1
+            rall = orc.match(synth.seeds, b, e, ncores)
+            line["cpu_baseline"] = {
+                "value": pts / med, "unit": "edge-points/s", "cores": 1, "kind": "port",
+                "sample": "full N=1 workload (%d seeds, %d edge-points), oracle -O3, 1 thread, median of %d runs "
+                          "(%.2f s each); scene/grid construction excluded" % (per_gpu, pts, len(secs), med),
+                "all_cores": {"value": rall["n_points"] / rall["stats"]["seconds"], "cores": ncores},
+                "same_point_count_as_gpu": bool(pts == total_points),
+                "oracle_algorithmic_bytes": int(r["stats"]["bytes_algorithmic"]),
+            }
+            line["speedup_vs_cpu_1thread"] = value / (pts / med)
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -41,6 +41,12 @@ class StageTimes(C.Structure):
                 ("ms_emit", C.c_float), ("bytes_algorithmic", C.c_uint64)]
 
 
+class DeviceEdgePoints(C.Structure):
+    _fields_ = [("n_points", C.c_uint64), ("n_obs", C.c_uint64), ("X", C.c_void_p), ("obs_off", C.c_void_p),
+                ("obs_view", C.c_void_p), ("obs_pl", C.c_void_p), ("obs_seg", C.c_void_p), ("obs_xy", C.c_void_p),
+                ("key", C.c_void_p), ("complete", C.c_int32)]
+
+
 class SynthConfig(C.Structure):
     _fields_ = [("n_views", C.c_int32), ("n_seeds", C.c_uint32), ("n_curves", C.c_int32),
                 ("rng_seed", C.c_uint64), ("max_track", C.c_int32), ("obs_noise_px", C.c_float),

@@ -46,6 +46,7 @@ def lib():
         L.eg3d_upload_seeds.argtypes = [C.c_void_p, C.POINTER(D.Seeds)]
         L.eg3d_match_resident.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(D.EdgePoints),
                                           C.POINTER(D.StageTimes)]
+        L.eg3d_last_device_output.argtypes = [C.c_void_p, C.POINTER(D.DeviceEdgePoints)]
         L.eg3d_gn_filter.argtypes = [C.c_void_p, D.f32p, D.u32p, D.i32p, D.f32p, C.c_uint64, C.c_float, C.c_int,
                                      D.f32p, D.u8p, D.f32p]
         _LIB = L
@@ -56,7 +57,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "eg3d_last_error", "eg3d_device_count", "eg3d_create", "eg3d_destroy", "eg3d_get_grid", "eg3d_candidates_run",
     "eg3d_free_candidates", "eg3d_match_refpoints", "eg3d_free_edgepoints", "eg3d_upload_seeds",
-    "eg3d_match_resident", "eg3d_gn_filter",
+    "eg3d_match_resident", "eg3d_gn_filter", "eg3d_last_device_output",
 ]
 
 
@@ -115,6 +116,11 @@ class Context:
             end = int(seeds_ptr.contents.n_seeds) if hasattr(seeds_ptr, "contents") else int(seeds_ptr.n_seeds)
         self.upload_seeds(seeds_ptr)
         return self.match_resident(begin, end, device_only)
+
+    def last_device_output(self):
+        d = D.DeviceEdgePoints()
+        _check(lib().eg3d_last_device_output(self._h, C.byref(d)), "eg3d_last_device_output")
+        return d
 
     def candidates(self, seeds_ptr, begin, end):
         c = D.Candidates()

@@ -88,9 +88,11 @@ struct eg3d_ctx {
       b_cscratch, b_couts, b_cpts, b_cobs, b_cpoff, b_cooff, b_scan_tmp;
   DevBuf o_X, o_off, o_view, o_pl, o_seg, o_xy, o_key;
   DevBuf f_X, f_off, f_view, f_xy, f_Xo, f_inl;
-  hipEvent_t ev[8];
+  hipEvent_t ea[8], eb[8];  // begin/end events per stage: 1 K1, 2 K2, 3 K3a, 4 K3s, 5 K3b, 6 K4, 0 misc
   uint32_t chain_cap = 384, pool_cap = 0, hyp_cap = 160;
   uint32_t k3a_blocks = 0;
+  uint64_t last_np = 0, last_no = 0;
+  int last_chunks = 0;
 };
 
 template <typename T>
@@ -138,7 +140,10 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
   eg3d_ctx* c = new eg3d_ctx();
   c->device = device;
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  for (int i = 0; i < 8; i++) HIP_TRY(hipEventCreate(&c->ev[i]));
+  for (int i = 0; i < 8; i++) {
+    HIP_TRY(hipEventCreate(&c->ea[i]));
+    HIP_TRY(hipEventCreate(&c->eb[i]));
+  }
   const int V = sc->n_views;
   c->V = V;
   c->W = sc->width;
@@ -236,8 +241,10 @@ extern "C" void eg3d_destroy(eg3d_ctx* c) {
                    &c->b_cpoff, &c->b_cooff, &c->b_scan_tmp, &c->o_X, &c->o_off, &c->o_view, &c->o_pl, &c->o_seg,
                    &c->o_xy, &c->o_key, &c->f_X, &c->f_off, &c->f_view, &c->f_xy, &c->f_Xo, &c->f_inl};
   for (DevBuf* b : all) b->release();
-  for (int i = 0; i < 8; i++)
-    if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  for (int i = 0; i < 8; i++) {
+    if (c->ea[i]) (void)hipEventDestroy(c->ea[i]);
+    if (c->eb[i]) (void)hipEventDestroy(c->eb[i]);
+  }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -304,7 +311,8 @@ int run_stage_a(eg3d_ctx* c, BatchState& B, eg3d_stage_times* tm) {
   BUF_TRY(c->b_cand_cnt.ensure(sizeof(uint32_t) * (n_sv + 1)));
   BUF_TRY(c->b_start_cnt.ensure(sizeof(uint32_t) * (n_sv + 1)));
   BUF_TRY(c->b_task_off.ensure(sizeof(uint32_t) * (n_sv + 1)));
-  HIP_TRY(hipEventRecord(c->ev[0], st));
+  BUF_TRY(c->b_ctr.ensure(sizeof(Counters)));
+  HIP_TRY(hipMemsetAsync(c->b_ctr.p, 0, sizeof(Counters), st));
   launch_seed_prep(st, B.sd, B.b, B.n_seeds, B.sv_base, c->b_sv_seed.as<uint32_t>(), c->b_map_view.as<int32_t>(),
                    c->b_map_entry.as<uint32_t>(), c->b_map_n.as<uint32_t>());
   HIP_TRY(hipMemsetAsync(c->b_raw_cnt.as<uint32_t>() + n_sv, 0, sizeof(uint32_t), st));
@@ -314,10 +322,11 @@ int run_stage_a(eg3d_ctx* c, BatchState& B, eg3d_stage_times* tm) {
   BUF_TRY(c->b_cand_pl.ensure(sizeof(uint32_t) * (B.total_raw + 1)));
   BUF_TRY(c->b_start_hits.ensure(sizeof(Obs) * (B.total_raw + 1)));
   HIP_TRY(hipMemsetAsync(c->b_start_cnt.as<uint32_t>() + n_sv, 0, sizeof(uint32_t), st));
+  HIP_TRY(hipEventRecord(c->ea[1], st));
   launch_k1(st, c->ds, B.sd, B.sv_base, n_sv, c->b_sv_seed.as<uint32_t>(), c->b_raw_off.as<uint32_t>(),
             c->b_cand_pl.as<uint32_t>(), c->b_start_hits.as<Obs>(), c->b_cand_cnt.as<uint32_t>(),
-            c->b_start_cnt.as<uint32_t>());
-  HIP_TRY(hipEventRecord(c->ev[1], st));
+            c->b_start_cnt.as<uint32_t>(), c->b_ctr.as<Counters>());
+  HIP_TRY(hipEventRecord(c->eb[1], st));
   BUF_TRY(scan_exclusive_u32(c, c->b_start_cnt.as<uint32_t>(), c->b_task_off.as<uint32_t>(), n_sv + 1));
   BUF_TRY(read_u32(c, c->b_task_off.as<uint32_t>() + n_sv, B.n_tasks));
   const uint32_t nt = B.n_tasks;
@@ -335,6 +344,7 @@ int run_stage_a(eg3d_ctx* c, BatchState& B, eg3d_stage_times* tm) {
   BUF_TRY(c->b_list_cnt.ensure(sizeof(uint32_t) * (B.n_lists + 1)));
   BUF_TRY(c->b_list_ptr.ensure(sizeof(uint32_t) * (B.n_lists + 1)));
   HIP_TRY(hipMemsetAsync(c->b_list_cnt.as<uint32_t>() + B.n_lists, 0, sizeof(uint32_t), st));
+  HIP_TRY(hipEventRecord(c->ea[2], st));
   launch_k2(st, false, c->ds, B.sd, B.sv_base, nt, c->b_task_seed.as<uint32_t>(), c->b_task_entry.as<uint32_t>(),
             c->b_task_hit.as<uint32_t>(), c->b_task_list_off.as<uint32_t>(), c->b_raw_off.as<uint32_t>(),
             c->b_cand_pl.as<uint32_t>(), c->b_cand_cnt.as<uint32_t>(), c->b_start_hits.as<Obs>(),
@@ -346,7 +356,7 @@ int run_stage_a(eg3d_ctx* c, BatchState& B, eg3d_stage_times* tm) {
             c->b_task_hit.as<uint32_t>(), c->b_task_list_off.as<uint32_t>(), c->b_raw_off.as<uint32_t>(),
             c->b_cand_pl.as<uint32_t>(), c->b_cand_cnt.as<uint32_t>(), c->b_start_hits.as<Obs>(),
             c->b_list_cnt.as<uint32_t>(), c->b_list_ptr.as<uint32_t>(), c->b_hits.as<Obs>());
-  HIP_TRY(hipEventRecord(c->ev[2], st));
+  HIP_TRY(hipEventRecord(c->eb[2], st));
   StageAView& a = B.a;
   a.trk_off = B.sd.trk_off;
   a.trk_view = B.sd.trk_view;
@@ -371,7 +381,7 @@ struct HostOut {
   std::vector<int32_t> view;
   uint64_t n_points = 0, n_obs = 0, n_tasks = 0, n_hyp = 0, n_chains = 0;
   uint32_t flags = 0;
-  uint64_t bytes_algorithmic = 0;
+  uint64_t bytes_algorithmic = 0, bytes_vertices = 0;
   float ms[7] = {0, 0, 0, 0, 0, 0, 0};
 };
 
@@ -394,7 +404,6 @@ int run_batch(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, HostOut& H) 
   BUF_TRY(read_u32(c, c->b_hyp_off.as<uint32_t>() + nt, B.n_hyp));
   // ---- K3a
   BUF_TRY(c->b_res.ensure(sizeof(HypResult) * (B.n_hyp + 1)));
-  BUF_TRY(c->b_ctr.ensure(sizeof(Counters)));
   const uint32_t k3a_blocks =
       std::max<uint32_t>(1, std::min<uint32_t>(c->k3a_blocks, (B.n_hyp + 255) / 256));
   BUF_TRY(c->b_hscratch.ensure(sizeof(HPoint) * 2 * c->hyp_cap * (size_t)k3a_blocks * 256));
@@ -402,10 +411,12 @@ int run_batch(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, HostOut& H) 
   Counters hc;
   for (int attempt = 0;; attempt++) {
     BUF_TRY(c->b_arena.ensure(sizeof(HPoint) * (size_t)arena_cap));
-    HIP_TRY(hipMemsetAsync(c->b_ctr.p, 0, sizeof(Counters), st));
+    HIP_TRY(hipMemsetAsync(c->b_ctr.p, 0, 2 * sizeof(uint32_t), st));  // arena_used, flags (keep bytes)
+    HIP_TRY(hipEventRecord(c->ea[3], st));
     launch_k3a(st, k3a_blocks, c->ds, B.a, c->b_tasks.as<TaskDesc>(), c->b_hyp_off.as<uint32_t>(), B.n_hyp,
                c->b_res.as<HypResult>(), c->b_hscratch.as<HPoint>(), c->hyp_cap, c->b_arena.as<HPoint>(), arena_cap,
                c->b_ctr.as<Counters>());
+    HIP_TRY(hipEventRecord(c->eb[3], st));
     HIP_TRY(hipMemcpyAsync(&hc, c->b_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (!(hc.flags & CTR_ARENA_OVERFLOW)) break;
@@ -416,12 +427,12 @@ int run_batch(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, HostOut& H) 
     arena_cap = std::max<uint32_t>(arena_cap * 2, hc.arena_used + (hc.arena_used >> 2));
   }
   H.flags |= (hc.flags & 0xffu);
-  HIP_TRY(hipEventRecord(c->ev[3], st));
   // ---- K3s
   BUF_TRY(c->b_cs_task.ensure(sizeof(ChainSeed) * (nt + 1)));
   BUF_TRY(c->b_valid.ensure(sizeof(uint32_t) * (nt + 1)));
   BUF_TRY(c->b_chain_off.ensure(sizeof(uint32_t) * (nt + 1)));
   HIP_TRY(hipMemsetAsync(c->b_valid.as<uint32_t>() + nt, 0, sizeof(uint32_t), st));
+  HIP_TRY(hipEventRecord(c->ea[4], st));
   launch_k3s(st, nt, c->b_hyp_off.as<uint32_t>(), c->b_res.as<HypResult>(), c->b_cs_task.as<ChainSeed>(),
              c->b_valid.as<uint32_t>());
   BUF_TRY(scan_exclusive_u32(c, c->b_valid.as<uint32_t>(), c->b_chain_off.as<uint32_t>(), nt + 1));
@@ -429,7 +440,7 @@ int run_batch(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, HostOut& H) 
   BUF_TRY(c->b_chains.ensure(sizeof(ChainSeed) * (B.n_chains + 1)));
   launch_compact_chains(st, nt, c->b_cs_task.as<ChainSeed>(), c->b_valid.as<uint32_t>(), c->b_chain_off.as<uint32_t>(),
                         c->b_chains.as<ChainSeed>());
-  HIP_TRY(hipEventRecord(c->ev[4], st));
+  HIP_TRY(hipEventRecord(c->eb[4], st));
   // ---- K3b + K4 in chunks bounded by scratch size
   const ChainLayout L = chain_layout(c->chain_cap, c->pool_cap, (uint32_t)c->V);
   const size_t max_scratch = (size_t)24 << 30;
@@ -445,14 +456,14 @@ int run_batch(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, HostOut& H) 
     BUF_TRY(c->b_cooff.ensure(sizeof(uint32_t) * (nc + 1)));
     HIP_TRY(hipMemsetAsync(c->b_cpts.as<uint32_t>() + nc, 0, sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(c->b_cobs.as<uint32_t>() + nc, 0, sizeof(uint32_t), st));
-    HIP_TRY(hipMemsetAsync(c->b_ctr.p, 0, sizeof(Counters), st));
-    HIP_TRY(hipEventRecord(c->ev[5], st));
+    HIP_TRY(hipMemsetAsync(c->b_ctr.p, 0, 2 * sizeof(uint32_t), st));
+    HIP_TRY(hipEventRecord(c->ea[5], st));
     launch_k3b(st, c->ds, B.a, c->b_tasks.as<TaskDesc>(), c->b_chains.as<ChainSeed>() + c0, nc,
                c->b_hyp_off.as<uint32_t>(), c->b_res.as<HypResult>(), c->b_arena.as<HPoint>(),
                c->b_map_view.as<int32_t>(), c->b_map_entry.as<uint32_t>(), c->b_map_n.as<uint32_t>(), L,
                c->b_cscratch.as<unsigned char>(), c->b_couts.as<ChainOut>(), c->b_cpts.as<uint32_t>(),
                c->b_cobs.as<uint32_t>(), c->b_ctr.as<Counters>());
-    HIP_TRY(hipEventRecord(c->ev[6], st));
+    HIP_TRY(hipEventRecord(c->eb[5], st));
     BUF_TRY(scan_exclusive_u32(c, c->b_cpts.as<uint32_t>(), c->b_cpoff.as<uint32_t>(), nc + 1));
     BUF_TRY(scan_exclusive_u32(c, c->b_cobs.as<uint32_t>(), c->b_cooff.as<uint32_t>(), nc + 1));
     uint32_t np = 0, no = 0;
@@ -467,17 +478,19 @@ int run_batch(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, HostOut& H) 
     BUF_TRY(c->o_seg.ensure(sizeof(uint32_t) * ((size_t)no + 1)));
     BUF_TRY(c->o_xy.ensure(sizeof(float) * 2 * ((size_t)no + 1)));
     // chunk-local indices on the device; the global observation base is added on the host
+    HIP_TRY(hipEventRecord(c->ea[6], st));
     launch_k4(st, c->b_tasks.as<TaskDesc>(), c->b_chains.as<ChainSeed>() + c0, nc, L, c->b_cscratch.as<unsigned char>(),
               c->b_couts.as<ChainOut>(), c->b_cpoff.as<uint32_t>(), c->b_cooff.as<uint32_t>(), 0, 0, c->o_X.as<float>(),
               c->o_off.as<uint32_t>(), c->o_view.as<int32_t>(), c->o_pl.as<uint32_t>(), c->o_seg.as<uint32_t>(),
               c->o_xy.as<float>(), c->o_key.as<uint32_t>());
-    HIP_TRY(hipEventRecord(c->ev[7], st));
+    HIP_TRY(hipEventRecord(c->eb[6], st));
     HIP_TRY(hipStreamSynchronize(st));
     H.flags |= (hc.flags & 0xffu);
+    H.bytes_vertices = hc.bytes;  // running total of this batch (K1 + K3b so far)
     float t = 0;
-    HIP_TRY(hipEventElapsedTime(&t, c->ev[5], c->ev[6]));
+    HIP_TRY(hipEventElapsedTime(&t, c->ea[5], c->eb[5]));
     ms_expand += t;
-    HIP_TRY(hipEventElapsedTime(&t, c->ev[6], c->ev[7]));
+    HIP_TRY(hipEventElapsedTime(&t, c->ea[6], c->eb[6]));
     ms_emit += t;
     if (!device_only && np) {
       const size_t p0 = H.X.size() / 3, o0 = H.view.size();
@@ -499,19 +512,30 @@ int run_batch(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, HostOut& H) 
     }
     H.n_points += np;
     H.n_obs += no;
+    c->last_np = np;
+    c->last_no = no;
+    c->last_chunks++;
   }
   HIP_TRY(hipStreamSynchronize(st));
   float t = 0;
-  HIP_TRY(hipEventElapsedTime(&t, c->ev[0], c->ev[1]));
-  H.ms[1] += t;
-  HIP_TRY(hipEventElapsedTime(&t, c->ev[1], c->ev[2]));
-  H.ms[2] += t;
-  HIP_TRY(hipEventElapsedTime(&t, c->ev[2], c->ev[3]));
-  H.ms[3] += t;
-  HIP_TRY(hipEventElapsedTime(&t, c->ev[3], c->ev[4]));
-  H.ms[4] += t;
+  for (int k = 1; k <= 4; k++) {
+    if ((k == 2 && !B.n_tasks) || (k == 3 && !B.n_hyp) || (k == 4 && !B.n_tasks)) continue;
+    HIP_TRY(hipEventElapsedTime(&t, c->ea[k], c->eb[k]));
+    H.ms[k] += t;
+  }
   H.ms[5] += ms_expand;
   H.ms[6] += ms_emit;
+  if (!B.n_chains) {
+    HIP_TRY(hipMemcpy(&hc, c->b_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost));
+    H.bytes_vertices = hc.bytes;
+  }
+  // per seed 12 + k*12 + k*64 + k(k-1)*72, plus the vertices touched, plus the output
+  for (uint32_t sd_i = b; sd_i < e; sd_i++) {
+    const uint64_t k = c->h_trk_off[sd_i + 1] - c->h_trk_off[sd_i];
+    H.bytes_algorithmic += 12 + k * 12 + k * 64 + k * (k - 1) * 72;
+  }
+  H.bytes_algorithmic += H.bytes_vertices;
+  H.bytes_vertices = 0;
   H.n_tasks += B.n_tasks;
   H.n_hyp += B.n_hyp;
   H.n_chains += B.n_chains;
@@ -536,6 +560,8 @@ extern "C" int eg3d_match_resident(eg3d_ctx* c, uint32_t b, uint32_t e, int devi
   HIP_TRY(hipSetDevice(c->device));
   memset(out, 0, sizeof(*out));
   HostOut H;
+  c->last_np = c->last_no = 0;
+  c->last_chunks = 0;
   const uint32_t SEED_BATCH = 16384;
   hipEvent_t t0, t1;
   HIP_TRY(hipEventCreate(&t0));
@@ -576,12 +602,30 @@ extern "C" int eg3d_match_resident(eg3d_ctx* c, uint32_t b, uint32_t e, int devi
     times->ms_select = H.ms[4];
     times->ms_expand = H.ms[5];
     times->ms_emit = H.ms[6];
-    times->bytes_algorithmic = 0;
+    times->bytes_algorithmic = H.bytes_algorithmic + 12 * H.n_points + 20 * H.n_obs;
   }
   if (H.flags & (EG3D_FLAG_CHAIN_OVERFLOW | EG3D_FLAG_OBS_OVERFLOW | EG3D_FLAG_HYP_OVERFLOW)) {
     g_err = "eg3d: a device-side capacity was exceeded (flags in out->flags)";
     return EG3D_ERR_CAPACITY;
   }
+  return EG3D_OK;
+}
+
+extern "C" int eg3d_last_device_output(eg3d_ctx* c, eg3d_device_edgepoints* out) {
+  if (!c || !out) {
+    g_err = "eg3d_last_device_output: bad arguments";
+    return EG3D_ERR_ARG;
+  }
+  out->n_points = c->last_np;
+  out->n_obs = c->last_no;
+  out->X = c->o_X.as<float>();
+  out->obs_off = c->o_off.as<uint32_t>();
+  out->obs_view = c->o_view.as<int32_t>();
+  out->obs_pl = c->o_pl.as<uint32_t>();
+  out->obs_seg = c->o_seg.as<uint32_t>();
+  out->obs_xy = c->o_xy.as<float>();
+  out->key = c->o_key.as<uint32_t>();
+  out->complete = c->last_chunks <= 1 ? 1 : 0;
   return EG3D_OK;
 }
 
@@ -721,16 +765,16 @@ extern "C" int eg3d_gn_filter(eg3d_ctx* c, const float* X, const uint32_t* obs_o
   BUF_TRY(upload(c->f_xy, obs_xy, m * 2, st));
   BUF_TRY(c->f_Xo.ensure(sizeof(float) * 3 * (n + 1)));
   BUF_TRY(c->f_inl.ensure(n + 1));
-  HIP_TRY(hipEventRecord(c->ev[0], st));
+  HIP_TRY(hipEventRecord(c->ea[0], st));
   launch_k5(st, c->ds.cam_P, c->f_X.as<float>(), c->f_off.as<uint32_t>(), c->f_view.as<int32_t>(), c->f_xy.as<float>(),
             n, gn_max_mse, legacy_abs, c->f_Xo.as<float>(), c->f_inl.as<uint8_t>());
-  HIP_TRY(hipEventRecord(c->ev[1], st));
+  HIP_TRY(hipEventRecord(c->eb[0], st));
   if (n) {
     HIP_TRY(hipMemcpyAsync(X_out, c->f_Xo.p, sizeof(float) * 3 * n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(inlier, c->f_inl.p, n, hipMemcpyDeviceToHost, st));
   }
   HIP_TRY(hipStreamSynchronize(st));
-  if (ms_kernel) HIP_TRY(hipEventElapsedTime(ms_kernel, c->ev[0], c->ev[1]));
+  if (ms_kernel) HIP_TRY(hipEventElapsedTime(ms_kernel, c->ea[0], c->eb[0]));
   return EG3D_OK;
 }
 

@@ -47,6 +47,7 @@ struct Chain {
   uint8_t* tmp_mask;     // [tmp_cap]
   int32_t tmp_cap;
   uint32_t flags;
+  uint64_t bytes;  // vertices of 4 px-grid polylines tested (algorithmic bytes)
 };
 
 EG3D_HD ChainPt& chain_at(Chain& c, int i) { return c.pts[c.head + i]; }
@@ -399,6 +400,7 @@ EG3D_HD void expand_to_view(const DevScene& s, Chain& c, int v, const Obs* epc, 
     uint32_t pl_id;
     if (!unique_polyline_4px(s, v, u, w, pl_id)) continue;
     PlRef pl = polyline_of(s, v, pl_id);
+    c.bytes += 8ull * pl.n;
     PlPt cp;
     if (polyline_closest(pl, u, w, cp) > 16.0f) return;  // abandons this view (Q4)
     Obs o;

@@ -215,6 +215,7 @@ EG3D_HD void chain_bind(Chain& c, const ChainLayout& L, unsigned char* slice) {
 
 struct ChainOut {
   uint32_t n_points, n_obs, flags, head;
+  uint64_t bytes;
 };
 
 // Build the chain reverse(pts1) + central + pts2, then offer it to every view except the
@@ -227,6 +228,7 @@ EG3D_HD void expand_chain(const DevScene& s, const StageAView& a, const TaskDesc
   Chain c;
   chain_bind(c, L, slice);
   c.flags = 0;
+  c.bytes = 0;
   c.pool_used = 0;
   const HypResult& w = res[cs.winner];
   const int L0 = (int)(cs.n1 + 1 + cs.n2);
@@ -299,6 +301,7 @@ EG3D_HD void expand_chain(const DevScene& s, const StageAView& a, const TaskDesc
   out.n_obs = nobs;
   out.flags = c.flags;
   out.head = (uint32_t)c.head;
+  out.bytes = c.bytes;
 }
 
 // K4 body: copy one finished chain into the ordered SoA output.

@@ -17,6 +17,7 @@ enum : uint32_t { CTR_ARENA_OVERFLOW = 0x100u };
 struct Counters {
   uint32_t arena_used;
   uint32_t flags;  // EG3D_FLAG_* bits | CTR_ARENA_OVERFLOW
+  unsigned long long bytes;  // algorithmic bytes of polyline vertices touched
 };
 
 void launch_seed_prep(hipStream_t st, SeedsDev sd, uint32_t seed_begin, uint32_t n_seeds, uint32_t sv_base,
@@ -24,7 +25,8 @@ void launch_seed_prep(hipStream_t st, SeedsDev sd, uint32_t seed_begin, uint32_t
 void launch_k1_count_raw(hipStream_t st, DevScene s, SeedsDev sd, uint32_t sv_base, uint32_t n_sv, const uint32_t* sv_seed,
                          uint32_t* raw_cnt);
 void launch_k1(hipStream_t st, DevScene s, SeedsDev sd, uint32_t sv_base, uint32_t n_sv, const uint32_t* sv_seed,
-               const uint32_t* raw_off, uint32_t* cand_pl, Obs* start_hits, uint32_t* cand_cnt, uint32_t* start_cnt);
+               const uint32_t* raw_off, uint32_t* cand_pl, Obs* start_hits, uint32_t* cand_cnt, uint32_t* start_cnt,
+               Counters* ctr);
 void launch_task_fill(hipStream_t st, SeedsDev sd, uint32_t sv_base, uint32_t n_sv, const uint32_t* sv_seed,
                       const uint32_t* start_cnt, const uint32_t* task_off, uint32_t* task_seed, uint32_t* task_entry,
                       uint32_t* task_hit, uint32_t* task_k);

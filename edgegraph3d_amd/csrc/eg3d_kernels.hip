@@ -91,7 +91,7 @@ __global__ void k1_count_raw(DevScene s, SeedsDev sd, uint32_t sv_base, uint32_t
 __global__ void __launch_bounds__(256) k1_seed_candidates(DevScene s, SeedsDev sd, uint32_t sv_base, uint32_t n_sv,
                                                          const uint32_t* sv_seed, const uint32_t* raw_off,
                                                          uint32_t* cand_pl, Obs* start_hits, uint32_t* cand_cnt,
-                                                         uint32_t* start_cnt) {
+                                                         uint32_t* start_cnt, Counters* ctr) {
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t lane = threadIdx.x & 63;
   if (wave >= n_sv) return;
@@ -114,12 +114,14 @@ __global__ void __launch_bounds__(256) k1_seed_candidates(DevScene s, SeedsDev s
   }
   const uint32_t out_base = raw_off[sv];
   uint32_t nc = 0, ns = 0;
+  unsigned long long vbytes = 0;
   for (;;) {
     const uint32_t head = (a < b) ? s.g30_ids[a] : 0xffffffffu;
     const uint32_t m = wave_min_u32(head);
     if (m == 0xffffffffu) break;
     if (head == m) a++;
     const PlRef pl = polyline_of(s, view, m);
+    vbytes += 8ull * pl.n;
     float best = __builtin_huge_valf();
     uint32_t bj = 0xffffffffu;
     float bx = 0.f, by = 0.f;
@@ -161,6 +163,7 @@ __global__ void __launch_bounds__(256) k1_seed_candidates(DevScene s, SeedsDev s
   if (lane == 0) {
     cand_cnt[sv] = nc;
     start_cnt[sv] = ns;
+    if (vbytes) atomicAdd(&ctr->bytes, vbytes);
   }
 }
 
@@ -356,6 +359,7 @@ __global__ void __launch_bounds__(64) k3b_expand(DevScene s, StageAView a, const
   out_points[j] = co.n_points;
   out_obs[j] = co.n_obs;
   if (co.flags) atomicOr(&ctr->flags, co.flags);
+  if (co.bytes) atomicAdd(&ctr->bytes, (unsigned long long)co.bytes);
 }
 
 // ------------------------------------------------------------------ K4 ---------
@@ -400,10 +404,11 @@ void launch_k1_count_raw(hipStream_t st, DevScene s, SeedsDev sd, uint32_t sv_ba
   hipLaunchKernelGGL(k1_count_raw, blocks_for(n_sv, 256), dim3(256), 0, st, s, sd, sv_base, n_sv, sv_seed, raw_cnt);
 }
 void launch_k1(hipStream_t st, DevScene s, SeedsDev sd, uint32_t sv_base, uint32_t n_sv, const uint32_t* sv_seed,
-               const uint32_t* raw_off, uint32_t* cand_pl, Obs* start_hits, uint32_t* cand_cnt, uint32_t* start_cnt) {
+               const uint32_t* raw_off, uint32_t* cand_pl, Obs* start_hits, uint32_t* cand_cnt, uint32_t* start_cnt,
+               Counters* ctr) {
   if (!n_sv) return;
   hipLaunchKernelGGL(k1_seed_candidates, blocks_for((uint64_t)n_sv * 64, 256), dim3(256), 0, st, s, sd, sv_base, n_sv,
-                     sv_seed, raw_off, cand_pl, start_hits, cand_cnt, start_cnt);
+                     sv_seed, raw_off, cand_pl, start_hits, cand_cnt, start_cnt, ctr);
 }
 void launch_task_fill(hipStream_t st, SeedsDev sd, uint32_t sv_base, uint32_t n_sv, const uint32_t* sv_seed,
                       const uint32_t* start_cnt, const uint32_t* task_off, uint32_t* task_seed, uint32_t* task_entry,

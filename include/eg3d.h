@@ -167,6 +167,23 @@ int eg3d_upload_seeds(eg3d_ctx* ctx, const eg3d_seeds* seeds);
 int eg3d_match_resident(eg3d_ctx* ctx, uint32_t seed_begin, uint32_t seed_end, int device_only,
                         eg3d_edgepoints* out, eg3d_stage_times* times);
 
+/* Device-resident view of the edge-points produced by the most recent eg3d_match_* call
+ * (pointers into the context's HBM buffers, valid until the next call on this context).
+ * `complete` is 1 when the call ran as a single chunk so the buffers hold its whole result —
+ * this is what the multi-GPU all-gather of the edge-point cloud consumes without a host trip. */
+typedef struct eg3d_device_edgepoints {
+  uint64_t n_points, n_obs;
+  const float* X;
+  const uint32_t* obs_off;
+  const int32_t* obs_view;
+  const uint32_t* obs_pl;
+  const uint32_t* obs_seg;
+  const float* obs_xy;
+  const uint32_t* key;
+  int32_t complete;
+} eg3d_device_edgepoints;
+int eg3d_last_device_output(eg3d_ctx* ctx, eg3d_device_edgepoints* out);
+
 /* Config 5: batched FP32 Gauss-Newton filter. view ids index ctx's cameras.
  * X_out may alias X. legacy_abs != 0 selects the Q9 integer-abs behaviour. */
 int eg3d_gn_filter(eg3d_ctx* ctx, const float* X, const uint32_t* obs_off, const int32_t* obs_view,
