@@ -28,6 +28,26 @@ struct ChainPt {
 struct Pending {
   float X[3];
   Obs o;
+  uint32_t ok;  // the ADD solve of this candidate succeeded
+  uint32_t pad;
+};
+// Per chain point, for the view being offered: unique 4 px-grid polyline and closest point.
+struct ViewCand {
+  uint32_t valid;  // exactly one polyline in the window
+  uint32_t pl, seg;
+  float x, y, d2;
+};
+
+// Execution team of one chain. The expand stage is written SPMD-style: every member runs the
+// same control flow on identical values ("uniform" sections, redundant across lanes) and only
+// the marked parallel sections split items across members, communicating through the chain's
+// scratch slice followed by sync(). TeamSeq (1 member) is the sequential semantics and what the
+// host instantiation uses; the GPU kernel uses a 64-lane wavefront (TeamWave in
+// eg3d_kernels.hip).
+struct TeamSeq {
+  EG3D_HD int lane() const { return 0; }
+  EG3D_HD int size() const { return 1; }
+  EG3D_HD void sync() const {}
 };
 
 // Per-chain working set (pointers into this chain's scratch slice).
@@ -42,6 +62,7 @@ struct Chain {
   uint32_t* end_dirs;    // [V]
   Pending* pend1;        // [cap_pts]
   Pending* pend2;        // [cap_pts]
+  ViewCand* cand;        // [cap_pts]
   Obs* tmp_a;            // [tmp_cap]
   Obs* tmp_b;            // [tmp_cap]
   uint8_t* tmp_mask;     // [tmp_cap]
@@ -231,11 +252,12 @@ EG3D_HD int follow_front(const DevScene& s, Chain& c) {
   return added;
 }
 
-// Walk view v's polyline from `from` towards node `direction`, visiting chain points
-// ci-1, ci-2, ... >= lo (towards_start) or ci+1, ... < hi: for each, the next hit of the
-// epipolar line of the point's FIRST observation, then ADD. Stops at the first failure.
-EG3D_HD int walk_side(const DevScene& s, Chain& c, int view, const Obs& from, uint32_t direction, int lo, int ci,
-                      int hi, bool towards_start, Pending* out) {
+// Side walk, phase 1 (uniform): from `from` on view `view` towards node `direction`, visit chain
+// points ci-1, ci-2, ... >= lo (towards_start) or ci+1, ... < hi; for each take the next hit of
+// the epipolar line of the point's FIRST observation. Walk positions do not depend on the
+// solver, so all candidates are generated first; returns how many walks succeeded.
+EG3D_HD int walk_side_candidates(const DevScene& s, Chain& c, int view, const Obs& from, uint32_t direction, int lo,
+                                 int ci, int hi, bool towards_start, Pending* out) {
   int cnt = 0;
   PlRef pl = polyline_of(s, view, from.pl);
   PlPt actual;
@@ -252,19 +274,13 @@ EG3D_HD int walk_side(const DevScene& s, Chain& c, int view, const Obs& from, ui
     uint32_t w = walk_by_line(pl, actual, direction, la, lb, lc, false, 0.0f, 0.0f, nx);
     if (w & WALK_BAD_DIR) c.flags |= 8u;
     if (!(w & WALK_FOUND)) break;
-    Obs o;
-    o.view = view;
-    o.pl = from.pl;
-    o.seg = nx.seg;
-    o.x = nx.x;
-    o.y = nx.y;
-    float X[3];
-    if (!add_observation_solve(s, c, pt, o, X)) break;
     Pending& pd = out[cnt++];
-    pd.X[0] = X[0];
-    pd.X[1] = X[1];
-    pd.X[2] = X[2];
-    pd.o = o;
+    pd.o.view = view;
+    pd.o.pl = from.pl;
+    pd.o.seg = nx.seg;
+    pd.o.x = nx.x;
+    pd.o.y = nx.y;
+    pd.ok = 0;
     actual = nx;
     if (towards_start)
       i--;
@@ -274,11 +290,37 @@ EG3D_HD int walk_side(const DevScene& s, Chain& c, int view, const Obs& from, ui
   return cnt;
 }
 
+// Side walk, phase 2 (PARALLEL over candidates): ADD-solve candidate j against chain point
+// ci-1-j / ci+1+j; then (uniform) count the leading successes — the reference stops at the
+// first failed walk or solve (plg_matching.cpp:866-914).
+template <class Team>
+EG3D_HD int walk_side(const Team& tm, const DevScene& s, Chain& c, int view, const Obs& from, uint32_t direction,
+                      int lo, int ci, int hi, bool towards_start, Pending* out) {
+  const int m = walk_side_candidates(s, c, view, from, direction, lo, ci, hi, towards_start, out);
+  tm.sync();
+  for (int j = tm.lane(); j < m; j += tm.size()) {
+    const ChainPt& pt = chain_at(c, towards_start ? ci - 1 - j : ci + 1 + j);
+    float X[3];
+    const Obs o = out[j].o;
+    if (add_observation_solve(s, c, pt, o, X)) {
+      out[j].X[0] = X[0];
+      out[j].X[1] = X[1];
+      out[j].X[2] = X[2];
+      out[j].ok = 1;
+    }
+  }
+  tm.sync();
+  int cnt = 0;
+  while (cnt < m && out[cnt].ok) cnt++;
+  return cnt;
+}
+
 // Try to attach observation `o` of view o.view to chain point ci, then to its neighbours within
 // [lo, hi). On success returns true with (to_start, to_end) = observations added on each side
 // including newly grown points. (add_view_to_3dpoint_and_sides_plgp_matches_vector, Q13.)
-EG3D_HD bool attach_view(const DevScene& s, Chain& c, const Obs& o, int lo, int ci, int hi, int& to_start,
-                         int& to_end) {
+template <class Team>
+EG3D_HD bool attach_view(const Team& tm, const DevScene& s, Chain& c, const Obs& o, int lo, int ci, int hi,
+                         int& to_start, int& to_end) {
   to_start = 0;
   to_end = 0;
   float Xc[3];
@@ -288,17 +330,17 @@ EG3D_HD bool attach_view(const DevScene& s, Chain& c, const Obs& o, int lo, int 
   uint32_t nd1 = 0, nd2 = 0;
   int n1 = 0, n2 = 0;
   if (ci > lo) {
-    n1 = walk_side(s, c, view, o, pl.start, lo, ci, hi, true, c.pend1);
+    n1 = walk_side(tm, s, c, view, o, pl.start, lo, ci, hi, true, c.pend1);
     if (n1 > 0) {
       nd1 = pl.start;
       nd2 = pl.end;
-      if (ci < hi) n2 = walk_side(s, c, view, o, pl.end, lo, ci, hi, false, c.pend2);
+      if (ci < hi) n2 = walk_side(tm, s, c, view, o, pl.end, lo, ci, hi, false, c.pend2);
     } else {
-      n1 = walk_side(s, c, view, o, pl.end, lo, ci, hi, true, c.pend1);
+      n1 = walk_side(tm, s, c, view, o, pl.end, lo, ci, hi, true, c.pend1);
       if (n1 > 0) {
         nd1 = pl.end;
         nd2 = pl.start;
-        if (ci < hi) n2 = walk_side(s, c, view, o, pl.start, lo, ci, hi, false, c.pend2);
+        if (ci < hi) n2 = walk_side(tm, s, c, view, o, pl.start, lo, ci, hi, false, c.pend2);
       }
       // else: neither orientation reaches the lower neighbour; with ci > lo >= 0 the
       // attachment is rejected below whatever the upper side would give.
@@ -306,7 +348,7 @@ EG3D_HD bool attach_view(const DevScene& s, Chain& c, const Obs& o, int lo, int 
   }
   if (ci > 0 && n1 == 0) return false;
   if (ci < c.len - 1 && n2 == 0) return false;
-  // commit
+  // commit (uniform: every member writes the same values)
   {
     ChainPt& cp = chain_at(c, ci);
     cp.X[0] = Xc[0];
@@ -340,6 +382,7 @@ EG3D_HD bool attach_view(const DevScene& s, Chain& c, const Obs& o, int lo, int 
     c.end_dirs[view] = nd2;
     to_end += follow_back(s, c);
   }
+  tm.sync();
   return true;
 }
 
@@ -367,13 +410,45 @@ EG3D_HD bool unique_polyline_4px(const DevScene& s, int view, float x, float y, 
   return have;
 }
 
+// PARALLEL over chain points [from, len): project the point into view v, look up the unique
+// polyline of the 4 px grid and its closest point (triangulation.cpp:791-806).
+template <class Team>
+EG3D_HD void view_candidates(const Team& tm, const DevScene& s, Chain& c, int v, int from) {
+  const float* P = s.cam_P + (size_t)v * 16;
+  for (int i = from + tm.lane(); i < c.len; i += tm.size()) {
+    const ChainPt& pt = chain_at(c, i);
+    ViewCand vc;
+    vc.valid = 0;
+    vc.pl = 0;
+    vc.seg = 0;
+    vc.x = vc.y = vc.d2 = 0.0f;
+    float u, w;
+    project_f32(P, pt.X[0], pt.X[1], pt.X[2], u, w);
+    uint32_t pl_id;
+    if (unique_polyline_4px(s, v, u, w, pl_id)) {
+      PlRef pl = polyline_of(s, v, pl_id);
+      PlPt cp;
+      vc.d2 = polyline_closest(pl, u, w, cp);
+      vc.valid = 1;
+      vc.pl = pl_id;
+      vc.seg = cp.seg;
+      vc.x = cp.x;
+      vc.y = cp.y;
+    }
+    c.cand[i] = vc;
+  }
+  tm.sync();
+}
+
 // Offer the chain to view v. epc = the task's epipolar hits in v (may be empty).
-EG3D_HD void expand_to_view(const DevScene& s, Chain& c, int v, const Obs* epc, int n_epc, int& centre) {
+template <class Team>
+EG3D_HD void expand_to_view(const Team& tm, const DevScene& s, Chain& c, int v, const Obs* epc, int n_epc,
+                            int& centre) {
   bool epc_matched = false;
   int idx_first = 0, idx_second = 0;
   for (int e = 0; e < n_epc; e++) {
     int a, b;
-    if (attach_view(s, c, epc[e], 0, centre, c.len, a, b)) {
+    if (attach_view(tm, s, c, epc[e], 0, centre, c.len, a, b)) {
       epc_matched = true;
       if (a > centre) {
         centre = a;
@@ -387,31 +462,26 @@ EG3D_HD void expand_to_view(const DevScene& s, Chain& c, int v, const Obs* epc, 
     }
   }
   int last_matched = -1;
-  const float* P = s.cam_P + (size_t)v * 16;
+  view_candidates(tm, s, c, v, 0);
   for (int cur = 0; cur < c.len; cur++) {
     if (epc_matched && cur == idx_first) {
       cur = idx_second;
       last_matched = idx_second;
       continue;
     }
-    const ChainPt& pt = chain_at(c, cur);
-    float u, w;
-    project_f32(P, pt.X[0], pt.X[1], pt.X[2], u, w);
-    uint32_t pl_id;
-    if (!unique_polyline_4px(s, v, u, w, pl_id)) continue;
-    PlRef pl = polyline_of(s, v, pl_id);
-    c.bytes += 8ull * pl.n;
-    PlPt cp;
-    if (polyline_closest(pl, u, w, cp) > 16.0f) return;  // abandons this view (Q4)
+    const ViewCand vc = c.cand[cur];
+    if (!vc.valid) continue;
+    c.bytes += 8ull * (s.pl_vtx_off[s.view_pl_off[v] + vc.pl + 1] - s.pl_vtx_off[s.view_pl_off[v] + vc.pl]);
+    if (vc.d2 > 16.0f) return;  // abandons this view (Q4)
     Obs o;
     o.view = v;
-    o.pl = pl_id;
-    o.seg = cp.seg;
-    o.x = cp.x;
-    o.y = cp.y;
+    o.pl = vc.pl;
+    o.seg = vc.seg;
+    o.x = vc.x;
+    o.y = vc.y;
     int hi = epc_matched ? (cur <= idx_first ? idx_first : c.len) : c.len;
     int a, b;
-    if (attach_view(s, c, o, last_matched + 1, cur, hi, a, b)) {
+    if (attach_view(tm, s, c, o, last_matched + 1, cur, hi, a, b)) {
       if (a > cur) {
         centre = a;
         cur = a + b;
@@ -419,6 +489,8 @@ EG3D_HD void expand_to_view(const DevScene& s, Chain& c, int v, const Obs* epc, 
         cur = cur + b;
       }
       last_matched = cur;
+      // the chain may have grown / shifted: refresh the candidates of the points still to visit
+      view_candidates(tm, s, c, v, cur + 1);
     }
   }
 }

@@ -167,7 +167,7 @@ EG3D_HD bool select_task(const HypResult* res, uint32_t h0, uint32_t h1, ChainSe
 // Scratch slice layout of one chain (bytes); all sub-arrays 8-byte aligned.
 struct ChainLayout {
   uint32_t cap_pts, pool_cap, tmp_cap, n_views;
-  size_t off_pts, off_pool, off_sdir, off_edir, off_p1, off_p2, off_ta, off_tb, off_tm, total;
+  size_t off_pts, off_pool, off_sdir, off_edir, off_p1, off_p2, off_cand, off_ta, off_tb, off_tm, total;
 };
 EG3D_HD size_t align8(size_t v) { return (v + 7) & ~(size_t)7; }
 EG3D_HD ChainLayout chain_layout(uint32_t cap_pts, uint32_t pool_cap, uint32_t n_views) {
@@ -189,6 +189,8 @@ EG3D_HD ChainLayout chain_layout(uint32_t cap_pts, uint32_t pool_cap, uint32_t n
   o = align8(o + sizeof(Pending) * cap_pts);
   L.off_p2 = o;
   o = align8(o + sizeof(Pending) * cap_pts);
+  L.off_cand = o;
+  o = align8(o + sizeof(ViewCand) * cap_pts);
   L.off_ta = o;
   o = align8(o + sizeof(Obs) * L.tmp_cap);
   L.off_tb = o;
@@ -207,6 +209,7 @@ EG3D_HD void chain_bind(Chain& c, const ChainLayout& L, unsigned char* slice) {
   c.end_dirs = (uint32_t*)(slice + L.off_edir);
   c.pend1 = (Pending*)(slice + L.off_p1);
   c.pend2 = (Pending*)(slice + L.off_p2);
+  c.cand = (ViewCand*)(slice + L.off_cand);
   c.tmp_a = (Obs*)(slice + L.off_ta);
   c.tmp_b = (Obs*)(slice + L.off_tb);
   c.tmp_mask = (uint8_t*)(slice + L.off_tm);
@@ -221,7 +224,8 @@ struct ChainOut {
 // Build the chain reverse(pts1) + central + pts2, then offer it to every view except the
 // three selected, ascending (triangulation.cpp:960-973). One lane, one chain.
 // hyp_base = global index of the task's first hypothesis.
-EG3D_HD void expand_chain(const DevScene& s, const StageAView& a, const TaskDesc& d, const ChainSeed& cs,
+template <class Team>
+EG3D_HD void expand_chain(const Team& tm, const DevScene& s, const StageAView& a, const TaskDesc& d, const ChainSeed& cs,
                           uint32_t hyp_base, const HypResult* res, const HPoint* arena, const int32_t* map_view,
                           const uint32_t* map_entry, const uint32_t* map_n, const ChainLayout& L,
                           unsigned char* slice, ChainOut& out) {
@@ -277,6 +281,7 @@ EG3D_HD void expand_chain(const DevScene& s, const StageAView& a, const TaskDesc
     const HypResult& r2 = res[cs.pts2_src];
     for (uint32_t i = 0; i < cs.n2; i++) push_h(arena[r2.pts2_off + i]);
   }
+  tm.sync();
   // every view except the three selected, ascending; epc = the task's hits in that view
   const uint32_t base = a.trk_off[d.seed] - a.sv_base;
   const uint32_t n = map_n[d.seed - a.seed_begin];
@@ -293,7 +298,7 @@ EG3D_HD void expand_chain(const DevScene& s, const StageAView& a, const TaskDesc
       epc = a.hits + a.list_ptr[lo + me[j]];
       n_epc = (int)a.list_cnt[lo + me[j]];
     }
-    expand_to_view(s, c, v, epc, n_epc, centre);
+    expand_to_view(tm, s, c, v, epc, n_epc, centre);
   }
   uint32_t nobs = 0;
   for (int i = 0; i < c.len; i++) nobs += chain_at(c, i).nobs;

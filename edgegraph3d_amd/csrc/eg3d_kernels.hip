@@ -342,24 +342,36 @@ __global__ void k_compact_chains(uint32_t n_tasks, const ChainSeed* per_task, co
 }
 
 // ------------------------------------------------------------------ K3b --------
+// One WAVEFRONT per chain (block = 64 lanes). Control flow is wave-uniform; the lane-parallel
+// sections are (a) the per-view projection + 4 px grid lookup + closest point of every chain
+// point and (b) the Gauss-Newton ADD solves of a side walk's candidates (see eg3d_dev_expand.h).
+struct TeamWave {
+  __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
+  __device__ __forceinline__ int size() const { return 64; }
+  __device__ __forceinline__ void sync() const { __syncthreads(); }
+};
+
 __global__ void __launch_bounds__(64) k3b_expand(DevScene s, StageAView a, const TaskDesc* tasks,
                                                  const ChainSeed* chains, uint32_t n_chains, const uint32_t* hyp_off,
                                                  const HypResult* res, const HPoint* arena, const int32_t* map_view,
                                                  const uint32_t* map_entry, const uint32_t* map_n, ChainLayout L,
                                                  unsigned char* scratch, ChainOut* outs, uint32_t* out_points,
                                                  uint32_t* out_obs, Counters* ctr) {
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t j = blockIdx.x;
   if (j >= n_chains) return;
   const ChainSeed cs = chains[j];
   const TaskDesc d = tasks[cs.task];
   ChainOut co;
-  expand_chain(s, a, d, cs, hyp_off[cs.task], res, arena, map_view, map_entry, map_n, L, scratch + L.total * (size_t)j,
-               co);
-  outs[j] = co;
-  out_points[j] = co.n_points;
-  out_obs[j] = co.n_obs;
-  if (co.flags) atomicOr(&ctr->flags, co.flags);
-  if (co.bytes) atomicAdd(&ctr->bytes, (unsigned long long)co.bytes);
+  TeamWave tm;
+  expand_chain(tm, s, a, d, cs, hyp_off[cs.task], res, arena, map_view, map_entry, map_n, L,
+               scratch + L.total * (size_t)j, co);
+  if (threadIdx.x == 0) {
+    outs[j] = co;
+    out_points[j] = co.n_points;
+    out_obs[j] = co.n_obs;
+    if (co.flags) atomicOr(&ctr->flags, co.flags);
+    if (co.bytes) atomicAdd(&ctr->bytes, (unsigned long long)co.bytes);
+  }
 }
 
 // ------------------------------------------------------------------ K4 ---------
@@ -460,7 +472,7 @@ void launch_k3b(hipStream_t st, DevScene s, StageAView a, const TaskDesc* tasks,
                 const int32_t* map_view, const uint32_t* map_entry, const uint32_t* map_n, ChainLayout L,
                 unsigned char* scratch, ChainOut* outs, uint32_t* out_points, uint32_t* out_obs, Counters* ctr) {
   if (!n_chains) return;
-  hipLaunchKernelGGL(k3b_expand, blocks_for(n_chains, 64), dim3(64), 0, st, s, a, tasks, chains, n_chains, hyp_off, res,
+  hipLaunchKernelGGL(k3b_expand, dim3(n_chains), dim3(64), 0, st, s, a, tasks, chains, n_chains, hyp_off, res,
                      arena, map_view, map_entry, map_n, L, scratch, outs, out_points, out_obs, ctr);
 }
 void launch_k4(hipStream_t st, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains, ChainLayout L,

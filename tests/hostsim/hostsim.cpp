@@ -167,7 +167,7 @@ extern "C" int hostsim_match(const eg3d_scene* sc, const eg3d_seeds* seeds, uint
   uint64_t np = 0, no = 0;
   for (size_t j = 0; j < chains.size(); j++) {
     const ChainSeed& cs = chains[j];
-    expand_chain(ds, a, tasks[cs.task], cs, hyp_off[cs.task], res.data(), arena.data(), map_view.data(),
+    expand_chain(TeamSeq(), ds, a, tasks[cs.task], cs, hyp_off[cs.task], res.data(), arena.data(), map_view.data(),
                  map_entry.data(), map_n.data(), L, scratch.data() + L.total * j, couts[j]);
     flags |= couts[j].flags;
     np += couts[j].n_points;
