@@ -120,17 +120,17 @@ extern "C" void eg3d_synth_default_config(eg3d_synth_config* c, int idx) {
     case 2:  // C2: 8 views / 2k seeds / ~5k segments per view
       c->n_views = 8;
       c->n_seeds = 2000;
-      c->n_curves = 36;
+      c->n_curves = 82;
       break;
     case 3:  // C3': dtu006-shaped, 25 views / 6268 seeds / ~12-18k segments per view
       c->n_views = 25;
       c->n_seeds = 6268;
-      c->n_curves = 110;
+      c->n_curves = 225;
       break;
     case 4:  // C4: 200 views / 100k seeds / ~20k segments per view
       c->n_views = 200;
       c->n_seeds = 100000;
-      c->n_curves = 145;
+      c->n_curves = 295;
       break;
     case 1:  // small: used by the CPU parity tests
       c->n_views = 6;
