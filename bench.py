@@ -82,38 +82,27 @@ def main():
     ctx.upload_seeds(synth.seeds)   # inputs resident in HBM before the timed region
     b, e = rank * per_gpu, (rank + 1) * per_gpu
 
-    staging = {}
+    gather = None
+    if world > 1:
+        from edgegraph3d_amd.distributed import CloudGather
+        gather = CloudGather(dist, world, dev)
 
     def allgather_cloud():
-        """RCCL all-gather of the variable-length edge-point cloud: counts, then one padded
-        all_gather_into_tensor of [X | obs_off | key | obs_view | obs_pl | obs_seg | obs_xy]."""
+        """RCCL all-gather of the variable-length edge-point cloud straight from the context's HBM
+        buffers (edgegraph3d_amd/distributed.py): counts, one padded all_gather_into_tensor, then
+        compaction into one ordered cloud on every rank."""
         d = ctx.last_device_output()
         if not d.complete:
             raise RuntimeError("bench: output spans several chunks; shrink the per-GPU batch")
         np_, no_ = int(d.n_points), int(d.n_obs)
-        cnt = torch.tensor([np_, no_], dtype=torch.int64, device=dev)
-        allc = torch.empty(2 * world, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(allc, cnt)
-        allc = allc.view(world, 2).cpu()
-        mp, mo = int(allc[:, 0].max()), int(allc[:, 1].max())
-        nbytes = mp * (12 + 4 + 16) + mo * (4 + 4 + 4 + 8)
-        if staging.get("n", 0) < nbytes:
-            staging["n"] = int(nbytes * 1.25) + 256
-            staging["send"] = torch.empty(staging["n"], dtype=torch.uint8, device=dev)
-            staging["recv"] = torch.empty(staging["n"] * world, dtype=torch.uint8, device=dev)
-        send = staging["send"][:nbytes]
-        o = 0
-        # (device pointer, bytes per element, elements this rank has, padded element count)
-        for ptr, per, have, cap in ((d.X, 12, np_, mp), (d.obs_off, 4, np_, mp), (d.key, 16, np_, mp),
-                                    (d.obs_view, 4, no_, mo), (d.obs_pl, 4, no_, mo), (d.obs_seg, 4, no_, mo),
-                                    (d.obs_xy, 8, no_, mo)):
-            if have:
-                src = torch.as_tensor(_DevArr(ptr, have * per), device=dev)
-                send[o:o + have * per].copy_(src)
-            o += cap * per
-        recv = staging["recv"][:nbytes * world]
-        dist.all_gather_into_tensor(recv, send)
-        return int(allc[:, 0].sum())
+        local = {}
+        for name, ptr, per, n in (("X", d.X, 12, np_), ("obs_off", d.obs_off, 4, np_), ("key", d.key, 16, np_),
+                                  ("obs_view", d.obs_view, 4, no_), ("obs_pl", d.obs_pl, 4, no_),
+                                  ("obs_seg", d.obs_seg, 4, no_), ("obs_xy", d.obs_xy, 8, no_)):
+            local[name] = torch.as_tensor(_DevArr(ptr, max(n, 1) * per), device=dev)
+        recv, counts, layout = gather.allgather(local, np_, no_)
+        cloud = gather.unpack(recv, counts, layout)
+        return cloud["n_points"]
 
     def step():
         r = ctx.match_resident(b, e, device_only=True)

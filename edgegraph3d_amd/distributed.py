@@ -1,0 +1,92 @@
+"""Multi-GPU plumbing of the path: seed sharding and the all-gather of the edge-point cloud.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI; "gloo" on CPU for
+tests). Seeds are independent units, so rank r owns the contiguous range shard_range(...)[r]
+and the concatenation of the per-rank outputs in rank order IS the single-process output. The
+only exchange step is the variable-length all-gather of the cloud: counts first (16 B/rank),
+then ONE padded all_gather_into_tensor of the packed SoA
+    [X(12 B/pt) | obs_off(4) | key(16) | obs_view(4/obs) | obs_pl(4) | obs_seg(4) | obs_xy(8)]
+— a single large message per rank so every xGMI link carries traffic at once.
+"""
+import torch
+
+POINT_FIELDS = (("X", 12), ("obs_off", 4), ("key", 16))
+OBS_FIELDS = (("obs_view", 4), ("obs_pl", 4), ("obs_seg", 4), ("obs_xy", 8))
+_DTYPES = {"X": torch.float32, "obs_off": torch.int32, "key": torch.int32, "obs_view": torch.int32,
+           "obs_pl": torch.int32, "obs_seg": torch.int32, "obs_xy": torch.float32}
+
+
+def shard_range(n_seeds, world):
+    """Contiguous, count-balanced seed ranges [(begin, end)] per rank."""
+    base, rem = divmod(n_seeds, world)
+    out, b = [], 0
+    for r in range(world):
+        e = b + base + (1 if r < rem else 0)
+        out.append((b, e))
+        b = e
+    return out
+
+
+class CloudGather:
+    """Reusable staging buffers + the two collectives. `local` maps field name -> 1-D uint8
+    tensor (raw bytes, on `device`) holding this rank's n_points / n_obs elements."""
+
+    def __init__(self, dist, world, device):
+        self.dist, self.world, self.device = dist, world, device
+        self.cap = 0
+        self.send = self.recv = None
+
+    def allgather(self, local, n_points, n_obs):
+        dist, world, dev = self.dist, self.world, self.device
+        cnt = torch.tensor([n_points, n_obs], dtype=torch.int64, device=dev)
+        allc = torch.empty(2 * world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allc, cnt)
+        counts = allc.view(world, 2).cpu()
+        mp, mo = int(counts[:, 0].max()), int(counts[:, 1].max())
+        nbytes = mp * sum(s for _, s in POINT_FIELDS) + mo * sum(s for _, s in OBS_FIELDS)
+        nbytes = max(nbytes, 16)
+        if self.cap < nbytes:
+            self.cap = int(nbytes * 1.25) + 256
+            self.send = torch.empty(self.cap, dtype=torch.uint8, device=dev)
+            self.recv = torch.empty(self.cap * world, dtype=torch.uint8, device=dev)
+        send = self.send[:nbytes]
+        o = 0
+        for name, per in POINT_FIELDS:
+            if n_points:
+                send[o:o + n_points * per].copy_(local[name][:n_points * per])
+            o += mp * per
+        for name, per in OBS_FIELDS:
+            if n_obs:
+                send[o:o + n_obs * per].copy_(local[name][:n_obs * per])
+            o += mo * per
+        recv = self.recv[:nbytes * world]
+        dist.all_gather_into_tensor(recv, send)
+        return recv, counts, (mp, mo, nbytes)
+
+    def unpack(self, recv, counts, layout):
+        """Compact the padded per-rank blocks into one cloud (rank order = seed order); obs_off is
+        rebased so it indexes the concatenated observation arrays."""
+        mp, mo, nbytes = layout
+        parts = {n: [] for n, _ in POINT_FIELDS + OBS_FIELDS}
+        obs_base = 0
+        for r in range(self.world):
+            np_, no_ = int(counts[r, 0]), int(counts[r, 1])
+            blk = recv[r * nbytes:(r + 1) * nbytes]
+            o = 0
+            for name, per in POINT_FIELDS:
+                t = blk[o:o + np_ * per].view(_DTYPES[name])
+                if name == "obs_off":
+                    t = t + obs_base
+                parts[name].append(t)
+                o += mp * per
+            for name, per in OBS_FIELDS:
+                parts[name].append(blk[o:o + no_ * per].view(_DTYPES[name]))
+                o += mo * per
+            obs_base += no_
+        out = {n: torch.cat(v) for n, v in parts.items()}
+        out["X"] = out["X"].view(-1, 3)
+        out["key"] = out["key"].view(-1, 4)
+        out["obs_xy"] = out["obs_xy"].view(-1, 2)
+        out["n_points"] = int(counts[:, 0].sum())
+        out["n_obs"] = int(counts[:, 1].sum())
+        return out

@@ -1,0 +1,505 @@
+// OpenMVG-JSON in/out for the hot path's host side (SURVEY row a-IO).
+//
+// Behaviour reproduced: OpenMvgParser::parse* (reference external/manifoldReconstructor/src/
+// OpenMvgParser.cpp:39-301: view index = position in `views`, observation keys mapped through the
+// position of the pose in `extrinsics`, t = -R*C, P = K4*[R t;0 1], distortion ignored) and
+// output_sfm_data (src/edgegraph3d/io/output/output_sfm_data.cpp:186-229: sfm_data_version,
+// root_path, views, intrinsics, control_points copied from the input file; extrinsics rewritten
+// with keys 0..V-1; structure rewritten with keys 0..N-1 and id_feat 0). Own design: a small
+// recursive-descent JSON DOM instead of rapidjson; numbers keep their source text when copied
+// through, floats are written with the shortest round-trip representation.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/eg3d_host.h"
+#include "camera_model.hpp"
+
+namespace {
+
+struct JVal {
+  enum T { NUL, BOOL, NUM, STR, ARR, OBJ } t = NUL;
+  bool b = false;
+  std::string s;  // string value, or the source text of a number
+  std::vector<JVal> a;
+  std::vector<std::pair<std::string, JVal>> o;
+  const JVal* get(const char* k) const {
+    for (auto& kv : o)
+      if (kv.first == k) return &kv.second;
+    return nullptr;
+  }
+  double num() const { return t == NUM ? strtod(s.c_str(), nullptr) : 0.0; }
+};
+
+struct Parser {
+  const char* p;
+  const char* e;
+  bool ok = true;
+  void ws() {
+    while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++;
+  }
+  JVal parse() {
+    ws();
+    JVal v;
+    if (p >= e) {
+      ok = false;
+      return v;
+    }
+    if (*p == '{') {
+      v.t = JVal::OBJ;
+      p++;
+      ws();
+      if (p < e && *p == '}') {
+        p++;
+        return v;
+      }
+      while (ok) {
+        ws();
+        JVal k = parse_string();
+        ws();
+        if (p >= e || *p != ':') {
+          ok = false;
+          break;
+        }
+        p++;
+        v.o.emplace_back(k.s, parse());
+        ws();
+        if (p < e && *p == ',') {
+          p++;
+          continue;
+        }
+        if (p < e && *p == '}') {
+          p++;
+          break;
+        }
+        ok = false;
+      }
+    } else if (*p == '[') {
+      v.t = JVal::ARR;
+      p++;
+      ws();
+      if (p < e && *p == ']') {
+        p++;
+        return v;
+      }
+      while (ok) {
+        v.a.push_back(parse());
+        ws();
+        if (p < e && *p == ',') {
+          p++;
+          continue;
+        }
+        if (p < e && *p == ']') {
+          p++;
+          break;
+        }
+        ok = false;
+      }
+    } else if (*p == '"') {
+      v = parse_string();
+    } else if (!strncmp(p, "true", 4)) {
+      v.t = JVal::BOOL;
+      v.b = true;
+      p += 4;
+    } else if (!strncmp(p, "false", 5)) {
+      v.t = JVal::BOOL;
+      p += 5;
+    } else if (!strncmp(p, "null", 4)) {
+      p += 4;
+    } else {
+      const char* q = p;
+      while (p < e && (strchr("+-0123456789.eE", *p))) p++;
+      if (p == q) ok = false;
+      v.t = JVal::NUM;
+      v.s.assign(q, p);
+    }
+    return v;
+  }
+  JVal parse_string() {
+    JVal v;
+    v.t = JVal::STR;
+    if (p >= e || *p != '"') {
+      ok = false;
+      return v;
+    }
+    p++;
+    while (p < e && *p != '"') {
+      if (*p == '\\' && p + 1 < e) {
+        v.s.push_back(*p++);
+      }
+      v.s.push_back(*p++);
+    }
+    if (p < e) p++;
+    return v;
+  }
+};
+
+void write_val(std::ostream& os, const JVal& v, int ind);
+void indent(std::ostream& os, int n) {
+  for (int i = 0; i < n; i++) os << "    ";
+}
+void write_val(std::ostream& os, const JVal& v, int ind) {
+  switch (v.t) {
+    case JVal::NUL: os << "null"; break;
+    case JVal::BOOL: os << (v.b ? "true" : "false"); break;
+    case JVal::NUM: os << v.s; break;
+    case JVal::STR: os << '"' << v.s << '"'; break;
+    case JVal::ARR:
+      if (v.a.empty()) {
+        os << "[]";
+        break;
+      }
+      os << "[\n";
+      for (size_t i = 0; i < v.a.size(); i++) {
+        indent(os, ind + 1);
+        write_val(os, v.a[i], ind + 1);
+        os << (i + 1 < v.a.size() ? ",\n" : "\n");
+      }
+      indent(os, ind);
+      os << "]";
+      break;
+    case JVal::OBJ:
+      if (v.o.empty()) {
+        os << "{}";
+        break;
+      }
+      os << "{\n";
+      for (size_t i = 0; i < v.o.size(); i++) {
+        indent(os, ind + 1);
+        os << '"' << v.o[i].first << "\": ";
+        write_val(os, v.o[i].second, ind + 1);
+        os << (i + 1 < v.o.size() ? ",\n" : "\n");
+      }
+      indent(os, ind);
+      os << "}";
+      break;
+  }
+}
+
+// shortest decimal text that round-trips a float widened to double (rapidjson writes doubles)
+std::string num_text(float f) {
+  double d = (double)f;
+  char buf[40];
+  for (int prec = 1; prec <= 17; prec++) {
+    snprintf(buf, sizeof(buf), "%.*g", prec, d);
+    if (strtod(buf, nullptr) == d) break;
+  }
+  std::string s(buf);
+  if (s.find_first_of(".eEn") == std::string::npos) s += ".0";
+  return s;
+}
+JVal jnum(float f) {
+  JVal v;
+  v.t = JVal::NUM;
+  v.s = num_text(f);
+  return v;
+}
+JVal jint(long long i) {
+  JVal v;
+  v.t = JVal::NUM;
+  v.s = std::to_string(i);
+  return v;
+}
+
+struct Cam {
+  float focal = 0, ppx = 0, ppy = 0;
+  float R[9] = {0}, C[3] = {0}, t[3] = {0}, P[16] = {0};
+  std::string path;
+};
+
+}  // namespace
+
+struct eg3d_sfm {
+  int width = 0, height = 0;
+  std::vector<Cam> cams;
+  std::vector<float> P;  // flattened
+  std::vector<float> X;  // [N][3]
+  std::vector<uint32_t> trk_off{0};
+  std::vector<int32_t> trk_view;
+  std::vector<float> trk_xy;
+  void refresh_P() {
+    P.resize(cams.size() * 16);
+    for (size_t i = 0; i < cams.size(); i++) memcpy(&P[i * 16], cams[i].P, sizeof(float) * 16);
+  }
+};
+
+extern "C" eg3d_sfm* eg3d_sfm_create(int n_views, int width, int height) {
+  eg3d_sfm* s = new eg3d_sfm();
+  s->cams.resize(n_views);
+  s->width = width;
+  s->height = height;
+  s->refresh_P();
+  return s;
+}
+extern "C" void eg3d_sfm_destroy(eg3d_sfm* s) { delete s; }
+extern "C" int eg3d_sfm_n_views(const eg3d_sfm* s) { return (int)s->cams.size(); }
+extern "C" uint64_t eg3d_sfm_n_points(const eg3d_sfm* s) { return s->X.size() / 3; }
+extern "C" const float* eg3d_sfm_cam_P(const eg3d_sfm* s) { return s->P.data(); }
+extern "C" const float* eg3d_sfm_points(const eg3d_sfm* s) { return s->X.data(); }
+
+extern "C" int eg3d_sfm_set_camera(eg3d_sfm* s, int view, float focal, float ppx, float ppy, const float* R9,
+                                   const float* C3, const char* image_path) {
+  if (!s || view < 0 || view >= (int)s->cams.size()) return -1;
+  Cam& c = s->cams[view];
+  c.focal = focal;
+  c.ppx = ppx;
+  c.ppy = ppy;
+  memcpy(c.R, R9, sizeof(float) * 9);
+  memcpy(c.C, C3, sizeof(float) * 3);
+  if (image_path) c.path = image_path;
+  eg3dh::translation_from_center(c.R, c.C, c.t);
+  eg3dh::camera_matrix(focal, ppx, ppy, c.R, c.t, c.P);
+  s->refresh_P();
+  return 0;
+}
+
+extern "C" int eg3d_sfm_seeds(const eg3d_sfm* s, eg3d_seeds* out) {
+  if (!s || !out) return -1;
+  out->n_seeds = (uint32_t)(s->trk_off.size() - 1);
+  out->trk_off = s->trk_off.data();
+  out->trk_view = s->trk_view.data();
+  out->trk_xy = s->trk_xy.data();
+  return 0;
+}
+
+extern "C" int eg3d_sfm_add_point(eg3d_sfm* s, const float* X3, int n_obs, const int32_t* views, const float* xy) {
+  if (!s) return -1;
+  s->X.insert(s->X.end(), X3, X3 + 3);
+  for (int i = 0; i < n_obs; i++) {
+    s->trk_view.push_back(views[i]);
+    s->trk_xy.push_back(xy[2 * i]);
+    s->trk_xy.push_back(xy[2 * i + 1]);
+  }
+  s->trk_off.push_back((uint32_t)s->trk_view.size());
+  return 0;
+}
+
+// add_3dpoints_to_sfmd (output_utilities.cpp:96-111)
+extern "C" int eg3d_sfm_add_edgepoints(eg3d_sfm* s, const eg3d_edgepoints* p, const uint8_t* keep) {
+  if (!s || !p) return -1;
+  for (uint64_t i = 0; i < p->n_points; i++) {
+    if (keep && !keep[i]) continue;
+    const uint32_t a = p->obs_off[i], b = p->obs_off[i + 1];
+    eg3d_sfm_add_point(s, p->X + 3 * i, (int)(b - a), p->obs_view + a, p->obs_xy + 2 * (size_t)a);
+  }
+  return 0;
+}
+
+// removeOutliers (outliers_filtering.cpp:66-92)
+extern "C" int eg3d_sfm_remove_outliers(eg3d_sfm* s, const uint8_t* inlier) {
+  if (!s || !inlier) return -1;
+  std::vector<float> X, xy;
+  std::vector<uint32_t> off{0};
+  std::vector<int32_t> view;
+  const size_t n = s->X.size() / 3;
+  for (size_t i = 0; i < n; i++)
+    if (inlier[i]) {
+      X.insert(X.end(), s->X.begin() + 3 * i, s->X.begin() + 3 * i + 3);
+      for (uint32_t j = s->trk_off[i]; j < s->trk_off[i + 1]; j++) {
+        view.push_back(s->trk_view[j]);
+        xy.push_back(s->trk_xy[2 * j]);
+        xy.push_back(s->trk_xy[2 * j + 1]);
+      }
+      off.push_back((uint32_t)view.size());
+    }
+  s->X.swap(X);
+  s->trk_off.swap(off);
+  s->trk_view.swap(view);
+  s->trk_xy.swap(xy);
+  return 0;
+}
+
+extern "C" int eg3d_sfm_set_point_coords(eg3d_sfm* s, const float* X) {
+  if (!s || !X) return -1;
+  memcpy(s->X.data(), X, sizeof(float) * s->X.size());
+  return 0;
+}
+
+extern "C" int eg3d_sfm_analytic_F(const eg3d_sfm* s, double* F, uint8_t* F_valid) {
+  if (!s) return -1;
+  const int V = (int)s->cams.size();
+  for (int i = 0; i < V; i++)
+    for (int j = 0; j < V; j++) {
+      double* f = F + ((size_t)i * V + j) * 9;
+      if (i == j) {
+        for (int k = 0; k < 9; k++) f[k] = 0;
+        F_valid[(size_t)i * V + j] = 0;
+        continue;
+      }
+      const Cam &a = s->cams[i], &b = s->cams[j];
+      eg3dh::fundamental_from_cameras(a.focal, a.ppx, a.ppy, a.R, a.t, b.focal, b.ppx, b.ppy, b.R, b.t, f);
+      F_valid[(size_t)i * V + j] = 1;
+    }
+  return 0;
+}
+
+static bool load_json(const char* path, JVal& root) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  std::stringstream ss;
+  ss << f.rdbuf();
+  std::string txt = ss.str();
+  Parser p{txt.data(), txt.data() + txt.size()};
+  root = p.parse();
+  return p.ok && root.t == JVal::OBJ;
+}
+
+extern "C" eg3d_sfm* eg3d_sfm_read_json(const char* path) {
+  JVal root;
+  if (!load_json(path, root)) return nullptr;
+  const JVal *views = root.get("views"), *intr = root.get("intrinsics"), *extr = root.get("extrinsics"),
+             *structure = root.get("structure"), *rp = root.get("root_path");
+  if (!views || !intr || !extr || !structure) return nullptr;
+  std::string base = rp ? rp->s : "";
+  struct K {
+    float f, px, py;
+  };
+  std::map<int, K> intrinsics;
+  for (const JVal& it : intr->a) {
+    const JVal* d = it.get("value");
+    d = d ? d->get("ptr_wrapper") : nullptr;
+    d = d ? d->get("data") : nullptr;
+    if (!d) continue;
+    K k;
+    k.f = (float)d->get("focal_length")->num();
+    k.px = (float)d->get("principal_point")->a[0].num();
+    k.py = (float)d->get("principal_point")->a[1].num();
+    intrinsics[(int)it.get("key")->num()] = k;
+  }
+  struct E {
+    float R[9], C[3];
+  };
+  std::map<int, E> extrinsics;
+  std::map<int, int> map_pos;
+  int pos = 0;
+  for (const JVal& it : extr->a) {
+    E e;
+    const JVal* v = it.get("value");
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) e.R[3 * r + c] = (float)v->get("rotation")->a[r].a[c].num();
+    for (int r = 0; r < 3; r++) e.C[r] = (float)v->get("center")->a[r].num();
+    const int key = (int)it.get("key")->num();
+    extrinsics[key] = e;
+    map_pos[key] = pos++;
+  }
+  eg3d_sfm* s = new eg3d_sfm();
+  s->cams.resize(views->a.size());
+  for (size_t i = 0; i < views->a.size(); i++) {
+    const JVal* d = views->a[i].get("value");
+    d = d ? d->get("ptr_wrapper") : nullptr;
+    d = d ? d->get("data") : nullptr;
+    if (!d) continue;
+    Cam& c = s->cams[i];
+    c.path = base + d->get("local_path")->s + d->get("filename")->s;
+    s->width = (int)d->get("width")->num();
+    s->height = (int)d->get("height")->num();
+    const int ii = (int)d->get("id_intrinsic")->num(), ie = (int)d->get("id_pose")->num();
+    auto ki = intrinsics.find(ii);
+    auto ke = extrinsics.find(ie);
+    if (ki == intrinsics.end() || ke == extrinsics.end()) continue;  // reference prints and leaves zeros
+    c.focal = ki->second.f;
+    c.ppx = ki->second.px;
+    c.ppy = ki->second.py;
+    memcpy(c.R, ke->second.R, sizeof(c.R));
+    memcpy(c.C, ke->second.C, sizeof(c.C));
+    eg3dh::translation_from_center(c.R, c.C, c.t);
+    eg3dh::camera_matrix(c.focal, c.ppx, c.ppy, c.R, c.t, c.P);
+  }
+  s->refresh_P();
+  for (const JVal& pt : structure->a) {
+    const JVal* v = pt.get("value");
+    float X[3] = {(float)v->get("X")->a[0].num(), (float)v->get("X")->a[1].num(), (float)v->get("X")->a[2].num()};
+    std::vector<int32_t> vw;
+    std::vector<float> xy;
+    for (const JVal& ob : v->get("observations")->a) {
+      auto it = map_pos.find((int)ob.get("key")->num());
+      if (it == map_pos.end()) continue;
+      vw.push_back(it->second);
+      const JVal* x = ob.get("value")->get("x");
+      xy.push_back((float)x->a[0].num());
+      xy.push_back((float)x->a[1].num());
+    }
+    eg3d_sfm_add_point(s, X, (int)vw.size(), vw.data(), xy.data());
+  }
+  return s;
+}
+
+extern "C" int eg3d_sfm_write_json(const eg3d_sfm* s, const char* in_path, const char* out_path) {
+  if (!s || !out_path) return -1;
+  JVal in;
+  bool have_in = in_path && load_json(in_path, in);
+  JVal root;
+  root.t = JVal::OBJ;
+  auto copy_or = [&](const char* k, JVal def) {
+    const JVal* v = have_in ? in.get(k) : nullptr;
+    root.o.emplace_back(k, v ? *v : def);
+  };
+  JVal empty_arr;
+  empty_arr.t = JVal::ARR;
+  JVal empty_str;
+  empty_str.t = JVal::STR;
+  copy_or("sfm_data_version", empty_str);
+  copy_or("root_path", empty_str);
+  copy_or("views", empty_arr);
+  copy_or("intrinsics", empty_arr);
+  JVal ex;
+  ex.t = JVal::ARR;
+  for (size_t i = 0; i < s->cams.size(); i++) {
+    const Cam& c = s->cams[i];
+    JVal e, pose, rot, cen;
+    e.t = pose.t = JVal::OBJ;
+    rot.t = cen.t = JVal::ARR;
+    for (int r = 0; r < 3; r++) {
+      JVal row;
+      row.t = JVal::ARR;
+      for (int cc = 0; cc < 3; cc++) row.a.push_back(jnum(c.R[3 * r + cc]));
+      rot.a.push_back(row);
+      cen.a.push_back(jnum(c.C[r]));
+    }
+    pose.o.emplace_back("rotation", rot);
+    pose.o.emplace_back("center", cen);
+    e.o.emplace_back("key", jint((long long)i));
+    e.o.emplace_back("value", pose);
+    ex.a.push_back(e);
+  }
+  root.o.emplace_back("extrinsics", ex);
+  JVal st;
+  st.t = JVal::ARR;
+  const size_t n = s->X.size() / 3;
+  for (size_t i = 0; i < n; i++) {
+    JVal p, val, X, obs;
+    p.t = val.t = JVal::OBJ;
+    X.t = obs.t = JVal::ARR;
+    for (int k = 0; k < 3; k++) X.a.push_back(jnum(s->X[3 * i + k]));
+    for (uint32_t j = s->trk_off[i]; j < s->trk_off[i + 1]; j++) {
+      JVal o, ov, x;
+      o.t = ov.t = JVal::OBJ;
+      x.t = JVal::ARR;
+      x.a.push_back(jnum(s->trk_xy[2 * j]));
+      x.a.push_back(jnum(s->trk_xy[2 * j + 1]));
+      ov.o.emplace_back("id_feat", jint(0));
+      ov.o.emplace_back("x", x);
+      o.o.emplace_back("key", jint(s->trk_view[j]));
+      o.o.emplace_back("value", ov);
+      obs.a.push_back(o);
+    }
+    val.o.emplace_back("X", X);
+    val.o.emplace_back("observations", obs);
+    p.o.emplace_back("key", jint((long long)i));
+    p.o.emplace_back("value", val);
+    st.a.push_back(p);
+  }
+  root.o.emplace_back("structure", st);
+  copy_or("control_points", empty_arr);
+  std::ofstream f(out_path, std::ios::binary);
+  if (!f) return -1;
+  write_val(f, root, 0);
+  return f.good() ? 0 : -1;
+}

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures. The reference ships no golden vectors and cannot be
+run here, so these are produced by the CPU oracle of this repo on seeded
+synthetic scenes (inputs AND expected outputs are stored, so the fixture also pins the synthetic
+generator). Regenerate with:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from edgegraph3d_amd import host  # noqa: E402
+from oracle import binding as ob  # noqa: E402
+
+
+def make(cfg_index, name):
+    s = host.Synth(cfg_index)
+    o = ob.Oracle(s.scene)
+    r = o.match(s.seeds, 0, s.n_seeds, 1)
+    c = o.candidates(s.seeds, 0, s.n_seeds)
+    sc = s.scene_np()
+    off, view, xy = s.seeds_np()
+    X, poff, pview, pxy = s.points(300)
+    Xo, inl = o.gn_filter(X, poff, pview, pxy, 3.0)
+    out = {"scene_" + k: v for k, v in sc.items()}
+    out.update({"seeds_trk_off": off, "seeds_trk_view": view, "seeds_trk_xy": xy})
+    for k in ("X", "obs_off", "obs_view", "obs_pl", "obs_seg", "obs_xy", "key"):
+        out["out_" + k] = r[k]
+    out["out_counts"] = np.array([r["n_tasks"], r["stats"]["n_chains"], r["flags"]], np.int64)
+    for k in ("cand_off", "cand_pl", "start_off", "start_pl", "start_seg", "start_xy", "task_sv", "task_hit",
+              "task_list_off", "list_off", "hit_pl", "hit_seg", "hit_xy"):
+        out["cand_" + k] = c[k]
+    out.update({"gn_X": X, "gn_off": poff, "gn_view": pview, "gn_xy": pxy, "gn_Xout": Xo, "gn_inlier": inl})
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(name, "points", r["n_points"], "obs", r["n_obs"])
+
+
+if __name__ == "__main__":
+    make(0, "synthetic_tiny_v1.npz")

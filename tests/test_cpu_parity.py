@@ -63,6 +63,15 @@ def test_abi_library_exports_every_declared_symbol():
     assert declared == set(api.EXPORTED_SYMBOLS), declared ^ set(api.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
+    probe = open(os.path.join(root, "include", "eg3d_probe.h")).read()
+    for name in set(re.findall(r"\b(eg3d_probe_[a-z_0-9]+)\s*\(", probe)):
+        assert hasattr(L, name), name
+    H = host.lib()
+    hhdr = open(os.path.join(root, "include", "eg3d_host.h")).read()
+    host_syms = set(re.findall(r"\b(eg3d_(?:synth|host|sfm)_[a-z_0-9A-Z]+)\s*\(", hhdr))
+    assert len(host_syms) > 20
+    for name in host_syms:
+        assert hasattr(H, name), name
 
 
 def test_no_gpu_means_loud_failure():

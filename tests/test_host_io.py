@@ -1,0 +1,125 @@
+"""Host-side rows either side of the path: OpenMVG JSON round trip (a-IO), dedup + observation
+filter (N3) against the oracle, and the C++ reference-surface shim compiles."""
+import ctypes as C
+import json
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+from edgegraph3d_amd import _cdefs as D
+from edgegraph3d_amd import host
+from oracle import binding as ob
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _sfm_lib():
+    L = host.lib()
+    L.eg3d_sfm_read_json.restype = C.c_void_p
+    L.eg3d_sfm_read_json.argtypes = [C.c_char_p]
+    L.eg3d_sfm_write_json.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    L.eg3d_sfm_destroy.argtypes = [C.c_void_p]
+    L.eg3d_sfm_n_views.argtypes = [C.c_void_p]
+    L.eg3d_sfm_n_points.argtypes = [C.c_void_p]
+    L.eg3d_sfm_n_points.restype = C.c_uint64
+    L.eg3d_sfm_cam_P.argtypes = [C.c_void_p]
+    L.eg3d_sfm_cam_P.restype = D.f32p
+    L.eg3d_sfm_seeds.argtypes = [C.c_void_p, C.POINTER(D.Seeds)]
+    L.eg3d_sfm_points.argtypes = [C.c_void_p]
+    L.eg3d_sfm_points.restype = D.f32p
+    L.eg3d_sfm_add_edgepoints.argtypes = [C.c_void_p, C.POINTER(D.EdgePoints), D.u8p]
+    return L
+
+
+def _openmvg_doc(base=10):
+    R = [[1, 0, 0], [0, 1, 0], [0, 0, 1]]
+    views, extr = [], []
+    for i in range(3):
+        views.append({"key": i, "value": {"polymorphic_id": 1073741824, "ptr_wrapper": {"id": 2147483649 + i, "data": {
+            "local_path": "/", "filename": "%04d.png" % i, "width": 1600, "height": 1200, "id_view": i,
+            "id_intrinsic": 0, "id_pose": base + i}}}})
+        extr.append({"key": base + i, "value": {"rotation": R, "center": [100.0 * i, 0.5, -2.25]}})
+    structure = [{"key": 7, "value": {"X": [1.5, -2.0, 800.0], "observations": [
+        {"key": base, "value": {"id_feat": 3, "x": [801.25, 597.5]}},
+        {"key": base + 2, "value": {"id_feat": 9, "x": [551.0, 597.5]}},
+        {"key": base + 1, "value": {"id_feat": 1, "x": [676.125, 597.5]}}]}}]
+    return {"sfm_data_version": "0.3", "root_path": "/data/imgs", "views": views,
+            "intrinsics": [{"key": 0, "value": {"polymorphic_id": 2147483649, "polymorphic_name": "pinhole", "ptr_wrapper": {
+                "id": 2147483660, "data": {"width": 1600, "height": 1200, "focal_length": 2890.5, "principal_point": [823.0, 619.0]}}}}],
+            "extrinsics": extr, "structure": structure, "control_points": []}
+
+
+def test_openmvg_json_round_trip():
+    L = _sfm_lib()
+    with tempfile.TemporaryDirectory() as d:
+        p_in, p_out = os.path.join(d, "in.json"), os.path.join(d, "out.json")
+        json.dump(_openmvg_doc(), open(p_in, "w"))
+        h = L.eg3d_sfm_read_json(p_in.encode())
+        assert h
+        assert L.eg3d_sfm_n_views(h) == 3 and L.eg3d_sfm_n_points(h) == 1
+        P = D.as_np(L.eg3d_sfm_cam_P(h), 48, np.float32).reshape(3, 16)
+        # P = K4 [R | -R C]: view 1 has C = (100, 0.5, -2.25)
+        assert np.allclose(P[1, :12].reshape(3, 4), [[2890.5, 0, 823, -2890.5 * 100 + 823 * 2.25],
+                                                     [0, 2890.5, 619, -2890.5 * 0.5 + 619 * 2.25], [0, 0, 1, 2.25]])
+        assert np.all(P[:, 12:] == 0)                      # last row zero (Q6)
+        s = D.Seeds()
+        L.eg3d_sfm_seeds(h, C.byref(s))
+        views = D.as_np(s.trk_view, 3, np.int32)
+        assert list(views) == [0, 2, 1]                    # pose keys 10,12,11 -> positions in `extrinsics`
+        assert L.eg3d_sfm_write_json(h, p_in.encode(), p_out.encode()) == 0
+        out = json.load(open(p_out))
+        assert list(out.keys()) == ["sfm_data_version", "root_path", "views", "intrinsics", "extrinsics", "structure", "control_points"]
+        assert out["views"] == _openmvg_doc()["views"] and out["intrinsics"] == _openmvg_doc()["intrinsics"]
+        assert [e["key"] for e in out["extrinsics"]] == [0, 1, 2]     # rewritten with keys 0..V-1
+        assert out["extrinsics"][2]["value"]["center"] == [200.0, 0.5, -2.25]
+        st = out["structure"][0]
+        assert st["key"] == 0 and st["value"]["X"] == [1.5, -2.0, 800.0]
+        assert [o["key"] for o in st["value"]["observations"]] == [0, 2, 1]
+        assert all(o["value"]["id_feat"] == 0 for o in st["value"]["observations"])
+        assert st["value"]["observations"][2]["value"]["x"] == [676.125, 597.5]
+        L.eg3d_sfm_destroy(h)
+        # with natural pose keys (id_pose == position, the usual OpenMVG layout) the written file reads back identically
+        json.dump(_openmvg_doc(0), open(p_in, "w"))
+        h = L.eg3d_sfm_read_json(p_in.encode())
+        P = D.as_np(L.eg3d_sfm_cam_P(h), 48, np.float32)
+        assert L.eg3d_sfm_write_json(h, p_in.encode(), p_out.encode()) == 0
+        h2 = L.eg3d_sfm_read_json(p_out.encode())
+        P2 = D.as_np(L.eg3d_sfm_cam_P(h2), 48, np.float32)
+        assert np.array_equal(P, P2) and P.any()
+        assert json.load(open(p_out))["structure"] == json.load(open(p_out))["structure"]
+        L.eg3d_sfm_destroy(h)
+        L.eg3d_sfm_destroy(h2)
+
+
+def test_dedup_and_observation_filter_match_oracle():
+    s = host.Synth(1)
+    o = ob.Oracle(s.scene)
+    e, st = D.EdgePoints(), ob.Stats()
+    assert ob.lib().orc_match_refpoints(o._h, s.seeds, 0, s.n_seeds, 1, C.byref(e), C.byref(st)) == 0
+    n = int(e.n_points)
+    keep_o, keep_h = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    assert ob.lib().orc_filter_close_2d(o._h, C.byref(e), D.np_ptr(keep_o, C.c_uint8)) == 0
+    sc = s.scene.contents
+    assert host.lib().eg3d_host_filter_close_2d(sc.n_views, sc.width, sc.height, C.byref(e), D.np_ptr(keep_h, C.c_uint8)) == 0
+    assert np.array_equal(keep_o, keep_h)
+    assert 0 < keep_h.sum() < n                     # the greedy 3 px dedup removes some, keeps some
+    assert keep_h[0] == 1                           # the first point is always new
+    off = D.as_np(e.obs_off, n + 1, np.uint32)
+    a, b = np.ones(n, np.uint8), np.ones(n, np.uint8)
+    ta = ob.lib().orc_observation_filter(sc.n_views, D.np_ptr(off, C.c_uint32), n, n // 2, -1, D.np_ptr(a, C.c_uint8))
+    tb = host.lib().eg3d_host_observation_filter(sc.n_views, D.np_ptr(off, C.c_uint32), n, n // 2, -1, D.np_ptr(b, C.c_uint8))
+    assert ta == tb == 3 and np.array_equal(a, b)
+    assert a[: n // 2].all()                        # points before first_edgepoint are never dropped
+    ob.lib().orc_free_edgepoints(C.byref(e))
+
+
+def test_reference_surface_shim_compiles():
+    """include/eg3d_refapi.hpp (the reference's call surface over the C ABI) is valid C++17."""
+    src = '#include "eg3d_refapi.hpp"\nint main(){ eg3d_ref::SfMData s; eg3d_ref::FundamentalMatrices F; ' \
+          'std::vector<eg3d_ref::PolyLineGraph2D> g; (void)sizeof(eg3d_ref::PLGEdgeManager); return s.numPoints_; }\n'
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "t.cpp")
+        open(p, "w").write(src)
+        subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), p])

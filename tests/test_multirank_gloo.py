@@ -1,0 +1,89 @@
+"""N>1 path on CPU: world_size-2 gloo. Each rank computes its contiguous seed shard (with the
+oracle standing in for the GPU kernels — this test is about the sharding, packing and ordering
+logic of edgegraph3d_amd/distributed.py, which bench.py runs over RCCL), all-gathers the
+edge-point cloud and must reproduce the single-process output exactly, on every rank."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from edgegraph3d_amd import host
+from edgegraph3d_amd.distributed import CloudGather, shard_range
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, cfg, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from oracle import binding as ob
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    s = host.Synth(cfg)
+    o = ob.Oracle(s.scene)
+    b, e = shard_range(s.n_seeds, world)[rank]
+    r = o.match(s.seeds, b, e, 1)
+    dev = torch.device("cpu")
+
+    def raw(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).view(torch.uint8).reshape(-1) if a.size else torch.zeros(16, dtype=torch.uint8)
+
+    local = {"X": raw(r["X"]), "obs_off": raw(r["obs_off"][:-1]), "key": raw(r["key"]), "obs_view": raw(r["obs_view"]),
+             "obs_pl": raw(r["obs_pl"]), "obs_seg": raw(r["obs_seg"]), "obs_xy": raw(r["obs_xy"])}
+    g = CloudGather(dist, world, dev)
+    recv, counts, layout = g.allgather(local, r["n_points"], r["n_obs"])
+    cloud = g.unpack(recv, counts, layout)
+    q.put((rank, {k: (v.numpy().copy() if torch.is_tensor(v) else v) for k, v in cloud.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_ranges_cover_and_balance():
+    for n, w in ((10, 3), (2000, 8), (5, 8), (0, 2)):
+        r = shard_range(n, w)
+        assert r[0][0] == 0 and r[-1][1] == n
+        assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+        sizes = [e - b for b, e in r]
+        assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_allgather_reproduces_single_process_output():
+    from oracle import binding as ob
+    cfg, world = 1, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cfg, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    s = host.Synth(cfg)
+    ref = ob.Oracle(s.scene).match(s.seeds, 0, s.n_seeds, 1)
+    for rank in range(world):
+        c = got[rank]
+        assert c["n_points"] == ref["n_points"] and c["n_obs"] == ref["n_obs"]
+        assert np.array_equal(c["X"].view(np.uint32), ref["X"].view(np.uint32))
+        assert np.array_equal(c["key"].astype(np.uint32), ref["key"])
+        assert np.array_equal(c["obs_off"].astype(np.uint32), ref["obs_off"][:-1])
+        assert np.array_equal(c["obs_view"], ref["obs_view"])
+        assert np.array_equal(c["obs_pl"].astype(np.uint32), ref["obs_pl"])
+        assert np.array_equal(c["obs_seg"].astype(np.uint32), ref["obs_seg"])
+        assert np.array_equal(c["obs_xy"].view(np.uint32), ref["obs_xy"].view(np.uint32))

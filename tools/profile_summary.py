@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 rocpd SQLite outputs (gpurun_out/prof_*/…_results.db) into the text/JSON
+summaries committed under profiles/.
+
+  python tools/profile_summary.py --tag r01 --kt gpurun_out/prof_kt/r01_results.db \
+      --fetch gpurun_out/prof_fetch/r01_results.db --write gpurun_out/prof_write/r01_results.db \
+      --sq gpurun_out/prof_sq/r01_results.db
+
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
+WRITE_SIZE are collected in separate --pmc passes, are reported in KiB, and on gfx950
+FETCH_SIZE reads half of the bytes of wide coalesced streams (128 B requests tallied as 64 B), so
+both the raw value and the x2-corrected upper bound are listed.
+"""
+import argparse
+import json
+import os
+import re
+import sqlite3
+from collections import defaultdict
+
+
+def short(name):
+    m = re.match(r"(?:void )?(?:eg3d::)?([A-Za-z0-9_]+)(<[a-z]+>)?", name)
+    if "rocprim" in name:
+        return "rocprim::scan(init)" if "init_lookback" in name else "rocprim::scan"
+    return (m.group(1) + (m.group(2) or "")) if m else name[:40]
+
+
+def kernel_stats(path):
+    db = sqlite3.connect(path)
+    rows = db.execute("select name, duration from kernels").fetchall()
+    agg = defaultdict(list)
+    for n, d in rows:
+        agg[short(n)].append(d)
+    total = sum(sum(v) for v in agg.values())
+    out = []
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        out.append({"kernel": k, "calls": len(v), "total_us": sum(v) / 1e3, "avg_us": sum(v) / len(v) / 1e3,
+                    "min_us": min(v) / 1e3, "max_us": max(v) / 1e3, "pct": 100.0 * sum(v) / total})
+    return out
+
+
+def counter_stats(path):
+    db = sqlite3.connect(path)
+    rows = db.execute("select kernel_name, counter_name, value from counters_collection").fetchall()
+    agg = defaultdict(lambda: defaultdict(list))
+    for n, c, v in rows:
+        agg[short(n)][c].append(v)
+    return {k: {c: (sum(v) / len(v), len(v)) for c, v in d.items()} for k, d in agg.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tag", required=True)
+    ap.add_argument("--kt")
+    ap.add_argument("--fetch")
+    ap.add_argument("--write")
+    ap.add_argument("--sq")
+    ap.add_argument("--cmd", default="python bench.py --steps 20 --warmup 3 --no-cpu-baseline")
+    ap.add_argument("--out", default="profiles")
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    lines = []
+    if a.kt:
+        ks = kernel_stats(a.kt)
+        lines.append("# rocprofv3 --kernel-trace --stats -- %s" % a.cmd)
+        lines.append("%-28s %6s %12s %12s %10s %10s %7s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct"))
+        for k in ks:
+            lines.append("%-28s %6d %12.1f %12.2f %10.2f %10.2f %6.2f%%" % (k["kernel"], k["calls"], k["total_us"],
+                                                                          k["avg_us"], k["min_us"], k["max_us"], k["pct"]))
+        json.dump(ks, open(os.path.join(a.out, "%s_kernel_stats.json" % a.tag), "w"), indent=1)
+    traffic = {}
+    for label, path in (("FETCH_SIZE", a.fetch), ("WRITE_SIZE", a.write)):
+        if not path:
+            continue
+        cs = counter_stats(path)
+        lines.append("")
+        lines.append("# rocprofv3 --pmc %s --kernel-trace (own pass)  [KiB per launch, mean]" % label)
+        for k, d in sorted(cs.items(), key=lambda kv: -kv[1].get(label, (0, 0))[0]):
+            if label in d and d[label][0] > 0:
+                kib, n = d[label]
+                lines.append("%-28s %12.1f KiB  (%d launches)" % (k, kib, n))
+                traffic.setdefault(k, {})[label] = kib * 1024.0
+    if traffic:
+        out = {}
+        for k, d in traffic.items():
+            f, w = d.get("FETCH_SIZE", 0.0), d.get("WRITE_SIZE", 0.0)
+            out[k] = {"fetch_bytes_raw": f, "write_bytes_raw": w, "hbm_bytes_per_launch": 2.0 * f + w,
+                      "note": "FETCH_SIZE x2 (gfx950 wide-read correction, upper bound) + WRITE_SIZE"}
+        json.dump(out, open(os.path.join(a.out, "pmc_traffic.json"), "w"), indent=1)
+        lines.append("")
+        lines.append("# HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (guide's gfx950 correction; upper bound)")
+        for k, d in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:8]:
+            lines.append("%-28s %14.0f B" % (k, d["hbm_bytes_per_launch"]))
+    if a.sq:
+        cs = counter_stats(a.sq)
+        lines.append("")
+        lines.append("# rocprofv3 --pmc SQ_* --kernel-trace (own pass) [mean per launch]")
+        for k, d in cs.items():
+            if not k.startswith("k"):
+                continue
+            lines.append("%-28s %s" % (k, "  ".join("%s=%.3g" % (c, v[0]) for c, v in sorted(d.items()))))
+    open(os.path.join(a.out, "%s_rocprof_summary.txt" % a.tag), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
