@@ -61,7 +61,8 @@ def build_hip(force=False):
     deps = srcs + host_srcs + _all_sources(CSRC_DIR, (".h", ".hpp")) + _all_sources(INC_DIR, (".h",))
     if force or _newer(HIP_LIB, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        _run([hipcc] + HIP_FLAGS + ["-I", INC_DIR, "-I", CSRC_DIR, "-I", HOST_DIR, "-o", HIP_LIB] + srcs + host_srcs)
+        extra = os.environ.get("EG3D_EXTRA_HIPFLAGS", "").split()
+        _run([hipcc] + HIP_FLAGS + extra + ["-I", INC_DIR, "-I", CSRC_DIR, "-I", HOST_DIR, "-o", HIP_LIB] + srcs + host_srcs)
     return HIP_LIB
 
 

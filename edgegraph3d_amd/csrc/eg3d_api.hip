@@ -85,7 +85,7 @@ struct eg3d_ctx {
   DevBuf b_sv_seed, b_map_view, b_map_entry, b_map_n, b_raw_cnt, b_raw_off, b_cand_pl, b_start_hits, b_cand_cnt,
       b_start_cnt, b_task_off, b_task_seed, b_task_entry, b_task_hit, b_task_k, b_task_list_off, b_list_cnt, b_list_ptr,
       b_hits, b_tasks, b_nhyp, b_hyp_off, b_res, b_hscratch, b_arena, b_ctr, b_cs_task, b_valid, b_chain_off, b_chains,
-      b_cscratch, b_couts, b_cpts, b_cobs, b_cpoff, b_cooff, b_scan_tmp;
+      b_cscratch, b_couts, b_cpts, b_cobs, b_cpoff, b_cooff, b_scan_tmp, b_cost, b_cidx, b_cost2, b_order;
   DevBuf o_X, o_off, o_view, o_pl, o_seg, o_xy, o_key;
   DevBuf f_X, f_off, f_view, f_xy, f_Xo, f_inl;
   hipEvent_t ea[8], eb[8];  // begin/end events per stage: 1 K1, 2 K2, 3 K3a, 4 K3s, 5 K3b, 6 K4, 0 misc
@@ -93,6 +93,7 @@ struct eg3d_ctx {
   uint32_t k3a_blocks = 0;
   uint64_t last_np = 0, last_no = 0;
   int last_chunks = 0;
+  uint32_t last_nc = 0;
 };
 
 template <typename T>
@@ -238,7 +239,7 @@ extern "C" void eg3d_destroy(eg3d_ctx* c) {
                    &c->b_task_k, &c->b_task_list_off, &c->b_list_cnt, &c->b_list_ptr, &c->b_hits, &c->b_tasks,
                    &c->b_nhyp, &c->b_hyp_off, &c->b_res, &c->b_hscratch, &c->b_arena, &c->b_ctr, &c->b_cs_task,
                    &c->b_valid, &c->b_chain_off, &c->b_chains, &c->b_cscratch, &c->b_couts, &c->b_cpts, &c->b_cobs,
-                   &c->b_cpoff, &c->b_cooff, &c->b_scan_tmp, &c->o_X, &c->o_off, &c->o_view, &c->o_pl, &c->o_seg,
+                   &c->b_cpoff, &c->b_cooff, &c->b_scan_tmp, &c->b_cost, &c->b_cidx, &c->b_cost2, &c->b_order, &c->o_X, &c->o_off, &c->o_view, &c->o_pl, &c->o_seg,
                    &c->o_xy, &c->o_key, &c->f_X, &c->f_off, &c->f_view, &c->f_xy, &c->f_Xo, &c->f_inl};
   for (DevBuf* b : all) b->release();
   for (int i = 0; i < 8; i++) {
@@ -457,12 +458,32 @@ int run_batch(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, HostOut& H) 
     HIP_TRY(hipMemsetAsync(c->b_cpts.as<uint32_t>() + nc, 0, sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(c->b_cobs.as<uint32_t>() + nc, 0, sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(c->b_ctr.p, 0, 2 * sizeof(uint32_t), st));
+    // longest-first launch order of this chunk's chains (sort by estimated cost, descending)
+    BUF_TRY(c->b_cost.ensure(sizeof(uint32_t) * (nc + 1)));
+    BUF_TRY(c->b_cidx.ensure(sizeof(uint32_t) * (nc + 1)));
+    BUF_TRY(c->b_cost2.ensure(sizeof(uint32_t) * (nc + 1)));
+    BUF_TRY(c->b_order.ensure(sizeof(uint32_t) * (nc + 1)));
+    static const bool use_lpt = !(getenv("EG3D_NO_LPT") && getenv("EG3D_NO_LPT")[0] == '1');
+    launch_chain_cost(st, B.a, c->b_tasks.as<TaskDesc>(), c->b_chains.as<ChainSeed>() + c0, nc, c->b_cost.as<uint32_t>(),
+                      c->b_cidx.as<uint32_t>());
+    {
+      size_t tmp_bytes = 0;
+      HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, c->b_cost.as<uint32_t>(),
+                                                           c->b_cost2.as<uint32_t>(), c->b_cidx.as<uint32_t>(),
+                                                           c->b_order.as<uint32_t>(), (int)nc, 0, 32, st));
+      BUF_TRY(c->b_scan_tmp.ensure(tmp_bytes));
+      HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(c->b_scan_tmp.p, tmp_bytes, c->b_cost.as<uint32_t>(),
+                                                           c->b_cost2.as<uint32_t>(), c->b_cidx.as<uint32_t>(),
+                                                           c->b_order.as<uint32_t>(), (int)nc, 0, 32, st));
+    }
+    if (!use_lpt)  // identity order (diagnostic): chain j runs in block j
+      HIP_TRY(hipMemcpyAsync(c->b_order.p, c->b_cidx.p, sizeof(uint32_t) * nc, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipEventRecord(c->ea[5], st));
     launch_k3b(st, c->ds, B.a, c->b_tasks.as<TaskDesc>(), c->b_chains.as<ChainSeed>() + c0, nc,
                c->b_hyp_off.as<uint32_t>(), c->b_res.as<HypResult>(), c->b_arena.as<HPoint>(),
                c->b_map_view.as<int32_t>(), c->b_map_entry.as<uint32_t>(), c->b_map_n.as<uint32_t>(), L,
                c->b_cscratch.as<unsigned char>(), c->b_couts.as<ChainOut>(), c->b_cpts.as<uint32_t>(),
-               c->b_cobs.as<uint32_t>(), c->b_ctr.as<Counters>());
+               c->b_cobs.as<uint32_t>(), c->b_ctr.as<Counters>(), c->b_order.as<uint32_t>());
     HIP_TRY(hipEventRecord(c->eb[5], st));
     BUF_TRY(scan_exclusive_u32(c, c->b_cpts.as<uint32_t>(), c->b_cpoff.as<uint32_t>(), nc + 1));
     BUF_TRY(scan_exclusive_u32(c, c->b_cobs.as<uint32_t>(), c->b_cooff.as<uint32_t>(), nc + 1));
@@ -515,6 +536,7 @@ int run_batch(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, HostOut& H) 
     c->last_np = np;
     c->last_no = no;
     c->last_chunks++;
+    c->last_nc = nc;
   }
   HIP_TRY(hipStreamSynchronize(st));
   float t = 0;
@@ -775,6 +797,23 @@ extern "C" int eg3d_gn_filter(eg3d_ctx* c, const float* X, const uint32_t* obs_o
   }
   HIP_TRY(hipStreamSynchronize(st));
   if (ms_kernel) HIP_TRY(hipEventElapsedTime(ms_kernel, c->ea[0], c->eb[0]));
+  return EG3D_OK;
+}
+
+extern "C" int eg3d_probe_sections(eg3d_ctx* c, double* sum, double* slowest, uint32_t* n_chains) {
+  if (!c || !sum || !slowest) return EG3D_ERR_ARG;
+  std::vector<ChainOut> co(c->last_nc ? c->last_nc : 1);
+  if (c->last_nc) HIP_TRY(hipMemcpy(co.data(), c->b_couts.p, sizeof(ChainOut) * c->last_nc, hipMemcpyDeviceToHost));
+  for (int k = 0; k < 8; k++) sum[k] = slowest[k] = 0;
+  uint64_t worst = 0;
+  for (uint32_t j = 0; j < c->last_nc; j++) {
+    for (int k = 0; k < 8; k++) sum[k] += (double)co[j].tsec[k];
+    if (co[j].tsec[7] >= worst) {
+      worst = co[j].tsec[7];
+      for (int k = 0; k < 8; k++) slowest[k] = (double)co[j].tsec[k];
+    }
+  }
+  if (n_chains) *n_chains = c->last_nc;
   return EG3D_OK;
 }
 

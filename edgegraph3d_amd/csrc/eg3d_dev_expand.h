@@ -36,6 +36,20 @@ struct ViewCand {
   uint32_t valid;  // exactly one polyline in the window
   uint32_t pl, seg;
   float x, y, d2;
+  uint32_t cok;    // speculative central ADD solve of (point + this observation) succeeded
+  float cX[3];     // its result
+};
+
+// One "starting observation" candidate of an N-view step, evaluated by one team member.
+#define EG3D_STEP_OBS 16
+struct StepSlot {
+  uint32_t ok;     // candidate produced a valid point
+  int32_t m;       // its observation count
+  float X[3];
+  uint32_t flags;  // EG3D_FLAG_* bits raised while evaluating it
+  Obs sel[EG3D_STEP_OBS];
+  Obs tmp[EG3D_STEP_OBS];
+  uint8_t mask[EG3D_STEP_OBS];
 };
 
 // Execution team of one chain. The expand stage is written SPMD-style: every member runs the
@@ -45,9 +59,15 @@ struct ViewCand {
 // host instantiation uses; the GPU kernel uses a 64-lane wavefront (TeamWave in
 // eg3d_kernels.hip).
 struct TeamSeq {
+  static constexpr bool kSlotStep = false;  // N-view step: plain sequential candidates
   EG3D_HD int lane() const { return 0; }
   EG3D_HD int size() const { return 1; }
   EG3D_HD void sync() const {}
+};
+// One member, but routed through the slot-based (parallel-capable) N-view step: lets the host
+// instantiation exercise exactly the code path the 64-lane team runs.
+struct TeamSeqSlots : TeamSeq {
+  static constexpr bool kSlotStep = true;
 };
 
 // Per-chain working set (pointers into this chain's scratch slice).
@@ -63,13 +83,20 @@ struct Chain {
   Pending* pend1;        // [cap_pts]
   Pending* pend2;        // [cap_pts]
   ViewCand* cand;        // [cap_pts]
+  StepSlot* slots;       // [EG3D_STEP_OBS]
   Obs* tmp_a;            // [tmp_cap]
   Obs* tmp_b;            // [tmp_cap]
   uint8_t* tmp_mask;     // [tmp_cap]
   int32_t tmp_cap;
   uint32_t flags;
   uint64_t bytes;  // vertices of 4 px-grid polylines tested (algorithmic bytes)
+  uint64_t tsec[8];  // diagnostic: shader-clock ticks per section (0 cand, 1 central, 2 walks, 3 batch GN, 4 follow, 5 commit)
 };
+#if defined(__HIP_DEVICE_COMPILE__) && defined(EG3D_SECTION_TIMING)
+#define EG3D_TICK() ((uint64_t)__builtin_readcyclecounter())
+#else
+#define EG3D_TICK() ((uint64_t)0)
+#endif
 
 EG3D_HD ChainPt& chain_at(Chain& c, int i) { return c.pts[c.head + i]; }
 
@@ -126,77 +153,159 @@ EG3D_HD bool pool_append(Chain& c, ChainPt& p, const Obs& o) {
 // GN from the stored X with the point's observations plus one more (ADD).
 EG3D_HD bool add_observation_solve(const DevScene& s, const Chain& c, const ChainPt& p, const Obs& extra,
                                    float Xout[3]) {
+  double X0[3] = {(double)p.X[0], (double)p.X[1], (double)p.X[2]};
+  const int n = (int)p.nobs;
+  if (n + 1 <= EG3D_LOCAL_OBS) {
+    // gather the list once; the solver then streams from lane-private arrays
+    LocalCursor lc;
+    uint32_t q = p.head;
+    for (int i = 0; i < n; i++) {
+      const PoolObs& po = c.pool[q];
+      lc.v[i] = po.o.view;
+      lc.x[i] = po.o.x;
+      lc.y[i] = po.o.y;
+      q = po.next;
+    }
+    lc.v[n] = extra.view;
+    lc.x[n] = extra.x;
+    lc.y[n] = extra.y;
+    lc.n = n + 1;
+    lc.i = 0;
+    return gauss_newton_f64(s.cam_P, lc, X0, Xout);
+  }
   ListCursor cur;
   cur.pool = c.pool;
   cur.head = p.head;
-  cur.n = (int)p.nobs;
+  cur.n = n;
   cur.extra = &extra;
   cur.rewind();
-  double X0[3] = {(double)p.X[0], (double)p.X[1], (double)p.X[2]};
   return gauss_newton_f64(s.cam_P, cur, X0, Xout);
 }
 
-// N-view step on a chain point with any number of observations; the new point is returned in
-// tmp_a[0..m) with its X. Returns the number of observations of the new point (0 = failure).
-EG3D_HD int stepn_chain(const DevScene& s, Chain& c, const ChainPt& cur, const uint32_t* dirs, float Xout[3]) {
+// Walk phase of one candidate of the N-view step on chain point `cur`: observation `st`
+// advances 10 px on its polyline, every other observation follows by a bounded (5..20 px)
+// epipolar walk. Returns the number of observations collected in sel (0 = candidate dead).
+EG3D_HD int stepn_walks(const DevScene& s, const Chain& c, const ChainPt& cur, int st, const uint32_t* dirs, Obs* sel,
+                        int sel_cap, uint32_t& flags) {
   const int n = (int)cur.nobs;
   uint32_t si = cur.head;
-  for (int st = 0; st < n; st++, si = c.pool[si].next) {
-    const Obs so = c.pool[si].o;
-    PlRef ps = polyline_of(s, so.view, so.pl);
-    PlPt p, q;
-    p.seg = so.seg;
-    p.x = so.x;
-    p.y = so.y;
-    uint32_t w = walk_by_distance(ps, p, dirs[so.view], EG3D_FOLLOW_STEP, q);
-    if (w & WALK_BAD_DIR) c.flags |= 8u;
-    if (w & WALK_EXTREME) continue;
-    Obs* sel = c.tmp_a;
-    int m = 0;
-    sel[m].view = so.view;
-    sel[m].pl = so.pl;
-    sel[m].seg = q.seg;
-    sel[m].x = q.x;
-    sel[m].y = q.y;
-    m++;
-    uint32_t oi = cur.head;
-    for (int i = 0; i < n; i++, oi = c.pool[oi].next) {
-      if (i == st) continue;
-      const Obs co = c.pool[oi].o;
-      float la, lb, lc;
-      if (!epiline(s.F, s.F_valid, s.n_views, so.view, co.view, q.x, q.y, la, lb, lc)) continue;
-      PlRef pk = polyline_of(s, co.view, co.pl);
-      PlPt cp, r;
-      cp.seg = co.seg;
-      cp.x = co.x;
-      cp.y = co.y;
-      uint32_t wr = walk_by_line(pk, cp, dirs[co.view], la, lb, lc, true, EG3D_FOLLOW_MIN, EG3D_FOLLOW_MAX, r);
-      if (wr & WALK_BAD_DIR) c.flags |= 8u;
-      if (wr & WALK_FOUND) {
-        if (m >= c.tmp_cap) {
-          c.flags |= 2u;
-          break;
-        }
-        sel[m].view = co.view;
-        sel[m].pl = co.pl;
-        sel[m].seg = r.seg;
-        sel[m].x = r.x;
-        sel[m].y = r.y;
-        m++;
+  for (int k = 0; k < st; k++) si = c.pool[si].next;
+  const Obs so = c.pool[si].o;
+  PlRef ps = polyline_of(s, so.view, so.pl);
+  PlPt p, q;
+  p.seg = so.seg;
+  p.x = so.x;
+  p.y = so.y;
+  uint32_t w = walk_by_distance(ps, p, dirs[so.view], EG3D_FOLLOW_STEP, q);
+  if (w & WALK_BAD_DIR) flags |= 8u;
+  if (w & WALK_EXTREME) return 0;
+  int m = 0;
+  sel[m].view = so.view;
+  sel[m].pl = so.pl;
+  sel[m].seg = q.seg;
+  sel[m].x = q.x;
+  sel[m].y = q.y;
+  m++;
+  uint32_t oi = cur.head;
+  for (int i = 0; i < n; i++, oi = c.pool[oi].next) {
+    if (i == st) continue;
+    const Obs co = c.pool[oi].o;
+    float la, lb, lc;
+    if (!epiline(s.F, s.F_valid, s.n_views, so.view, co.view, q.x, q.y, la, lb, lc)) continue;
+    PlRef pk = polyline_of(s, co.view, co.pl);
+    PlPt cp, r;
+    cp.seg = co.seg;
+    cp.x = co.x;
+    cp.y = co.y;
+    uint32_t wr = walk_by_line(pk, cp, dirs[co.view], la, lb, lc, true, EG3D_FOLLOW_MIN, EG3D_FOLLOW_MAX, r);
+    if (wr & WALK_BAD_DIR) flags |= 8u;
+    if (wr & WALK_FOUND) {
+      if (m >= sel_cap) {
+        flags |= 2u;
+        break;
       }
+      sel[m].view = co.view;
+      sel[m].pl = co.pl;
+      sel[m].seg = r.seg;
+      sel[m].x = r.x;
+      sel[m].y = r.y;
+      m++;
     }
-    if (m < 3) continue;
-    bool valid = triangulate_array(s.cam_P, sel, m, Xout, c.flags);
-    if (!valid && m > 3) {
-      valid = triangulate_combinations(s.cam_P, sel, m, c.tmp_b, c.tmp_mask, Xout, c.flags);
-      if (valid) {
-        int k = 0;
-        for (int i = 0; i < m; i++)
-          if (c.tmp_mask[i]) sel[k++] = sel[i];
-        m = k;
-      }
+  }
+  return m < 3 ? 0 : m;
+}
+
+// Triangulation fallback of a candidate whose all-observation solve failed: first valid 3-subset
+// + greedy ADD (triangulation.cpp:1105-1158); compacts sel to the kept observations.
+EG3D_HD int stepn_fallback(const DevScene& s, Obs* sel, int m, Obs* tmp, uint8_t* mask, float Xout[3], uint32_t& flags) {
+  if (m <= 3) return 0;
+  if (!triangulate_combinations(s.cam_P, sel, m, tmp, mask, Xout, flags)) return 0;
+  int k = 0;
+  for (int i = 0; i < m; i++)
+    if (mask[i]) sel[k++] = sel[i];
+  return k;
+}
+
+// N-view step (compatible() vector form, plg_matching.cpp:633-759): the first candidate, in
+// observation order, that yields a valid point wins. Team version: (1) PARALLEL walk phase, one
+// member per starting observation; (2) PARALLEL, convergent all-observation triangulation of
+// every live candidate; (3) uniform scan in observation order — a candidate whose solve failed
+// runs the (rare, expensive) 3-subset fallback only when the sequential order actually reaches
+// it. Flags of candidates past the winner are dropped, as the sequential order never ran them.
+// The new point is returned in tmp_a[0..m) with its X.
+template <class Team>
+EG3D_HD int stepn_chain(const Team& tm, const DevScene& s, Chain& c, const ChainPt& cur, const uint32_t* dirs,
+                        float Xout[3]) {
+  const int n = (int)cur.nobs;
+  if (n > EG3D_STEP_OBS || !Team::kSlotStep) {
+    for (int st = 0; st < n; st++) {
+      int m = stepn_walks(s, c, cur, st, dirs, c.tmp_a, c.tmp_cap, c.flags);
+      if (!m) continue;
+      if (triangulate_array(s.cam_P, c.tmp_a, m, Xout, c.flags)) return m;
+      m = stepn_fallback(s, c.tmp_a, m, c.tmp_b, c.tmp_mask, Xout, c.flags);
+      if (m) return m;
     }
-    if (valid) return m;
+    return 0;
+  }
+  tm.sync();
+  for (int st = tm.lane(); st < n; st += tm.size()) {
+    StepSlot& sl = c.slots[st];
+    uint32_t fl = 0;
+    sl.m = stepn_walks(s, c, cur, st, dirs, sl.sel, EG3D_STEP_OBS, fl);
+    sl.flags = fl;
+    sl.ok = 0;
+  }
+  tm.sync();
+  for (int st = tm.lane(); st < n; st += tm.size()) {
+    StepSlot& sl = c.slots[st];
+    if (sl.m) {
+      uint32_t fl = sl.flags;
+      float X[3] = {0.f, 0.f, 0.f};
+      sl.ok = triangulate_array(s.cam_P, sl.sel, sl.m, X, fl) ? 1u : 0u;
+      sl.X[0] = X[0];
+      sl.X[1] = X[1];
+      sl.X[2] = X[2];
+      sl.flags = fl;
+    }
+  }
+  tm.sync();
+  for (int st = 0; st < n; st++) {
+    StepSlot& sl = c.slots[st];
+    c.flags |= sl.flags;
+    int m = sl.m;
+    if (!m) continue;
+    if (sl.ok) {
+      Xout[0] = sl.X[0];
+      Xout[1] = sl.X[1];
+      Xout[2] = sl.X[2];
+    } else {
+      for (int i = 0; i < m; i++) c.tmp_a[i] = sl.sel[i];
+      m = stepn_fallback(s, c.tmp_a, m, c.tmp_b, c.tmp_mask, Xout, c.flags);
+      if (!m) continue;
+      return m;
+    }
+    for (int i = 0; i < m; i++) c.tmp_a[i] = sl.sel[i];
+    return m;
   }
   return 0;
 }
@@ -214,11 +323,12 @@ EG3D_HD bool new_point_from_tmp(Chain& c, ChainPt& np, int m, const float X[3]) 
 }
 
 // Grow the chain at the back / at the front while steps succeed. Returns points added.
-EG3D_HD int follow_back(const DevScene& s, Chain& c) {
+template <class Team>
+EG3D_HD int follow_back(const Team& tm, const DevScene& s, Chain& c) {
   int added = 0;
   for (;;) {
     float X[3];
-    int m = stepn_chain(s, c, chain_at(c, c.len - 1), c.end_dirs, X);
+    int m = stepn_chain(tm, s, c, chain_at(c, c.len - 1), c.end_dirs, X);
     if (m == 0) break;
     if (c.head + c.len >= c.cap_pts) {
       c.flags |= 1u;
@@ -232,11 +342,12 @@ EG3D_HD int follow_back(const DevScene& s, Chain& c) {
   }
   return added;
 }
-EG3D_HD int follow_front(const DevScene& s, Chain& c) {
+template <class Team>
+EG3D_HD int follow_front(const Team& tm, const DevScene& s, Chain& c) {
   int added = 0;
   for (;;) {
     float X[3];
-    int m = stepn_chain(s, c, chain_at(c, 0), c.start_dirs, X);
+    int m = stepn_chain(tm, s, c, chain_at(c, 0), c.start_dirs, X);
     if (m == 0) break;
     if (c.head <= 0) {
       c.flags |= 1u;
@@ -296,8 +407,11 @@ EG3D_HD int walk_side_candidates(const DevScene& s, Chain& c, int view, const Ob
 template <class Team>
 EG3D_HD int walk_side(const Team& tm, const DevScene& s, Chain& c, int view, const Obs& from, uint32_t direction,
                       int lo, int ci, int hi, bool towards_start, Pending* out) {
+  uint64_t t0 = EG3D_TICK();
   const int m = walk_side_candidates(s, c, view, from, direction, lo, ci, hi, towards_start, out);
   tm.sync();
+  uint64_t t1 = EG3D_TICK();
+  c.tsec[2] += t1 - t0;
   for (int j = tm.lane(); j < m; j += tm.size()) {
     const ChainPt& pt = chain_at(c, towards_start ? ci - 1 - j : ci + 1 + j);
     float X[3];
@@ -310,6 +424,7 @@ EG3D_HD int walk_side(const Team& tm, const DevScene& s, Chain& c, int view, con
     }
   }
   tm.sync();
+  c.tsec[3] += EG3D_TICK() - t1;
   int cnt = 0;
   while (cnt < m && out[cnt].ok) cnt++;
   return cnt;
@@ -320,11 +435,22 @@ EG3D_HD int walk_side(const Team& tm, const DevScene& s, Chain& c, int view, con
 // including newly grown points. (add_view_to_3dpoint_and_sides_plgp_matches_vector, Q13.)
 template <class Team>
 EG3D_HD bool attach_view(const Team& tm, const DevScene& s, Chain& c, const Obs& o, int lo, int ci, int hi,
-                         int& to_start, int& to_end) {
+                         int& to_start, int& to_end, const uint32_t* pre_ok, const float* pre_X) {
   to_start = 0;
   to_end = 0;
   float Xc[3];
-  if (!add_observation_solve(s, c, chain_at(c, ci), o, Xc)) return false;
+  if (pre_ok) {
+    // the central solve was done speculatively (chain state unchanged since): reuse it
+    if (!*pre_ok) return false;
+    Xc[0] = pre_X[0];
+    Xc[1] = pre_X[1];
+    Xc[2] = pre_X[2];
+  } else {
+    uint64_t t0 = EG3D_TICK();
+    bool okc = add_observation_solve(s, c, chain_at(c, ci), o, Xc);
+    c.tsec[1] += EG3D_TICK() - t0;
+    if (!okc) return false;
+  }
   const int view = o.view;
   PlRef pl = polyline_of(s, view, o.pl);
   uint32_t nd1 = 0, nd2 = 0;
@@ -372,16 +498,18 @@ EG3D_HD bool attach_view(const Team& tm, const DevScene& s, Chain& c, const Obs&
   }
   to_start = n1;
   to_end = n2;
+  uint64_t tf0 = EG3D_TICK();
   if (n1 > 0 && n1 == ci) {
     c.start_dirs[view] = nd1;
-    int g = follow_front(s, c);
+    int g = follow_front(tm, s, c);
     to_start += g;
     ci += g;
   }
   if (n2 > 0 && n2 == (c.len - ci - 1)) {
     c.end_dirs[view] = nd2;
-    to_end += follow_back(s, c);
+    to_end += follow_back(tm, s, c);
   }
+  c.tsec[4] += EG3D_TICK() - tf0;
   tm.sync();
   return true;
 }
@@ -415,6 +543,7 @@ EG3D_HD bool unique_polyline_4px(const DevScene& s, int view, float x, float y, 
 template <class Team>
 EG3D_HD void view_candidates(const Team& tm, const DevScene& s, Chain& c, int v, int from) {
   const float* P = s.cam_P + (size_t)v * 16;
+  uint64_t tc0 = EG3D_TICK();
   for (int i = from + tm.lane(); i < c.len; i += tm.size()) {
     const ChainPt& pt = chain_at(c, i);
     ViewCand vc;
@@ -422,6 +551,8 @@ EG3D_HD void view_candidates(const Team& tm, const DevScene& s, Chain& c, int v,
     vc.pl = 0;
     vc.seg = 0;
     vc.x = vc.y = vc.d2 = 0.0f;
+    vc.cok = 0;
+    vc.cX[0] = vc.cX[1] = vc.cX[2] = 0.0f;
     float u, w;
     project_f32(P, pt.X[0], pt.X[1], pt.X[2], u, w);
     uint32_t pl_id;
@@ -434,10 +565,20 @@ EG3D_HD void view_candidates(const Team& tm, const DevScene& s, Chain& c, int v,
       vc.seg = cp.seg;
       vc.x = cp.x;
       vc.y = cp.y;
+      if (vc.d2 <= 16.0f) {
+        Obs o;
+        o.view = v;
+        o.pl = pl_id;
+        o.seg = cp.seg;
+        o.x = cp.x;
+        o.y = cp.y;
+        vc.cok = add_observation_solve(s, c, pt, o, vc.cX) ? 1u : 0u;
+      }
     }
     c.cand[i] = vc;
   }
   tm.sync();
+  c.tsec[0] += EG3D_TICK() - tc0;
 }
 
 // Offer the chain to view v. epc = the task's epipolar hits in v (may be empty).
@@ -446,9 +587,25 @@ EG3D_HD void expand_to_view(const Team& tm, const DevScene& s, Chain& c, int v, 
                             int& centre) {
   bool epc_matched = false;
   int idx_first = 0, idx_second = 0;
+  // PARALLEL over the epipolar candidates: speculative central solves against chain[centre]
+  // (results parked in the candidate array, which is rebuilt below before its own use)
+  const int n_pre = n_epc < c.cap_pts ? n_epc : c.cap_pts;
+  if (n_epc > 1) {
+    for (int e = tm.lane(); e < n_pre; e += tm.size()) {
+      ViewCand vc;
+      vc.valid = 0;
+      vc.pl = vc.seg = 0;
+      vc.x = vc.y = vc.d2 = 0.0f;
+      vc.cok = add_observation_solve(s, c, chain_at(c, centre), epc[e], vc.cX) ? 1u : 0u;
+      c.cand[e] = vc;
+    }
+    tm.sync();
+  }
   for (int e = 0; e < n_epc; e++) {
     int a, b;
-    if (attach_view(tm, s, c, epc[e], 0, centre, c.len, a, b)) {
+    const bool pre = (n_epc > 1 && e < n_pre);
+    if (attach_view(tm, s, c, epc[e], 0, centre, c.len, a, b, pre ? &c.cand[e].cok : nullptr,
+                    pre ? c.cand[e].cX : nullptr)) {
       epc_matched = true;
       if (a > centre) {
         centre = a;
@@ -481,7 +638,7 @@ EG3D_HD void expand_to_view(const Team& tm, const DevScene& s, Chain& c, int v, 
     o.y = vc.y;
     int hi = epc_matched ? (cur <= idx_first ? idx_first : c.len) : c.len;
     int a, b;
-    if (attach_view(tm, s, c, o, last_matched + 1, cur, hi, a, b)) {
+    if (attach_view(tm, s, c, o, last_matched + 1, cur, hi, a, b, &c.cand[cur].cok, c.cand[cur].cX)) {
       if (a > cur) {
         centre = a;
         cur = a + b;

@@ -167,7 +167,7 @@ EG3D_HD bool select_task(const HypResult* res, uint32_t h0, uint32_t h1, ChainSe
 // Scratch slice layout of one chain (bytes); all sub-arrays 8-byte aligned.
 struct ChainLayout {
   uint32_t cap_pts, pool_cap, tmp_cap, n_views;
-  size_t off_pts, off_pool, off_sdir, off_edir, off_p1, off_p2, off_cand, off_ta, off_tb, off_tm, total;
+  size_t off_pts, off_pool, off_sdir, off_edir, off_p1, off_p2, off_cand, off_slots, off_ta, off_tb, off_tm, total;
 };
 EG3D_HD size_t align8(size_t v) { return (v + 7) & ~(size_t)7; }
 EG3D_HD ChainLayout chain_layout(uint32_t cap_pts, uint32_t pool_cap, uint32_t n_views) {
@@ -191,6 +191,8 @@ EG3D_HD ChainLayout chain_layout(uint32_t cap_pts, uint32_t pool_cap, uint32_t n
   o = align8(o + sizeof(Pending) * cap_pts);
   L.off_cand = o;
   o = align8(o + sizeof(ViewCand) * cap_pts);
+  L.off_slots = o;
+  o = align8(o + sizeof(StepSlot) * EG3D_STEP_OBS);
   L.off_ta = o;
   o = align8(o + sizeof(Obs) * L.tmp_cap);
   L.off_tb = o;
@@ -210,6 +212,7 @@ EG3D_HD void chain_bind(Chain& c, const ChainLayout& L, unsigned char* slice) {
   c.pend1 = (Pending*)(slice + L.off_p1);
   c.pend2 = (Pending*)(slice + L.off_p2);
   c.cand = (ViewCand*)(slice + L.off_cand);
+  c.slots = (StepSlot*)(slice + L.off_slots);
   c.tmp_a = (Obs*)(slice + L.off_ta);
   c.tmp_b = (Obs*)(slice + L.off_tb);
   c.tmp_mask = (uint8_t*)(slice + L.off_tm);
@@ -219,6 +222,7 @@ EG3D_HD void chain_bind(Chain& c, const ChainLayout& L, unsigned char* slice) {
 struct ChainOut {
   uint32_t n_points, n_obs, flags, head;
   uint64_t bytes;
+  uint64_t tsec[8];  // diagnostic section ticks (zero unless built with EG3D_SECTION_TIMING)
 };
 
 // Build the chain reverse(pts1) + central + pts2, then offer it to every view except the
@@ -233,6 +237,8 @@ EG3D_HD void expand_chain(const Team& tm, const DevScene& s, const StageAView& a
   chain_bind(c, L, slice);
   c.flags = 0;
   c.bytes = 0;
+  for (int k = 0; k < 8; k++) c.tsec[k] = 0;
+  const uint64_t t_begin = EG3D_TICK();
   c.pool_used = 0;
   const HypResult& w = res[cs.winner];
   const int L0 = (int)(cs.n1 + 1 + cs.n2);
@@ -307,6 +313,8 @@ EG3D_HD void expand_chain(const Team& tm, const DevScene& s, const StageAView& a
   out.flags = c.flags;
   out.head = (uint32_t)c.head;
   out.bytes = c.bytes;
+  c.tsec[7] = EG3D_TICK() - t_begin;
+  for (int k = 0; k < 8; k++) out.tsec[k] = c.tsec[k];
 }
 
 // K4 body: copy one finished chain into the ordered SoA output.

@@ -188,6 +188,26 @@ struct ArrayCursor {
   }
 };
 
+// Observations gathered once into per-lane arrays (private memory is lane-interleaved on
+// gfx950, so these reads coalesce across the wave) — used when the source is a linked list in
+// HBM, whose dependent loads would otherwise be repeated in every pass of every iteration.
+#define EG3D_LOCAL_OBS 16
+struct LocalCursor {
+  int32_t v[EG3D_LOCAL_OBS];
+  float x[EG3D_LOCAL_OBS], y[EG3D_LOCAL_OBS];
+  int n, i;
+  EG3D_HD void rewind() { i = 0; }
+  EG3D_HD int count() const { return n; }
+  EG3D_HD bool next(int32_t& view, float& ox, float& oy) {
+    if (i >= n) return false;
+    view = v[i];
+    ox = x[i];
+    oy = y[i];
+    i++;
+    return true;
+  }
+};
+
 // FP64 Gauss-Newton over the cursor's observations from X0 (triangulation.cpp:105-176):
 // <=30 iterations; stop when |mse/(2n) - last| < 5e-7; fail when det(H) < 1e-5; accept iff
 // last mse < 9. H and the update are accumulated in observation order (rows 2m, 2m+1).

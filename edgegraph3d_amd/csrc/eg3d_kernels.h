@@ -46,7 +46,10 @@ void launch_compact_chains(hipStream_t st, uint32_t n_tasks, const ChainSeed* pe
 void launch_k3b(hipStream_t st, DevScene s, StageAView a, const TaskDesc* tasks, const ChainSeed* chains,
                 uint32_t n_chains, const uint32_t* hyp_off, const HypResult* res, const HPoint* arena,
                 const int32_t* map_view, const uint32_t* map_entry, const uint32_t* map_n, ChainLayout L,
-                unsigned char* scratch, ChainOut* outs, uint32_t* out_points, uint32_t* out_obs, Counters* ctr);
+                unsigned char* scratch, ChainOut* outs, uint32_t* out_points, uint32_t* out_obs, Counters* ctr,
+                const uint32_t* order);
+void launch_chain_cost(hipStream_t st, StageAView a, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains,
+                       uint32_t* cost, uint32_t* idx);
 void launch_k4(hipStream_t st, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains, ChainLayout L,
                const unsigned char* scratch, const ChainOut* outs, const uint32_t* point_off, const uint32_t* obs_off_in,
                uint64_t point_base, uint64_t obs_base, float* X, uint32_t* obs_off, int32_t* obs_view, uint32_t* obs_pl,

@@ -345,7 +345,11 @@ __global__ void k_compact_chains(uint32_t n_tasks, const ChainSeed* per_task, co
 // One WAVEFRONT per chain (block = 64 lanes). Control flow is wave-uniform; the lane-parallel
 // sections are (a) the per-view projection + 4 px grid lookup + closest point of every chain
 // point and (b) the Gauss-Newton ADD solves of a side walk's candidates (see eg3d_dev_expand.h).
+#ifndef EG3D_WAVE_SLOT_STEP
+#define EG3D_WAVE_SLOT_STEP 0 /* measured slower: failed speculative candidates run all 30 GN iterations */
+#endif
 struct TeamWave {
+  static constexpr bool kSlotStep = EG3D_WAVE_SLOT_STEP != 0;
   __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
   __device__ __forceinline__ int size() const { return 64; }
   __device__ __forceinline__ void sync() const { __syncthreads(); }
@@ -356,9 +360,9 @@ __global__ void __launch_bounds__(64) k3b_expand(DevScene s, StageAView a, const
                                                  const HypResult* res, const HPoint* arena, const int32_t* map_view,
                                                  const uint32_t* map_entry, const uint32_t* map_n, ChainLayout L,
                                                  unsigned char* scratch, ChainOut* outs, uint32_t* out_points,
-                                                 uint32_t* out_obs, Counters* ctr) {
-  const uint32_t j = blockIdx.x;
-  if (j >= n_chains) return;
+                                                 uint32_t* out_obs, Counters* ctr, const uint32_t* order) {
+  if (blockIdx.x >= n_chains) return;
+  const uint32_t j = order[blockIdx.x];  // longest-first schedule; results stay indexed by chain
   const ChainSeed cs = chains[j];
   const TaskDesc d = tasks[cs.task];
   ChainOut co;
@@ -372,6 +376,19 @@ __global__ void __launch_bounds__(64) k3b_expand(DevScene s, StageAView a, const
     if (co.flags) atomicOr(&ctr->flags, co.flags);
     if (co.bytes) atomicAdd(&ctr->bytes, (unsigned long long)co.bytes);
   }
+}
+
+// Cost estimate of a chain for the longest-processing-time-first launch order of K3b:
+// initial length x track size of its seed (every track view may attach to every point).
+__global__ void k_chain_cost(StageAView a, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains,
+                             uint32_t* cost, uint32_t* idx) {
+  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_chains) return;
+  const ChainSeed cs = chains[j];
+  const uint32_t seed = tasks[cs.task].seed;
+  const uint32_t k = a.trk_off[seed + 1] - a.trk_off[seed];
+  cost[j] = (cs.n1 + 1 + cs.n2) * k;
+  idx[j] = j;
 }
 
 // ------------------------------------------------------------------ K4 ---------
@@ -470,10 +487,16 @@ void launch_compact_chains(hipStream_t st, uint32_t n_tasks, const ChainSeed* pe
 void launch_k3b(hipStream_t st, DevScene s, StageAView a, const TaskDesc* tasks, const ChainSeed* chains,
                 uint32_t n_chains, const uint32_t* hyp_off, const HypResult* res, const HPoint* arena,
                 const int32_t* map_view, const uint32_t* map_entry, const uint32_t* map_n, ChainLayout L,
-                unsigned char* scratch, ChainOut* outs, uint32_t* out_points, uint32_t* out_obs, Counters* ctr) {
+                unsigned char* scratch, ChainOut* outs, uint32_t* out_points, uint32_t* out_obs, Counters* ctr,
+                const uint32_t* order) {
   if (!n_chains) return;
   hipLaunchKernelGGL(k3b_expand, dim3(n_chains), dim3(64), 0, st, s, a, tasks, chains, n_chains, hyp_off, res,
-                     arena, map_view, map_entry, map_n, L, scratch, outs, out_points, out_obs, ctr);
+                     arena, map_view, map_entry, map_n, L, scratch, outs, out_points, out_obs, ctr, order);
+}
+void launch_chain_cost(hipStream_t st, StageAView a, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains,
+                       uint32_t* cost, uint32_t* idx) {
+  if (!n_chains) return;
+  hipLaunchKernelGGL(k_chain_cost, blocks_for(n_chains, 256), dim3(256), 0, st, a, tasks, chains, n_chains, cost, idx);
 }
 void launch_k4(hipStream_t st, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains, ChainLayout L,
                const unsigned char* scratch, const ChainOut* outs, const uint32_t* point_off, const uint32_t* obs_off_in,

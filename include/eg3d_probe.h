@@ -15,6 +15,11 @@ int eg3d_probe_arith(eg3d_ctx* ctx, uint64_t n, const double* a, const double* b
 /* n_cases triangulations of k observations each (views index ctx's cameras) */
 int eg3d_probe_triangulate(eg3d_ctx* ctx, uint64_t n_cases, int k, const int32_t* views, const float* xy, float* X,
                            uint8_t* valid, double* dlt_X0);
+/* Per-section shader-clock ticks of the most recent k3b_expand launch, summed over chains
+ * (sum[8]) and of the slowest chain (slowest[8]); all zero unless the library was built with
+ * -DEG3D_SECTION_TIMING. Index: 0 candidates, 1 central solve, 2 side walks, 3 batched GN,
+ * 4 chain following, 7 whole chain. */
+int eg3d_probe_sections(eg3d_ctx* ctx, double* sum, double* slowest, uint32_t* n_chains);
 #ifdef __cplusplus
 }
 #endif

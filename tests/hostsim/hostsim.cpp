@@ -63,7 +63,7 @@ static int build_dev_scene(const eg3d_scene* sc, HostScene& hs) {
 
 extern "C" int hostsim_match(const eg3d_scene* sc, const eg3d_seeds* seeds, uint32_t b, uint32_t e,
                              const eg3d_candidates* ca, uint32_t hyp_cap, uint32_t chain_cap, uint32_t pool_cap,
-                             eg3d_edgepoints* out) {
+                             int slot_step, eg3d_edgepoints* out) {
   memset(out, 0, sizeof(*out));
   HostScene hs;
   if (build_dev_scene(sc, hs) != 0) return -1;
@@ -167,8 +167,12 @@ extern "C" int hostsim_match(const eg3d_scene* sc, const eg3d_seeds* seeds, uint
   uint64_t np = 0, no = 0;
   for (size_t j = 0; j < chains.size(); j++) {
     const ChainSeed& cs = chains[j];
-    expand_chain(TeamSeq(), ds, a, tasks[cs.task], cs, hyp_off[cs.task], res.data(), arena.data(), map_view.data(),
-                 map_entry.data(), map_n.data(), L, scratch.data() + L.total * j, couts[j]);
+    if (slot_step)
+      expand_chain(TeamSeqSlots(), ds, a, tasks[cs.task], cs, hyp_off[cs.task], res.data(), arena.data(),
+                   map_view.data(), map_entry.data(), map_n.data(), L, scratch.data() + L.total * j, couts[j]);
+    else
+      expand_chain(TeamSeq(), ds, a, tasks[cs.task], cs, hyp_off[cs.task], res.data(), arena.data(), map_view.data(),
+                   map_entry.data(), map_n.data(), L, scratch.data() + L.total * j, couts[j]);
     flags |= couts[j].flags;
     np += couts[j].n_points;
     no += couts[j].n_obs;

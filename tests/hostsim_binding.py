@@ -17,7 +17,7 @@ def lib():
         subprocess.check_call(["make", "-s", "-C", d])
         L = C.CDLL(os.path.join(d, "libhostsim.so"))
         L.hostsim_match.argtypes = [C.POINTER(D.Scene), C.POINTER(D.Seeds), C.c_uint32, C.c_uint32,
-                                    C.POINTER(D.Candidates), C.c_uint32, C.c_uint32, C.c_uint32,
+                                    C.POINTER(D.Candidates), C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                     C.POINTER(D.EdgePoints)]
         L.hostsim_free_edgepoints.argtypes = [C.POINTER(D.EdgePoints)]
         L.hostsim_dist2.restype = C.c_float
@@ -35,10 +35,10 @@ def lib():
     return _LIB
 
 
-def match(scene_ptr, seeds_ptr, begin, end, cand_struct, hyp_cap=192, chain_cap=768, pool_cap=8192):
+def match(scene_ptr, seeds_ptr, begin, end, cand_struct, hyp_cap=192, chain_cap=768, pool_cap=8192, slot_step=False):
     e = D.EdgePoints()
     rc = lib().hostsim_match(scene_ptr, seeds_ptr, begin, end, C.byref(cand_struct), hyp_cap, chain_cap, pool_cap,
-                             C.byref(e))
+                             1 if slot_step else 0, C.byref(e))
     if rc != 0:
         raise RuntimeError("hostsim_match rc=%d" % rc)
     d = D.edgepoints_to_dict(e)

@@ -25,13 +25,14 @@ def test_host_grid_builder_matches_oracle(cfg):
             assert ids.size > 0
 
 
+@pytest.mark.parametrize("slot_step", [False, True])
 @pytest.mark.parametrize("cfg", [0, 1])
-def test_kernel_bodies_hostsim_vs_oracle(cfg):
+def test_kernel_bodies_hostsim_vs_oracle(cfg, slot_step):
     s = host.Synth(cfg)
     o = ob.Oracle(s.scene)
     ref = o.match(s.seeds, 0, s.n_seeds, 1)
     cand = o.candidates_raw(s.seeds, 0, s.n_seeds)
-    got = hs.match(s.scene, s.seeds, 0, s.n_seeds, cand)
+    got = hs.match(s.scene, s.seeds, 0, s.n_seeds, cand, slot_step=slot_step)
     rep = compare_edgepoints(ref, got)
     assert rep["ok"], rep["msgs"]
     assert rep["bitexact_X"] and rep["bitexact_xy"]

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-section shader-clock breakdown of k3b_expand (needs libeg3d.so built with
+EG3D_EXTRA_HIPFLAGS=-DEG3D_SECTION_TIMING)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from edgegraph3d_amd import api, host  # noqa: E402
+
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+s = host.Synth(cfg)
+ctx = api.Context(s.scene)
+ctx.upload_seeds(s.seeds)
+for _ in range(2):
+    r = ctx.match_resident(0, s.n_seeds, device_only=True)
+L = api.lib()
+L.eg3d_probe_sections.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+sm, sl, n = (C.c_double * 8)(), (C.c_double * 8)(), C.c_uint32()
+assert L.eg3d_probe_sections(ctx._h, sm, sl, C.byref(n)) == 0
+names = ["candidates", "central", "walks", "batchGN", "follow", "5", "6", "whole"]
+tot = sm[7] or 1
+print("chains", n.value, "times", r["times"])
+for k in range(8):
+    print("%-11s sum %12.3e (%5.1f%%)   slowest chain %10.3e (%5.1f%%)" % (names[k], sm[k], 100 * sm[k] / tot, sl[k], 100 * sl[k] / (sl[7] or 1)))
+print("mean ticks per chain %.3e ; slowest %.3e" % (sm[7] / max(1, n.value), sl[7]))
