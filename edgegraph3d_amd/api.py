@@ -22,7 +22,8 @@ class Eg3dError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libeg3d.so")
+    # EG3D_LIB selects an alternative build of the same library (tuning experiments only)
+    return os.environ.get("EG3D_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libeg3d.so")
 
 
 def lib():

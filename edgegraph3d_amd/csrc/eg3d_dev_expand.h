@@ -412,6 +412,10 @@ EG3D_HD int walk_side(const Team& tm, const DevScene& s, Chain& c, int view, con
   tm.sync();
   uint64_t t1 = EG3D_TICK();
   c.tsec[2] += t1 - t0;
+#if defined(EG3D_SECTION_TIMING)
+  c.tsec[5] += 1;              // walk_side calls (= GN batches)
+  c.tsec[6] += (uint64_t)m;    // walk steps that produced a candidate
+#endif
   for (int j = tm.lane(); j < m; j += tm.size()) {
     const ChainPt& pt = chain_at(c, towards_start ? ci - 1 - j : ci + 1 + j);
     float X[3];

@@ -217,12 +217,18 @@ EG3D_HD bool gauss_newton_f64(const float* cam_P, Cursor& cur, const double X0[3
   double X[3] = {X0[0], X0[1], X0[2]};
   double last_mse = 0;
   const double two_n = (double)(n * 2);
+  // Jacobian rows and residuals of the first pass are kept in lane-private memory (8 doubles per
+  // observation, lane-interleaved => coalesced) so the update pass does not redo the projection
+  // and its 8 FP64 divisions; same values, same order => same bits. Larger n recomputes.
+  double keep[EG3D_LOCAL_OBS][8];
+  const bool stored = n <= EG3D_LOCAL_OBS;
   for (int it = 0; it < 30; it++) {
     double mse = 0;
     double H00 = 0, H01 = 0, H02 = 0, H11 = 0, H12 = 0, H22 = 0;
     cur.rewind();
     int32_t view;
     float ox, oy;
+    int oi = 0;
     while (cur.next(view, ox, oy)) {
       const float* P = cam_P + (size_t)view * 16;
       double p00 = P[0], p01 = P[1], p02 = P[2], p03 = P[3];
@@ -254,6 +260,18 @@ EG3D_HD bool gauss_newton_f64(const float* cam_P, Cursor& cur, const double X0[3
       H12 += j11 * j12;
       H22 += j02 * j02;
       H22 += j12 * j12;
+      if (stored) {
+        double* kp = keep[oi];
+        kp[0] = j00;
+        kp[1] = j01;
+        kp[2] = j02;
+        kp[3] = j10;
+        kp[4] = j11;
+        kp[5] = j12;
+        kp[6] = r0;
+        kp[7] = r1;
+      }
+      oi++;
     }
     if (absd(mse / two_n - last_mse) < 0.0000005) break;
     last_mse = mse / two_n;
@@ -271,6 +289,23 @@ EG3D_HD bool gauss_newton_f64(const float* cam_P, Cursor& cur, const double X0[3
     double I21 = (H01 * H20 - H00 * H21) * id;
     double I22 = (H00 * H11 - H01 * H10) * id;
     double d0 = 0, d1 = 0, d2 = 0;
+    if (stored) {
+      for (int k = 0; k < n; k++) {
+        const double* kp = keep[k];
+        const double j00 = kp[0], j01 = kp[1], j02 = kp[2], j10 = kp[3], j11 = kp[4], j12 = kp[5];
+        const double r0 = kp[6], r1 = kp[7];
+        d0 += ((I00 * j00 + I01 * j01) + I02 * j02) * r0;
+        d0 += ((I00 * j10 + I01 * j11) + I02 * j12) * r1;
+        d1 += ((I10 * j00 + I11 * j01) + I12 * j02) * r0;
+        d1 += ((I10 * j10 + I11 * j11) + I12 * j12) * r1;
+        d2 += ((I20 * j00 + I21 * j01) + I22 * j02) * r0;
+        d2 += ((I20 * j10 + I21 * j11) + I22 * j12) * r1;
+      }
+      X[0] += d0;
+      X[1] += d1;
+      X[2] += d2;
+      continue;
+    }
     cur.rewind();
     while (cur.next(view, ox, oy)) {
       const float* P = cam_P + (size_t)view * 16;

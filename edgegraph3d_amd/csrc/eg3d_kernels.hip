@@ -12,7 +12,7 @@
 //   k3a_hypotheses    1 lane / hypothesis   orientation + following (wave-synchronous batches)
 //   k3s_select        1 lane / task         uniqueness rule -> chain seeds
 //   k3b_expand        1 lane / chain        expand-all-views
-//   k4_emit           1 lane / chain        ordered SoA output
+//   k4_emit           1 WAVE / chain        ordered SoA output (wave prefix sum of obs counts)
 //   k5_gn_filter      1 lane / point        config 5, FP32 Gauss-Newton outlier filter
 // All arithmetic follows the contract in DESIGN.md (no FMA contraction: -ffp-contract=off).
 #include <hip/hip_runtime.h>
@@ -355,7 +355,10 @@ struct TeamWave {
   __device__ __forceinline__ void sync() const { __syncthreads(); }
 };
 
-__global__ void __launch_bounds__(64) k3b_expand(DevScene s, StageAView a, const TaskDesc* tasks,
+#ifndef EG3D_K3B_WAVES
+#define EG3D_K3B_WAVES 3 /* measured: 3 waves/SIMD (168 VGPRs) beats 2 and 4 on C2 and C3 */
+#endif
+__global__ void __launch_bounds__(64, EG3D_K3B_WAVES) k3b_expand(DevScene s, StageAView a, const TaskDesc* tasks,
                                                  const ChainSeed* chains, uint32_t n_chains, const uint32_t* hyp_off,
                                                  const HypResult* res, const HPoint* arena, const int32_t* map_view,
                                                  const uint32_t* map_entry, const uint32_t* map_n, ChainLayout L,
@@ -392,14 +395,63 @@ __global__ void k_chain_cost(StageAView a, const TaskDesc* tasks, const ChainSee
 }
 
 // ------------------------------------------------------------------ K4 ---------
-__global__ void k4_emit(const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains, ChainLayout L,
-                        const unsigned char* scratch, const ChainOut* outs, const uint32_t* point_off,
-                        const uint32_t* obs_off_in, uint64_t point_base, uint64_t obs_base, float* X, uint32_t* obs_off,
-                        int32_t* obs_view, uint32_t* obs_pl, uint32_t* obs_seg, float* obs_xy, uint32_t* key) {
-  uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+// One wavefront per chain: lanes take consecutive chain points; the observation offset of each
+// point is the chain's base plus a wave prefix sum of the per-point observation counts, so the
+// writes of X / key / obs_off are coalesced and the per-point list walks run in parallel.
+__global__ void __launch_bounds__(256) k4_emit(const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains,
+                                               ChainLayout L, const unsigned char* scratch, const ChainOut* outs,
+                                               const uint32_t* point_off, const uint32_t* obs_off_in,
+                                               uint64_t point_base, uint64_t obs_base, float* X, uint32_t* obs_off,
+                                               int32_t* obs_view, uint32_t* obs_pl, uint32_t* obs_seg, float* obs_xy,
+                                               uint32_t* key) {
+  const uint32_t j = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t lane = threadIdx.x & 63;
   if (j >= n_chains) return;
-  emit_chain(L, scratch + L.total * (size_t)j, outs[j], tasks[chains[j].task], point_base + point_off[j],
-             obs_base + obs_off_in[j], X, obs_off, obs_view, obs_pl, obs_seg, obs_xy, key);
+  const unsigned char* slice = scratch + L.total * (size_t)j;
+  const ChainPt* pts = (const ChainPt*)(slice + L.off_pts);
+  const PoolObs* pool = (const PoolObs*)(slice + L.off_pool);
+  const ChainOut co = outs[j];
+  const TaskDesc d = tasks[chains[j].task];
+  const uint64_t pbase = point_base + point_off[j];
+  uint64_t obase = obs_base + obs_off_in[j];
+  for (uint32_t i0 = 0; i0 < co.n_points; i0 += 64) {
+    const uint32_t i = i0 + lane;
+    const bool act = i < co.n_points;
+    ChainPt p;
+    p.nobs = 0;
+    if (act) p = pts[co.head + i];
+    uint32_t incl = p.nobs;  // inclusive wave scan of the observation counts
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+      if ((int)lane >= o) incl += t;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+    if (act) {
+      const uint64_t pi = pbase + i;
+      uint64_t o = obase + (incl - p.nobs);
+      X[3 * pi] = p.X[0];
+      X[3 * pi + 1] = p.X[1];
+      X[3 * pi + 2] = p.X[2];
+      obs_off[pi] = (uint32_t)o;
+      key[4 * pi] = d.seed;
+      key[4 * pi + 1] = d.entry;
+      key[4 * pi + 2] = d.hit;
+      key[4 * pi + 3] = i;
+      uint32_t q = p.head;
+      for (uint32_t k = 0; k < p.nobs; k++) {
+        const PoolObs po = pool[q];
+        obs_view[o] = po.o.view;
+        obs_pl[o] = po.o.pl;
+        obs_seg[o] = po.o.seg;
+        obs_xy[2 * o] = po.o.x;
+        obs_xy[2 * o + 1] = po.o.y;
+        o++;
+        q = po.next;
+      }
+    }
+    obase += total;
+  }
 }
 
 // ------------------------------------------------------------------ K5 ---------
@@ -503,7 +555,7 @@ void launch_k4(hipStream_t st, const TaskDesc* tasks, const ChainSeed* chains, u
                uint64_t point_base, uint64_t obs_base, float* X, uint32_t* obs_off, int32_t* obs_view, uint32_t* obs_pl,
                uint32_t* obs_seg, float* obs_xy, uint32_t* key) {
   if (!n_chains) return;
-  hipLaunchKernelGGL(k4_emit, blocks_for(n_chains, 64), dim3(64), 0, st, tasks, chains, n_chains, L, scratch, outs,
+  hipLaunchKernelGGL(k4_emit, blocks_for((uint64_t)n_chains * 64, 256), dim3(256), 0, st, tasks, chains, n_chains, L, scratch, outs,
                      point_off, obs_off_in, point_base, obs_base, X, obs_off, obs_view, obs_pl, obs_seg, obs_xy, key);
 }
 void launch_k5(hipStream_t st, const float* cam_P, const float* X, const uint32_t* obs_off, const int32_t* obs_view,
