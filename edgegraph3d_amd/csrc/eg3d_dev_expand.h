@@ -38,6 +38,13 @@ struct ViewCand {
   float x, y, d2;
   uint32_t cok;    // speculative central ADD solve of (point + this observation) succeeded
   float cX[3];     // its result
+  uint32_t eok;    // epipolar line of the point's FIRST observation in the offered view is valid
+  float ea, eb, ec;
+};
+// speculative central solve of one epipolar candidate against the chain's central point
+struct EpcSolve {
+  uint32_t ok;
+  float X[3];
 };
 
 // One "starting observation" candidate of an N-view step, evaluated by one team member.
@@ -84,6 +91,7 @@ struct Chain {
   Pending* pend2;        // [cap_pts]
   ViewCand* cand;        // [cap_pts]
   StepSlot* slots;       // [EG3D_STEP_OBS]
+  EpcSolve* epcres;      // [cap_pts]
   Obs* tmp_a;            // [tmp_cap]
   Obs* tmp_b;            // [tmp_cap]
   uint8_t* tmp_mask;     // [tmp_cap]
@@ -377,10 +385,11 @@ EG3D_HD int walk_side_candidates(const DevScene& s, Chain& c, int view, const Ob
   actual.y = from.y;
   int i = towards_start ? ci - 1 : ci + 1;
   while ((towards_start && i >= lo) || (!towards_start && i < hi)) {
-    const ChainPt& pt = chain_at(c, i);
-    const Obs& first = c.pool[pt.head].o;
-    float la, lb, lc;
-    if (!epiline(s.F, s.F_valid, s.n_views, first.view, view, first.x, first.y, la, lb, lc)) break;
+    // epipolar line of chain point i's first observation in `view`: precomputed lane-parallel by
+    // view_epilines() for the view being offered
+    const ViewCand& ve = c.cand[i];
+    if (!ve.eok) break;
+    const float la = ve.ea, lb = ve.eb, lc = ve.ec;
     PlPt nx;
     uint32_t w = walk_by_line(pl, actual, direction, la, lb, lc, false, 0.0f, 0.0f, nx);
     if (w & WALK_BAD_DIR) c.flags |= 8u;
@@ -557,6 +566,10 @@ EG3D_HD void view_candidates(const Team& tm, const DevScene& s, Chain& c, int v,
     vc.x = vc.y = vc.d2 = 0.0f;
     vc.cok = 0;
     vc.cX[0] = vc.cX[1] = vc.cX[2] = 0.0f;
+    {
+      const Obs& first = c.pool[pt.head].o;
+      vc.eok = epiline(s.F, s.F_valid, s.n_views, first.view, v, first.x, first.y, vc.ea, vc.eb, vc.ec) ? 1u : 0u;
+    }
     float u, w;
     project_f32(P, pt.X[0], pt.X[1], pt.X[2], u, w);
     uint32_t pl_id;
@@ -594,22 +607,25 @@ EG3D_HD void expand_to_view(const Team& tm, const DevScene& s, Chain& c, int v, 
   // PARALLEL over the epipolar candidates: speculative central solves against chain[centre]
   // (results parked in the candidate array, which is rebuilt below before its own use)
   const int n_pre = n_epc < c.cap_pts ? n_epc : c.cap_pts;
-  if (n_epc > 1) {
+  if (n_epc > 0) {
+    // PARALLEL: epipolar lines of every chain point in view v (the side walks read them)
+    for (int i = tm.lane(); i < c.len; i += tm.size()) {
+      const Obs& first = c.pool[chain_at(c, i).head].o;
+      ViewCand& vc = c.cand[i];
+      vc.eok = epiline(s.F, s.F_valid, s.n_views, first.view, v, first.x, first.y, vc.ea, vc.eb, vc.ec) ? 1u : 0u;
+    }
     for (int e = tm.lane(); e < n_pre; e += tm.size()) {
-      ViewCand vc;
-      vc.valid = 0;
-      vc.pl = vc.seg = 0;
-      vc.x = vc.y = vc.d2 = 0.0f;
-      vc.cok = add_observation_solve(s, c, chain_at(c, centre), epc[e], vc.cX) ? 1u : 0u;
-      c.cand[e] = vc;
+      EpcSolve r;
+      r.ok = add_observation_solve(s, c, chain_at(c, centre), epc[e], r.X) ? 1u : 0u;
+      c.epcres[e] = r;
     }
     tm.sync();
   }
   for (int e = 0; e < n_epc; e++) {
     int a, b;
-    const bool pre = (n_epc > 1 && e < n_pre);
-    if (attach_view(tm, s, c, epc[e], 0, centre, c.len, a, b, pre ? &c.cand[e].cok : nullptr,
-                    pre ? c.cand[e].cX : nullptr)) {
+    const bool pre = e < n_pre;
+    if (attach_view(tm, s, c, epc[e], 0, centre, c.len, a, b, pre ? &c.epcres[e].ok : nullptr,
+                    pre ? c.epcres[e].X : nullptr)) {
       epc_matched = true;
       if (a > centre) {
         centre = a;

@@ -167,7 +167,7 @@ EG3D_HD bool select_task(const HypResult* res, uint32_t h0, uint32_t h1, ChainSe
 // Scratch slice layout of one chain (bytes); all sub-arrays 8-byte aligned.
 struct ChainLayout {
   uint32_t cap_pts, pool_cap, tmp_cap, n_views;
-  size_t off_pts, off_pool, off_sdir, off_edir, off_p1, off_p2, off_cand, off_slots, off_ta, off_tb, off_tm, total;
+  size_t off_pts, off_pool, off_sdir, off_edir, off_p1, off_p2, off_cand, off_slots, off_epc, off_ta, off_tb, off_tm, total;
 };
 EG3D_HD size_t align8(size_t v) { return (v + 7) & ~(size_t)7; }
 EG3D_HD ChainLayout chain_layout(uint32_t cap_pts, uint32_t pool_cap, uint32_t n_views) {
@@ -193,6 +193,8 @@ EG3D_HD ChainLayout chain_layout(uint32_t cap_pts, uint32_t pool_cap, uint32_t n
   o = align8(o + sizeof(ViewCand) * cap_pts);
   L.off_slots = o;
   o = align8(o + sizeof(StepSlot) * EG3D_STEP_OBS);
+  L.off_epc = o;
+  o = align8(o + sizeof(EpcSolve) * cap_pts);
   L.off_ta = o;
   o = align8(o + sizeof(Obs) * L.tmp_cap);
   L.off_tb = o;
@@ -213,6 +215,7 @@ EG3D_HD void chain_bind(Chain& c, const ChainLayout& L, unsigned char* slice) {
   c.pend2 = (Pending*)(slice + L.off_p2);
   c.cand = (ViewCand*)(slice + L.off_cand);
   c.slots = (StepSlot*)(slice + L.off_slots);
+  c.epcres = (EpcSolve*)(slice + L.off_epc);
   c.tmp_a = (Obs*)(slice + L.off_ta);
   c.tmp_b = (Obs*)(slice + L.off_tb);
   c.tmp_mask = (uint8_t*)(slice + L.off_tm);
