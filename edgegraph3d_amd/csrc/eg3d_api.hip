@@ -94,6 +94,7 @@ struct eg3d_ctx {
   uint64_t last_np = 0, last_no = 0;
   int last_chunks = 0;
   uint32_t last_nc = 0;
+  uint32_t last_nhyp = 0;
 };
 
 template <typename T>
@@ -405,16 +406,20 @@ int run_batch(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, HostOut& H) 
   BUF_TRY(read_u32(c, c->b_hyp_off.as<uint32_t>() + nt, B.n_hyp));
   // ---- K3a
   BUF_TRY(c->b_res.ensure(sizeof(HypResult) * (B.n_hyp + 1)));
+  // small batches are latency-bound by their slowest hypothesis: give each hypothesis a 4-lane team
+  static const int k3a_mode = getenv("EG3D_K3A_TEAM") ? atoi(getenv("EG3D_K3A_TEAM")) : -1;  // -1 auto, 0 lanes, 1 teams
+  const bool team4 = k3a_mode < 0 ? (B.n_hyp <= 131072u) : (k3a_mode != 0);
+  const uint32_t k3a_lanes_needed = B.n_hyp * (team4 ? 4u : 1u);
   const uint32_t k3a_blocks =
-      std::max<uint32_t>(1, std::min<uint32_t>(c->k3a_blocks, (B.n_hyp + 255) / 256));
-  BUF_TRY(c->b_hscratch.ensure(sizeof(HPoint) * 2 * c->hyp_cap * (size_t)k3a_blocks * 256));
+      std::max<uint32_t>(1, std::min<uint32_t>(c->k3a_blocks * (team4 ? 2u : 1u), (k3a_lanes_needed + 255) / 256));
+  BUF_TRY(c->b_hscratch.ensure(sizeof(HPoint) * 2 * c->hyp_cap * ((size_t)k3a_blocks * 256 / (team4 ? 4 : 1))));
   uint32_t arena_cap = std::max<uint32_t>(1u << 16, std::min<uint64_t>((uint64_t)B.n_hyp * 24, 1ull << 26));
   Counters hc;
   for (int attempt = 0;; attempt++) {
     BUF_TRY(c->b_arena.ensure(sizeof(HPoint) * (size_t)arena_cap));
     HIP_TRY(hipMemsetAsync(c->b_ctr.p, 0, 2 * sizeof(uint32_t), st));  // arena_used, flags (keep bytes)
     HIP_TRY(hipEventRecord(c->ea[3], st));
-    launch_k3a(st, k3a_blocks, c->ds, B.a, c->b_tasks.as<TaskDesc>(), c->b_hyp_off.as<uint32_t>(), B.n_hyp,
+    launch_k3a(st, team4, k3a_blocks, c->ds, B.a, c->b_tasks.as<TaskDesc>(), c->b_hyp_off.as<uint32_t>(), B.n_hyp,
                c->b_res.as<HypResult>(), c->b_hscratch.as<HPoint>(), c->hyp_cap, c->b_arena.as<HPoint>(), arena_cap,
                c->b_ctr.as<Counters>());
     HIP_TRY(hipEventRecord(c->eb[3], st));
@@ -560,6 +565,7 @@ int run_batch(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, HostOut& H) 
   H.bytes_vertices = 0;
   H.n_tasks += B.n_tasks;
   H.n_hyp += B.n_hyp;
+  c->last_nhyp = B.n_hyp;
   H.n_chains += B.n_chains;
   return EG3D_OK;
 }
@@ -814,6 +820,23 @@ extern "C" int eg3d_probe_sections(eg3d_ctx* c, double* sum, double* slowest, ui
     }
   }
   if (n_chains) *n_chains = c->last_nc;
+  return EG3D_OK;
+}
+
+extern "C" int eg3d_probe_hyp_sections(eg3d_ctx* c, double* sum, double* slowest, uint32_t* counts) {
+  if (!c || !sum || !slowest || !counts) return EG3D_ERR_ARG;
+  const uint32_t n = c->last_nhyp;
+  std::vector<HypResult> r(n ? n : 1);
+  if (n) HIP_TRY(hipMemcpy(r.data(), c->b_res.p, sizeof(HypResult) * n, hipMemcpyDeviceToHost));
+  for (int k = 0; k < 6; k++) sum[k] = slowest[k] = 0;
+  for (int k = 0; k < 5; k++) counts[k] = 0;
+  counts[0] = n;
+  for (uint32_t h = 0; h < n; h++) {
+    if (r[h].status & HYP_TRI) counts[1]++;
+    if (r[h].status & HYP_D1) counts[2]++;
+    if (r[h].status & HYP_D2) counts[3]++;
+    if (r[h].status & HYP_COMPAT) counts[4]++;
+  }
   return EG3D_OK;
 }
 

@@ -36,7 +36,7 @@ void launch_k2(hipStream_t st, bool fill, DevScene s, SeedsDev sd, uint32_t sv_b
                const Obs* start_hits, uint32_t* list_cnt, const uint32_t* list_ptr, Obs* hits);
 void launch_task_setup(hipStream_t st, StageAView a, const int32_t* map_view, const uint32_t* map_entry,
                        const uint32_t* map_n, TaskDesc* tasks, uint32_t* n_hyp);
-void launch_k3a(hipStream_t st, uint32_t n_blocks, DevScene s, StageAView a, const TaskDesc* tasks,
+void launch_k3a(hipStream_t st, bool team4, uint32_t n_blocks, DevScene s, StageAView a, const TaskDesc* tasks,
                 const uint32_t* hyp_off, uint32_t n_hyp, HypResult* res, HPoint* scratch, uint32_t hyp_cap, HPoint* arena,
                 uint32_t arena_cap, Counters* ctr);
 void launch_k3s(hipStream_t st, uint32_t n_tasks, const uint32_t* hyp_off, const HypResult* res, ChainSeed* per_task,

@@ -281,40 +281,66 @@ __device__ __forceinline__ uint32_t find_owner(const uint32_t* off, uint32_t n, 
 }
 
 // ------------------------------------------------------------------ K3a --------
-// One lane per hypothesis, wave-synchronous batches of 64 so every lane of a wave starts the
-// same routine together (divergence then comes only from data-dependent trip counts). Each
-// lane owns two HPoint lists in the scratch arena; finished lists that later stages need are
-// copied to a bump-allocated result arena.
+// Hypothesis evaluation. Two instantiations of the same body (eg3d_dev_follow.h):
+//  * HTeamSeq: one lane per hypothesis, wave-synchronous batches of 64 — most work per wave
+//    instruction; used when there are enough hypotheses to fill the chip (throughput-bound).
+//  * HTeam4:   four lanes per hypothesis (16 per wave): the four direction combinations of the
+//    orientation search run on four lanes and the two following directions on two, cutting the
+//    critical path of the slowest hypothesis; used for small, latency-bound batches.
+// Each hypothesis owns two HPoint lists in the scratch arena; finished lists that later stages
+// need are copied to a bump-allocated result arena by the team's lane 0.
+struct HTeam4 {
+  static constexpr int kSize = 4;
+  __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 3u); }
+  __device__ __forceinline__ int sum(int v) const {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    return v;
+  }
+  __device__ __forceinline__ uint32_t or_(uint32_t v) const {
+    v |= (uint32_t)__shfl_xor((int)v, 1, 64);
+    v |= (uint32_t)__shfl_xor((int)v, 2, 64);
+    return v;
+  }
+  __device__ __forceinline__ uint32_t bcast(uint32_t v, int src) const {
+    return (uint32_t)__shfl((int)v, (int)((threadIdx.x & 63u & ~3u) + (uint32_t)src), 64);
+  }
+};
+
+template <class Team>
 __global__ void __launch_bounds__(256) k3a_hypotheses(DevScene s, StageAView a, const TaskDesc* tasks,
                                                      const uint32_t* hyp_off, uint32_t n_hyp, HypResult* res,
                                                      HPoint* scratch, uint32_t hyp_cap, HPoint* arena,
                                                      uint32_t arena_cap, Counters* ctr) {
-  const uint32_t lane_global = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t n_lanes = gridDim.x * blockDim.x;
-  HPoint* pts1 = scratch + (size_t)lane_global * 2 * hyp_cap;
+  const uint32_t slot = (blockIdx.x * blockDim.x + threadIdx.x) / Team::kSize;
+  const uint32_t n_slots = (gridDim.x * blockDim.x) / Team::kSize;
+  HPoint* pts1 = scratch + (size_t)slot * 2 * hyp_cap;
   HPoint* pts2 = pts1 + hyp_cap;
-  for (uint32_t h = lane_global; h < n_hyp; h += n_lanes) {
+  Team tm;
+  for (uint32_t h = slot; h < n_hyp; h += n_slots) {
     const uint32_t t = find_owner(hyp_off, a.n_tasks, h);
     const TaskDesc d = tasks[t];
     Obs c[3];
     hypothesis_hits(a, d, t, h - hyp_off[t], c);
     HypResult r;
-    evaluate_hypothesis(s, c, pts1, pts2, hyp_cap, r);
-    uint32_t need1 = (r.status & HYP_COMPAT) ? r.n1 : 0;
-    uint32_t need2 = (r.status & HYP_D2) ? r.n2 : 0;
-    if (need1 + need2) {
-      uint32_t base = atomicAdd(&ctr->arena_used, need1 + need2);
-      if (base + need1 + need2 <= arena_cap) {
-        r.pts1_off = base;
-        r.pts2_off = base + need1;
-        for (uint32_t i = 0; i < need1; i++) arena[base + i] = pts1[i];
-        for (uint32_t i = 0; i < need2; i++) arena[base + need1 + i] = pts2[i];
-      } else {
-        atomicOr(&ctr->flags, CTR_ARENA_OVERFLOW);
+    evaluate_hypothesis(tm, s, c, pts1, pts2, hyp_cap, r);
+    if (tm.lane() == 0) {
+      uint32_t need1 = (r.status & HYP_COMPAT) ? r.n1 : 0;
+      uint32_t need2 = (r.status & HYP_D2) ? r.n2 : 0;
+      if (need1 + need2) {
+        uint32_t base = atomicAdd(&ctr->arena_used, need1 + need2);
+        if (base + need1 + need2 <= arena_cap) {
+          r.pts1_off = base;
+          r.pts2_off = base + need1;
+          for (uint32_t i = 0; i < need1; i++) arena[base + i] = pts1[i];
+          for (uint32_t i = 0; i < need2; i++) arena[base + need1 + i] = pts2[i];
+        } else {
+          atomicOr(&ctr->flags, CTR_ARENA_OVERFLOW);
+        }
       }
+      if (r.flags) atomicOr(&ctr->flags, r.flags);
+      res[h] = r;
     }
-    if (r.flags) atomicOr(&ctr->flags, r.flags);
-    res[h] = r;
   }
 }
 
@@ -518,12 +544,16 @@ void launch_task_setup(hipStream_t st, StageAView a, const int32_t* map_view, co
   hipLaunchKernelGGL(k_task_setup, blocks_for(a.n_tasks, 256), dim3(256), 0, st, a, map_view, map_entry, map_n, tasks,
                      n_hyp);
 }
-void launch_k3a(hipStream_t st, uint32_t n_blocks, DevScene s, StageAView a, const TaskDesc* tasks,
+void launch_k3a(hipStream_t st, bool team4, uint32_t n_blocks, DevScene s, StageAView a, const TaskDesc* tasks,
                 const uint32_t* hyp_off, uint32_t n_hyp, HypResult* res, HPoint* scratch, uint32_t hyp_cap, HPoint* arena,
                 uint32_t arena_cap, Counters* ctr) {
   if (!n_hyp) return;
-  hipLaunchKernelGGL(k3a_hypotheses, dim3(n_blocks), dim3(256), 0, st, s, a, tasks, hyp_off, n_hyp, res, scratch,
-                     hyp_cap, arena, arena_cap, ctr);
+  if (team4)
+    hipLaunchKernelGGL(k3a_hypotheses<HTeam4>, dim3(n_blocks), dim3(256), 0, st, s, a, tasks, hyp_off, n_hyp, res,
+                       scratch, hyp_cap, arena, arena_cap, ctr);
+  else
+    hipLaunchKernelGGL(k3a_hypotheses<HTeamSeq>, dim3(n_blocks), dim3(256), 0, st, s, a, tasks, hyp_off, n_hyp, res,
+                       scratch, hyp_cap, arena, arena_cap, ctr);
 }
 void launch_k3s(hipStream_t st, uint32_t n_tasks, const uint32_t* hyp_off, const HypResult* res, ChainSeed* per_task,
                 uint32_t* valid) {

@@ -20,6 +20,9 @@ int eg3d_probe_triangulate(eg3d_ctx* ctx, uint64_t n_cases, int k, const int32_t
  * -DEG3D_SECTION_TIMING. Index: 0 candidates, 1 central solve, 2 side walks, 3 batched GN,
  * 4 chain following, 7 whole chain. */
 int eg3d_probe_sections(eg3d_ctx* ctx, double* sum, double* slowest, uint32_t* n_chains);
+/* Same for k3a_hypotheses (per hypothesis): 0 first TRI, 1 orient, 2 replay, 3 opposite test,
+ * 4 follow dir1, 5 follow dir2; sum over hypotheses and the slowest hypothesis; n by status. */
+int eg3d_probe_hyp_sections(eg3d_ctx* ctx, double* sum, double* slowest, uint32_t* counts /*[5]: n, tri, d1, d2, compat*/);
 #ifdef __cplusplus
 }
 #endif

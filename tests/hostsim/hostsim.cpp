@@ -142,7 +142,7 @@ extern "C" int hostsim_match(const eg3d_scene* sc, const eg3d_seeds* seeds, uint
     for (uint32_t h = hyp_off[t]; h < hyp_off[t + 1]; h++) {
       Obs c[3];
       hypothesis_hits(a, tasks[t], t, h - hyp_off[t], c);
-      evaluate_hypothesis(ds, c, s1.data(), s2.data(), hyp_cap, res[h]);
+      evaluate_hypothesis(HTeamSeq(), ds, c, s1.data(), s2.data(), hyp_cap, res[h]);
       flags |= res[h].flags;
       if (res[h].status & HYP_COMPAT) {
         res[h].pts1_off = (uint32_t)arena.size();

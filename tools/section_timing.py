@@ -27,3 +27,13 @@ for k in range(8):
     print("%-11s sum %12.3e (%5.1f%%)   slowest chain %10.3e (%5.1f%%)" % (names[k], sm[k], 100 * sm[k] / tot, sl[k], 100 * sl[k] / (sl[7] or 1)))
 print("slowest chain points/obs:", "n/a")
 print("mean ticks per chain %.3e ; slowest %.3e" % (sm[7] / max(1, n.value), sl[7]))
+
+L.eg3d_probe_hyp_sections.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+hs_, hl_, cnt = (C.c_double * 6)(), (C.c_double * 6)(), (C.c_uint32 * 5)()
+assert L.eg3d_probe_hyp_sections(ctx._h, hs_, hl_, cnt) == 0
+print("hypotheses n/tri/d1/d2/compat:", list(cnt))
+hn = ["TRI0", "orient", "replay", "opp-test", "follow1", "follow2"]
+ht = sum(hs_) or 1
+for k in range(6):
+    print("%-9s sum %12.3e (%5.1f%%)   slowest hyp %10.3e" % (hn[k], hs_[k], 100 * hs_[k] / ht, hl_[k]))
+print("slowest hypothesis total %.3e ticks; mean %.3e" % (sum(hl_), ht / max(1, cnt[0])))
