@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--config", type=int, default=2, help="synthetic config index (2 = C2, BASELINE configs[1])")
     ap.add_argument("--seeds-per-gpu", type=int, default=0, help="override the per-GPU seed count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="run the RCCL all-gather of the cloud even with one rank (exercises the N>1 code path)")
     ap.add_argument("--cpu-runs", type=int, default=5)
     ap.add_argument("--cpu-seeds", type=int, default=0,
                     help="bound the CPU baseline to the first K seeds of the workload (0 = all); its rate is "
@@ -64,8 +66,11 @@ def main():
         raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, args.gpus))
     dist = None
-    if world > 1:
+    if world > 1 or args.force_gather:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
@@ -86,7 +91,7 @@ def main():
     b, e = rank * per_gpu, (rank + 1) * per_gpu
 
     gather = None
-    if world > 1:
+    if dist is not None:
         from edgegraph3d_amd.distributed import CloudGather
         gather = CloudGather(dist, world, dev)
 
@@ -110,7 +115,7 @@ def main():
     def step():
         r = ctx.match_resident(b, e, device_only=True)
         total = r["n_points"]
-        if world > 1:
+        if gather is not None:
             total = allgather_cloud()
         return r, total
 
