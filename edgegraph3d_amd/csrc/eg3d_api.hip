@@ -448,12 +448,17 @@ int run_batch(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, HostOut& H) 
                         c->b_chains.as<ChainSeed>());
   HIP_TRY(hipEventRecord(c->eb[4], st));
   // ---- K3b + K4 in chunks bounded by scratch size
-  const ChainLayout L = chain_layout(c->chain_cap, c->pool_cap, (uint32_t)c->V);
   const size_t max_scratch = (size_t)24 << 30;
-  const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(B.n_chains ? B.n_chains : 1, max_scratch / L.total));
   float ms_expand = 0, ms_emit = 0;
+  uint32_t chunk = 0;
+  unsigned long long bytes_before_chunk = 0;
   for (uint32_t c0 = 0; c0 < B.n_chains; c0 += chunk) {
+    // capacities can grow between chunks (overflow -> retry below), so the layout is per chunk
+    const ChainLayout L = chain_layout(c->chain_cap, c->pool_cap, (uint32_t)c->V);
+    chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(B.n_chains - c0, max_scratch / L.total));
     const uint32_t nc = std::min(chunk, B.n_chains - c0);
+    HIP_TRY(hipMemcpyAsync(&bytes_before_chunk, &c->b_ctr.as<Counters>()->bytes, sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost, st));
     BUF_TRY(c->b_cscratch.ensure(L.total * (size_t)nc));
     BUF_TRY(c->b_couts.ensure(sizeof(ChainOut) * (nc + 1)));
     BUF_TRY(c->b_cpts.ensure(sizeof(uint32_t) * (nc + 1)));
@@ -490,6 +495,23 @@ int run_batch(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, HostOut& H) 
                c->b_cscratch.as<unsigned char>(), c->b_couts.as<ChainOut>(), c->b_cpts.as<uint32_t>(),
                c->b_cobs.as<uint32_t>(), c->b_ctr.as<Counters>(), c->b_order.as<uint32_t>());
     HIP_TRY(hipEventRecord(c->eb[5], st));
+    HIP_TRY(hipMemcpyAsync(&hc, c->b_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (hc.flags & (EG3D_FLAG_CHAIN_OVERFLOW | EG3D_FLAG_OBS_OVERFLOW)) {
+      // a chain outgrew its scratch slice: enlarge the capacities (kept for later calls) and redo
+      // this chunk; results of the overflowing attempt are discarded
+      const bool can_grow = ((hc.flags & EG3D_FLAG_CHAIN_OVERFLOW) && c->chain_cap < 8192) ||
+                            ((hc.flags & EG3D_FLAG_OBS_OVERFLOW) && c->pool_cap < (1u << 20));
+      if (can_grow) {
+        if (hc.flags & EG3D_FLAG_CHAIN_OVERFLOW) c->chain_cap *= 2;
+        if (hc.flags & EG3D_FLAG_OBS_OVERFLOW) c->pool_cap *= 2;
+        HIP_TRY(hipMemcpyAsync(&c->b_ctr.as<Counters>()->bytes, &bytes_before_chunk, sizeof(unsigned long long),
+                               hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        chunk = 0;  // do not advance
+        continue;
+      }
+    }
     BUF_TRY(scan_exclusive_u32(c, c->b_cpts.as<uint32_t>(), c->b_cpoff.as<uint32_t>(), nc + 1));
     BUF_TRY(scan_exclusive_u32(c, c->b_cobs.as<uint32_t>(), c->b_cooff.as<uint32_t>(), nc + 1));
     uint32_t np = 0, no = 0;

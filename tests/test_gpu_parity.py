@@ -88,3 +88,20 @@ def test_gn_filter_parity(have_gpu):
     assert np.array_equal(Xo.view(np.uint32), Xr.view(np.uint32))
     assert 0.5 < inl.mean() < 1.0
     ctx.close()
+
+
+def test_c4_shaped_subset_parity_and_capacity_growth(have_gpu):
+    """200 views / ~20k segments per view (BASELINE configs[3] shape), first 40 seeds: points carry
+    dozens of observations, which outgrows the default per-chain pool -> the library must enlarge
+    it and still match the oracle exactly."""
+    cfg = host.default_config(4)
+    cfg.n_seeds = 40
+    s = host.Synth(cfg)
+    ctx = api.Context(s.scene)
+    got = ctx.match_refpoints(s.seeds)
+    ref = _oracle(s.scene).match(s.seeds, 0, s.n_seeds, nthreads=16)
+    rep = compare_edgepoints(ref, got, rel_tol=1e-4)
+    assert rep["ok"], rep["msgs"]
+    assert (got["flags"] & 7) == 0
+    assert got["n_obs"] > 20 * got["n_points"]
+    ctx.close()
