@@ -219,8 +219,10 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
   d.g30_ids = c->b_g30i.as<uint32_t>();
   d.g4_off = c->b_g4o.as<uint32_t>();
   d.g4_ids = c->b_g4i.as<uint32_t>();
-  c->pool_cap = std::min<uint32_t>(8192, 256u * (uint32_t)std::min(V, 32));
-  if (c->pool_cap < 1536) c->pool_cap = 1536;
+  // observation slots per chain (blocks double when they fill, so budget ~3x the live count);
+  // grown automatically when a chain overflows
+  c->pool_cap = std::min<uint32_t>(32768, 768u * (uint32_t)std::min(V, 32));
+  if (c->pool_cap < 6144) c->pool_cap = 6144;
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   c->k3a_blocks = (uint32_t)prop.multiProcessorCount * 2;  // 2 blocks x 4 waves per CU

@@ -17,13 +17,13 @@
 
 namespace eg3d {
 
-struct PoolObs {
-  Obs o;
-  uint32_t next;  // index in pool, 0xffffffff = end
-};
+// A chain point: its observations are a CONTIGUOUS block pool[off .. off+nobs) of the chain's
+// append-only pool (capacity `cap`; a full block is relocated to a block of twice the size at the
+// pool's end), so a solve reads them with independent, coalescable loads — no pointer chasing —
+// and a team can address observation k directly.
 struct ChainPt {
   float X[3];
-  uint32_t head, tail, nobs;
+  uint32_t off, nobs, cap;
 };
 struct Pending {
   float X[3];
@@ -83,7 +83,7 @@ struct Chain {
   int32_t cap_pts;
   int32_t head;  // index of chain[0] in pts
   int32_t len;
-  PoolObs* pool;
+  Obs* pool;
   uint32_t pool_used, pool_cap;
   uint32_t* start_dirs;  // [V] node id the chain front is heading to, per view
   uint32_t* end_dirs;    // [V]
@@ -108,52 +108,39 @@ struct Chain {
 
 EG3D_HD ChainPt& chain_at(Chain& c, int i) { return c.pts[c.head + i]; }
 
-struct ListCursor {
-  const PoolObs* pool;
-  uint32_t head;
-  int n;
-  const Obs* extra;
-  uint32_t cur;
-  int i;
-  EG3D_HD void rewind() {
-    cur = head;
-    i = 0;
-  }
-  EG3D_HD int count() const { return n + (extra ? 1 : 0); }
-  EG3D_HD bool next(int32_t& view, float& x, float& y) {
-    if (i < n) {
-      const PoolObs& p = pool[cur];
-      view = p.o.view;
-      x = p.o.x;
-      y = p.o.y;
-      cur = p.next;
-      i++;
-      return true;
-    }
-    if (extra && i == n) {
-      view = extra->view;
-      x = extra->x;
-      y = extra->y;
-      i++;
-      return true;
-    }
-    return false;
-  }
-};
-
-EG3D_HD bool pool_append(Chain& c, ChainPt& p, const Obs& o) {
-  if (c.pool_used >= c.pool_cap) {
+EG3D_HD void point_init(ChainPt& p) {
+  p.off = 0;
+  p.nobs = 0;
+  p.cap = 0;
+}
+// Reserve room for `want` observations in a fresh block (used when a point is created).
+EG3D_HD bool point_reserve(Chain& c, ChainPt& p, uint32_t want) {
+  uint32_t cap = 4;
+  while (cap < want) cap <<= 1;
+  if (c.pool_used + cap > c.pool_cap) {
     c.flags |= 2u;
     return false;
   }
-  uint32_t idx = c.pool_used++;
-  c.pool[idx].o = o;
-  c.pool[idx].next = 0xffffffffu;
-  if (p.nobs == 0)
-    p.head = idx;
-  else
-    c.pool[p.tail].next = idx;
-  p.tail = idx;
+  p.off = c.pool_used;
+  p.cap = cap;
+  p.nobs = 0;
+  c.pool_used += cap;
+  return true;
+}
+EG3D_HD bool pool_append(Chain& c, ChainPt& p, const Obs& o) {
+  if (p.nobs == p.cap) {
+    const uint32_t ncap = p.cap ? p.cap * 2 : 4;
+    if (c.pool_used + ncap > c.pool_cap) {
+      c.flags |= 2u;
+      return false;
+    }
+    const uint32_t noff = c.pool_used;
+    for (uint32_t i = 0; i < p.nobs; i++) c.pool[noff + i] = c.pool[p.off + i];
+    c.pool_used += ncap;
+    p.off = noff;
+    p.cap = ncap;
+  }
+  c.pool[p.off + p.nobs] = o;
   p.nobs++;
   return true;
 }
@@ -163,16 +150,14 @@ EG3D_HD bool add_observation_solve(const DevScene& s, const Chain& c, const Chai
                                    float Xout[3]) {
   double X0[3] = {(double)p.X[0], (double)p.X[1], (double)p.X[2]};
   const int n = (int)p.nobs;
+  const Obs* a = c.pool + p.off;
   if (n + 1 <= EG3D_LOCAL_OBS) {
-    // gather the list once; the solver then streams from lane-private arrays
+    // gather the block once (independent loads); the solver then streams from lane-private arrays
     LocalCursor lc;
-    uint32_t q = p.head;
     for (int i = 0; i < n; i++) {
-      const PoolObs& po = c.pool[q];
-      lc.v[i] = po.o.view;
-      lc.x[i] = po.o.x;
-      lc.y[i] = po.o.y;
-      q = po.next;
+      lc.v[i] = a[i].view;
+      lc.x[i] = a[i].x;
+      lc.y[i] = a[i].y;
     }
     lc.v[n] = extra.view;
     lc.x[n] = extra.x;
@@ -181,12 +166,11 @@ EG3D_HD bool add_observation_solve(const DevScene& s, const Chain& c, const Chai
     lc.i = 0;
     return gauss_newton_f64(s.cam_P, lc, X0, Xout);
   }
-  ListCursor cur;
-  cur.pool = c.pool;
-  cur.head = p.head;
+  ArrayCursor cur;
+  cur.a = a;
   cur.n = n;
   cur.extra = &extra;
-  cur.rewind();
+  cur.i = 0;
   return gauss_newton_f64(s.cam_P, cur, X0, Xout);
 }
 
@@ -196,9 +180,8 @@ EG3D_HD bool add_observation_solve(const DevScene& s, const Chain& c, const Chai
 EG3D_HD int stepn_walks(const DevScene& s, const Chain& c, const ChainPt& cur, int st, const uint32_t* dirs, Obs* sel,
                         int sel_cap, uint32_t& flags) {
   const int n = (int)cur.nobs;
-  uint32_t si = cur.head;
-  for (int k = 0; k < st; k++) si = c.pool[si].next;
-  const Obs so = c.pool[si].o;
+  const Obs* co_all = c.pool + cur.off;
+  const Obs so = co_all[st];
   PlRef ps = polyline_of(s, so.view, so.pl);
   PlPt p, q;
   p.seg = so.seg;
@@ -214,10 +197,9 @@ EG3D_HD int stepn_walks(const DevScene& s, const Chain& c, const ChainPt& cur, i
   sel[m].x = q.x;
   sel[m].y = q.y;
   m++;
-  uint32_t oi = cur.head;
-  for (int i = 0; i < n; i++, oi = c.pool[oi].next) {
+  for (int i = 0; i < n; i++) {
     if (i == st) continue;
-    const Obs co = c.pool[oi].o;
+    const Obs co = co_all[i];
     float la, lb, lc;
     if (!epiline(s.F, s.F_valid, s.n_views, so.view, co.view, q.x, q.y, la, lb, lc)) continue;
     PlRef pk = polyline_of(s, co.view, co.pl);
@@ -322,9 +304,8 @@ EG3D_HD bool new_point_from_tmp(Chain& c, ChainPt& np, int m, const float X[3]) 
   np.X[0] = X[0];
   np.X[1] = X[1];
   np.X[2] = X[2];
-  np.nobs = 0;
-  np.head = 0xffffffffu;
-  np.tail = 0xffffffffu;
+  point_init(np);
+  if (!point_reserve(c, np, (uint32_t)m + 1)) return false;
   for (int i = 0; i < m; i++)
     if (!pool_append(c, np, c.tmp_a[i])) return false;
   return true;
@@ -567,7 +548,7 @@ EG3D_HD void view_candidates(const Team& tm, const DevScene& s, Chain& c, int v,
     vc.cok = 0;
     vc.cX[0] = vc.cX[1] = vc.cX[2] = 0.0f;
     {
-      const Obs& first = c.pool[pt.head].o;
+      const Obs& first = c.pool[pt.off];
       vc.eok = epiline(s.F, s.F_valid, s.n_views, first.view, v, first.x, first.y, vc.ea, vc.eb, vc.ec) ? 1u : 0u;
     }
     float u, w;
@@ -610,7 +591,7 @@ EG3D_HD void expand_to_view(const Team& tm, const DevScene& s, Chain& c, int v, 
   if (n_epc > 0) {
     // PARALLEL: epipolar lines of every chain point in view v (the side walks read them)
     for (int i = tm.lane(); i < c.len; i += tm.size()) {
-      const Obs& first = c.pool[chain_at(c, i).head].o;
+      const Obs& first = c.pool[chain_at(c, i).off];
       ViewCand& vc = c.cand[i];
       vc.eok = epiline(s.F, s.F_valid, s.n_views, first.view, v, first.x, first.y, vc.ea, vc.eb, vc.ec) ? 1u : 0u;
     }

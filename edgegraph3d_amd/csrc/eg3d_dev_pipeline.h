@@ -180,7 +180,7 @@ EG3D_HD ChainLayout chain_layout(uint32_t cap_pts, uint32_t pool_cap, uint32_t n
   L.off_pts = o;
   o = align8(o + sizeof(ChainPt) * cap_pts);
   L.off_pool = o;
-  o = align8(o + sizeof(PoolObs) * pool_cap);
+  o = align8(o + sizeof(Obs) * pool_cap);
   L.off_sdir = o;
   o = align8(o + sizeof(uint32_t) * n_views);
   L.off_edir = o;
@@ -207,7 +207,7 @@ EG3D_HD ChainLayout chain_layout(uint32_t cap_pts, uint32_t pool_cap, uint32_t n
 EG3D_HD void chain_bind(Chain& c, const ChainLayout& L, unsigned char* slice) {
   c.pts = (ChainPt*)(slice + L.off_pts);
   c.cap_pts = (int32_t)L.cap_pts;
-  c.pool = (PoolObs*)(slice + L.off_pool);
+  c.pool = (Obs*)(slice + L.off_pool);
   c.pool_cap = L.pool_cap;
   c.start_dirs = (uint32_t*)(slice + L.off_sdir);
   c.end_dirs = (uint32_t*)(slice + L.off_edir);
@@ -268,9 +268,8 @@ EG3D_HD void expand_chain(const Team& tm, const DevScene& s, const StageAView& a
     p.X[0] = hp.X[0];
     p.X[1] = hp.X[1];
     p.X[2] = hp.X[2];
-    p.nobs = 0;
-    p.head = 0xffffffffu;
-    p.tail = 0xffffffffu;
+    point_init(p);
+    point_reserve(c, p, hp.nobs + 1);
     for (uint32_t i = 0; i < hp.nobs; i++) pool_append(c, p, hp.o[i]);
     c.len++;
   };
@@ -325,7 +324,7 @@ EG3D_HD void emit_chain(const ChainLayout& L, const unsigned char* slice, const 
                         uint64_t point_base, uint64_t obs_base, float* X, uint32_t* obs_off, int32_t* obs_view,
                         uint32_t* obs_pl, uint32_t* obs_seg, float* obs_xy, uint32_t* key) {
   const ChainPt* pts = (const ChainPt*)(slice + L.off_pts);
-  const PoolObs* pool = (const PoolObs*)(slice + L.off_pool);
+  const Obs* pool = (const Obs*)(slice + L.off_pool);
   uint64_t o = obs_base;
   for (uint32_t i = 0; i < co.n_points; i++) {
     const ChainPt& p = pts[co.head + i];
@@ -338,16 +337,14 @@ EG3D_HD void emit_chain(const ChainLayout& L, const unsigned char* slice, const 
     key[4 * pi + 1] = d.entry;
     key[4 * pi + 2] = d.hit;
     key[4 * pi + 3] = i;
-    uint32_t q = p.head;
     for (uint32_t k = 0; k < p.nobs; k++) {
-      const PoolObs& po = pool[q];
-      obs_view[o] = po.o.view;
-      obs_pl[o] = po.o.pl;
-      obs_seg[o] = po.o.seg;
-      obs_xy[2 * o] = po.o.x;
-      obs_xy[2 * o + 1] = po.o.y;
+      const Obs& po = pool[p.off + k];
+      obs_view[o] = po.view;
+      obs_pl[o] = po.pl;
+      obs_seg[o] = po.seg;
+      obs_xy[2 * o] = po.x;
+      obs_xy[2 * o + 1] = po.y;
       o++;
-      q = po.next;
     }
   }
 }

@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(256) k4_emit(const TaskDesc* tasks, const Chai
   if (j >= n_chains) return;
   const unsigned char* slice = scratch + L.total * (size_t)j;
   const ChainPt* pts = (const ChainPt*)(slice + L.off_pts);
-  const PoolObs* pool = (const PoolObs*)(slice + L.off_pool);
+  const Obs* pool = (const Obs*)(slice + L.off_pool);
   const ChainOut co = outs[j];
   const TaskDesc d = tasks[chains[j].task];
   const uint64_t pbase = point_base + point_off[j];
@@ -464,16 +464,14 @@ __global__ void __launch_bounds__(256) k4_emit(const TaskDesc* tasks, const Chai
       key[4 * pi + 1] = d.entry;
       key[4 * pi + 2] = d.hit;
       key[4 * pi + 3] = i;
-      uint32_t q = p.head;
       for (uint32_t k = 0; k < p.nobs; k++) {
-        const PoolObs po = pool[q];
-        obs_view[o] = po.o.view;
-        obs_pl[o] = po.o.pl;
-        obs_seg[o] = po.o.seg;
-        obs_xy[2 * o] = po.o.x;
-        obs_xy[2 * o + 1] = po.o.y;
+        const Obs po = pool[p.off + k];
+        obs_view[o] = po.view;
+        obs_pl[o] = po.pl;
+        obs_seg[o] = po.seg;
+        obs_xy[2 * o] = po.x;
+        obs_xy[2 * o + 1] = po.y;
         o++;
-        q = po.next;
       }
     }
     obase += total;
