@@ -2,7 +2,7 @@
 // (found by a 3-view hypothesis) is offered to every other view in ascending view order; a
 // view that sees the edge contributes one observation per chain point it can follow, each
 // addition re-solving the point with FP64 Gauss-Newton, and may extend the chain at either end.
-// One GPU lane owns one chain (kernel k3b_expand).
+// One wavefront owns one chain (kernel k3b_expand).
 //
 // Behaviour reproduced (reference): expand_allpoints_to_other_view_using_plmap
 // (src/edgegraph3d/utils/geometry/triangulation.cpp:742-833, SWITCH_DISABLE_INTERVAL branch),
@@ -10,8 +10,8 @@
 // follow_direction_vector_start/_end, compatible() vector form
 // (src/edgegraph3d/matching/plg_matching/plg_matching.cpp:1345-1412, 866-914, 771-795, 633-759).
 // Design: the chain is a deque of fixed-size point headers in an HBM scratch slice with the
-// observations of each point in an append-only pool threaded as singly linked lists, so that
-// adding a view never moves data; all solver state stays in registers.
+// observations of each point in a contiguous block of an append-only pool (blocks double when
+// they fill); one wavefront owns one chain and spreads the Gauss-Newton solves over its lanes.
 #pragma once
 #include "eg3d_dev_follow.h"
 
@@ -57,24 +57,6 @@ struct StepSlot {
   Obs sel[EG3D_STEP_OBS];
   Obs tmp[EG3D_STEP_OBS];
   uint8_t mask[EG3D_STEP_OBS];
-};
-
-// Execution team of one chain. The expand stage is written SPMD-style: every member runs the
-// same control flow on identical values ("uniform" sections, redundant across lanes) and only
-// the marked parallel sections split items across members, communicating through the chain's
-// scratch slice followed by sync(). TeamSeq (1 member) is the sequential semantics and what the
-// host instantiation uses; the GPU kernel uses a 64-lane wavefront (TeamWave in
-// eg3d_kernels.hip).
-struct TeamSeq {
-  static constexpr bool kSlotStep = false;  // N-view step: plain sequential candidates
-  EG3D_HD int lane() const { return 0; }
-  EG3D_HD int size() const { return 1; }
-  EG3D_HD void sync() const {}
-};
-// One member, but routed through the slot-based (parallel-capable) N-view step: lets the host
-// instantiation exercise exactly the code path the 64-lane team runs.
-struct TeamSeqSlots : TeamSeq {
-  static constexpr bool kSlotStep = true;
 };
 
 // Per-chain working set (pointers into this chain's scratch slice).
@@ -174,6 +156,48 @@ EG3D_HD bool add_observation_solve(const DevScene& s, const Chain& c, const Chai
   return gauss_newton_f64(s.cam_P, cur, X0, Xout);
 }
 
+// Execution team of one chain. The expand stage is written SPMD-style: every member runs the
+// same control flow on identical values ("uniform" sections, redundant across lanes) and only
+// the marked parallel sections split items across members, communicating through the chain's
+// scratch slice followed by sync(). TeamSeq (1 member) is the sequential semantics and what the
+// host instantiation uses; the GPU kernel uses a 64-lane wavefront (TeamWave in
+// eg3d_kernels.hip).
+//
+// Solver hooks: gn_array() is ONE Gauss-Newton solve inside a uniform section; add_solves() is a
+// batch of B independent ADD solves, request j described by get(j, point, extra) -> wanted and
+// answered through put(j, ok, X). The sequential team runs them one after the other; the
+// wavefront team spreads the observations of the solves over its lanes (eg3d_dev_coopgn.h).
+struct TeamSeq {
+  static constexpr bool kSlotStep = false;  // N-view step: plain sequential candidates
+  EG3D_HD int lane() const { return 0; }
+  EG3D_HD int size() const { return 1; }
+  EG3D_HD void sync() const {}
+  EG3D_HD bool gn_array(const DevScene& s, const Obs* a, int n, const double X0[3], float Xout[3]) const {
+    ArrayCursor cur;
+    cur.a = a;
+    cur.n = n;
+    cur.extra = nullptr;
+    cur.i = 0;
+    return gauss_newton_f64(s.cam_P, cur, X0, Xout);
+  }
+  template <class Get, class Put>
+  EG3D_HD void add_solves(const DevScene& s, Chain& c, int B, Get get, Put put) const {
+    for (int j = 0; j < B; j++) {
+      const ChainPt* pt = nullptr;
+      Obs o;
+      if (!get(j, pt, o)) continue;
+      float X[3];
+      const bool ok = add_observation_solve(s, c, *pt, o, X);
+      put(j, ok, X);
+    }
+  }
+};
+// One member, but routed through the slot-based (parallel-capable) N-view step: lets the host
+// instantiation exercise exactly the code path the 64-lane team runs.
+struct TeamSeqSlots : TeamSeq {
+  static constexpr bool kSlotStep = true;
+};
+
 // Walk phase of one candidate of the N-view step on chain point `cur`: observation `st`
 // advances 10 px on its polyline, every other observation follows by a bounded (5..20 px)
 // epipolar walk. Returns the number of observations collected in sel (0 = candidate dead).
@@ -225,6 +249,25 @@ EG3D_HD int stepn_walks(const DevScene& s, const Chain& c, const ChainPt& cur, i
   return m < 3 ? 0 : m;
 }
 
+// TRI on an observation array inside a uniform section: DLT as triangulate_array, the
+// Gauss-Newton solve through the team.
+template <class Team>
+EG3D_HD bool triangulate_array_team(const Team& tm, const DevScene& s, const Obs* a, int n, float Xout[3],
+                                    uint32_t& flags) {
+  int mi = 0;
+  int32_t mv = a[0].view;
+  for (int i = 0; i < n; i++)
+    if (a[i].view < mv) {
+      mv = a[i].view;
+      mi = i;
+    }
+  const int la = n - 1;
+  if (a[mi].view == a[la].view) flags |= 16u;
+  double X0[3];
+  dlt2(s.cam_P + (size_t)a[mi].view * 16, a[mi].x, a[mi].y, s.cam_P + (size_t)a[la].view * 16, a[la].x, a[la].y, X0);
+  return tm.gn_array(s, a, n, X0, Xout);
+}
+
 // Triangulation fallback of a candidate whose all-observation solve failed: first valid 3-subset
 // + greedy ADD (triangulation.cpp:1105-1158); compacts sel to the kept observations.
 EG3D_HD int stepn_fallback(const DevScene& s, Obs* sel, int m, Obs* tmp, uint8_t* mask, float Xout[3], uint32_t& flags) {
@@ -251,7 +294,7 @@ EG3D_HD int stepn_chain(const Team& tm, const DevScene& s, Chain& c, const Chain
     for (int st = 0; st < n; st++) {
       int m = stepn_walks(s, c, cur, st, dirs, c.tmp_a, c.tmp_cap, c.flags);
       if (!m) continue;
-      if (triangulate_array(s.cam_P, c.tmp_a, m, Xout, c.flags)) return m;
+      if (triangulate_array_team(tm, s, c.tmp_a, m, Xout, c.flags)) return m;
       m = stepn_fallback(s, c.tmp_a, m, c.tmp_b, c.tmp_mask, Xout, c.flags);
       if (m) return m;
     }
@@ -406,17 +449,21 @@ EG3D_HD int walk_side(const Team& tm, const DevScene& s, Chain& c, int view, con
   c.tsec[5] += 1;              // walk_side calls (= GN batches)
   c.tsec[6] += (uint64_t)m;    // walk steps that produced a candidate
 #endif
-  for (int j = tm.lane(); j < m; j += tm.size()) {
-    const ChainPt& pt = chain_at(c, towards_start ? ci - 1 - j : ci + 1 + j);
-    float X[3];
-    const Obs o = out[j].o;
-    if (add_observation_solve(s, c, pt, o, X)) {
-      out[j].X[0] = X[0];
-      out[j].X[1] = X[1];
-      out[j].X[2] = X[2];
-      out[j].ok = 1;
-    }
-  }
+  tm.add_solves(
+      s, c, m,
+      [&](int j, const ChainPt*& pt, Obs& o) {
+        pt = &chain_at(c, towards_start ? ci - 1 - j : ci + 1 + j);
+        o = out[j].o;
+        return true;
+      },
+      [&](int j, bool ok, const float* X) {
+        if (ok) {
+          out[j].X[0] = X[0];
+          out[j].X[1] = X[1];
+          out[j].X[2] = X[2];
+          out[j].ok = 1;
+        }
+      });
   tm.sync();
   c.tsec[3] += EG3D_TICK() - t1;
   int cnt = 0;
@@ -563,18 +610,31 @@ EG3D_HD void view_candidates(const Team& tm, const DevScene& s, Chain& c, int v,
       vc.seg = cp.seg;
       vc.x = cp.x;
       vc.y = cp.y;
-      if (vc.d2 <= 16.0f) {
-        Obs o;
-        o.view = v;
-        o.pl = pl_id;
-        o.seg = cp.seg;
-        o.x = cp.x;
-        o.y = cp.y;
-        vc.cok = add_observation_solve(s, c, pt, o, vc.cX) ? 1u : 0u;
-      }
     }
     c.cand[i] = vc;
   }
+  tm.sync();
+  // speculative central ADD solve of every point whose candidate is within 4 px
+  tm.add_solves(
+      s, c, c.len - from,
+      [&](int j, const ChainPt*& pt, Obs& o) {
+        const ViewCand& vc = c.cand[from + j];
+        if (!vc.valid || !(vc.d2 <= 16.0f)) return false;
+        pt = &chain_at(c, from + j);
+        o.view = v;
+        o.pl = vc.pl;
+        o.seg = vc.seg;
+        o.x = vc.x;
+        o.y = vc.y;
+        return true;
+      },
+      [&](int j, bool ok, const float* X) {
+        ViewCand& vc = c.cand[from + j];
+        vc.cok = ok ? 1u : 0u;
+        vc.cX[0] = X[0];
+        vc.cX[1] = X[1];
+        vc.cX[2] = X[2];
+      });
   tm.sync();
   c.tsec[0] += EG3D_TICK() - tc0;
 }
@@ -595,11 +655,21 @@ EG3D_HD void expand_to_view(const Team& tm, const DevScene& s, Chain& c, int v, 
       ViewCand& vc = c.cand[i];
       vc.eok = epiline(s.F, s.F_valid, s.n_views, first.view, v, first.x, first.y, vc.ea, vc.eb, vc.ec) ? 1u : 0u;
     }
-    for (int e = tm.lane(); e < n_pre; e += tm.size()) {
-      EpcSolve r;
-      r.ok = add_observation_solve(s, c, chain_at(c, centre), epc[e], r.X) ? 1u : 0u;
-      c.epcres[e] = r;
-    }
+    tm.add_solves(
+        s, c, n_pre,
+        [&](int e, const ChainPt*& pt, Obs& o) {
+          pt = &chain_at(c, centre);
+          o = epc[e];
+          return true;
+        },
+        [&](int e, bool ok, const float* X) {
+          EpcSolve r;
+          r.ok = ok ? 1u : 0u;
+          r.X[0] = X[0];
+          r.X[1] = X[1];
+          r.X[2] = X[2];
+          c.epcres[e] = r;
+        });
     tm.sync();
   }
   for (int e = 0; e < n_epc; e++) {

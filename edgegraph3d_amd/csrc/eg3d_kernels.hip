@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "eg3d_dev_pipeline.h"
+#include "eg3d_dev_coopgn.h"
 #include "eg3d_kernels.h"
 
 namespace eg3d {
@@ -374,11 +375,68 @@ __global__ void k_compact_chains(uint32_t n_tasks, const ChainSeed* per_task, co
 #ifndef EG3D_WAVE_SLOT_STEP
 #define EG3D_WAVE_SLOT_STEP 0 /* measured slower: failed speculative candidates run all 30 GN iterations */
 #endif
+#ifndef EG3D_COOP_GN
+#define EG3D_COOP_GN 1 /* wave-cooperative Gauss-Newton (eg3d_dev_coopgn.h); 0 = one lane per solve */
+#endif
 struct TeamWave {
   static constexpr bool kSlotStep = EG3D_WAVE_SLOT_STEP != 0;
+  CoopLds* L;
   __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
   __device__ __forceinline__ int size() const { return 64; }
   __device__ __forceinline__ void sync() const { __syncthreads(); }
+  // uniform section: all lanes hold the same (a, n, X0) and receive the same answer
+  __device__ __forceinline__ bool gn_array(const DevScene& s, const Obs* a, int n, const double X0[3],
+                                           float Xout[3]) const {
+    if (EG3D_COOP_GN && n <= EG3D_COOP_ROWS) return coop_gn_single(s.cam_P, *L, a, n, X0, Xout);
+    ArrayCursor cur;
+    cur.a = a;
+    cur.n = n;
+    cur.extra = nullptr;
+    cur.i = 0;
+    return gauss_newton_f64(s.cam_P, cur, X0, Xout);
+  }
+  // B independent ADD solves, 64 per window, request j on lane j. A window goes cooperative
+  // (rows = observations) when that needs fewer row-passes than the longest single solve;
+  // otherwise each lane runs its own solve. Both produce the same bits.
+  template <class Get, class Put>
+  __device__ __forceinline__ void add_solves(const DevScene& s, Chain& c, int B, Get get, Put put) const {
+    for (int w0 = 0; w0 < B; w0 += 64) {
+      const int j = w0 + lane();
+      const ChainPt* pt = nullptr;
+      Obs o;
+      o.view = 0;
+      o.pl = o.seg = 0;
+      o.x = o.y = 0.f;
+      const bool want = j < B && get(j, pt, o);
+      const int n = want ? (int)pt->nobs + 1 : 0;
+      int tot = n, mx = n;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        tot += __shfl_xor(tot, d);
+        const int t = __shfl_xor(mx, d);
+        mx = t > mx ? t : mx;
+      }
+      if (mx == 0) continue;
+      const int passes = (tot + EG3D_COOP_ROWS - 1) / EG3D_COOP_ROWS;
+      const bool coop = EG3D_COOP_GN && mx <= EG3D_COOP_ROWS && passes * 3 < mx * 2;
+      float X[3] = {0.f, 0.f, 0.f};
+      bool ok = false;
+      if (coop) {
+        float X0[3] = {0.f, 0.f, 0.f};
+        uint32_t off = 0;
+        if (want) {
+          X0[0] = pt->X[0];
+          X0[1] = pt->X[1];
+          X0[2] = pt->X[2];
+          off = pt->off;
+        }
+        ok = coop_gn_window(s.cam_P, c.pool, *L, want, off, n - 1, o, X0, X);
+      } else if (want) {
+        ok = add_observation_solve(s, c, *pt, o, X);
+      }
+      if (want) put(j, ok, X);
+    }
+  }
 };
 
 #ifndef EG3D_K3B_WAVES
@@ -395,7 +453,9 @@ __global__ void __launch_bounds__(64, EG3D_K3B_WAVES) k3b_expand(DevScene s, Sta
   const ChainSeed cs = chains[j];
   const TaskDesc d = tasks[cs.task];
   ChainOut co;
+  __shared__ CoopLds lds;
   TeamWave tm;
+  tm.L = &lds;
   expand_chain(tm, s, a, d, cs, hyp_off[cs.task], res, arena, map_view, map_entry, map_n, L,
                scratch + L.total * (size_t)j, co);
   if (threadIdx.x == 0) {
