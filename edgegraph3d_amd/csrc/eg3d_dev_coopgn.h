@@ -17,8 +17,19 @@
 namespace eg3d {
 
 #define EG3D_COOP_ROWS 64
+#define EG3D_STAGE_VTX 512
+#define EG3D_STAGE_EPI 192
 struct CoopLds {
-  double prod[14][EG3D_COOP_ROWS + 1];
+  union {
+    double prod[14][EG3D_COOP_ROWS + 1];
+    // side-walk staging (never live at the same time as a solve): the polyline being walked and
+    // the epipolar lines of the chain points ahead
+    struct {
+      f2 vtx[EG3D_STAGE_VTX];
+      float epi[EG3D_STAGE_EPI][4];
+    } walk;
+  };
+  Obs tmp_a[EG3D_COOP_ROWS];     // the N-view step's candidate observations (Chain::tmp_a) when they fit
   double sums[22][8];            // a group has >= 3 rows => <= 21 groups per round
   float x0[EG3D_COOP_ROWS][3];   // in: start point of request j; out: its result
   uint32_t off[EG3D_COOP_ROWS];  // first observation of request j in the chain's pool

@@ -172,6 +172,19 @@ struct TeamSeq {
   EG3D_HD int lane() const { return 0; }
   EG3D_HD int size() const { return 1; }
   EG3D_HD void sync() const {}
+  EG3D_HD void bind(Chain&) const {}
+  // rank of this member among the members whose flag is set (+ their number)
+  EG3D_HD int rank(bool flag, int& total) const {
+    total = flag ? 1 : 0;
+    return 0;
+  }
+  EG3D_HD uint32_t or_reduce(uint32_t v) const { return v; }
+  // side-walk staging: the polyline being walked and the epipolar lines (eok, a, b, c) of chain
+  // points first, first+step, ... may be copied to fast memory; returns how many lines were staged
+  EG3D_HD int stage_side_walk(PlRef&, const Chain&, int, int, int, const float*& epi) const {
+    epi = nullptr;
+    return 0;
+  }
   EG3D_HD bool gn_array(const DevScene& s, const Obs* a, int n, const double X0[3], float Xout[3]) const {
     ArrayCursor cur;
     cur.a = a;
@@ -199,10 +212,12 @@ struct TeamSeqSlots : TeamSeq {
 };
 
 // Walk phase of one candidate of the N-view step on chain point `cur`: observation `st`
-// advances 10 px on its polyline, every other observation follows by a bounded (5..20 px)
-// epipolar walk. Returns the number of observations collected in sel (0 = candidate dead).
-EG3D_HD int stepn_walks(const DevScene& s, const Chain& c, const ChainPt& cur, int st, const uint32_t* dirs, Obs* sel,
-                        int sel_cap, uint32_t& flags) {
+// advances 10 px on its polyline (uniform), every other observation follows by a bounded
+// (5..20 px) epipolar walk — PARALLEL over the observations, the survivors compacted in
+// observation order. Returns the number of observations collected in sel (0 = candidate dead).
+template <class Team>
+EG3D_HD int stepn_walks(const Team& tm, const DevScene& s, const Chain& c, const ChainPt& cur, int st,
+                        const uint32_t* dirs, Obs* sel, int sel_cap, uint32_t& flags) {
   const int n = (int)cur.nobs;
   const Obs* co_all = c.pool + cur.off;
   const Obs so = co_all[st];
@@ -221,31 +236,47 @@ EG3D_HD int stepn_walks(const DevScene& s, const Chain& c, const ChainPt& cur, i
   sel[m].x = q.x;
   sel[m].y = q.y;
   m++;
-  for (int i = 0; i < n; i++) {
-    if (i == st) continue;
-    const Obs co = co_all[i];
-    float la, lb, lc;
-    if (!epiline(s.F, s.F_valid, s.n_views, so.view, co.view, q.x, q.y, la, lb, lc)) continue;
-    PlRef pk = polyline_of(s, co.view, co.pl);
-    PlPt cp, r;
-    cp.seg = co.seg;
-    cp.x = co.x;
-    cp.y = co.y;
-    uint32_t wr = walk_by_line(pk, cp, dirs[co.view], la, lb, lc, true, EG3D_FOLLOW_MIN, EG3D_FOLLOW_MAX, r);
-    if (wr & WALK_BAD_DIR) flags |= 8u;
-    if (wr & WALK_FOUND) {
-      if (m >= sel_cap) {
-        flags |= 2u;
-        break;
+  uint32_t fl = 0;
+  for (int i0 = 0; i0 < n; i0 += tm.size()) {
+    const int i = i0 + tm.lane();
+    bool found = false;
+    Obs r;
+    r.view = 0;
+    r.pl = r.seg = 0;
+    r.x = r.y = 0.f;
+    if (i < n && i != st) {
+      const Obs co = co_all[i];
+      float la, lb, lc;
+      if (epiline(s.F, s.F_valid, s.n_views, so.view, co.view, q.x, q.y, la, lb, lc)) {
+        PlRef pk = polyline_of(s, co.view, co.pl);
+        PlPt cp, rp;
+        cp.seg = co.seg;
+        cp.x = co.x;
+        cp.y = co.y;
+        uint32_t wr = walk_by_line(pk, cp, dirs[co.view], la, lb, lc, true, EG3D_FOLLOW_MIN, EG3D_FOLLOW_MAX, rp);
+        if (wr & WALK_BAD_DIR) fl |= 8u;
+        if (wr & WALK_FOUND) {
+          found = true;
+          r.view = co.view;
+          r.pl = co.pl;
+          r.seg = rp.seg;
+          r.x = rp.x;
+          r.y = rp.y;
+        }
       }
-      sel[m].view = co.view;
-      sel[m].pl = co.pl;
-      sel[m].seg = r.seg;
-      sel[m].x = r.x;
-      sel[m].y = r.y;
-      m++;
     }
+    int total;
+    const int rk = tm.rank(found, total);
+    if (found && m + rk < sel_cap) sel[m + rk] = r;
+    if (m + total > sel_cap) {
+      flags |= 2u;
+      m = sel_cap;
+      break;
+    }
+    m += total;
   }
+  flags |= tm.or_reduce(fl);
+  tm.sync();
   return m < 3 ? 0 : m;
 }
 
@@ -292,7 +323,7 @@ EG3D_HD int stepn_chain(const Team& tm, const DevScene& s, Chain& c, const Chain
   const int n = (int)cur.nobs;
   if (n > EG3D_STEP_OBS || !Team::kSlotStep) {
     for (int st = 0; st < n; st++) {
-      int m = stepn_walks(s, c, cur, st, dirs, c.tmp_a, c.tmp_cap, c.flags);
+      int m = stepn_walks(tm, s, c, cur, st, dirs, c.tmp_a, c.tmp_cap, c.flags);
       if (!m) continue;
       if (triangulate_array_team(tm, s, c.tmp_a, m, Xout, c.flags)) return m;
       m = stepn_fallback(s, c.tmp_a, m, c.tmp_b, c.tmp_mask, Xout, c.flags);
@@ -304,7 +335,7 @@ EG3D_HD int stepn_chain(const Team& tm, const DevScene& s, Chain& c, const Chain
   for (int st = tm.lane(); st < n; st += tm.size()) {
     StepSlot& sl = c.slots[st];
     uint32_t fl = 0;
-    sl.m = stepn_walks(s, c, cur, st, dirs, sl.sel, EG3D_STEP_OBS, fl);
+    sl.m = stepn_walks(TeamSeq(), s, c, cur, st, dirs, sl.sel, EG3D_STEP_OBS, fl);
     sl.flags = fl;
     sl.ok = 0;
   }
@@ -399,10 +430,15 @@ EG3D_HD int follow_front(const Team& tm, const DevScene& s, Chain& c) {
 // points ci-1, ci-2, ... >= lo (towards_start) or ci+1, ... < hi; for each take the next hit of
 // the epipolar line of the point's FIRST observation. Walk positions do not depend on the
 // solver, so all candidates are generated first; returns how many walks succeeded.
-EG3D_HD int walk_side_candidates(const DevScene& s, Chain& c, int view, const Obs& from, uint32_t direction, int lo,
-                                 int ci, int hi, bool towards_start, Pending* out) {
+template <class Team>
+EG3D_HD int walk_side_candidates(const Team& tm, const DevScene& s, Chain& c, int view, const Obs& from,
+                                 uint32_t direction, int lo, int ci, int hi, bool towards_start, Pending* out) {
   int cnt = 0;
   PlRef pl = polyline_of(s, view, from.pl);
+  const float* epi = nullptr;
+  const int n_epi = tm.stage_side_walk(pl, c, towards_start ? ci - 1 : ci + 1, towards_start ? -1 : 1,
+                                       towards_start ? ci - lo : hi - ci - 1, epi);
+  int t = 0;
   PlPt actual;
   actual.seg = from.seg;
   actual.x = from.x;
@@ -411,9 +447,20 @@ EG3D_HD int walk_side_candidates(const DevScene& s, Chain& c, int view, const Ob
   while ((towards_start && i >= lo) || (!towards_start && i < hi)) {
     // epipolar line of chain point i's first observation in `view`: precomputed lane-parallel by
     // view_epilines() for the view being offered
-    const ViewCand& ve = c.cand[i];
-    if (!ve.eok) break;
-    const float la = ve.ea, lb = ve.eb, lc = ve.ec;
+    float la, lb, lc;
+    if (t < n_epi) {
+      if (epi[4 * t] == 0.0f) break;
+      la = epi[4 * t + 1];
+      lb = epi[4 * t + 2];
+      lc = epi[4 * t + 3];
+    } else {
+      const ViewCand& ve = c.cand[i];
+      if (!ve.eok) break;
+      la = ve.ea;
+      lb = ve.eb;
+      lc = ve.ec;
+    }
+    t++;
     PlPt nx;
     uint32_t w = walk_by_line(pl, actual, direction, la, lb, lc, false, 0.0f, 0.0f, nx);
     if (w & WALK_BAD_DIR) c.flags |= 8u;
@@ -441,7 +488,7 @@ template <class Team>
 EG3D_HD int walk_side(const Team& tm, const DevScene& s, Chain& c, int view, const Obs& from, uint32_t direction,
                       int lo, int ci, int hi, bool towards_start, Pending* out) {
   uint64_t t0 = EG3D_TICK();
-  const int m = walk_side_candidates(s, c, view, from, direction, lo, ci, hi, towards_start, out);
+  const int m = walk_side_candidates(tm, s, c, view, from, direction, lo, ci, hi, towards_start, out);
   tm.sync();
   uint64_t t1 = EG3D_TICK();
   c.tsec[2] += t1 - t0;

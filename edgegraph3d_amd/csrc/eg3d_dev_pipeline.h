@@ -238,6 +238,7 @@ EG3D_HD void expand_chain(const Team& tm, const DevScene& s, const StageAView& a
                           unsigned char* slice, ChainOut& out) {
   Chain c;
   chain_bind(c, L, slice);
+  tm.bind(c);
   c.flags = 0;
   c.bytes = 0;
   for (int k = 0; k < 8; k++) c.tsec[k] = 0;

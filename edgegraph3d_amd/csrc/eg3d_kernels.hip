@@ -384,6 +384,38 @@ struct TeamWave {
   __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
   __device__ __forceinline__ int size() const { return 64; }
   __device__ __forceinline__ void sync() const { __syncthreads(); }
+  __device__ __forceinline__ void bind(Chain& c) const {
+    if (c.tmp_cap <= EG3D_COOP_ROWS) c.tmp_a = L->tmp_a;
+  }
+  __device__ __forceinline__ int rank(bool flag, int& total) const {
+    const unsigned long long m = __ballot(flag);
+    total = __popcll(m);
+    return __popcll(m & ((1ull << lane()) - 1ull));
+  }
+  __device__ __forceinline__ uint32_t or_reduce(uint32_t v) const {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v |= (uint32_t)__shfl_xor((int)v, d);
+    return v;
+  }
+  __device__ __forceinline__ int stage_side_walk(PlRef& pl, const Chain& c, int first, int step, int count,
+                                                 const float*& epi) const {
+    __syncthreads();
+    const bool fits = pl.n <= EG3D_STAGE_VTX;
+    if (fits)
+      for (uint32_t i = (uint32_t)lane(); i < pl.n; i += 64) L->walk.vtx[i] = pl.v[i];
+    const int staged = count < EG3D_STAGE_EPI ? (count < 0 ? 0 : count) : EG3D_STAGE_EPI;
+    for (int t = lane(); t < staged; t += 64) {
+      const ViewCand& ve = c.cand[first + step * t];
+      L->walk.epi[t][0] = ve.eok ? 1.0f : 0.0f;
+      L->walk.epi[t][1] = ve.ea;
+      L->walk.epi[t][2] = ve.eb;
+      L->walk.epi[t][3] = ve.ec;
+    }
+    __syncthreads();
+    if (fits) pl.v = L->walk.vtx;
+    epi = &L->walk.epi[0][0];
+    return staged;
+  }
   // uniform section: all lanes hold the same (a, n, X0) and receive the same answer
   __device__ __forceinline__ bool gn_array(const DevScene& s, const Obs* a, int n, const double X0[3],
                                            float Xout[3]) const {
