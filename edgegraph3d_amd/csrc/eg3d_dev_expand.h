@@ -80,7 +80,7 @@ struct Chain {
   int32_t tmp_cap;
   uint32_t flags;
   uint64_t bytes;  // vertices of 4 px-grid polylines tested (algorithmic bytes)
-  uint64_t tsec[8];  // diagnostic: shader-clock ticks per section (0 cand, 1 central, 2 walks, 3 batch GN, 4 follow, 5 commit)
+  uint64_t tsec[8];  // diagnostic: shader-clock ticks per section (0 cand, 1 step walks, 2 side walks, 3 batch GN, 4 follow, 5 step DLT, 6 step GN, 7 whole)
 };
 #if defined(__HIP_DEVICE_COMPILE__) && defined(EG3D_SECTION_TIMING)
 #define EG3D_TICK() ((uint64_t)__builtin_readcyclecounter())
@@ -284,7 +284,8 @@ EG3D_HD int stepn_walks(const Team& tm, const DevScene& s, const Chain& c, const
 // Gauss-Newton solve through the team.
 template <class Team>
 EG3D_HD bool triangulate_array_team(const Team& tm, const DevScene& s, const Obs* a, int n, float Xout[3],
-                                    uint32_t& flags) {
+                                    uint32_t& flags, uint64_t* tsec = nullptr) {
+  const uint64_t t0 = EG3D_TICK();
   int mi = 0;
   int32_t mv = a[0].view;
   for (int i = 0; i < n; i++)
@@ -296,7 +297,13 @@ EG3D_HD bool triangulate_array_team(const Team& tm, const DevScene& s, const Obs
   if (a[mi].view == a[la].view) flags |= 16u;
   double X0[3];
   dlt2(s.cam_P + (size_t)a[mi].view * 16, a[mi].x, a[mi].y, s.cam_P + (size_t)a[la].view * 16, a[la].x, a[la].y, X0);
-  return tm.gn_array(s, a, n, X0, Xout);
+  const uint64_t t1 = EG3D_TICK();
+  const bool ok = tm.gn_array(s, a, n, X0, Xout);
+  if (tsec) {
+    tsec[5] += t1 - t0;
+    tsec[6] += EG3D_TICK() - t1;
+  }
+  return ok;
 }
 
 // Triangulation fallback of a candidate whose all-observation solve failed: first valid 3-subset
@@ -323,9 +330,11 @@ EG3D_HD int stepn_chain(const Team& tm, const DevScene& s, Chain& c, const Chain
   const int n = (int)cur.nobs;
   if (n > EG3D_STEP_OBS || !Team::kSlotStep) {
     for (int st = 0; st < n; st++) {
+      const uint64_t tw0 = EG3D_TICK();
       int m = stepn_walks(tm, s, c, cur, st, dirs, c.tmp_a, c.tmp_cap, c.flags);
+      c.tsec[1] += EG3D_TICK() - tw0;
       if (!m) continue;
-      if (triangulate_array_team(tm, s, c.tmp_a, m, Xout, c.flags)) return m;
+      if (triangulate_array_team(tm, s, c.tmp_a, m, Xout, c.flags, c.tsec)) return m;
       m = stepn_fallback(s, c.tmp_a, m, c.tmp_b, c.tmp_mask, Xout, c.flags);
       if (m) return m;
     }
@@ -454,7 +463,7 @@ EG3D_HD int walk_side_candidates(const Team& tm, const DevScene& s, Chain& c, in
       lb = epi[4 * t + 2];
       lc = epi[4 * t + 3];
     } else {
-      const ViewCand& ve = c.cand[i];
+      const ViewCand& ve = c.cand[c.head + i];
       if (!ve.eok) break;
       la = ve.ea;
       lb = ve.eb;
@@ -492,10 +501,6 @@ EG3D_HD int walk_side(const Team& tm, const DevScene& s, Chain& c, int view, con
   tm.sync();
   uint64_t t1 = EG3D_TICK();
   c.tsec[2] += t1 - t0;
-#if defined(EG3D_SECTION_TIMING)
-  c.tsec[5] += 1;              // walk_side calls (= GN batches)
-  c.tsec[6] += (uint64_t)m;    // walk steps that produced a candidate
-#endif
   tm.add_solves(
       s, c, m,
       [&](int j, const ChainPt*& pt, Obs& o) {
@@ -658,14 +663,14 @@ EG3D_HD void view_candidates(const Team& tm, const DevScene& s, Chain& c, int v,
       vc.x = cp.x;
       vc.y = cp.y;
     }
-    c.cand[i] = vc;
+    c.cand[c.head + i] = vc;
   }
   tm.sync();
   // speculative central ADD solve of every point whose candidate is within 4 px
   tm.add_solves(
       s, c, c.len - from,
       [&](int j, const ChainPt*& pt, Obs& o) {
-        const ViewCand& vc = c.cand[from + j];
+        const ViewCand& vc = c.cand[c.head + from + j];
         if (!vc.valid || !(vc.d2 <= 16.0f)) return false;
         pt = &chain_at(c, from + j);
         o.view = v;
@@ -676,7 +681,7 @@ EG3D_HD void view_candidates(const Team& tm, const DevScene& s, Chain& c, int v,
         return true;
       },
       [&](int j, bool ok, const float* X) {
-        ViewCand& vc = c.cand[from + j];
+        ViewCand& vc = c.cand[c.head + from + j];
         vc.cok = ok ? 1u : 0u;
         vc.cX[0] = X[0];
         vc.cX[1] = X[1];
@@ -699,7 +704,7 @@ EG3D_HD void expand_to_view(const Team& tm, const DevScene& s, Chain& c, int v, 
     // PARALLEL: epipolar lines of every chain point in view v (the side walks read them)
     for (int i = tm.lane(); i < c.len; i += tm.size()) {
       const Obs& first = c.pool[chain_at(c, i).off];
-      ViewCand& vc = c.cand[i];
+      ViewCand& vc = c.cand[c.head + i];
       vc.eok = epiline(s.F, s.F_valid, s.n_views, first.view, v, first.x, first.y, vc.ea, vc.eb, vc.ec) ? 1u : 0u;
     }
     tm.add_solves(
@@ -744,7 +749,7 @@ EG3D_HD void expand_to_view(const Team& tm, const DevScene& s, Chain& c, int v, 
       last_matched = idx_second;
       continue;
     }
-    const ViewCand vc = c.cand[cur];
+    const ViewCand vc = c.cand[c.head + cur];
     if (!vc.valid) continue;
     c.bytes += 8ull * (s.pl_vtx_off[s.view_pl_off[v] + vc.pl + 1] - s.pl_vtx_off[s.view_pl_off[v] + vc.pl]);
     if (vc.d2 > 16.0f) return;  // abandons this view (Q4)
@@ -756,7 +761,7 @@ EG3D_HD void expand_to_view(const Team& tm, const DevScene& s, Chain& c, int v, 
     o.y = vc.y;
     int hi = epc_matched ? (cur <= idx_first ? idx_first : c.len) : c.len;
     int a, b;
-    if (attach_view(tm, s, c, o, last_matched + 1, cur, hi, a, b, &c.cand[cur].cok, c.cand[cur].cX)) {
+    if (attach_view(tm, s, c, o, last_matched + 1, cur, hi, a, b, &c.cand[c.head + cur].cok, c.cand[c.head + cur].cX)) {
       if (a > cur) {
         centre = a;
         cur = a + b;
@@ -764,8 +769,9 @@ EG3D_HD void expand_to_view(const Team& tm, const DevScene& s, Chain& c, int v, 
         cur = cur + b;
       }
       last_matched = cur;
-      // the chain may have grown / shifted: refresh the candidates of the points still to visit
-      view_candidates(tm, s, c, v, cur + 1);
+      // the points still to visit (> cur) were not touched by the attachment and the candidate
+      // array is indexed by absolute slot, so their candidates stay valid even if the chain grew
+      // at the front; points appended at the back are never visited in this view (cur = len-1)
     }
   }
 }

@@ -405,7 +405,7 @@ struct TeamWave {
       for (uint32_t i = (uint32_t)lane(); i < pl.n; i += 64) L->walk.vtx[i] = pl.v[i];
     const int staged = count < EG3D_STAGE_EPI ? (count < 0 ? 0 : count) : EG3D_STAGE_EPI;
     for (int t = lane(); t < staged; t += 64) {
-      const ViewCand& ve = c.cand[first + step * t];
+      const ViewCand& ve = c.cand[c.head + first + step * t];
       L->walk.epi[t][0] = ve.eok ? 1.0f : 0.0f;
       L->walk.epi[t][1] = ve.ea;
       L->walk.epi[t][2] = ve.eb;

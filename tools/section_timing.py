@@ -20,7 +20,7 @@ L = api.lib()
 L.eg3d_probe_sections.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
 sm, sl, n = (C.c_double * 8)(), (C.c_double * 8)(), C.c_uint32()
 assert L.eg3d_probe_sections(ctx._h, sm, sl, C.byref(n)) == 0
-names = ["candidates", "central", "walks", "batchGN", "follow", "#batches", "#walksteps", "whole"]
+names = ["candidates", "stepwalks", "sidewalks", "batchGN", "follow", "stepDLT", "stepGN", "whole"]
 tot = sm[7] or 1
 print("chains", n.value, "times", r["times"])
 for k in range(8):
