@@ -834,13 +834,13 @@ extern "C" int eg3d_probe_sections(eg3d_ctx* c, double* sum, double* slowest, ui
   if (!c || !sum || !slowest) return EG3D_ERR_ARG;
   std::vector<ChainOut> co(c->last_nc ? c->last_nc : 1);
   if (c->last_nc) HIP_TRY(hipMemcpy(co.data(), c->b_couts.p, sizeof(ChainOut) * c->last_nc, hipMemcpyDeviceToHost));
-  for (int k = 0; k < 8; k++) sum[k] = slowest[k] = 0;
+  for (int k = 0; k < 12; k++) sum[k] = slowest[k] = 0;
   uint64_t worst = 0;
   for (uint32_t j = 0; j < c->last_nc; j++) {
-    for (int k = 0; k < 8; k++) sum[k] += (double)co[j].tsec[k];
+    for (int k = 0; k < 12; k++) sum[k] += (double)co[j].tsec[k];
     if (co[j].tsec[7] >= worst) {
       worst = co[j].tsec[7];
-      for (int k = 0; k < 8; k++) slowest[k] = (double)co[j].tsec[k];
+      for (int k = 0; k < 12; k++) slowest[k] = (double)co[j].tsec[k];
     }
   }
   if (n_chains) *n_chains = c->last_nc;

@@ -80,7 +80,7 @@ struct Chain {
   int32_t tmp_cap;
   uint32_t flags;
   uint64_t bytes;  // vertices of 4 px-grid polylines tested (algorithmic bytes)
-  uint64_t tsec[8];  // diagnostic: shader-clock ticks per section (0 cand, 1 step walks, 2 side walks, 3 batch GN, 4 follow, 5 step DLT, 6 step GN, 7 whole)
+  uint64_t tsec[12];  // diagnostic: shader-clock ticks per section (0 cand, 1 step walks, 2 side walks, 3 batch GN, 4 follow, 5 step DLT, 6 step GN, 7 whole, 8 commit, 9 chain init, 10 epc pre-solves, 11 new point)
 };
 #if defined(__HIP_DEVICE_COMPILE__) && defined(EG3D_SECTION_TIMING)
 #define EG3D_TICK() ((uint64_t)__builtin_readcyclecounter())
@@ -179,6 +179,11 @@ struct TeamSeq {
     return 0;
   }
   EG3D_HD uint32_t or_reduce(uint32_t v) const { return v; }
+  // exclusive prefix sum of v over the members (+ the total)
+  EG3D_HD uint32_t excl_scan(uint32_t v, uint32_t& total) const {
+    total = v;
+    return 0;
+  }
   // side-walk staging: the polyline being walked and the epipolar lines (eok, a, b, c) of chain
   // points first, first+step, ... may be copied to fast memory; returns how many lines were staged
   EG3D_HD int stage_side_walk(PlRef&, const Chain&, int, int, int, const float*& epi) const {
@@ -407,8 +412,10 @@ EG3D_HD int follow_back(const Team& tm, const DevScene& s, Chain& c) {
       break;
     }
     ChainPt np;
+    const uint64_t tn0 = EG3D_TICK();
     if (!new_point_from_tmp(c, np, m, X)) break;
     c.pts[c.head + c.len] = np;
+    c.tsec[11] += EG3D_TICK() - tn0;
     c.len++;
     added++;
   }
@@ -426,9 +433,11 @@ EG3D_HD int follow_front(const Team& tm, const DevScene& s, Chain& c) {
       break;
     }
     ChainPt np;
+    const uint64_t tn0 = EG3D_TICK();
     if (!new_point_from_tmp(c, np, m, X)) break;
     c.head--;
     c.pts[c.head] = np;
+    c.tsec[11] += EG3D_TICK() - tn0;
     c.len++;
     added++;
   }
@@ -567,31 +576,69 @@ EG3D_HD bool attach_view(const Team& tm, const DevScene& s, Chain& c, const Obs&
   }
   if (ci > 0 && n1 == 0) return false;
   if (ci < c.len - 1 && n2 == 0) return false;
-  // commit (uniform: every member writes the same values)
+  // commit — PARALLEL over the 1 + n1 + n2 touched points (distinct points; blocks that are full
+  // are relocated to space reserved by a prefix sum over the members)
+  const uint64_t tcm0 = EG3D_TICK();
   {
-    ChainPt& cp = chain_at(c, ci);
-    cp.X[0] = Xc[0];
-    cp.X[1] = Xc[1];
-    cp.X[2] = Xc[2];
-    pool_append(c, cp, o);
-  }
-  for (int i = 0; i < n1; i++) {
-    ChainPt& p = chain_at(c, ci - 1 - i);
-    p.X[0] = c.pend1[i].X[0];
-    p.X[1] = c.pend1[i].X[1];
-    p.X[2] = c.pend1[i].X[2];
-    pool_append(c, p, c.pend1[i].o);
-  }
-  for (int i = 0; i < n2; i++) {
-    ChainPt& p = chain_at(c, ci + 1 + i);
-    p.X[0] = c.pend2[i].X[0];
-    p.X[1] = c.pend2[i].X[1];
-    p.X[2] = c.pend2[i].X[2];
-    pool_append(c, p, c.pend2[i].o);
+    const int T = 1 + n1 + n2;
+    for (int t0 = 0; t0 < T; t0 += tm.size()) {
+      const int t = t0 + tm.lane();
+      const bool act = t < T;
+      ChainPt* p = nullptr;
+      const Pending* pd = nullptr;
+      if (act) {
+        if (t == 0)
+          p = &chain_at(c, ci);
+        else if (t <= n1) {
+          p = &chain_at(c, ci - t);
+          pd = &c.pend1[t - 1];
+        } else {
+          p = &chain_at(c, ci + (t - n1));
+          pd = &c.pend2[t - n1 - 1];
+        }
+      }
+      uint32_t nobs = 0, cap = 0, off = 0, need = 0;
+      if (act) {
+        nobs = p->nobs;
+        cap = p->cap;
+        off = p->off;
+        if (nobs == cap) need = cap ? cap * 2 : 4;
+      }
+      uint32_t total;
+      const uint32_t ex = tm.excl_scan(need, total);
+      if (c.pool_used + total > c.pool_cap) {
+        c.flags |= 2u;  // the host enlarges the pool and reruns the chunk
+        break;
+      }
+      if (act) {
+        if (need) {
+          const uint32_t noff = c.pool_used + ex;
+          for (uint32_t i = 0; i < nobs; i++) c.pool[noff + i] = c.pool[off + i];
+          off = noff;
+          p->off = noff;
+          p->cap = need;
+        }
+        if (pd) {
+          c.pool[off + nobs] = pd->o;
+          p->X[0] = pd->X[0];
+          p->X[1] = pd->X[1];
+          p->X[2] = pd->X[2];
+        } else {
+          c.pool[off + nobs] = o;
+          p->X[0] = Xc[0];
+          p->X[1] = Xc[1];
+          p->X[2] = Xc[2];
+        }
+        p->nobs = nobs + 1;
+      }
+      c.pool_used += total;
+    }
+    tm.sync();
   }
   to_start = n1;
   to_end = n2;
   uint64_t tf0 = EG3D_TICK();
+  c.tsec[8] += tf0 - tcm0;
   if (n1 > 0 && n1 == ci) {
     c.start_dirs[view] = nd1;
     int g = follow_front(tm, s, c);
@@ -700,6 +747,7 @@ EG3D_HD void expand_to_view(const Team& tm, const DevScene& s, Chain& c, int v, 
   // PARALLEL over the epipolar candidates: speculative central solves against chain[centre]
   // (results parked in the candidate array, which is rebuilt below before its own use)
   const int n_pre = n_epc < c.cap_pts ? n_epc : c.cap_pts;
+  const uint64_t te0 = EG3D_TICK();
   if (n_epc > 0) {
     // PARALLEL: epipolar lines of every chain point in view v (the side walks read them)
     for (int i = tm.lane(); i < c.len; i += tm.size()) {
@@ -724,6 +772,7 @@ EG3D_HD void expand_to_view(const Team& tm, const DevScene& s, Chain& c, int v, 
         });
     tm.sync();
   }
+  c.tsec[10] += EG3D_TICK() - te0;
   for (int e = 0; e < n_epc; e++) {
     int a, b;
     const bool pre = e < n_pre;

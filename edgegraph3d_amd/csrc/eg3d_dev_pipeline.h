@@ -225,7 +225,7 @@ EG3D_HD void chain_bind(Chain& c, const ChainLayout& L, unsigned char* slice) {
 struct ChainOut {
   uint32_t n_points, n_obs, flags, head;
   uint64_t bytes;
-  uint64_t tsec[8];  // diagnostic section ticks (zero unless built with EG3D_SECTION_TIMING)
+  uint64_t tsec[12];  // diagnostic section ticks (zero unless built with EG3D_SECTION_TIMING)
 };
 
 // Build the chain reverse(pts1) + central + pts2, then offer it to every view except the
@@ -241,7 +241,7 @@ EG3D_HD void expand_chain(const Team& tm, const DevScene& s, const StageAView& a
   tm.bind(c);
   c.flags = 0;
   c.bytes = 0;
-  for (int k = 0; k < 8; k++) c.tsec[k] = 0;
+  for (int k = 0; k < 12; k++) c.tsec[k] = 0;
   const uint64_t t_begin = EG3D_TICK();
   c.pool_used = 0;
   const HypResult& w = res[cs.winner];
@@ -291,6 +291,7 @@ EG3D_HD void expand_chain(const Team& tm, const DevScene& s, const StageAView& a
     for (uint32_t i = 0; i < cs.n2; i++) push_h(arena[r2.pts2_off + i]);
   }
   tm.sync();
+  c.tsec[9] = EG3D_TICK() - t_begin;
   // every view except the three selected, ascending; epc = the task's hits in that view
   const uint32_t base = a.trk_off[d.seed] - a.sv_base;
   const uint32_t n = map_n[d.seed - a.seed_begin];
@@ -317,7 +318,7 @@ EG3D_HD void expand_chain(const Team& tm, const DevScene& s, const StageAView& a
   out.head = (uint32_t)c.head;
   out.bytes = c.bytes;
   c.tsec[7] = EG3D_TICK() - t_begin;
-  for (int k = 0; k < 8; k++) out.tsec[k] = c.tsec[k];
+  for (int k = 0; k < 12; k++) out.tsec[k] = c.tsec[k];
 }
 
 // K4 body: copy one finished chain into the ordered SoA output.

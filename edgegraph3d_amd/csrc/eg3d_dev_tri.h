@@ -76,7 +76,20 @@ EG3D_HD void svd4_smallest_v(const double A[4][4], double out[4]) {
       for (int j = i + 1; j < 4; j++) {
         double a = W[i], p = 0, b = W[j];
         for (int k = 0; k < 4; k++) p += At[i][k] * At[j][k];
-        if (absd(p) <= eps * EG3D_SQRT(a * b)) continue;
+        // skip test |p| <= eps*sqrt(a*b): decided on the squares whenever that is unambiguous
+        // (relative margin 1e-7 >> the few-ulp error of either form), so the FP64 sqrt is only
+        // evaluated in the knife-edge band — same decisions, same bits
+        {
+          const double ab = a * b, p2 = p * p, t = (eps * eps) * ab;
+          bool skip;
+          if (t > 1e-250 && p2 > t * 1.0000001)
+            skip = false;
+          else if (t > 1e-250 && p2 < t * 0.9999999)
+            skip = true;
+          else
+            skip = absd(p) <= eps * EG3D_SQRT(ab);
+          if (skip) continue;
+        }
         p *= 2;
         double beta = a - b, gamma = EG3D_SQRT(p * p + beta * beta);
         double c, s;

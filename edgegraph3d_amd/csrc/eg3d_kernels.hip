@@ -397,6 +397,16 @@ struct TeamWave {
     for (int d = 32; d >= 1; d >>= 1) v |= (uint32_t)__shfl_xor((int)v, d);
     return v;
   }
+  __device__ __forceinline__ uint32_t excl_scan(uint32_t v, uint32_t& total) const {
+    uint32_t pre = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)pre, d);
+      if (lane() >= d) pre += t;
+    }
+    total = (uint32_t)__shfl((int)pre, 63);
+    return pre - v;
+  }
   __device__ __forceinline__ int stage_side_walk(PlRef& pl, const Chain& c, int first, int step, int count,
                                                  const float*& epi) const {
     __syncthreads();

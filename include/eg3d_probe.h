@@ -16,9 +16,10 @@ int eg3d_probe_arith(eg3d_ctx* ctx, uint64_t n, const double* a, const double* b
 int eg3d_probe_triangulate(eg3d_ctx* ctx, uint64_t n_cases, int k, const int32_t* views, const float* xy, float* X,
                            uint8_t* valid, double* dlt_X0);
 /* Per-section shader-clock ticks of the most recent k3b_expand launch, summed over chains
- * (sum[8]) and of the slowest chain (slowest[8]); all zero unless the library was built with
- * -DEG3D_SECTION_TIMING. Index: 0 candidates, 1 central solve, 2 side walks, 3 batched GN,
- * 4 chain following, 7 whole chain. */
+ * (sum[12]) and of the slowest chain (slowest[12]); all zero unless the library was built with
+ * -DEG3D_SECTION_TIMING. Index: 0 candidates, 1 N-view step walks, 2 side walks, 3 batched GN,
+ * 4 chain following (includes 1, 5, 6, 11), 5 step DLT, 6 step GN, 7 whole chain, 8 commit,
+ * 9 chain init, 10 epipolar-candidate pre-solves, 11 new point. */
 int eg3d_probe_sections(eg3d_ctx* ctx, double* sum, double* slowest, uint32_t* n_chains);
 /* Same for k3a_hypotheses (per hypothesis): 0 first TRI, 1 orient, 2 replay, 3 opposite test,
  * 4 follow dir1, 5 follow dir2; sum over hypotheses and the slowest hypothesis; n by status. */
