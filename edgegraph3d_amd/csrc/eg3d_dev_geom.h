@@ -151,10 +151,44 @@ EG3D_HD float seg_line_cos(float x1, float y1, float x2, float y2, float la, flo
   return d / EG3D_SQRTF(aa * bb);
 }
 
+// Direction (1,-a/b) or (0,1) of a line and its squared norm: invariant along a walk, so the walk
+// evaluates the division once (same operands => same bits as per-segment evaluation).
+struct LineDir {
+  float bx, by, bb;
+};
+EG3D_HD LineDir line_dir(float la, float lb) {
+  LineDir d;
+  if (lb == 0.0f) {
+    d.bx = 0.0f;
+    d.by = 1.0f;
+  } else {
+    d.bx = 1.0f;
+    d.by = -la / lb;
+  }
+  d.bb = dotf(d.bx, d.by, d.bx, d.by);
+  return d;
+}
+// seg_line_cos(...) > thr, decided on the squares when that is unambiguous (relative margin 1e-4
+// >> the few-ulp error of either form); the division and square root are evaluated only in the
+// knife-edge band and for degenerate magnitudes — same decisions as the plain expression.
+EG3D_HD bool seg_line_cos_gt(float x1, float y1, float x2, float y2, const LineDir& ld, float thr) {
+  float ax = x2 - x1, ay = y2 - y1;
+  float d = dotf(ax, ay, ld.bx, ld.by);
+  float aa = dotf(ax, ay, ax, ay);
+  float prod = aa * ld.bb;
+  if (prod > 1e-30f && prod < 1e30f) {
+    if (d <= 0.0f) return false;
+    const float d2 = d * d, rhs = (thr * thr) * prod;
+    if (d2 > rhs * 1.0001f) return true;
+    if (d2 < rhs * 0.9999f) return false;
+  }
+  return d / EG3D_SQRTF(prod) > thr;
+}
+
 // Segment/line test with the quasi-parallel guard (cos > 0.965 within 5 px),
 // geometric_utilities.cpp:365-430. Returns bit0 = hit found, bit1 = quasi-parallel within distance.
 EG3D_HD uint32_t seg_line_hit_guarded(float x1, float y1, float x2, float y2, float la, float lb, float lc,
-                                      float& hx, float& hy) {
+                                      const LineDir& ld, float& hx, float& hy) {
   const float QP_COS = (float)0.965;
   const float QP_DIST = 5.0f;
   uint32_t r = 0;
@@ -171,7 +205,7 @@ EG3D_HD uint32_t seg_line_hit_guarded(float x1, float y1, float x2, float y2, fl
       hy = y1 + ty;
       r |= 1u;
     }
-    if (seg_line_cos(x1, y1, x2, y2, la, lb) > QP_COS) {
+    if (seg_line_cos_gt(x1, y1, x2, y2, ld, QP_COS)) {
       float distance;
       if (t < 0.0f)
         distance = point_line_dist(x1, y1, la, lb, lc);
@@ -261,15 +295,16 @@ EG3D_HD uint32_t walk_by_line(const PlRef& pl, const PlPt& p, uint32_t direction
   uint32_t r;
   uint32_t seg_found = 0;
   bool got = false;
+  const LineDir ld = line_dir(la, lb);
   if (direction == pl.start) {
-    r = seg_line_hit_guarded(p.x, p.y, pl.v[p.seg].x, pl.v[p.seg].y, la, lb, lc, hx, hy);
+    r = seg_line_hit_guarded(p.x, p.y, pl.v[p.seg].x, pl.v[p.seg].y, la, lb, lc, ld, hx, hy);
     if (r & 2u) return WALK_QUASIPARALLEL;
     if (r & 1u) {
       got = true;
       seg_found = p.seg;
     } else {
       for (uint32_t i = p.seg; i > 0; i--) {
-        r = seg_line_hit_guarded(pl.v[i].x, pl.v[i].y, pl.v[i - 1].x, pl.v[i - 1].y, la, lb, lc, hx, hy);
+        r = seg_line_hit_guarded(pl.v[i].x, pl.v[i].y, pl.v[i - 1].x, pl.v[i - 1].y, la, lb, lc, ld, hx, hy);
         if (r & 2u) return WALK_QUASIPARALLEL;
         if (r & 1u) {
           got = true;
@@ -280,14 +315,14 @@ EG3D_HD uint32_t walk_by_line(const PlRef& pl, const PlPt& p, uint32_t direction
       if (!got) return WALK_EXTREME;
     }
   } else if (direction == pl.end) {
-    r = seg_line_hit_guarded(p.x, p.y, pl.v[p.seg + 1].x, pl.v[p.seg + 1].y, la, lb, lc, hx, hy);
+    r = seg_line_hit_guarded(p.x, p.y, pl.v[p.seg + 1].x, pl.v[p.seg + 1].y, la, lb, lc, ld, hx, hy);
     if (r & 2u) return WALK_QUASIPARALLEL;
     if (r & 1u) {
       got = true;
       seg_found = p.seg;
     } else {
       for (uint32_t i = p.seg + 1; i < pl.n - 1; i++) {
-        r = seg_line_hit_guarded(pl.v[i].x, pl.v[i].y, pl.v[i + 1].x, pl.v[i + 1].y, la, lb, lc, hx, hy);
+        r = seg_line_hit_guarded(pl.v[i].x, pl.v[i].y, pl.v[i + 1].x, pl.v[i + 1].y, la, lb, lc, ld, hx, hy);
         if (r & 2u) return WALK_QUASIPARALLEL;
         if (r & 1u) {
           got = true;
