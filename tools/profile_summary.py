@@ -55,7 +55,7 @@ def main():
     ap.add_argument("--kt")
     ap.add_argument("--fetch")
     ap.add_argument("--write")
-    ap.add_argument("--sq")
+    ap.add_argument("--sq", nargs="*")
     ap.add_argument("--cmd", default="python bench.py --steps 20 --warmup 3 --no-cpu-baseline")
     ap.add_argument("--out", default="profiles")
     a = ap.parse_args()
@@ -92,8 +92,10 @@ def main():
         lines.append("# HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (guide's gfx950 correction; upper bound)")
         for k, d in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:8]:
             lines.append("%-28s %14.0f B" % (k, d["hbm_bytes_per_launch"]))
-    if a.sq:
-        cs = counter_stats(a.sq)
+    for sq in (a.sq or []):
+        if not os.path.exists(sq):
+            continue
+        cs = counter_stats(sq)
         lines.append("")
         lines.append("# rocprofv3 --pmc SQ_* --kernel-trace (own pass) [mean per launch]")
         for k, d in cs.items():
