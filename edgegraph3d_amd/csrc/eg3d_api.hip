@@ -860,6 +860,13 @@ extern "C" int eg3d_probe_hyp_sections(eg3d_ctx* c, double* sum, double* slowest
     if (r[h].status & HYP_D1) counts[2]++;
     if (r[h].status & HYP_D2) counts[3]++;
     if (r[h].status & HYP_COMPAT) counts[4]++;
+    // list lengths (the per-section tick fields were retired): sum[0..1] = total n1, n2;
+    // slowest[0..1] = longest n1, n2; sum[2] = hypotheses whose lists total >= 32 points
+    sum[0] += r[h].n1;
+    sum[1] += r[h].n2;
+    if (r[h].n1 > slowest[0]) slowest[0] = r[h].n1;
+    if (r[h].n2 > slowest[1]) slowest[1] = r[h].n2;
+    if (r[h].n1 + r[h].n2 >= 32) sum[2] += 1;
   }
   return EG3D_OK;
 }

@@ -32,8 +32,4 @@ L.eg3d_probe_hyp_sections.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINT
 hs_, hl_, cnt = (C.c_double * 6)(), (C.c_double * 6)(), (C.c_uint32 * 5)()
 assert L.eg3d_probe_hyp_sections(ctx._h, hs_, hl_, cnt) == 0
 print("hypotheses n/tri/d1/d2/compat:", list(cnt))
-hn = ["TRI0", "orient", "replay", "opp-test", "follow1", "follow2"]
-ht = sum(hs_) or 1
-for k in range(6):
-    print("%-9s sum %12.3e (%5.1f%%)   slowest hyp %10.3e" % (hn[k], hs_[k], 100 * hs_[k] / ht, hl_[k]))
-print("slowest hypothesis total %.3e ticks; mean %.3e" % (sum(hl_), ht / max(1, cnt[0])))
+print("follow lists: total n1 %d n2 %d ; longest n1 %d n2 %d ; hypotheses with >=32 points %d" % (hs_[0], hs_[1], hl_[0], hl_[1], hs_[2]))
