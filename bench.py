@@ -152,7 +152,7 @@ def main():
         achieved = (bytes_alg / (dom_ms * 1e-3)) / 1e9 if dom_ms > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and args.config == 2 and not args.seeds_per_gpu:  # counters were collected on C2
             try:
                 traffic = json.load(open(pmc)).get(dom_name, {}).get("hbm_bytes_per_launch")
             except Exception:

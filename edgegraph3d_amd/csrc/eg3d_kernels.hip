@@ -375,6 +375,10 @@ __global__ void k_compact_chains(uint32_t n_tasks, const ChainSeed* per_task, co
 #ifndef EG3D_WAVE_SLOT_STEP
 #define EG3D_WAVE_SLOT_STEP 0 /* measured slower: failed speculative candidates run all 30 GN iterations */
 #endif
+#ifndef EG3D_COOP_NUM
+#define EG3D_COOP_NUM 3 /* cooperative when passes*NUM < longest_solve*DEN */
+#define EG3D_COOP_DEN 2
+#endif
 #ifndef EG3D_COOP_GN
 #define EG3D_COOP_GN 1 /* wave-cooperative Gauss-Newton (eg3d_dev_coopgn.h); 0 = one lane per solve */
 #endif
@@ -460,7 +464,7 @@ struct TeamWave {
       }
       if (mx == 0) continue;
       const int passes = (tot + EG3D_COOP_ROWS - 1) / EG3D_COOP_ROWS;
-      const bool coop = EG3D_COOP_GN && mx <= EG3D_COOP_ROWS && passes * 3 < mx * 2;
+      const bool coop = EG3D_COOP_GN && mx <= EG3D_COOP_ROWS && passes * EG3D_COOP_NUM < mx * EG3D_COOP_DEN;
       float X[3] = {0.f, 0.f, 0.f};
       bool ok = false;
       if (coop) {
