@@ -11,7 +11,7 @@
 //   k_task_setup      1 lane / task         3-view selection, hypothesis count
 //   k3a_hypotheses    1 lane / hypothesis   orientation + following (wave-synchronous batches)
 //   k3s_select        1 lane / task         uniqueness rule -> chain seeds
-//   k3b_expand        1 lane / chain        expand-all-views
+//   k3b_expand        1 WAVE / chain        expand-all-views (wave-cooperative Gauss-Newton)
 //   k4_emit           1 WAVE / chain        ordered SoA output (wave prefix sum of obs counts)
 //   k5_gn_filter      1 lane / point        config 5, FP32 Gauss-Newton outlier filter
 // All arithmetic follows the contract in DESIGN.md (no FMA contraction: -ffp-contract=off).
