@@ -113,6 +113,8 @@ def main():
         return cloud["n_points"]
 
     def step():
+        if gather is not None:
+            gather.wait_pack()  # the previous cloud has left the context's buffers; its all-gather may still be in flight
         r = ctx.match_resident(b, e, device_only=True)
         total = r["n_points"]
         if gather is not None:

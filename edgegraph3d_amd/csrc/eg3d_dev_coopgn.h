@@ -197,6 +197,171 @@ __device__ __forceinline__ bool coop_gn_single(const float* cam_P, CoopLds& L, c
   return oki != 0;
 }
 
+// ONE solve with any number of observations, all 64 lanes on it: rows are processed in chunks of
+// 64; the <=7 accumulating lanes carry their sums across the chunks, so the additions still happen
+// in observation order. The update pass recomputes the rows (no per-row state survives a chunk).
+// Arguments are wave-uniform; `a` holds n_arr observations, an optional extra one follows them.
+__device__ __forceinline__ bool coop_gn_big(const float* cam_P, CoopLds& L, const Obs* a, int n_arr, bool has_extra,
+                                            int32_t ex_view, float ex_x, float ex_y, const double X0[3],
+                                            float Xout[3]) {
+  const int lane = (int)(threadIdx.x & 63u);
+  const int n = n_arr + (has_extra ? 1 : 0);
+  double X[3] = {X0[0], X0[1], X0[2]};
+  double last_mse = 0;
+  const double two_n = (double)(n * 2);
+  bool ok = false, done = false;
+  for (int it = 0; it < 30 && !done; it++) {
+    double acc = 0;  // lane e < 7: H00 H01 H02 H11 H12 H22 mse
+    for (int c0 = 0; c0 < n; c0 += 64) {
+      const int r = c0 + lane;
+      const int rows = (n - c0) < 64 ? (n - c0) : 64;
+      if (r < n) {
+        int32_t view;
+        float ox, oy;
+        if (r < n_arr) {
+          view = a[r].view;
+          ox = a[r].x;
+          oy = a[r].y;
+        } else {
+          view = ex_view;
+          ox = ex_x;
+          oy = ex_y;
+        }
+        const float* P = cam_P + (size_t)view * 16;
+        const double p00 = P[0], p01 = P[1], p02 = P[2], p03 = P[3];
+        const double p10 = P[4], p11 = P[5], p12 = P[6], p13 = P[7];
+        const double p20 = P[8], p21 = P[9], p22 = P[10], p23 = P[11];
+        double xH = ((p00 * X[0] + p01 * X[1]) + p02 * X[2]) + p03 * 1.0;
+        double yH = ((p10 * X[0] + p11 * X[1]) + p12 * X[2]) + p13 * 1.0;
+        double zH = ((p20 * X[0] + p21 * X[1]) + p22 * X[2]) + p23 * 1.0;
+        double r0 = (double)ox - xH / zH;
+        double r1 = (double)oy - yH / zH;
+        double zz = zH * zH;
+        double j00 = (p00 * zH - p20 * xH) / zz;
+        double j10 = (p10 * zH - p20 * yH) / zz;
+        double j01 = (p01 * zH - p21 * xH) / zz;
+        double j11 = (p11 * zH - p21 * yH) / zz;
+        double j02 = (p02 * zH - p22 * xH) / zz;
+        double j12 = (p12 * zH - p22 * yH) / zz;
+        L.prod[0][lane] = j00 * j00;
+        L.prod[1][lane] = j10 * j10;
+        L.prod[2][lane] = j00 * j01;
+        L.prod[3][lane] = j10 * j11;
+        L.prod[4][lane] = j00 * j02;
+        L.prod[5][lane] = j10 * j12;
+        L.prod[6][lane] = j01 * j01;
+        L.prod[7][lane] = j11 * j11;
+        L.prod[8][lane] = j01 * j02;
+        L.prod[9][lane] = j11 * j12;
+        L.prod[10][lane] = j02 * j02;
+        L.prod[11][lane] = j12 * j12;
+        L.prod[12][lane] = r0 * r0;
+        L.prod[13][lane] = r1 * r1;
+      }
+      __syncthreads();
+      if (lane < 7) {
+        const double* A = &L.prod[2 * lane][0];
+        const double* B = &L.prod[2 * lane + 1][0];
+        for (int m = 0; m < rows; m++) {
+          acc += A[m];
+          acc += B[m];
+        }
+      }
+      __syncthreads();
+    }
+    if (lane < 7) L.sums[0][lane] = acc;
+    __syncthreads();
+    const double H00 = L.sums[0][0], H01 = L.sums[0][1], H02 = L.sums[0][2];
+    const double H11 = L.sums[0][3], H12 = L.sums[0][4], H22 = L.sums[0][5];
+    const double mse = L.sums[0][6];
+    __syncthreads();
+    if (absd(mse / two_n - last_mse) < 0.0000005) {
+      done = true;
+      ok = last_mse < 9;
+      break;
+    }
+    last_mse = mse / two_n;
+    const double H10 = H01, H20 = H02, H21 = H12;
+    double d = H00 * (H11 * H22 - H12 * H21) - H01 * (H10 * H22 - H12 * H20) + H02 * (H10 * H21 - H11 * H20);
+    if (d < 0.00001) {
+      done = true;
+      ok = false;
+      break;
+    }
+    double id = 1. / d;
+    const double I00 = (H11 * H22 - H12 * H21) * id;
+    const double I01 = (H02 * H21 - H01 * H22) * id;
+    const double I02 = (H01 * H12 - H02 * H11) * id;
+    const double I10 = (H12 * H20 - H10 * H22) * id;
+    const double I11 = (H00 * H22 - H02 * H20) * id;
+    const double I12 = (H02 * H10 - H00 * H12) * id;
+    const double I20 = (H10 * H21 - H11 * H20) * id;
+    const double I21 = (H01 * H20 - H00 * H21) * id;
+    const double I22 = (H00 * H11 - H01 * H10) * id;
+    double dacc = 0;  // lane e < 3: d0 d1 d2
+    for (int c0 = 0; c0 < n; c0 += 64) {
+      const int r = c0 + lane;
+      const int rows = (n - c0) < 64 ? (n - c0) : 64;
+      if (r < n) {
+        int32_t view;
+        float ox, oy;
+        if (r < n_arr) {
+          view = a[r].view;
+          ox = a[r].x;
+          oy = a[r].y;
+        } else {
+          view = ex_view;
+          ox = ex_x;
+          oy = ex_y;
+        }
+        const float* P = cam_P + (size_t)view * 16;
+        const double p00 = P[0], p01 = P[1], p02 = P[2], p03 = P[3];
+        const double p10 = P[4], p11 = P[5], p12 = P[6], p13 = P[7];
+        const double p20 = P[8], p21 = P[9], p22 = P[10], p23 = P[11];
+        double xH = ((p00 * X[0] + p01 * X[1]) + p02 * X[2]) + p03 * 1.0;
+        double yH = ((p10 * X[0] + p11 * X[1]) + p12 * X[2]) + p13 * 1.0;
+        double zH = ((p20 * X[0] + p21 * X[1]) + p22 * X[2]) + p23 * 1.0;
+        double r0 = (double)ox - xH / zH;
+        double r1 = (double)oy - yH / zH;
+        double zz = zH * zH;
+        double j00 = (p00 * zH - p20 * xH) / zz;
+        double j10 = (p10 * zH - p20 * yH) / zz;
+        double j01 = (p01 * zH - p21 * xH) / zz;
+        double j11 = (p11 * zH - p21 * yH) / zz;
+        double j02 = (p02 * zH - p22 * xH) / zz;
+        double j12 = (p12 * zH - p22 * yH) / zz;
+        L.prod[0][lane] = ((I00 * j00 + I01 * j01) + I02 * j02) * r0;
+        L.prod[1][lane] = ((I00 * j10 + I01 * j11) + I02 * j12) * r1;
+        L.prod[2][lane] = ((I10 * j00 + I11 * j01) + I12 * j02) * r0;
+        L.prod[3][lane] = ((I10 * j10 + I11 * j11) + I12 * j12) * r1;
+        L.prod[4][lane] = ((I20 * j00 + I21 * j01) + I22 * j02) * r0;
+        L.prod[5][lane] = ((I20 * j10 + I21 * j11) + I22 * j12) * r1;
+      }
+      __syncthreads();
+      if (lane < 3) {
+        const double* A = &L.prod[2 * lane][0];
+        const double* B = &L.prod[2 * lane + 1][0];
+        for (int m = 0; m < rows; m++) {
+          dacc += A[m];
+          dacc += B[m];
+        }
+      }
+      __syncthreads();
+    }
+    if (lane < 3) L.sums[0][lane] = dacc;
+    __syncthreads();
+    X[0] += L.sums[0][0];
+    X[1] += L.sums[0][1];
+    X[2] += L.sums[0][2];
+    __syncthreads();
+  }
+  if (!done) ok = last_mse < 9;
+  Xout[0] = (float)X[0];
+  Xout[1] = (float)X[1];
+  Xout[2] = (float)X[2];
+  return ok;
+}
+
 // A window of up to 64 ADD requests, request j held by lane j: (want, block offset, block size,
 // extra observation, start point). Requests are packed into rounds of <= 64 rows. On return lane
 // j holds the verdict and solution of its request. Every request must have 3 <= rows <= 64.

@@ -434,12 +434,7 @@ struct TeamWave {
   __device__ __forceinline__ bool gn_array(const DevScene& s, const Obs* a, int n, const double X0[3],
                                            float Xout[3]) const {
     if (EG3D_COOP_GN && n <= EG3D_COOP_ROWS) return coop_gn_single(s.cam_P, *L, a, n, X0, Xout);
-    ArrayCursor cur;
-    cur.a = a;
-    cur.n = n;
-    cur.extra = nullptr;
-    cur.i = 0;
-    return gauss_newton_f64(s.cam_P, cur, X0, Xout);
+    return coop_gn_big(s.cam_P, *L, a, n, false, 0, 0.f, 0.f, X0, Xout);
   }
   // B independent ADD solves, 64 per window, request j on lane j. A window goes cooperative
   // (rows = observations) when that needs fewer row-passes than the longest single solve;
@@ -455,10 +450,11 @@ struct TeamWave {
       o.x = o.y = 0.f;
       const bool want = j < B && get(j, pt, o);
       const int n = want ? (int)pt->nobs + 1 : 0;
-      int tot = n, mx = n;
+      int tot = n, mx = n, chunks_total = (n + 63) >> 6;
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) {
         tot += __shfl_xor(tot, d);
+        chunks_total += __shfl_xor(chunks_total, d);
         const int t = __shfl_xor(mx, d);
         mx = t > mx ? t : mx;
       }
@@ -477,6 +473,27 @@ struct TeamWave {
           off = pt->off;
         }
         ok = coop_gn_window(s.cam_P, c.pool, *L, want, off, n - 1, o, X0, X);
+      } else if (EG3D_COOP_GN && mx > EG3D_COOP_ROWS && chunks_total * 2 < mx) {
+        // long solves (V > 64 scenes), few of them: the whole wave takes the requests one at a time
+        const unsigned long long wanted = __ballot(want);
+        for (int q = 0; q < 64; q++) {
+          if (!((wanted >> q) & 1ull)) continue;
+          const uint32_t off_q = (uint32_t)__shfl((int)(want ? pt->off : 0u), q);
+          const int nb_q = __shfl(n - 1, q);
+          const int32_t ev = __shfl(o.view, q);
+          const float ex = __shfl(o.x, q), ey = __shfl(o.y, q);
+          const float x0 = __shfl(want ? pt->X[0] : 0.f, q), x1 = __shfl(want ? pt->X[1] : 0.f, q),
+                      x2 = __shfl(want ? pt->X[2] : 0.f, q);
+          const double X0d[3] = {(double)x0, (double)x1, (double)x2};
+          float Xq[3];
+          const bool okq = coop_gn_big(s.cam_P, *L, c.pool + off_q, nb_q, true, ev, ex, ey, X0d, Xq);
+          if (lane() == q) {
+            ok = okq;
+            X[0] = Xq[0];
+            X[1] = Xq[1];
+            X[2] = Xq[2];
+          }
+        }
       } else if (want) {
         ok = add_observation_solve(s, c, *pt, o, X);
       }

@@ -35,6 +35,7 @@ class CloudGather:
         self.dist, self.world, self.device = dist, world, device
         self.cap = 0
         self.send = self.recv = None
+        self.pack_done = None  # event recorded once `local` has been copied into the send buffer
 
     def allgather(self, local, n_points, n_obs):
         dist, world, dev = self.dist, self.world, self.device
@@ -59,9 +60,20 @@ class CloudGather:
             if n_obs:
                 send[o:o + n_obs * per].copy_(local[name][:n_obs * per])
             o += mo * per
+        if dev.type == "cuda":
+            # the producer may overwrite `local` (the context's output buffers) once this has fired;
+            # the collective itself then overlaps with the producer's next step
+            self.pack_done = torch.cuda.Event()
+            self.pack_done.record()
         recv = self.recv[:nbytes * world]
         dist.all_gather_into_tensor(recv, send)
         return recv, counts, (mp, mo, nbytes)
+
+    def wait_pack(self):
+        """Block the host until the last allgather() no longer reads its `local` buffers."""
+        if self.pack_done is not None:
+            self.pack_done.synchronize()
+            self.pack_done = None
 
     def unpack(self, recv, counts, layout):
         """Compact the padded per-rank blocks into one cloud (rank order = seed order); obs_off is
