@@ -50,12 +50,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the RCCL all-gather of the cloud even with one rank (exercises the N>1 code path)")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="independent steps kept in flight per GPU, each on its own context/HIP stream driven by its "
+                         "own host thread (1 = strictly one step at a time)")
     ap.add_argument("--cpu-runs", type=int, default=5)
     ap.add_argument("--cpu-seeds", type=int, default=0,
                     help="bound the CPU baseline to the first K seeds of the workload (0 = all); its rate is "
                          "edge-points of that sample / its time")
     args = ap.parse_args()
 
+    # Several steps are kept in flight on separate HIP streams (plus the gather stream and RCCL's):
+    # with the runtime's default of 4 hardware queues two of them can share a queue and serialise
+    # (measured: the all-gather of one step then waits for another step's whole expand kernel).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     from edgegraph3d_amd import api, host
 
@@ -86,16 +93,42 @@ def main():
         per_gpu = SEEDS_PER_GPU
     cfg.n_seeds = per_gpu * world  # same scene on every rank; rank r owns seeds [r*per_gpu, (r+1)*per_gpu)
     synth = host.Synth(cfg)
-    ctx = api.Context(synth.scene, local_rank)
-    ctx.upload_seeds(synth.seeds)   # inputs resident in HBM before the timed region
     b, e = rank * per_gpu, (rank + 1) * per_gpu
+    inflight = max(1, args.inflight)
+
+    # One context (own HIP stream, own work buffers) + one host thread per step in flight: the
+    # tail of one step's chain expansion (a few long chains on an otherwise idle GPU) overlaps
+    # with the next step's candidate search and hypothesis evaluation. ctypes releases the GIL
+    # during the library call, so the threads really run concurrently.
+    import queue
+    import threading
+
+    class Worker(threading.Thread):
+        def __init__(self):
+            super().__init__(daemon=True)
+            self.ctx = api.Context(synth.scene, local_rank)
+            self.ctx.upload_seeds(synth.seeds)   # inputs resident in HBM before the timed region
+            self.todo, self.done = queue.Queue(), queue.Queue()
+            self.start()
+
+        def run(self):
+            while self.todo.get() is not None:
+                try:
+                    self.done.put(self.ctx.match_resident(b, e, device_only=True))
+                except Exception as ex:  # surfaced by the main thread
+                    self.done.put(ex)
+
+    workers = [Worker() for _ in range(inflight)]
 
     gather = None
     if dist is not None:
         from edgegraph3d_amd.distributed import CloudGather
         gather = CloudGather(dist, world, dev)
+        # the gather's small pack/unpack kernels share the GPU with a saturating expand kernel of
+        # another step: give them a high-priority stream so they are dispatched as slots free up
+        gstream = torch.cuda.Stream(device=dev, priority=-1)
 
-    def allgather_cloud():
+    def allgather_cloud(ctx):
         """RCCL all-gather of the variable-length edge-point cloud straight from the context's HBM
         buffers (edgegraph3d_amd/distributed.py): counts, one padded all_gather_into_tensor, then
         compaction into one ordered cloud on every rank."""
@@ -112,30 +145,35 @@ def main():
         cloud = gather.unpack(recv, counts, layout)
         return cloud["n_points"]
 
-    def step():
-        if gather is not None:
-            gather.wait_pack()  # the previous cloud has left the context's buffers; its all-gather may still be in flight
-        r = ctx.match_resident(b, e, device_only=True)
-        total = r["n_points"]
-        if gather is not None:
-            total = allgather_cloud()
-        return r, total
+    def run_steps(n, pool):
+        """n steps, at most len(pool) in flight; results (and the collectives, which must be issued
+        in the same order on every rank) are handled in step order by this thread."""
+        out, submitted = [], 0
+        for w in pool[:n]:
+            w.todo.put(1)
+            submitted += 1
+        for i in range(n):
+            w = pool[i % len(pool)]
+            r = w.done.get()
+            if isinstance(r, Exception):
+                raise r
+            total = r["n_points"]
+            if gather is not None:
+                with torch.cuda.stream(gstream):
+                    total = allgather_cloud(w.ctx)
+                gather.wait_pack()  # the cloud has left the context's buffers; its all-gather may still be in flight
+            if submitted < n:
+                w.todo.put(1)
+                submitted += 1
+            out.append((r, total))
+        return out
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(max(args.warmup, inflight), workers)  # every context sizes its buffers before the timed region
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    stage_ms = {k: [] for _, k in STAGES}
-    bytes_alg = 0
-    last = None
-    total_points = 0
-    for _ in range(args.steps):
-        last, total_points = step()
-        for _, k in STAGES:
-            stage_ms[k].append(last["times"][k])
-        bytes_alg = last["times"]["bytes_algorithmic"]
+    results = run_steps(args.steps, workers)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -144,6 +182,19 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    stage_ms = {k: [r["times"][k] for r, _ in results] for _, k in STAGES}
+    last, total_points = results[-1]
+    bytes_alg = last["times"]["bytes_algorithmic"]
+    # the same steps strictly one at a time (untimed side measurement, reported beside the value)
+    single = None
+    if inflight > 1 and rank == 0 and world == 1:
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        ns = max(3, min(10, args.steps))
+        run_steps(ns, workers[:1])
+        torch.cuda.synchronize()
+        single = (time.perf_counter() - ts) / ns
+    ctx = workers[0].ctx
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -162,7 +213,7 @@ def main():
         line = {
             "metric": "triangulated edge-points/sec", "value": value, "unit": "edge-points/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "steps_in_flight": inflight,
             "config": {
                 "workload": "C%d synthetic: %d views / %d seeds per GPU / %.0f polyline segments per view"
                             % (args.config, synth.n_views, per_gpu, synth.total_segments / synth.n_views),
@@ -176,6 +227,8 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(bytes_alg), "kernel_ms": dom_ms},
         }
+        if single is not None:
+            line["one_step_at_a_time"] = {"ms_per_step": single * 1e3, "value": total_points / single}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import binding as ob   # cpu_baseline leg: the checker timed as the CPU port
             orc = ob.Oracle(synth.scene)
@@ -200,7 +253,10 @@ def main():
             }
             line["speedup_vs_cpu_1thread"] = value / (pts / med)
         print(json.dumps(line), flush=True)
-    ctx.close()
+    for w in workers:
+        w.todo.put(None)
+        w.join(timeout=10)
+        w.ctx.close()
     if dist is not None:
         dist.destroy_process_group()
 
