@@ -105,3 +105,40 @@ def test_c4_shaped_subset_parity_and_capacity_growth(have_gpu):
     assert (got["flags"] & 7) == 0
     assert got["n_obs"] > 20 * got["n_points"]
     ctx.close()
+
+
+def test_contexts_in_concurrent_threads(have_gpu):
+    """bench.py keeps several steps in flight: one context per host thread on the same device.
+    Concurrent contexts must give exactly what one context gives alone."""
+    import threading
+    s = host.Synth(1)
+    n = s.n_seeds
+    ref_ctx = api.Context(s.scene)
+    ref_ctx.upload_seeds(s.seeds)
+    ranges = [(0, n), (0, n // 2), (n // 2, n)]
+    ref = [ref_ctx.match_resident(b, e) for b, e in ranges]
+    ref_ctx.close()
+    out = [None] * len(ranges)
+    errs = []
+
+    def work(i):
+        try:
+            ctx = api.Context(s.scene)
+            ctx.upload_seeds(s.seeds)
+            for _ in range(3):
+                out[i] = ctx.match_resident(*ranges[i])
+            ctx.close()
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(ranges))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for r, g in zip(ref, out):
+        assert g["n_points"] == r["n_points"] and g["n_obs"] == r["n_obs"]
+        assert np.array_equal(g["X"].view(np.uint32), r["X"].view(np.uint32))
+        assert np.array_equal(g["key"], r["key"])
+        assert np.array_equal(g["obs_xy"].view(np.uint32), r["obs_xy"].view(np.uint32))
