@@ -184,12 +184,10 @@ struct TeamSeq {
     total = v;
     return 0;
   }
-  // side-walk staging: the polyline being walked and the epipolar lines (eok, a, b, c) of chain
-  // points first, first+step, ... may be copied to fast memory; returns how many lines were staged
-  EG3D_HD int stage_side_walk(PlRef&, const Chain&, int, int, int, const float*& epi) const {
-    epi = nullptr;
-    return 0;
-  }
+  // candidates of one side walk (walk_side_candidates_core); a team may first stage the polyline
+  // and the epipolar lines of the chain points ahead in fast memory
+  EG3D_HD int side_walk(const DevScene& s, Chain& c, int view, const Obs& from, uint32_t direction, int lo, int ci,
+                        int hi, bool towards_start, Pending* out) const;
   EG3D_HD bool gn_array(const DevScene& s, const Obs* a, int n, const double X0[3], float Xout[3]) const {
     ArrayCursor cur;
     cur.a = a;
@@ -448,14 +446,11 @@ EG3D_HD int follow_front(const Team& tm, const DevScene& s, Chain& c) {
 // points ci-1, ci-2, ... >= lo (towards_start) or ci+1, ... < hi; for each take the next hit of
 // the epipolar line of the point's FIRST observation. Walk positions do not depend on the
 // solver, so all candidates are generated first; returns how many walks succeeded.
-template <class Team>
-EG3D_HD int walk_side_candidates(const Team& tm, const DevScene& s, Chain& c, int view, const Obs& from,
-                                 uint32_t direction, int lo, int ci, int hi, bool towards_start, Pending* out) {
+template <class PlT, class EpiPtr>
+EG3D_HD int walk_side_candidates_core(const DevScene& s, Chain& c, const PlT& pl, EpiPtr epi, int n_epi, int view,
+                                      const Obs& from, uint32_t direction, int lo, int ci, int hi, bool towards_start,
+                                      Pending* out) {
   int cnt = 0;
-  PlRef pl = polyline_of(s, view, from.pl);
-  const float* epi = nullptr;
-  const int n_epi = tm.stage_side_walk(pl, c, towards_start ? ci - 1 : ci + 1, towards_start ? -1 : 1,
-                                       towards_start ? ci - lo : hi - ci - 1, epi);
   int t = 0;
   PlPt actual;
   actual.seg = from.seg;
@@ -498,6 +493,12 @@ EG3D_HD int walk_side_candidates(const Team& tm, const DevScene& s, Chain& c, in
   }
   return cnt;
 }
+EG3D_HD int TeamSeq::side_walk(const DevScene& s, Chain& c, int view, const Obs& from, uint32_t direction, int lo,
+                               int ci, int hi, bool towards_start, Pending* out) const {
+  const PlRef pl = polyline_of(s, view, from.pl);
+  return walk_side_candidates_core(s, c, pl, (const float*)nullptr, 0, view, from, direction, lo, ci, hi,
+                                   towards_start, out);
+}
 
 // Side walk, phase 2 (PARALLEL over candidates): ADD-solve candidate j against chain point
 // ci-1-j / ci+1+j; then (uniform) count the leading successes — the reference stops at the
@@ -506,7 +507,7 @@ template <class Team>
 EG3D_HD int walk_side(const Team& tm, const DevScene& s, Chain& c, int view, const Obs& from, uint32_t direction,
                       int lo, int ci, int hi, bool towards_start, Pending* out) {
   uint64_t t0 = EG3D_TICK();
-  const int m = walk_side_candidates(tm, s, c, view, from, direction, lo, ci, hi, towards_start, out);
+  const int m = tm.side_walk(s, c, view, from, direction, lo, ci, hi, towards_start, out);
   tm.sync();
   uint64_t t1 = EG3D_TICK();
   c.tsec[2] += t1 - t0;

@@ -41,12 +41,16 @@ struct f2 {
 };
 
 // A polyline as the kernels see it: a contiguous slice of the vertex array + its two node ids.
-struct PlRef {
-  const f2* v;
+// VPtr is `const f2*` everywhere except in the expand kernel's side walks, which walk a copy of
+// the polyline staged in LDS through an address_space(3) pointer (ds_read instead of flat loads).
+template <class VPtr>
+struct PlRefT {
+  VPtr v;
   uint32_t n;      // vertex count
   uint32_t start;  // node ids (reference polyline::start / ::end)
   uint32_t end;
 };
+typedef PlRefT<const f2*> PlRef;
 
 // A point on a polyline: segment index + coordinates (reference pl_point).
 struct PlPt {
@@ -289,7 +293,8 @@ EG3D_HD uint32_t walk_by_distance(const PlRef& pl, const PlPt& p, uint32_t direc
 
 // Next intersection with the line towards `direction`, stopping at quasi-parallel segments;
 // optional [min,max] distance window (polyline_graph_2d.cpp:579-655 and :657-780).
-EG3D_HD uint32_t walk_by_line(const PlRef& pl, const PlPt& p, uint32_t direction, float la, float lb, float lc,
+template <class VPtr>
+EG3D_HD uint32_t walk_by_line(const PlRefT<VPtr>& pl, const PlPt& p, uint32_t direction, float la, float lb, float lc,
                               bool bounded, float min_d, float max_d, PlPt& out) {
   float hx = 0.0f, hy = 0.0f;
   uint32_t r;

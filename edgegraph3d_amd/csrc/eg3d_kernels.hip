@@ -411,8 +411,15 @@ struct TeamWave {
     total = (uint32_t)__shfl((int)pre, 63);
     return pre - v;
   }
-  __device__ __forceinline__ int stage_side_walk(PlRef& pl, const Chain& c, int first, int step, int count,
-                                                 const float*& epi) const {
+  // One side walk: the polyline (when it fits) and the epipolar lines of the chain points ahead
+  // are first copied to LDS by all lanes, then walked through address_space(3) pointers (ds_read).
+  __device__ __forceinline__ int side_walk(const DevScene& s, Chain& c, int view, const Obs& from, uint32_t direction,
+                                           int lo, int ci, int hi, bool towards_start, Pending* out) const {
+    typedef const __attribute__((address_space(3))) f2* lds_f2p;
+    typedef const __attribute__((address_space(3))) float* lds_fp;
+    const PlRef pl = polyline_of(s, view, from.pl);
+    const int first = towards_start ? ci - 1 : ci + 1, step = towards_start ? -1 : 1;
+    const int count = towards_start ? ci - lo : hi - ci - 1;
     __syncthreads();
     const bool fits = pl.n <= EG3D_STAGE_VTX;
     if (fits)
@@ -426,9 +433,16 @@ struct TeamWave {
       L->walk.epi[t][3] = ve.ec;
     }
     __syncthreads();
-    if (fits) pl.v = L->walk.vtx;
-    epi = &L->walk.epi[0][0];
-    return staged;
+    const lds_fp epi = (lds_fp)&L->walk.epi[0][0];
+    if (fits) {
+      PlRefT<lds_f2p> pls;
+      pls.v = (lds_f2p)&L->walk.vtx[0];
+      pls.n = pl.n;
+      pls.start = pl.start;
+      pls.end = pl.end;
+      return walk_side_candidates_core(s, c, pls, epi, staged, view, from, direction, lo, ci, hi, towards_start, out);
+    }
+    return walk_side_candidates_core(s, c, pl, epi, staged, view, from, direction, lo, ci, hi, towards_start, out);
   }
   // uniform section: all lanes hold the same (a, n, X0) and receive the same answer
   __device__ __forceinline__ bool gn_array(const DevScene& s, const Obs* a, int n, const double X0[3],
