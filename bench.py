@@ -104,10 +104,13 @@ def main():
     import threading
 
     class Worker(threading.Thread):
-        def __init__(self):
+        def __init__(self, parent=None):
             super().__init__(daemon=True)
-            self.ctx = api.Context(synth.scene, local_rank)
-            self.ctx.upload_seeds(synth.seeds)   # inputs resident in HBM before the timed region
+            if parent is None:
+                self.ctx = api.Context(synth.scene, local_rank)
+                self.ctx.upload_seeds(synth.seeds)   # inputs resident in HBM before the timed region
+            else:
+                self.ctx = parent.ctx.clone()        # shares the resident scene and seeds (eg3d_clone)
             self.todo, self.done = queue.Queue(), queue.Queue()
             self.start()
 
@@ -118,7 +121,8 @@ def main():
                 except Exception as ex:  # surfaced by the main thread
                     self.done.put(ex)
 
-    workers = [Worker() for _ in range(inflight)]
+    workers = [Worker()]
+    workers += [Worker(workers[0]) for _ in range(inflight - 1)]
 
     gather = None
     if dist is not None:

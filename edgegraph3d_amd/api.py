@@ -38,6 +38,7 @@ def lib():
         L.eg3d_device_count.restype = C.c_int
         L.eg3d_create.argtypes = [C.POINTER(D.Scene), C.c_int, C.POINTER(C.c_void_p)]
         L.eg3d_destroy.argtypes = [C.c_void_p]
+        L.eg3d_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.eg3d_get_grid.argtypes = [C.c_void_p, C.c_int, C.c_int, D.u32p, D.u32p, C.POINTER(D.u32p), C.POINTER(D.u32p)]
         L.eg3d_candidates_run.argtypes = [C.c_void_p, C.POINTER(D.Seeds), C.c_uint32, C.c_uint32, C.POINTER(D.Candidates)]
         L.eg3d_free_candidates.argtypes = [C.POINTER(D.Candidates)]
@@ -56,7 +57,7 @@ def lib():
 
 # every symbol include/eg3d.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTED_SYMBOLS = [
-    "eg3d_last_error", "eg3d_device_count", "eg3d_create", "eg3d_destroy", "eg3d_get_grid", "eg3d_candidates_run",
+    "eg3d_last_error", "eg3d_device_count", "eg3d_create", "eg3d_clone", "eg3d_destroy", "eg3d_get_grid", "eg3d_candidates_run",
     "eg3d_free_candidates", "eg3d_match_refpoints", "eg3d_free_edgepoints", "eg3d_upload_seeds",
     "eg3d_match_resident", "eg3d_gn_filter", "eg3d_last_device_output",
 ]
@@ -72,9 +73,18 @@ def device_count():
 
 
 class Context:
-    def __init__(self, scene_ptr, device=0):
+    def __init__(self, scene_ptr, device=0, _handle=None):
         self._h = C.c_void_p()
-        _check(lib().eg3d_create(scene_ptr, device, C.byref(self._h)), "eg3d_create")
+        if _handle is not None:
+            self._h = _handle
+        else:
+            _check(lib().eg3d_create(scene_ptr, device, C.byref(self._h)), "eg3d_create")
+
+    def clone(self):
+        """A context sharing this one's scene and resident seeds (own stream and work buffers)."""
+        h = C.c_void_p()
+        _check(lib().eg3d_clone(self._h, C.byref(h)), "eg3d_clone")
+        return Context(None, _handle=h)
 
     def close(self):
         if self._h:

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -66,21 +67,37 @@ struct DevBuf {
     if (_r != EG3D_OK) return _r; \
   } while (0)
 
+// Device allocations shared by a context and its clones (immutable scene / resident seeds): freed
+// when the last context referring to them goes away.
+struct DevOwner {
+  int device = 0;
+  std::vector<void*> ptrs;
+  ~DevOwner() {
+    (void)hipSetDevice(device);
+    for (void* p : ptrs)
+      if (p) (void)hipFree(p);
+  }
+};
+struct HostGrids {
+  std::vector<std::vector<uint32_t>> h_off[2], h_ids[2];
+};
+
 struct eg3d_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   int V = 0, W = 0, H = 0;
   DevScene ds;
   DevBuf b_camP, b_F, b_Fv, b_vpo, b_pvo, b_vtx, b_pls, b_ple, b_g30o, b_g30i, b_g4o, b_g4i;
+  std::shared_ptr<DevOwner> scene_owner;  // owns b_camP .. b_g4i
   // host copies of the grids for eg3d_get_grid (per view CSR with view-local offsets)
-  std::vector<std::vector<uint32_t>> h_off[2], h_ids[2];
+  std::shared_ptr<HostGrids> hg;
   uint32_t gw[2] = {0, 0}, gh[2] = {0, 0};
   uint32_t grid_dropped = 0;
-  std::vector<uint32_t> h_pl_nvtx_dummy;
   // resident seeds
   uint32_t n_seeds = 0;
-  std::vector<uint32_t> h_trk_off;
+  std::shared_ptr<std::vector<uint32_t>> h_trk;
   DevBuf b_toff, b_tview, b_txy;
+  std::shared_ptr<DevOwner> seeds_owner;  // owns b_toff, b_tview, b_txy
   // work buffers
   DevBuf b_sv_seed, b_map_view, b_map_entry, b_map_n, b_raw_cnt, b_raw_off, b_cand_pl, b_start_hits, b_cand_cnt,
       b_start_cnt, b_task_off, b_task_seed, b_task_entry, b_task_hit, b_task_k, b_task_list_off, b_list_cnt, b_list_ptr,
@@ -124,6 +141,11 @@ extern "C" int eg3d_device_count(void) {
   return n;
 }
 
+static std::vector<DevBuf*> scene_bufs(eg3d_ctx* c) {
+  return {&c->b_camP, &c->b_F,   &c->b_Fv,   &c->b_vpo,  &c->b_pvo, &c->b_vtx,
+          &c->b_pls,  &c->b_ple, &c->b_g30o, &c->b_g30i, &c->b_g4o, &c->b_g4i};
+}
+
 extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
   if (!sc || !out || sc->n_views < 1) {
     g_err = "eg3d_create: bad arguments";
@@ -141,6 +163,7 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
   HIP_TRY(hipSetDevice(device));
   eg3d_ctx* c = new eg3d_ctx();
   c->device = device;
+  c->hg = std::make_shared<HostGrids>();
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   for (int i = 0; i < 8; i++) {
     HIP_TRY(hipEventCreate(&c->ea[i]));
@@ -169,8 +192,8 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
   // grids: built on the host (row a3), one CSR over (view, cell) per cell size
   for (int which = 0; which < 2; which++) {
     std::vector<uint32_t> off(1, 0), ids;
-    c->h_off[which].resize(V);
-    c->h_ids[which].resize(V);
+    c->hg->h_off[which].resize(V);
+    c->hg->h_ids[which].resize(V);
     for (int v = 0; v < V; v++) {
       uint32_t w = 0, h = 0, *o = nullptr, *i = nullptr, dropped = 0;
       if (eg3d_host_build_grid(sc, v, which == 0 ? 30.0f : 4.0f, &w, &h, &o, &i, &dropped) != 0) {
@@ -184,8 +207,8 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
       const uint32_t base = (uint32_t)ids.size();
       for (uint32_t cc = 0; cc < w * h; cc++) off.push_back(base + o[cc + 1]);
       ids.insert(ids.end(), i, i + o[w * h]);
-      c->h_off[which][v].assign(o, o + w * h + 1);
-      c->h_ids[which][v].assign(i, i + o[w * h]);
+      c->hg->h_off[which][v].assign(o, o + w * h + 1);
+      c->hg->h_ids[which][v].assign(i, i + o[w * h]);
       free(o);
       free(i);
     }
@@ -227,6 +250,55 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   c->k3a_blocks = (uint32_t)prop.multiProcessorCount * 2;  // 2 blocks x 4 waves per CU
   HIP_TRY(hipStreamSynchronize(c->stream));
+  // from here on the scene buffers belong to the (shareable) owner, not to this context
+  c->scene_owner = std::make_shared<DevOwner>();
+  c->scene_owner->device = device;
+  for (DevBuf* b : scene_bufs(c)) c->scene_owner->ptrs.push_back(b->p);
+  *out = c;
+  return EG3D_OK;
+}
+
+/* A second context on the same device that SHARES the parent's immutable scene (cameras, F,
+ * polylines, grids) and its currently resident seeds, with its own stream, events and work
+ * buffers: the way to keep several independent batches in flight (one host thread per context). */
+extern "C" int eg3d_clone(eg3d_ctx* parent, eg3d_ctx** out) {
+  if (!parent || !out) {
+    g_err = "eg3d_clone: bad arguments";
+    return EG3D_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(parent->device));
+  eg3d_ctx* c = new eg3d_ctx();
+  c->device = parent->device;
+  HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  for (int i = 0; i < 8; i++) {
+    HIP_TRY(hipEventCreate(&c->ea[i]));
+    HIP_TRY(hipEventCreate(&c->eb[i]));
+  }
+  c->V = parent->V;
+  c->W = parent->W;
+  c->H = parent->H;
+  c->ds = parent->ds;
+  {
+    std::vector<DevBuf*> src = scene_bufs(parent), dst = scene_bufs(c);
+    for (size_t i = 0; i < src.size(); i++) *dst[i] = *src[i];
+  }
+  c->scene_owner = parent->scene_owner;
+  c->hg = parent->hg;
+  for (int k = 0; k < 2; k++) {
+    c->gw[k] = parent->gw[k];
+    c->gh[k] = parent->gh[k];
+  }
+  c->grid_dropped = parent->grid_dropped;
+  c->n_seeds = parent->n_seeds;
+  c->h_trk = parent->h_trk;
+  c->b_toff = parent->b_toff;
+  c->b_tview = parent->b_tview;
+  c->b_txy = parent->b_txy;
+  c->seeds_owner = parent->seeds_owner;
+  c->chain_cap = parent->chain_cap;
+  c->pool_cap = parent->pool_cap;
+  c->hyp_cap = parent->hyp_cap;
+  c->k3a_blocks = parent->k3a_blocks;
   *out = c;
   return EG3D_OK;
 }
@@ -235,8 +307,11 @@ extern "C" void eg3d_destroy(eg3d_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  DevBuf* all[] = {&c->b_camP, &c->b_F, &c->b_Fv, &c->b_vpo, &c->b_pvo, &c->b_vtx, &c->b_pls, &c->b_ple, &c->b_g30o,
-                   &c->b_g30i, &c->b_g4o, &c->b_g4i, &c->b_toff, &c->b_tview, &c->b_txy, &c->b_sv_seed, &c->b_map_view,
+  if (!c->scene_owner)  // creation failed half-way: the scene buffers are still this context's
+    for (DevBuf* b : scene_bufs(c)) b->release();
+  c->scene_owner.reset();
+  c->seeds_owner.reset();
+  DevBuf* all[] = {&c->b_sv_seed, &c->b_map_view,
                    &c->b_map_entry, &c->b_map_n, &c->b_raw_cnt, &c->b_raw_off, &c->b_cand_pl, &c->b_start_hits,
                    &c->b_cand_cnt, &c->b_start_cnt, &c->b_task_off, &c->b_task_seed, &c->b_task_entry, &c->b_task_hit,
                    &c->b_task_k, &c->b_task_list_off, &c->b_list_cnt, &c->b_list_ptr, &c->b_hits, &c->b_tasks,
@@ -261,8 +336,8 @@ extern "C" int eg3d_get_grid(eg3d_ctx* c, int view, int which, uint32_t* ncols, 
   }
   *ncols = c->gw[which];
   *nrows = c->gh[which];
-  *cell_off = c->h_off[which][view].data();
-  *ids = c->h_ids[which][view].data();
+  *cell_off = c->hg->h_off[which][view].data();
+  *ids = c->hg->h_ids[which][view].data();
   return EG3D_OK;
 }
 
@@ -279,12 +354,26 @@ extern "C" int eg3d_upload_seeds(eg3d_ctx* c, const eg3d_seeds* s) {
       g_err = "eg3d_upload_seeds: view id out of range";
       return EG3D_ERR_ARG;
     }
-  c->n_seeds = n;
-  c->h_trk_off.assign(s->trk_off, s->trk_off + n + 1);
-  BUF_TRY(upload(c->b_toff, s->trk_off, n + 1, c->stream));
-  BUF_TRY(upload(c->b_tview, s->trk_view, m, c->stream));
-  BUF_TRY(upload(c->b_txy, s->trk_xy, (size_t)m * 2, c->stream));
+  // fresh buffers: the previous ones may still be in use by clones of this context
+  c->seeds_owner.reset();
+  c->b_toff = DevBuf();
+  c->b_tview = DevBuf();
+  c->b_txy = DevBuf();
+  c->n_seeds = 0;
+  auto owner = std::make_shared<DevOwner>();
+  owner->device = c->device;
+  int rc = upload(c->b_toff, s->trk_off, n + 1, c->stream);
+  if (rc == EG3D_OK) rc = upload(c->b_tview, s->trk_view, m, c->stream);
+  if (rc == EG3D_OK) rc = upload(c->b_txy, s->trk_xy, (size_t)m * 2, c->stream);
+  owner->ptrs = {c->b_toff.p, c->b_tview.p, c->b_txy.p};
+  if (rc != EG3D_OK) {
+    c->b_toff = c->b_tview = c->b_txy = DevBuf();
+    return rc;
+  }
   HIP_TRY(hipStreamSynchronize(c->stream));
+  c->seeds_owner = owner;
+  c->h_trk = std::make_shared<std::vector<uint32_t>>(s->trk_off, s->trk_off + n + 1);
+  c->n_seeds = n;
   return EG3D_OK;
 }
 
@@ -300,8 +389,8 @@ struct BatchState {
 int run_stage_a(eg3d_ctx* c, BatchState& B, eg3d_stage_times* tm) {
   hipStream_t st = c->stream;
   B.n_seeds = B.e - B.b;
-  B.sv_base = c->h_trk_off[B.b];
-  B.n_sv = c->h_trk_off[B.e] - B.sv_base;
+  B.sv_base = (*c->h_trk)[B.b];
+  B.n_sv = (*c->h_trk)[B.e] - B.sv_base;
   B.sd.trk_off = c->b_toff.as<uint32_t>();
   B.sd.trk_view = c->b_tview.as<int32_t>();
   B.sd.trk_xy = c->b_txy.as<float>();
@@ -582,7 +671,7 @@ int run_batch(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, HostOut& H) 
   }
   // per seed 12 + k*12 + k*64 + k(k-1)*72, plus the vertices touched, plus the output
   for (uint32_t sd_i = b; sd_i < e; sd_i++) {
-    const uint64_t k = c->h_trk_off[sd_i + 1] - c->h_trk_off[sd_i];
+    const uint64_t k = (*c->h_trk)[sd_i + 1] - (*c->h_trk)[sd_i];
     H.bytes_algorithmic += 12 + k * 12 + k * 64 + k * (k - 1) * 72;
   }
   H.bytes_algorithmic += H.bytes_vertices;
@@ -749,7 +838,7 @@ extern "C" int eg3d_candidates_run(eg3d_ctx* c, const eg3d_seeds* seeds, uint32_
     }
     o_start_off.push_back((uint32_t)o_start_pl.size());
   }
-  for (uint32_t t = 0; t < nt; t++) o_task_sv[t] = c->h_trk_off[task_seed[t]] - B.sv_base + task_entry[t];
+  for (uint32_t t = 0; t < nt; t++) o_task_sv[t] = (*c->h_trk)[task_seed[t]] - B.sv_base + task_entry[t];
   for (uint32_t h = 0; h < B.n_hits; h++) {
     o_hit_pl[h] = hits[h].pl;
     o_hit_seg[h] = hits[h].seg;

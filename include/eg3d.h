@@ -7,7 +7,7 @@
  * functions and virtual classes. Each entry point below names the reference seam
  * it replaces (paths relative to the reference tree):
  *
- *   eg3d_create / eg3d_destroy
+ *   eg3d_create / eg3d_clone / eg3d_destroy
  *       context construction in edge_matching(): PolyLine2DMapSearch per view at
  *       4 px (src/edgegraph3d/edge_matcher.cpp:101-103), PLGEdgeManager ctor with
  *       the 30 px maps (edge_managers/plg_edge_manager.cpp:46-75),
@@ -144,6 +144,14 @@ int eg3d_device_count(void);
 
 int eg3d_create(const eg3d_scene* scene, int device, eg3d_ctx** out);
 void eg3d_destroy(eg3d_ctx* ctx);
+
+/* A second context on the same device that SHARES `parent`'s immutable scene and its currently
+ * resident seeds (reference-counted; either may be destroyed first) but has its own HIP stream,
+ * events and work buffers. Seeds are independent units on this path
+ * (plg_matching_from_refpoints.cpp:83-104 loops over them with no carried state), so a host keeps
+ * several batches in flight by driving one context per thread; eg3d_upload_seeds on one context
+ * does not affect the others. */
+int eg3d_clone(eg3d_ctx* parent, eg3d_ctx** out);
 
 /* which: 0 = 30 px candidate grid, 1 = 4 px expand-all-views grid. Pointers stay
  * valid until eg3d_destroy. cell index = row*ncols + col. */

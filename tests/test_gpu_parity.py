@@ -117,14 +117,18 @@ def test_contexts_in_concurrent_threads(have_gpu):
     ref_ctx.upload_seeds(s.seeds)
     ranges = [(0, n), (0, n // 2), (n // 2, n)]
     ref = [ref_ctx.match_resident(b, e) for b, e in ranges]
-    ref_ctx.close()
     out = [None] * len(ranges)
     errs = []
+    clones = [ref_ctx.clone(), ref_ctx.clone()]  # eg3d_clone: share the resident scene and seeds
+    ref_ctx.close()                               # the clones keep the shared buffers alive
 
     def work(i):
         try:
-            ctx = api.Context(s.scene)
-            ctx.upload_seeds(s.seeds)
+            if i < len(clones):
+                ctx = clones[i]
+            else:
+                ctx = api.Context(s.scene)
+                ctx.upload_seeds(s.seeds)
             for _ in range(3):
                 out[i] = ctx.match_resident(*ranges[i])
             ctx.close()
