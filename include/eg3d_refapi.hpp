@@ -16,8 +16,10 @@
 // last_status()).
 #pragma once
 #include <array>
+#include <atomic>
 #include <cstdint>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <utility>
 #include <vector>
@@ -168,24 +170,61 @@ class PLGEdgeManager {
     return res;
   }
 
+  // plg_matching_from_refpoints_parallel over all reference points. Seeds are independent
+  // (plg_matching_from_refpoints.cpp:83-104), so the points are cut into batches that are kept in
+  // flight on `contexts` clones of the context (eg3d_clone: shared scene and seeds, own stream), one
+  // host thread each; batch results are appended in seed order, which is the reference's order.
+  void set_batching(uint32_t seeds_per_batch, int contexts) {
+    batch_ = seeds_per_batch ? seeds_per_batch : 2048;
+    n_ctx_ = contexts < 1 ? 1 : contexts;
+  }
   std::vector<new_3dpoint_plgp_matches> match_all() {
     std::vector<new_3dpoint_plgp_matches> res;
     if (!ctx_) return res;
-    eg3d_edgepoints e;
-    status_ = eg3d_match_resident(ctx_, 0, (uint32_t)sfmd_.numPoints_, 0, &e, nullptr);
+    const uint32_t n = (uint32_t)sfmd_.numPoints_;
+    const uint32_t nb = (n + batch_ - 1) / batch_;
+    std::vector<eg3d_edgepoints> parts(nb);
+    std::vector<int> rc(nb, EG3D_OK);
+    std::vector<eg3d_ctx*> ctxs(1, ctx_);
+    for (int k = 1; k < n_ctx_ && (uint32_t)k < nb; k++) {
+      eg3d_ctx* c = nullptr;
+      if (eg3d_clone(ctx_, &c) != EG3D_OK) break;
+      ctxs.push_back(c);
+    }
+    std::atomic<uint32_t> next(0);
+    auto work = [&](eg3d_ctx* c) {
+      for (uint32_t i = next.fetch_add(1); i < nb; i = next.fetch_add(1)) {
+        const uint32_t b = i * batch_, e = (b + batch_ < n) ? b + batch_ : n;
+        rc[i] = eg3d_match_resident(c, b, e, 0, &parts[i], nullptr);
+      }
+    };
+    std::vector<std::thread> th;
+    for (size_t k = 1; k < ctxs.size(); k++) th.emplace_back(work, ctxs[k]);
+    work(ctxs[0]);
+    for (auto& t : th) t.join();
+    for (size_t k = 1; k < ctxs.size(); k++) eg3d_destroy(ctxs[k]);
+    status_ = EG3D_OK;
+    for (uint32_t i = 0; i < nb; i++)
+      if (rc[i] != EG3D_OK) status_ = rc[i];
     if (status_ == EG3D_OK) {
-      res.reserve(e.n_points);
-      for (uint64_t i = 0; i < e.n_points; i++) {
-        std::vector<PolyLineGraph2D::plg_point> obs;
-        std::vector<int> views;
-        for (uint32_t j = e.obs_off[i]; j < e.obs_off[i + 1]; j++) {
-          obs.push_back({e.obs_pl[j], {e.obs_seg[j], {e.obs_xy[2 * j], e.obs_xy[2 * j + 1]}}});
-          views.push_back(e.obs_view[j]);
+      uint64_t total = 0;
+      for (uint32_t i = 0; i < nb; i++) total += parts[i].n_points;
+      res.reserve(total);
+      for (uint32_t p = 0; p < nb; p++) {
+        const eg3d_edgepoints& e = parts[p];
+        for (uint64_t i = 0; i < e.n_points; i++) {
+          std::vector<PolyLineGraph2D::plg_point> obs;
+          std::vector<int> views;
+          for (uint32_t j = e.obs_off[i]; j < e.obs_off[i + 1]; j++) {
+            obs.push_back({e.obs_pl[j], {e.obs_seg[j], {e.obs_xy[2 * j], e.obs_xy[2 * j + 1]}}});
+            views.push_back(e.obs_view[j]);
+          }
+          res.emplace_back(vec3{e.X[3 * i], e.X[3 * i + 1], e.X[3 * i + 2]}, std::move(obs), std::move(views));
         }
-        res.emplace_back(vec3{e.X[3 * i], e.X[3 * i + 1], e.X[3 * i + 2]}, std::move(obs), std::move(views));
       }
     }
-    eg3d_free_edgepoints(&e);
+    for (uint32_t i = 0; i < nb; i++)
+      if (rc[i] == EG3D_OK) eg3d_free_edgepoints(&parts[i]);
     return res;
   }
 
@@ -219,6 +258,8 @@ class PLGEdgeManager {
   std::vector<int32_t> tview_;
   eg3d_ctx* ctx_ = nullptr;
   int status_ = EG3D_OK;
+  uint32_t batch_ = 2048;
+  int n_ctx_ = 3;
 };
 
 // plg_matching_from_refpoints[_parallel]: the consensus manager and the matches manager of the

@@ -1,0 +1,113 @@
+// GPU check of include/eg3d_refapi.hpp (the reference's call surface over the C ABI): a synthetic
+// scene is poured into the shim's SfMData / PolyLineGraph2D / F types the way reference-side
+// host code holds them, matched through PLGEdgeManager::match_all() with several batches in
+// flight, and compared with one direct eg3d_match_refpoints call on the same scene.
+// Build: g++ -std=c++17 -pthread -I include refapi_check.cpp -L edgegraph3d_amd -leg3d -leg3d_host ...
+#include <cstdio>
+#include <cstring>
+
+#include "eg3d_host.h"
+#include "eg3d_refapi.hpp"
+
+using namespace eg3d_ref;
+
+int main(int argc, char** argv) {
+  const int cfg_index = argc > 1 ? atoi(argv[1]) : 1;
+  eg3d_synth_config cfg;
+  eg3d_synth_default_config(&cfg, cfg_index);
+  eg3d_synth* syn = eg3d_synth_create(&cfg);
+  const eg3d_scene* sc = eg3d_synth_scene(syn);
+  const eg3d_seeds* sd = eg3d_synth_seeds(syn);
+  const int V = sc->n_views;
+
+  SfMData sfm;
+  sfm.numCameras_ = V;
+  sfm.numPoints_ = (int)sd->n_seeds;
+  sfm.imageWidth_ = sc->width;
+  sfm.imageHeight_ = sc->height;
+  sfm.camerasList_.resize(V);
+  for (int v = 0; v < V; v++)
+    for (int r = 0; r < 4; r++)
+      for (int c = 0; c < 4; c++) sfm.camerasList_[v].cameraMatrix[r][c] = sc->cam_P[v * 16 + r * 4 + c];
+  sfm.points_.assign(sd->n_seeds, vec3{0, 0, 0});
+  sfm.camViewingPointN_.resize(sd->n_seeds);
+  sfm.point2DoncamViewingPoint_.resize(sd->n_seeds);
+  for (uint32_t i = 0; i < sd->n_seeds; i++)
+    for (uint32_t j = sd->trk_off[i]; j < sd->trk_off[i + 1]; j++) {
+      sfm.camViewingPointN_[i].push_back(sd->trk_view[j]);
+      sfm.point2DoncamViewingPoint_[i].push_back(vec2{sd->trk_xy[2 * j], sd->trk_xy[2 * j + 1]});
+    }
+  FundamentalMatrices F(V, std::vector<std::array<double, 9>>(V));
+  for (int i = 0; i < V; i++)
+    for (int j = 0; j < V; j++)
+      for (int k = 0; k < 9; k++) F[i][j][k] = sc->F_valid[i * V + j] ? sc->F[((size_t)i * V + j) * 9 + k] : 0.0;
+  // polyline graphs: node ids of the flat scene become node coordinates = the end vertices
+  std::vector<PolyLineGraph2D> plgs(V);
+  for (int v = 0; v < V; v++) {
+    PolyLineGraph2D& g = plgs[v];
+    for (uint32_t p = sc->view_pl_off[v]; p < sc->view_pl_off[v + 1]; p++) {
+      PolyLineGraph2D::polyline pl;
+      const uint32_t a = sc->pl_vtx_off[p], b = sc->pl_vtx_off[p + 1];
+      for (uint32_t k = a; k < b; k++) pl.polyline_coords.push_back(vec2{sc->vtx_xy[2 * k], sc->vtx_xy[2 * k + 1]});
+      pl.start = sc->pl_start[p];
+      pl.end = sc->pl_end[p];
+      const unsigned long hi = pl.start > pl.end ? pl.start : pl.end;
+      if (g.nodes_coords.size() <= hi) g.nodes_coords.resize(hi + 1, vec2{-1, -1});
+      if (b - a > 1 && sc->pl_valid[p]) {
+        g.nodes_coords[pl.start] = pl.polyline_coords.front();
+        g.nodes_coords[pl.end] = pl.polyline_coords.back();
+      }
+      g.polylines.push_back(std::move(pl));
+    }
+  }
+
+  PLGEdgeManager em(sfm, F, plgs, 0);
+  if (em.last_status() != EG3D_OK) {
+    std::printf("FAIL create: %s\n", eg3d_last_error());
+    return 1;
+  }
+  em.set_batching(37, 3);  // ragged batches, three contexts in flight
+  auto many = plg_matching_from_refpoints_parallel(sfm, &em);
+  if (em.last_status() != EG3D_OK) {
+    std::printf("FAIL match_all: %s\n", eg3d_last_error());
+    return 1;
+  }
+  em.set_batching(1u << 30, 1);  // one batch, one context
+  auto one = plg_matching_from_refpoints(sfm, &em);
+
+  // the same scene straight through the C ABI
+  eg3d_ctx* ctx = nullptr;
+  eg3d_edgepoints e;
+  if (eg3d_create(sc, 0, &ctx) != EG3D_OK || eg3d_match_refpoints(ctx, sd, 0, sd->n_seeds, 0, &e, nullptr) != EG3D_OK) {
+    std::printf("FAIL direct: %s\n", eg3d_last_error());
+    return 1;
+  }
+  int bad = 0;
+  if (many.size() != e.n_points || one.size() != e.n_points) bad++;
+  for (uint64_t i = 0; i < e.n_points && !bad; i++) {
+    for (const auto* r : {&many[i], &one[i]}) {
+      const vec3& X = std::get<0>(*r);
+      if (std::memcmp(&X, e.X + 3 * i, 12) != 0) bad++;
+      const auto& obs = std::get<1>(*r);
+      const auto& views = std::get<2>(*r);
+      if (obs.size() != e.obs_off[i + 1] - e.obs_off[i]) {
+        bad++;
+        continue;
+      }
+      for (size_t j = 0; j < obs.size(); j++) {
+        const uint32_t o = e.obs_off[i] + (uint32_t)j;
+        if (views[j] != e.obs_view[o] || obs[j].polyline_id != e.obs_pl[o] || obs[j].plp.segment_index != e.obs_seg[o] ||
+            std::memcmp(&obs[j].plp.coords, e.obs_xy + 2 * o, 8) != 0)
+          bad++;
+      }
+    }
+  }
+  // stage A through the reference's per-point entry
+  auto cand = em.detect_nearby_intersections_and_correspondences_plgp(0);
+  std::printf("%s points=%llu shim_batched=%zu shim_single=%zu track0_entries=%zu\n", bad ? "FAIL" : "OK",
+              (unsigned long long)e.n_points, many.size(), one.size(), cand.size());
+  eg3d_free_edgepoints(&e);
+  eg3d_destroy(ctx);
+  eg3d_synth_destroy(syn);
+  return bad ? 1 : 0;
+}

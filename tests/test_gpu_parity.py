@@ -146,3 +146,19 @@ def test_contexts_in_concurrent_threads(have_gpu):
         assert np.array_equal(g["X"].view(np.uint32), r["X"].view(np.uint32))
         assert np.array_equal(g["key"], r["key"])
         assert np.array_equal(g["obs_xy"].view(np.uint32), r["obs_xy"].view(np.uint32))
+
+
+def test_reference_surface_shim_on_gpu(have_gpu, tmp_path):
+    """include/eg3d_refapi.hpp driven the way reference-side C++ host code would: SfMData /
+    PolyLineGraph2D / F in, plg_matching_from_refpoints_parallel out — with three batches in flight
+    on clones — equals one direct C-ABI call bit for bit (tests/refapi/refapi_check.cpp)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "edgegraph3d_amd")
+    exe = str(tmp_path / "refapi_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "refapi", "refapi_check.cpp"), "-L", pkg, "-leg3d", "-leg3d_host",
+                           "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-L", "/opt/rocm/lib", "-lamdhip64", "-o", exe])
+    out = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
