@@ -21,6 +21,10 @@ class Seeds(C.Structure):
     _fields_ = [("n_seeds", C.c_uint32), ("trk_off", u32p), ("trk_view", i32p), ("trk_xy", f32p)]
 
 
+class PolylineSets(C.Structure):
+    _fields_ = [("n_sets", C.c_uint32), ("row_off", u32p), ("pl_ids", u32p)]
+
+
 class EdgePoints(C.Structure):
     _fields_ = [("n_points", C.c_uint64), ("n_obs", C.c_uint64), ("X", f32p), ("obs_off", u32p),
                 ("obs_view", i32p), ("obs_pl", u32p), ("obs_seg", u32p), ("obs_xy", f32p), ("key", u32p),

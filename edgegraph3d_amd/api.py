@@ -48,6 +48,8 @@ def lib():
         L.eg3d_upload_seeds.argtypes = [C.c_void_p, C.POINTER(D.Seeds)]
         L.eg3d_match_resident.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(D.EdgePoints),
                                           C.POINTER(D.StageTimes)]
+        L.eg3d_match_polyline_sets.argtypes = [C.c_void_p, C.POINTER(D.PolylineSets), C.c_uint32, C.c_uint32, C.c_int,
+                                               C.POINTER(D.EdgePoints), C.POINTER(D.StageTimes)]
         L.eg3d_last_device_output.argtypes = [C.c_void_p, C.POINTER(D.DeviceEdgePoints)]
         L.eg3d_gn_filter.argtypes = [C.c_void_p, D.f32p, D.u32p, D.i32p, D.f32p, C.c_uint64, C.c_float, C.c_int,
                                      D.f32p, D.u8p, D.f32p]
@@ -59,7 +61,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "eg3d_last_error", "eg3d_device_count", "eg3d_create", "eg3d_clone", "eg3d_destroy", "eg3d_get_grid", "eg3d_candidates_run",
     "eg3d_free_candidates", "eg3d_match_refpoints", "eg3d_free_edgepoints", "eg3d_upload_seeds",
-    "eg3d_match_resident", "eg3d_gn_filter", "eg3d_last_device_output",
+    "eg3d_match_resident", "eg3d_gn_filter", "eg3d_last_device_output", "eg3d_match_polyline_sets",
 ]
 
 
@@ -127,6 +129,26 @@ class Context:
             end = int(seeds_ptr.contents.n_seeds) if hasattr(seeds_ptr, "contents") else int(seeds_ptr.n_seeds)
         self.upload_seeds(seeds_ptr)
         return self.match_resident(begin, end, device_only)
+
+    def match_polyline_sets(self, n_sets, row_off, pl_ids, begin=0, end=None, device_only=False):
+        """Pipelines 1-2 extractor: sets = CSR over rows (set * V + view) of polyline ids."""
+        if end is None:
+            end = n_sets
+        row_off = np.ascontiguousarray(row_off, np.uint32)
+        pl_ids = np.ascontiguousarray(pl_ids if len(pl_ids) else [0], np.uint32)
+        ps = D.PolylineSets(n_sets, D.np_ptr(row_off, C.c_uint32), D.np_ptr(pl_ids, C.c_uint32))
+        e, tm = D.EdgePoints(), D.StageTimes()
+        rc = lib().eg3d_match_polyline_sets(self._h, C.byref(ps), begin, end, 1 if device_only else 0, C.byref(e),
+                                            C.byref(tm))
+        _check(rc, "eg3d_match_polyline_sets")
+        if device_only:
+            d = {"n_points": int(e.n_points), "n_obs": int(e.n_obs), "n_tasks": int(e.n_tasks),
+                 "n_hypotheses": int(e.n_hypotheses), "n_chains": int(e.n_chains), "flags": int(e.flags)}
+        else:
+            d = D.edgepoints_to_dict(e)
+        lib().eg3d_free_edgepoints(C.byref(e))
+        d["times"] = {f[0]: getattr(tm, f[0]) for f in D.StageTimes._fields_}
+        return d
 
     def last_device_output(self):
         d = D.DeviceEdgePoints()

@@ -105,6 +105,7 @@ struct eg3d_ctx {
       b_cscratch, b_couts, b_cpts, b_cobs, b_cpoff, b_cooff, b_scan_tmp, b_cost, b_cidx, b_cost2, b_order;
   DevBuf o_X, o_off, o_view, o_pl, o_seg, o_xy, o_key;
   DevBuf f_X, f_off, f_view, f_xy, f_Xo, f_inl;
+  DevBuf b_sets_off, b_sets_ids;  // polyline sets of the current eg3d_match_polyline_sets call
   hipEvent_t ea[8], eb[8];  // begin/end events per stage: 1 K1, 2 K2, 3 K3a, 4 K3s, 5 K3b, 6 K4, 0 misc
   uint32_t chain_cap = 384, pool_cap = 0, hyp_cap = 160;
   uint32_t k3a_blocks = 0;
@@ -318,7 +319,7 @@ extern "C" void eg3d_destroy(eg3d_ctx* c) {
                    &c->b_nhyp, &c->b_hyp_off, &c->b_res, &c->b_hscratch, &c->b_arena, &c->b_ctr, &c->b_cs_task,
                    &c->b_valid, &c->b_chain_off, &c->b_chains, &c->b_cscratch, &c->b_couts, &c->b_cpts, &c->b_cobs,
                    &c->b_cpoff, &c->b_cooff, &c->b_scan_tmp, &c->b_cost, &c->b_cidx, &c->b_cost2, &c->b_order, &c->o_X, &c->o_off, &c->o_view, &c->o_pl, &c->o_seg,
-                   &c->o_xy, &c->o_key, &c->f_X, &c->f_off, &c->f_view, &c->f_xy, &c->f_Xo, &c->f_inl};
+                   &c->o_xy, &c->o_key, &c->f_X, &c->f_off, &c->f_view, &c->f_xy, &c->f_Xo, &c->f_inl, &c->b_sets_off, &c->b_sets_ids};
   for (DevBuf* b : all) b->release();
   for (int i = 0; i < 8; i++) {
     if (c->ea[i]) (void)hipEventDestroy(c->ea[i]);
@@ -478,13 +479,10 @@ struct HostOut {
   float ms[7] = {0, 0, 0, 0, 0, 0, 0};
 };
 
-int run_batch(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, HostOut& H) {
+// Stage B: task setup, K3a, K3s, K3b + K4 in chunks. Consumes the StageAView in B (from the seed
+// path's stage A or from the polyline-set sampler) and appends to H.
+int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
   hipStream_t st = c->stream;
-  BatchState B;
-  memset(&B, 0, sizeof(B));
-  B.b = b;
-  B.e = e;
-  BUF_TRY(run_stage_a(c, B, nullptr));
   const uint32_t nt = B.n_tasks;
   // ---- task setup + hypothesis offsets
   BUF_TRY(c->b_tasks.ensure(sizeof(TaskDesc) * (nt + 1)));
@@ -669,17 +667,118 @@ int run_batch(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, HostOut& H) 
     HIP_TRY(hipMemcpy(&hc, c->b_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost));
     H.bytes_vertices = hc.bytes;
   }
-  // per seed 12 + k*12 + k*64 + k(k-1)*72, plus the vertices touched, plus the output
-  for (uint32_t sd_i = b; sd_i < e; sd_i++) {
-    const uint64_t k = (*c->h_trk)[sd_i + 1] - (*c->h_trk)[sd_i];
-    H.bytes_algorithmic += 12 + k * 12 + k * 64 + k * (k - 1) * 72;
-  }
   H.bytes_algorithmic += H.bytes_vertices;
   H.bytes_vertices = 0;
   H.n_tasks += B.n_tasks;
   H.n_hyp += B.n_hyp;
   c->last_nhyp = B.n_hyp;
   H.n_chains += B.n_chains;
+  return EG3D_OK;
+}
+
+int run_batch(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, HostOut& H) {
+  BatchState B;
+  memset(&B, 0, sizeof(B));
+  B.b = b;
+  B.e = e;
+  BUF_TRY(run_stage_a(c, B, nullptr));
+  BUF_TRY(run_stage_b(c, B, device_only, H));
+  // per seed 12 + k*12 + k*64 + k(k-1)*72 (the vertices touched and the output were
+  // added by stage B)
+  for (uint32_t sd_i = b; sd_i < e; sd_i++) {
+    const uint64_t k = (*c->h_trk)[sd_i + 1] - (*c->h_trk)[sd_i];
+    H.bytes_algorithmic += 12 + k * 12 + k * 64 + k * (k - 1) * 72;
+  }
+  return EG3D_OK;
+}
+
+// Pipelines 1-2 extractor, stage A: sample the polylines of sets [set_b, set_e) and
+// collect the epipolar hits of every sample; then the common stage B. `sets` is already on the
+// device; h_row_off is its host copy of the row offsets.
+int run_sets_batch(eg3d_ctx* c, const SetsDev& sets, const uint32_t* h_row_off, uint32_t n_rows_total, uint32_t set_b,
+                   uint32_t set_e, int device_only, HostOut& H) {
+  hipStream_t st = c->stream;
+  const uint32_t V = (uint32_t)c->V;
+  BatchState B;
+  memset(&B, 0, sizeof(B));
+  const uint32_t item_b = h_row_off[(size_t)set_b * V], item_e = h_row_off[(size_t)set_e * V];
+  const uint32_t n_items = item_e - item_b;
+  BUF_TRY(c->b_ctr.ensure(sizeof(Counters)));
+  HIP_TRY(hipMemsetAsync(c->b_ctr.p, 0, sizeof(Counters), st));
+  BUF_TRY(c->b_raw_cnt.ensure(sizeof(uint32_t) * (n_items + 1)));
+  BUF_TRY(c->b_raw_off.ensure(sizeof(uint32_t) * (n_items + 1)));
+  HIP_TRY(hipMemsetAsync(c->b_raw_cnt.as<uint32_t>() + n_items, 0, sizeof(uint32_t), st));
+  HIP_TRY(hipEventRecord(c->ea[1], st));
+  launch_n1_samples(st, false, c->ds, sets, n_rows_total, item_b, n_items, c->b_raw_cnt.as<uint32_t>(), nullptr, nullptr,
+                    nullptr, nullptr, nullptr, nullptr, nullptr, c->b_ctr.as<Counters>());
+  BUF_TRY(scan_exclusive_u32(c, c->b_raw_cnt.as<uint32_t>(), c->b_raw_off.as<uint32_t>(), n_items + 1));
+  BUF_TRY(read_u32(c, c->b_raw_off.as<uint32_t>() + n_items, B.n_tasks));
+  const uint32_t nt = B.n_tasks;
+  if ((uint64_t)nt * V > 0x7fffffffull) {
+    g_err = "eg3d_match_polyline_sets: too many samples in one batch of sets";
+    return EG3D_ERR_CAPACITY;
+  }
+  BUF_TRY(c->b_start_hits.ensure(sizeof(Obs) * (nt + 1)));  // the samples
+  BUF_TRY(c->b_task_seed.ensure(sizeof(uint32_t) * (nt + 1)));
+  BUF_TRY(c->b_task_entry.ensure(sizeof(uint32_t) * (nt + 1)));
+  BUF_TRY(c->b_task_hit.ensure(sizeof(uint32_t) * (nt + 1)));
+  BUF_TRY(c->b_task_k.ensure(sizeof(uint32_t) * (nt + 1)));  // first row of the task's set
+  BUF_TRY(c->b_task_list_off.ensure(sizeof(uint32_t) * (nt + 1)));
+  launch_n1_samples(st, true, c->ds, sets, n_rows_total, item_b, n_items, nullptr, c->b_raw_off.as<uint32_t>(),
+                    c->b_start_hits.as<Obs>(), c->b_task_seed.as<uint32_t>(), c->b_task_entry.as<uint32_t>(),
+                    c->b_task_hit.as<uint32_t>(), c->b_task_list_off.as<uint32_t>(), c->b_task_k.as<uint32_t>(),
+                    c->b_ctr.as<Counters>());
+  {
+    const uint32_t last = nt * V;
+    HIP_TRY(hipMemcpyAsync(c->b_task_list_off.as<uint32_t>() + nt, &last, sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // `last` leaves scope
+  }
+  HIP_TRY(hipEventRecord(c->eb[1], st));
+  B.n_lists = nt * V;
+  BUF_TRY(c->b_list_cnt.ensure(sizeof(uint32_t) * ((size_t)B.n_lists + 1)));
+  BUF_TRY(c->b_list_ptr.ensure(sizeof(uint32_t) * ((size_t)B.n_lists + 1)));
+  HIP_TRY(hipMemsetAsync(c->b_list_cnt.as<uint32_t>() + B.n_lists, 0, sizeof(uint32_t), st));
+  HIP_TRY(hipEventRecord(c->ea[2], st));
+  launch_n1_hits(st, false, c->ds, sets, nt, c->b_start_hits.as<Obs>(), c->b_task_k.as<uint32_t>(),
+                 c->b_list_cnt.as<uint32_t>(), nullptr, nullptr, c->b_ctr.as<Counters>());
+  BUF_TRY(scan_exclusive_u32(c, c->b_list_cnt.as<uint32_t>(), c->b_list_ptr.as<uint32_t>(), (size_t)B.n_lists + 1));
+  BUF_TRY(read_u32(c, c->b_list_ptr.as<uint32_t>() + B.n_lists, B.n_hits));
+  BUF_TRY(c->b_hits.ensure(sizeof(Obs) * ((size_t)B.n_hits + 1)));
+  launch_n1_hits(st, true, c->ds, sets, nt, c->b_start_hits.as<Obs>(), c->b_task_k.as<uint32_t>(),
+                 c->b_list_cnt.as<uint32_t>(), c->b_list_ptr.as<uint32_t>(), c->b_hits.as<Obs>(), c->b_ctr.as<Counters>());
+  HIP_TRY(hipEventRecord(c->eb[2], st));
+  // identity view map: one row of V entries shared by every sample (StageAView::dense_k)
+  {
+    std::vector<int32_t> mv(V);
+    std::vector<uint32_t> me(V);
+    for (uint32_t j = 0; j < V; j++) {
+      mv[j] = (int32_t)j;
+      me[j] = j;
+    }
+    BUF_TRY(upload(c->b_map_view, mv.data(), V, st));
+    BUF_TRY(upload(c->b_map_entry, me.data(), V, st));
+    BUF_TRY(c->b_map_n.ensure(sizeof(uint32_t)));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  StageAView& a = B.a;
+  a.trk_off = nullptr;
+  a.trk_view = nullptr;
+  a.trk_xy = nullptr;
+  a.seed_begin = 0;
+  a.sv_base = 0;
+  a.n_tasks = nt;
+  a.task_seed = c->b_task_seed.as<uint32_t>();
+  a.task_entry = c->b_task_entry.as<uint32_t>();
+  a.task_hit = c->b_task_hit.as<uint32_t>();
+  a.task_list_off = c->b_task_list_off.as<uint32_t>();
+  a.list_ptr = c->b_list_ptr.as<uint32_t>();
+  a.list_cnt = c->b_list_cnt.as<uint32_t>();
+  a.hits = c->b_hits.as<Obs>();
+  a.dense_k = V;
+  BUF_TRY(run_stage_b(c, B, device_only, H));
+  // per sample: its coordinates, V camera matrices, V-1 fundamental matrices (the scanned vertices
+  // and the output were added by the kernels)
+  H.bytes_algorithmic += (uint64_t)nt * (8 + (uint64_t)V * 64 + (uint64_t)(V - 1) * 72);
   return EG3D_OK;
 }
 
@@ -692,32 +791,7 @@ T* dup_to_malloc(const std::vector<T>& v, size_t extra = 0) {
 
 }  // namespace
 
-extern "C" int eg3d_match_resident(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, eg3d_edgepoints* out,
-                                   eg3d_stage_times* times) {
-  if (!c || !out || b > e || e > c->n_seeds) {
-    g_err = "eg3d_match_resident: bad arguments (seeds uploaded?)";
-    return EG3D_ERR_ARG;
-  }
-  HIP_TRY(hipSetDevice(c->device));
-  memset(out, 0, sizeof(*out));
-  HostOut H;
-  c->last_np = c->last_no = 0;
-  c->last_chunks = 0;
-  const uint32_t SEED_BATCH = 16384;
-  hipEvent_t t0, t1;
-  HIP_TRY(hipEventCreate(&t0));
-  HIP_TRY(hipEventCreate(&t1));
-  HIP_TRY(hipEventRecord(t0, c->stream));
-  for (uint32_t s = b; s < e; s += SEED_BATCH) {
-    int rc = run_batch(c, s, std::min(e, s + SEED_BATCH), device_only, H);
-    if (rc != EG3D_OK) return rc;
-  }
-  HIP_TRY(hipEventRecord(t1, c->stream));
-  HIP_TRY(hipEventSynchronize(t1));
-  float total = 0;
-  HIP_TRY(hipEventElapsedTime(&total, t0, t1));
-  (void)hipEventDestroy(t0);
-  (void)hipEventDestroy(t1);
+static int finish_match(HostOut& H, int device_only, float total, eg3d_edgepoints* out, eg3d_stage_times* times) {
   out->n_points = H.n_points;
   out->n_obs = H.n_obs;
   out->n_tasks = H.n_tasks;
@@ -752,6 +826,36 @@ extern "C" int eg3d_match_resident(eg3d_ctx* c, uint32_t b, uint32_t e, int devi
   return EG3D_OK;
 }
 
+
+extern "C" int eg3d_match_resident(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, eg3d_edgepoints* out,
+                                   eg3d_stage_times* times) {
+  if (!c || !out || b > e || e > c->n_seeds) {
+    g_err = "eg3d_match_resident: bad arguments (seeds uploaded?)";
+    return EG3D_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  memset(out, 0, sizeof(*out));
+  HostOut H;
+  c->last_np = c->last_no = 0;
+  c->last_chunks = 0;
+  const uint32_t SEED_BATCH = 16384;
+  hipEvent_t t0, t1;
+  HIP_TRY(hipEventCreate(&t0));
+  HIP_TRY(hipEventCreate(&t1));
+  HIP_TRY(hipEventRecord(t0, c->stream));
+  for (uint32_t s = b; s < e; s += SEED_BATCH) {
+    int rc = run_batch(c, s, std::min(e, s + SEED_BATCH), device_only, H);
+    if (rc != EG3D_OK) return rc;
+  }
+  HIP_TRY(hipEventRecord(t1, c->stream));
+  HIP_TRY(hipEventSynchronize(t1));
+  float total = 0;
+  HIP_TRY(hipEventElapsedTime(&total, t0, t1));
+  (void)hipEventDestroy(t0);
+  (void)hipEventDestroy(t1);
+  return finish_match(H, device_only, total, out, times);
+}
+
 extern "C" int eg3d_last_device_output(eg3d_ctx* c, eg3d_device_edgepoints* out) {
   if (!c || !out) {
     g_err = "eg3d_last_device_output: bad arguments";
@@ -775,6 +879,69 @@ extern "C" int eg3d_match_refpoints(eg3d_ctx* c, const eg3d_seeds* seeds, uint32
   int rc = eg3d_upload_seeds(c, seeds);
   if (rc != EG3D_OK) return rc;
   return eg3d_match_resident(c, b, e, device_only, out, times);
+}
+
+extern "C" int eg3d_match_polyline_sets(eg3d_ctx* c, const eg3d_polyline_sets* ps, uint32_t set_b, uint32_t set_e,
+                                        int device_only, eg3d_edgepoints* out, eg3d_stage_times* times) {
+  if (!c || !ps || !out || !ps->row_off || set_b > set_e || set_e > ps->n_sets) {
+    g_err = "eg3d_match_polyline_sets: bad arguments";
+    return EG3D_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(c->device));
+  memset(out, 0, sizeof(*out));
+  const uint32_t V = (uint32_t)c->V;
+  const uint32_t n_rows = ps->n_sets * V;
+  const uint32_t n_ids = ps->row_off[n_rows];
+  {
+    std::vector<uint32_t> vpo(V + 1);
+    HIP_TRY(hipMemcpy(vpo.data(), c->ds.view_pl_off, sizeof(uint32_t) * (V + 1), hipMemcpyDeviceToHost));
+    for (uint32_t r = 0; r < n_rows; r++) {
+      if (ps->row_off[r + 1] < ps->row_off[r]) {
+        g_err = "eg3d_match_polyline_sets: row_off is not ascending";
+        return EG3D_ERR_ARG;
+      }
+      const uint32_t npl = vpo[r % V + 1] - vpo[r % V];
+      for (uint32_t k = ps->row_off[r]; k < ps->row_off[r + 1]; k++)
+        if (ps->pl_ids[k] >= npl) {
+          g_err = "eg3d_match_polyline_sets: polyline id out of range";
+          return EG3D_ERR_ARG;
+        }
+    }
+  }
+  BUF_TRY(upload(c->b_sets_off, ps->row_off, (size_t)n_rows + 1, c->stream));
+  BUF_TRY(upload(c->b_sets_ids, ps->pl_ids, n_ids, c->stream));
+  SetsDev sd;
+  sd.n_views = V;
+  sd.row_off = c->b_sets_off.as<uint32_t>();
+  sd.pl_ids = c->b_sets_ids.as<uint32_t>();
+  HostOut H;
+  c->last_np = c->last_no = 0;
+  c->last_chunks = 0;
+  hipEvent_t t0, t1;
+  HIP_TRY(hipEventCreate(&t0));
+  HIP_TRY(hipEventCreate(&t1));
+  HIP_TRY(hipEventRecord(t0, c->stream));
+  // batches of whole sets, bounded by the number of polylines (every sample owns V lists)
+  const uint32_t max_items = V >= 64 ? 2048u : 16384u;
+  uint32_t sample_base = 0;
+  for (uint32_t s0 = set_b; s0 < set_e;) {
+    uint32_t s1 = s0 + 1;
+    while (s1 < set_e && ps->row_off[(size_t)(s1 + 1) * V] - ps->row_off[(size_t)s0 * V] <= max_items) s1++;
+    const size_t p0 = H.key.size() / 4;
+    const uint64_t tasks_before = H.n_tasks;
+    int rc = run_sets_batch(c, sd, ps->row_off, n_rows, s0, s1, device_only, H);
+    if (rc != EG3D_OK) return rc;
+    for (size_t i = p0; i < H.key.size() / 4; i++) H.key[4 * i] += sample_base;  // sample index of the call
+    sample_base += (uint32_t)(H.n_tasks - tasks_before);
+    s0 = s1;
+  }
+  HIP_TRY(hipEventRecord(t1, c->stream));
+  HIP_TRY(hipEventSynchronize(t1));
+  float total = 0;
+  HIP_TRY(hipEventElapsedTime(&total, t0, t1));
+  (void)hipEventDestroy(t0);
+  (void)hipEventDestroy(t1);
+  return finish_match(H, device_only, total, out, times);
 }
 
 extern "C" void eg3d_free_edgepoints(eg3d_edgepoints* e) {

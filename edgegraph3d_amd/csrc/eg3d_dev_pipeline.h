@@ -32,7 +32,21 @@ struct StageAView {
   const uint32_t* list_ptr;       // [n_lists] offset into hits
   const uint32_t* list_cnt;       // [n_lists]
   const Obs* hits;                // epipolar hits (view filled in)
+  // Dense mode (pipelines 1-2 extractor): every "seed" is a sampled polyline point whose track is
+  // the identity over all dense_k = V views (entry j = view j, one list per view); no per-seed
+  // track or view-map arrays exist — map_view/map_entry hold ONE identity row of dense_k entries.
+  uint32_t dense_k = 0;
 };
+EG3D_HD uint32_t track_base(const StageAView& a, uint32_t seed) { return a.dense_k ? 0u : a.trk_off[seed] - a.sv_base; }
+EG3D_HD uint32_t track_len(const StageAView& a, uint32_t seed) {
+  return a.dense_k ? a.dense_k : a.trk_off[seed + 1] - a.trk_off[seed];
+}
+EG3D_HD int32_t track_view(const StageAView& a, uint32_t seed, uint32_t entry) {
+  return a.dense_k ? (int32_t)entry : a.trk_view[a.trk_off[seed] + entry];
+}
+EG3D_HD uint32_t track_n_views(const StageAView& a, const uint32_t* map_n, uint32_t seed) {
+  return a.dense_k ? a.dense_k : map_n[seed - a.seed_begin];
+}
 
 // view-indexed scatter of a seed's track: distinct views ascending, last entry wins (Q2-like,
 // plgpcm_3views_plg_following.cpp:42-43). Written per seed at trk_off[seed]-sv_base.
@@ -77,12 +91,12 @@ EG3D_HD void task_setup(const StageAView& a, uint32_t t, const int32_t* map_view
     d.sel_entry[k] = 0;
     d.cnt[k] = 0;
   }
-  const uint32_t base = a.trk_off[d.seed] - a.sv_base;
-  const uint32_t n = map_n[d.seed - a.seed_begin];
+  const uint32_t base = track_base(a, d.seed);
+  const uint32_t n = track_n_views(a, map_n, d.seed);
   const int32_t* mv = map_view + base;
   const uint32_t* me = map_entry + base;
   const uint32_t lo = a.task_list_off[t];
-  const int32_t start_view = a.trk_view[a.trk_off[d.seed] + d.entry];
+  const int32_t start_view = track_view(a, d.seed, d.entry);
   int non_empty = 0, min_j = -1, max_j = -1;
   for (uint32_t j = 0; j < n; j++)
     if (a.list_cnt[lo + me[j]] > 0) {
@@ -293,8 +307,8 @@ EG3D_HD void expand_chain(const Team& tm, const DevScene& s, const StageAView& a
   tm.sync();
   c.tsec[9] = EG3D_TICK() - t_begin;
   // every view except the three selected, ascending; epc = the task's hits in that view
-  const uint32_t base = a.trk_off[d.seed] - a.sv_base;
-  const uint32_t n = map_n[d.seed - a.seed_begin];
+  const uint32_t base = track_base(a, d.seed);
+  const uint32_t n = track_n_views(a, map_n, d.seed);
   const int32_t* mv = map_view + base;
   const uint32_t* me = map_entry + base;
   const uint32_t lo = a.task_list_off[cs.task];

@@ -34,6 +34,22 @@ void launch_k2(hipStream_t st, bool fill, DevScene s, SeedsDev sd, uint32_t sv_b
                const uint32_t* task_seed, const uint32_t* task_entry, const uint32_t* task_hit,
                const uint32_t* task_list_off, const uint32_t* raw_off, const uint32_t* cand_pl, const uint32_t* cand_cnt,
                const Obs* start_hits, uint32_t* list_cnt, const uint32_t* list_ptr, Obs* hits);
+// ---- pipelines 1-2 extractor: sets of potentially compatible polylines -> tasks ----
+// CSR over rows (set * V + view) of view-local polyline ids, ascending per row (device copies).
+struct SetsDev {
+  uint32_t n_views;
+  const uint32_t* row_off;  // [n_sets * V + 1]
+  const uint32_t* pl_ids;
+};
+// items = entries [item_begin, item_begin + n_items) of pl_ids; fill=false counts the 20 px samples
+// of each item's polyline, fill=true writes them (one task per sample) at sample_off[item]
+void launch_n1_samples(hipStream_t st, bool fill, DevScene s, SetsDev sets, uint32_t n_rows, uint32_t item_begin,
+                       uint32_t n_items, uint32_t* sample_cnt, const uint32_t* sample_off, Obs* samples,
+                       uint32_t* task_seed, uint32_t* task_entry, uint32_t* task_hit, uint32_t* task_list_off,
+                       uint32_t* task_row0, Counters* ctr);
+// one wavefront per (task, view): hits of the sample's epipolar line on the set's polylines of that view
+void launch_n1_hits(hipStream_t st, bool fill, DevScene s, SetsDev sets, uint32_t n_tasks, const Obs* samples,
+                    const uint32_t* task_row0, uint32_t* list_cnt, const uint32_t* list_ptr, Obs* hits, Counters* ctr);
 void launch_task_setup(hipStream_t st, StageAView a, const int32_t* map_view, const uint32_t* map_entry,
                        const uint32_t* map_n, TaskDesc* tasks, uint32_t* n_hyp);
 void launch_k3a(hipStream_t st, bool team4, uint32_t n_blocks, DevScene s, StageAView a, const TaskDesc* tasks,

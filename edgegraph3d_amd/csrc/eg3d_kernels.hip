@@ -257,6 +257,122 @@ __global__ void __launch_bounds__(256) k2_epipolar_hits(DevScene s, SeedsDev sd,
   }
 }
 
+// ------------------------------------------------------------------ N1 ---------
+// Pipelines 1-2 extractor, stage A (polyline_matching.cpp:153-208 with :45-73): every polyline of a
+// set is sampled every 20 px from its start towards its end; each sample is one task whose V lists
+// are the hits of its epipolar line on the set's polylines of the other views (all hits, no
+// radius; the list of its own view is the sample itself).
+__device__ __forceinline__ uint32_t n1_row_of_item(const uint32_t* row_off, uint32_t n_rows, uint32_t item) {
+  uint32_t lo = 0, hi = n_rows;  // largest row with row_off[row] <= item (empty rows skipped by <=)
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (row_off[mid] <= item)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+template <bool FILL>
+__global__ void k_n1_samples(DevScene s, SetsDev sets, uint32_t n_rows, uint32_t item_begin, uint32_t n_items,
+                             uint32_t* sample_cnt, const uint32_t* sample_off, Obs* samples, uint32_t* task_seed,
+                             uint32_t* task_entry, uint32_t* task_hit, uint32_t* task_list_off, uint32_t* task_row0,
+                             Counters* ctr) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_items) return;
+  const uint32_t item = item_begin + i;
+  const uint32_t row = n1_row_of_item(sets.row_off, n_rows, item);
+  const int view = (int)(row % sets.n_views);
+  const uint32_t pl_id = sets.pl_ids[item];
+  const PlRef pl = polyline_of(s, view, pl_id);
+  uint32_t n = 0;
+  if (pl.n >= 2) {
+    PlPt p, q;
+    p.seg = 0;
+    p.x = pl.v[0].x;
+    p.y = pl.v[0].y;
+    const uint32_t base = FILL ? sample_off[i] : 0u;
+    for (;;) {
+      const uint32_t w = walk_by_distance(pl, p, pl.end, 20.0f, q);
+      if (w & WALK_BAD_DIR) atomicOr(&ctr->flags, 8u);
+      if (w & WALK_EXTREME) break;
+      if (FILL) {
+        const uint32_t t = base + n;
+        Obs o;
+        o.view = view;
+        o.pl = pl_id;
+        o.seg = q.seg;
+        o.x = q.x;
+        o.y = q.y;
+        samples[t] = o;
+        task_seed[t] = t;
+        task_entry[t] = (uint32_t)view;
+        task_hit[t] = 0;
+        task_list_off[t] = t * sets.n_views;
+        task_row0[t] = (row / sets.n_views) * sets.n_views;  // first row of the task's set
+      }
+      n++;
+      p = q;
+    }
+  }
+  if (!FILL) sample_cnt[i] = n;
+}
+
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_n1_hits(DevScene s, SetsDev sets, uint32_t n_tasks, const Obs* samples,
+                                                const uint32_t* task_row0, uint32_t* list_cnt,
+                                                const uint32_t* list_ptr, Obs* hits, Counters* ctr) {
+  const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // list index = task * V + view
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t V = sets.n_views;
+  if (w >= n_tasks * V) return;
+  const uint32_t t = w / V;
+  const int cur_view = (int)(w % V);
+  const Obs smp = samples[t];
+  uint32_t cnt = 0;
+  unsigned long long bytes = 0;
+  if (cur_view == smp.view) {
+    cnt = 1;
+    if (FILL && lane == 0) hits[list_ptr[w]] = smp;
+  } else {
+    float la, lb, lc;
+    if (epiline(s.F, s.F_valid, s.n_views, smp.view, cur_view, smp.x, smp.y, la, lb, lc)) {
+      const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      const uint32_t row = task_row0[t] + (uint32_t)cur_view;
+      const uint32_t wbase = FILL ? list_ptr[w] : 0;
+      for (uint32_t c = sets.row_off[row]; c < sets.row_off[row + 1]; c++) {
+        const uint32_t pl_id = sets.pl_ids[c];
+        const PlRef pl = polyline_of(s, cur_view, pl_id);
+        bytes += 8ull * pl.n;
+        for (uint32_t base = 1; base < pl.n; base += 64) {
+          const uint32_t ii = base + lane;
+          bool ok = false;
+          float hx = 0.f, hy = 0.f;
+          if (ii < pl.n) {
+            const f2 v1 = pl.v[ii], v0 = pl.v[ii - 1];
+            ok = seg_line_hit(v1.x, v1.y, v0.x, v0.y, la, lb, lc, hx, hy);  // (v[i], v[i-1]), tagged i-1: Q10
+          }
+          const unsigned long long mask = __ballot(ok);
+          if (FILL && ok) {
+            Obs o;
+            o.view = cur_view;
+            o.pl = pl_id;
+            o.seg = ii - 1;
+            o.x = hx;
+            o.y = hy;
+            hits[wbase + cnt + __popcll(mask & lt_mask)] = o;
+          }
+          cnt += __popcll(mask);
+        }
+      }
+    }
+  }
+  if (!FILL && lane == 0) {
+    list_cnt[w] = cnt;
+    if (bytes) atomicAdd(&ctr->bytes, bytes);
+  }
+}
+
 // ------------------------------------------------------------------ tasks ------
 __global__ void k_task_setup(StageAView a, const int32_t* map_view, const uint32_t* map_entry, const uint32_t* map_n,
                              TaskDesc* tasks, uint32_t* n_hyp) {
@@ -552,7 +668,7 @@ __global__ void k_chain_cost(StageAView a, const TaskDesc* tasks, const ChainSee
   if (j >= n_chains) return;
   const ChainSeed cs = chains[j];
   const uint32_t seed = tasks[cs.task].seed;
-  const uint32_t k = a.trk_off[seed + 1] - a.trk_off[seed];
+  const uint32_t k = track_len(a, seed);
   cost[j] = (cs.n1 + 1 + cs.n2) * k;
   idx[j] = j;
 }
@@ -672,6 +788,31 @@ void launch_k2(hipStream_t st, bool fill, DevScene s, SeedsDev sd, uint32_t sv_b
     hipLaunchKernelGGL(k2_epipolar_hits<false>, blocks_for((uint64_t)n_tasks * 64, 256), dim3(256), 0, st, s, sd,
                        sv_base, n_tasks, task_seed, task_entry, task_hit, task_list_off, raw_off, cand_pl, cand_cnt,
                        start_hits, list_cnt, list_ptr, hits);
+}
+void launch_n1_samples(hipStream_t st, bool fill, DevScene s, SetsDev sets, uint32_t n_rows, uint32_t item_begin,
+                       uint32_t n_items, uint32_t* sample_cnt, const uint32_t* sample_off, Obs* samples,
+                       uint32_t* task_seed, uint32_t* task_entry, uint32_t* task_hit, uint32_t* task_list_off,
+                       uint32_t* task_row0, Counters* ctr) {
+  if (!n_items) return;
+  if (fill)
+    hipLaunchKernelGGL(k_n1_samples<true>, blocks_for(n_items, 64), dim3(64), 0, st, s, sets, n_rows, item_begin,
+                       n_items, sample_cnt, sample_off, samples, task_seed, task_entry, task_hit, task_list_off,
+                       task_row0, ctr);
+  else
+    hipLaunchKernelGGL(k_n1_samples<false>, blocks_for(n_items, 64), dim3(64), 0, st, s, sets, n_rows, item_begin,
+                       n_items, sample_cnt, sample_off, samples, task_seed, task_entry, task_hit, task_list_off,
+                       task_row0, ctr);
+}
+void launch_n1_hits(hipStream_t st, bool fill, DevScene s, SetsDev sets, uint32_t n_tasks, const Obs* samples,
+                    const uint32_t* task_row0, uint32_t* list_cnt, const uint32_t* list_ptr, Obs* hits, Counters* ctr) {
+  if (!n_tasks) return;
+  const uint64_t waves = (uint64_t)n_tasks * sets.n_views;
+  if (fill)
+    hipLaunchKernelGGL(k_n1_hits<true>, blocks_for(waves * 64, 256), dim3(256), 0, st, s, sets, n_tasks, samples,
+                       task_row0, list_cnt, list_ptr, hits, ctr);
+  else
+    hipLaunchKernelGGL(k_n1_hits<false>, blocks_for(waves * 64, 256), dim3(256), 0, st, s, sets, n_tasks, samples,
+                       task_row0, list_cnt, list_ptr, hits, ctr);
 }
 void launch_task_setup(hipStream_t st, StageAView a, const int32_t* map_view, const uint32_t* map_entry,
                        const uint32_t* map_n, TaskDesc* tasks, uint32_t* n_hyp) {

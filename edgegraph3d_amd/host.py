@@ -28,6 +28,9 @@ def lib():
         L.eg3d_synth_total_segments.argtypes = [C.c_void_p]
         L.eg3d_synth_total_segments.restype = C.c_uint64
         L.eg3d_synth_destroy.argtypes = [C.c_void_p]
+        L.eg3d_synth_polyline_curve.argtypes = [C.c_void_p]
+        L.eg3d_synth_polyline_curve.restype = D.u32p
+        L.eg3d_synth_n_curves.argtypes = [C.c_void_p]
         L.eg3d_synth_points.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(D.f32p), C.POINTER(D.u32p),
                                         C.POINTER(D.i32p), C.POINTER(D.f32p)]
         L.eg3d_host_free.argtypes = [C.c_void_p]
@@ -105,6 +108,28 @@ class Synth:
             "pl_start": D.as_np(s.pl_start, NP, np.uint32), "pl_end": D.as_np(s.pl_end, NP, np.uint32),
             "pl_valid": D.as_np(s.pl_valid, NP, np.uint8),
         }
+
+    def polyline_sets(self, max_sets=None):
+        """Synthetic "potentially compatible polylines" sets (the input of pipelines 1-2, produced in
+        the reference by the polyline matcher): one set per 3-D curve = the valid polylines of every
+        view generated from it. Returns (n_sets, row_off[n_sets*V+1], pl_ids) — a CSR over rows
+        (set * V + view), view-local polyline ids ascending per row."""
+        sc = self.scene_np()
+        V, vpo = sc["n_views"], sc["view_pl_off"]
+        NP = int(vpo[-1])
+        curve = D.as_np(lib().eg3d_synth_polyline_curve(self._h), NP, np.uint32)
+        n_sets = int(lib().eg3d_synth_n_curves(self._h))
+        if max_sets is not None:
+            n_sets = min(n_sets, max_sets)
+        nvtx = np.diff(sc["pl_vtx_off"])
+        row_off, ids = [0], []
+        for c in range(n_sets):
+            for v in range(V):
+                a, b = int(vpo[v]), int(vpo[v + 1])
+                sel = np.nonzero((curve[a:b] == c) & (sc["pl_valid"][a:b] != 0) & (nvtx[a:b] >= 2))[0]
+                ids.extend(int(i) for i in sel)
+                row_off.append(len(ids))
+        return n_sets, np.asarray(row_off, np.uint32), np.asarray(ids if ids else [0], np.uint32)[:len(ids)]
 
     def points(self, n_points, rng_seed=0xC5):
         """Config-5 workload: returns X, obs_off, obs_view, obs_xy (numpy copies)."""

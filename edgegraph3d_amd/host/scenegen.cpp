@@ -93,6 +93,8 @@ struct eg3d_synth {
   std::vector<uint8_t> F_valid;
   std::vector<uint32_t> view_pl_off, pl_vtx_off, pl_start, pl_end;
   std::vector<uint8_t> pl_valid;
+  std::vector<uint32_t> pl_curve;  // generating 3-D curve of every polyline (for synthetic polyline match sets)
+  uint32_t cur_curve = 0;
   std::vector<float> vtx_xy;
   std::vector<uint32_t> trk_off;
   std::vector<int32_t> trk_view;
@@ -240,6 +242,7 @@ static void emit_polyline(eg3d_synth* s, Rng& rng, const std::vector<float>& run
   bool invalid = rng.uni() < s->cfg.invalid_frac;
   s->pl_start.push_back(n0);
   s->pl_end.push_back(n1);
+  s->pl_curve.push_back(s->cur_curve);
   if (invalid) {
     s->pl_valid.push_back(0);
   } else {
@@ -263,6 +266,7 @@ static void make_polylines(eg3d_synth* s, Rng& rng) {
     uint32_t next_node = 0;
     const Cam& cam = s->cams[v];
     for (const Curve& c : s->curves) {
+      s->cur_curve = (uint32_t)(&c - s->curves.data());
       int ns = std::max(8, (int)std::ceil(c.length / 0.2));
       std::vector<float> run;
       bool in_run = false, whole_visible = true;
@@ -437,6 +441,8 @@ extern "C" eg3d_synth* eg3d_synth_create(const eg3d_synth_config* cfg) {
 extern "C" const eg3d_scene* eg3d_synth_scene(const eg3d_synth* s) { return &s->scene; }
 extern "C" const eg3d_seeds* eg3d_synth_seeds(const eg3d_synth* s) { return &s->seeds; }
 extern "C" const float* eg3d_synth_seed_truth(const eg3d_synth* s) { return s->seed_truth.data(); }
+extern "C" const uint32_t* eg3d_synth_polyline_curve(const eg3d_synth* s) { return s->pl_curve.data(); }
+extern "C" int eg3d_synth_n_curves(const eg3d_synth* s) { return (int)s->curves.size(); }
 extern "C" uint64_t eg3d_synth_total_segments(const eg3d_synth* s) { return s->total_segments; }
 extern "C" void eg3d_synth_destroy(eg3d_synth* s) { delete s; }
 extern "C" void eg3d_host_free(void* p) { free(p); }

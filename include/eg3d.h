@@ -167,6 +167,26 @@ void eg3d_free_candidates(eg3d_candidates* c);
 int eg3d_match_refpoints(eg3d_ctx* ctx, const eg3d_seeds* seeds, uint32_t seed_begin,
                          uint32_t seed_end, int device_only, eg3d_edgepoints* out,
                          eg3d_stage_times* times /* may be NULL */);
+/* Pipelines 1-2 extractor:
+ * find_new_3d_points_from_compatible_polylines_expandallviews_parallel
+ * (src/edgegraph3d/matching/plg_matching/polyline_matching.cpp:153-208, called per set from
+ * pipelines.cpp:98,144) with find_epipolar_correspondences (:45-73). A set of "potentially
+ * compatible polylines" is, per view, an ascending list of view-local polyline ids (the
+ * reference's vector<set<ulong>>). Every polyline of a set is sampled every 20 px from its start
+ * to its end; each sample collects the hits of its epipolar line on the set's polylines of all
+ * other views and goes through the same 3-view consensus + expand-all-views as a seed's starting
+ * hit. As in the reference's parallel build the PLGMatchesManager is not consulted
+ * (is_matched() == false: it is empty when pipelines 1-2 run and never updated inside the loop).
+ * Output as eg3d_match_refpoints, in the reference's order (set, start view, polyline id, sample);
+ * key = (sample index of the call, start view, 0, index in chain). */
+typedef struct eg3d_polyline_sets {
+  uint32_t n_sets;
+  const uint32_t* row_off; /* [n_sets * n_views + 1] CSR over rows (set * n_views + view) */
+  const uint32_t* pl_ids;  /* view-local polyline ids, ascending within a row */
+} eg3d_polyline_sets;
+int eg3d_match_polyline_sets(eg3d_ctx* ctx, const eg3d_polyline_sets* sets, uint32_t set_begin, uint32_t set_end,
+                             int device_only, eg3d_edgepoints* out, eg3d_stage_times* times);
+
 void eg3d_free_edgepoints(eg3d_edgepoints* e);
 
 /* Resident-seed variant: upload once, run many times (bench: inputs in HBM before the

@@ -36,6 +36,10 @@ const eg3d_seeds* eg3d_synth_seeds(const eg3d_synth* s);
 /* true 3-D position of each seed's curve point ([n_seeds][3]) — for sanity checks only */
 const float* eg3d_synth_seed_truth(const eg3d_synth* s);
 uint64_t eg3d_synth_total_segments(const eg3d_synth* s);
+/* index of the 3-D curve every polyline was generated from ([view_pl_off[V]], global polyline
+ * order) — ground truth for synthetic "potentially compatible polylines" sets (pipelines 1-2) */
+const uint32_t* eg3d_synth_polyline_curve(const eg3d_synth* s);
+int eg3d_synth_n_curves(const eg3d_synth* s);
 void eg3d_synth_destroy(eg3d_synth* s);
 
 /* Config 5 workload: n points with k~U[3,10] observations, X = truth + N(0, 2 mm),

@@ -34,6 +34,8 @@ def lib():
         L.orc_get_grid.argtypes = [C.c_void_p, C.c_int, C.c_int, D.u32p, D.u32p, C.POINTER(D.u32p), C.POINTER(D.u32p)]
         L.orc_match_refpoints.argtypes = [C.c_void_p, C.POINTER(D.Seeds), C.c_uint32, C.c_uint32, C.c_int,
                                           C.POINTER(D.EdgePoints), C.POINTER(Stats)]
+        L.orc_match_polyline_sets.argtypes = [C.c_void_p, C.c_uint32, D.u32p, D.u32p, C.c_uint32, C.c_uint32, C.c_int,
+                                              C.POINTER(D.EdgePoints), C.POINTER(Stats)]
         L.orc_free_edgepoints.argtypes = [C.POINTER(D.EdgePoints)]
         L.orc_candidates.argtypes = [C.c_void_p, C.POINTER(D.Seeds), C.c_uint32, C.c_uint32, C.POINTER(D.Candidates)]
         L.orc_free_candidates.argtypes = [C.POINTER(D.Candidates)]
@@ -93,6 +95,22 @@ class Oracle:
         rc = lib().orc_match_refpoints(self._h, seeds_ptr, begin, end, nthreads, C.byref(e), C.byref(st))
         if rc != 0:
             raise RuntimeError("orc_match_refpoints failed")
+        d = D.edgepoints_to_dict(e)
+        lib().orc_free_edgepoints(C.byref(e))
+        d["stats"] = {f[0]: getattr(st, f[0]) for f in Stats._fields_}
+        return d
+
+    def match_polyline_sets(self, n_sets, row_off, pl_ids, begin=0, end=None, nthreads=1):
+        """Pipelines 1-2 extractor on sets [begin, end)."""
+        if end is None:
+            end = n_sets
+        row_off = np.ascontiguousarray(row_off, np.uint32)
+        pl_ids = np.ascontiguousarray(pl_ids if len(pl_ids) else [0], np.uint32)
+        e, st = D.EdgePoints(), Stats()
+        rc = lib().orc_match_polyline_sets(self._h, n_sets, D.np_ptr(row_off, C.c_uint32), D.np_ptr(pl_ids, C.c_uint32),
+                                           begin, end, nthreads, C.byref(e), C.byref(st))
+        if rc != 0:
+            raise RuntimeError("orc_match_polyline_sets failed")
         d = D.edgepoints_to_dict(e)
         lib().orc_free_edgepoints(C.byref(e))
         d["stats"] = {f[0]: getattr(st, f[0]) for f in Stats._fields_}

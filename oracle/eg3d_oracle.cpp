@@ -108,22 +108,8 @@ static SeedView seed_view(const eg3d_seeds* s, uint32_t i) {
   return sv;
 }
 
-extern "C" int orc_match_refpoints(orc_ctx* c, const eg3d_seeds* seeds, uint32_t b, uint32_t e, int nthreads,
-                                   eg3d_edgepoints* out, orc_stats* stats) {
-  if (!c || !seeds || e > seeds->n_seeds || b > e) return -1;
-  memset(out, 0, sizeof(*out));
-  const uint32_t n = e - b;
-  std::vector<std::vector<EdgePoint>> per_seed(n);
-  if (nthreads < 1) nthreads = 1;
-  std::vector<Stats> tstats(nthreads);
-  c->sc.dir_mismatch = 0;
-  auto t0 = std::chrono::steady_clock::now();
-#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
-  for (uint32_t i = 0; i < n; i++) {
-    int t = omp_get_thread_num();
-    SeedView sv = seed_view(seeds, b + i);
-    plg_matching_from_refpoint(c->sc, sv, b + i, per_seed[i], &tstats[t]);
-  }
+static int pack_edgepoints(orc_ctx* c, std::vector<std::vector<EdgePoint>>& per_seed, std::vector<Stats>& tstats,
+                           std::chrono::steady_clock::time_point t0, eg3d_edgepoints* out, orc_stats* stats) {
   auto t1 = std::chrono::steady_clock::now();
   uint64_t np = 0, no = 0;
   for (auto& v : per_seed)
@@ -193,6 +179,52 @@ extern "C" int orc_match_refpoints(orc_ctx* c, const eg3d_seeds* seeds, uint32_t
     stats->seconds = std::chrono::duration<double>(t1 - t0).count();
   }
   return 0;
+}
+
+extern "C" int orc_match_refpoints(orc_ctx* c, const eg3d_seeds* seeds, uint32_t b, uint32_t e, int nthreads,
+                                   eg3d_edgepoints* out, orc_stats* stats) {
+  if (!c || !seeds || e > seeds->n_seeds || b > e) return -1;
+  memset(out, 0, sizeof(*out));
+  const uint32_t n = e - b;
+  std::vector<std::vector<EdgePoint>> per_seed(n);
+  if (nthreads < 1) nthreads = 1;
+  std::vector<Stats> tstats(nthreads);
+  c->sc.dir_mismatch = 0;
+  auto t0 = std::chrono::steady_clock::now();
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+  for (uint32_t i = 0; i < n; i++) {
+    int t = omp_get_thread_num();
+    SeedView sv = seed_view(seeds, b + i);
+    plg_matching_from_refpoint(c->sc, sv, b + i, per_seed[i], &tstats[t]);
+  }
+  return pack_edgepoints(c, per_seed, tstats, t0, out, stats);
+}
+
+extern "C" int orc_match_polyline_sets(orc_ctx* c, uint32_t n_sets, const uint32_t* row_off, const uint32_t* pl_ids,
+                                       uint32_t b, uint32_t e, int nthreads, eg3d_edgepoints* out, orc_stats* stats) {
+  if (!c || !row_off || !out || e > n_sets || b > e) return -1;
+  memset(out, 0, sizeof(*out));
+  const int V = (int)c->sc.plgs.size();
+  const uint32_t n = e - b;
+  std::vector<std::vector<std::vector<ulong_t>>> sets(n, std::vector<std::vector<ulong_t>>(V));
+  for (uint32_t i = 0; i < n; i++)
+    for (int v = 0; v < V; v++) {
+      const uint32_t row = (b + i) * (uint32_t)V + (uint32_t)v;
+      for (uint32_t k = row_off[row]; k < row_off[row + 1]; k++) sets[i][v].push_back(pl_ids[k]);
+    }
+  std::vector<uint32_t> base(n + 1, 0);
+  for (uint32_t i = 0; i < n; i++) base[i + 1] = base[i] + count_set_samples(c->sc, sets[i]);
+  std::vector<std::vector<EdgePoint>> per_set(n);
+  if (nthreads < 1) nthreads = 1;
+  std::vector<Stats> tstats(nthreads);
+  c->sc.dir_mismatch = 0;
+  auto t0 = std::chrono::steady_clock::now();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+  for (uint32_t i = 0; i < n; i++) {
+    int t = omp_get_thread_num();
+    match_polyline_set(c->sc, sets[i], base[i], per_set[i], &tstats[t]);
+  }
+  return pack_edgepoints(c, per_set, tstats, t0, out, stats);
 }
 
 extern "C" void orc_free_edgepoints(eg3d_edgepoints* e) {

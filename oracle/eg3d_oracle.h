@@ -28,6 +28,12 @@ int orc_get_grid(orc_ctx*, int view, int which, uint32_t* ncols, uint32_t* nrows
 /* out uses the eg3d_edgepoints layout; release with orc_free_edgepoints. nthreads<=1: serial. */
 int orc_match_refpoints(orc_ctx*, const eg3d_seeds* seeds, uint32_t seed_begin, uint32_t seed_end, int nthreads,
                         eg3d_edgepoints* out, orc_stats* stats);
+/* Pipelines 1-2 extractor: find_new_3d_points_from_compatible_polylines_expandallviews_parallel
+ * (polyline_matching.cpp:153-208) over sets [set_begin, set_end). Sets are a CSR over rows
+ * (set * n_views + view): row_off[n_sets*n_views + 1], pl_ids ascending per row. key = (sample of
+ * the call, start view, 0, index in chain). */
+int orc_match_polyline_sets(orc_ctx*, uint32_t n_sets, const uint32_t* row_off, const uint32_t* pl_ids,
+                            uint32_t set_begin, uint32_t set_end, int nthreads, eg3d_edgepoints* out, orc_stats* stats);
 void orc_free_edgepoints(eg3d_edgepoints* e);
 int orc_candidates(orc_ctx*, const eg3d_seeds* seeds, uint32_t seed_begin, uint32_t seed_end, eg3d_candidates* out);
 void orc_free_candidates(eg3d_candidates* c);

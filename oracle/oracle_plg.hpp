@@ -739,4 +739,83 @@ static inline void plg_matching_from_refpoint(const Scene& sc, const SeedView& s
   }
 }
 
+// ---- pipelines 1-2 extractor ----
+// find_new_3d_points_from_compatible_polylines_expandallviews_parallel (polyline_matching.cpp:153-208)
+// with find_epipolar_correspondences (:45-73) for ONE set of potentially compatible polylines
+// (per view, ascending polyline ids — the std::set order). Every polyline of the set is sampled
+// every SPLIT_INTERVAL_DISTANCE = 20 px from its start towards its end (polyline_matching.hpp:51);
+// each sample looks for the hits of its epipolar line on the set's polylines of every other view
+// (ALL hits, no radius) and runs the same 3-view consensus + expand-all-views as a seed's starting
+// hit. The PLGMatchesManager is not updated inside this loop in the parallel build
+// (SWITCH_RUNPARALLEL) and is empty when pipelines 1-2 run, so is_matched() is false throughout.
+// Invalid / empty polylines (for which the reference's get_start_plp() would read out of bounds)
+// are skipped. `sample_base` numbers the samples of the call; key = (sample, view, polyline, i).
+static const float SPLIT_INTERVAL_DISTANCE = (float)20.0;
+static inline uint32_t count_set_samples(const Scene& sc, const std::vector<std::vector<ulong_t>>& compat) {
+  uint32_t n = 0;
+  for (size_t v = 0; v < compat.size(); v++)
+    for (ulong_t pl_id : compat[v]) {
+      const polyline& pl = sc.plgs[v].polylines[pl_id];
+      if (!pl.valid || pl.polyline_coords.size() < 2) continue;
+      bool reached;
+      pl_point plp = pl.next_pl_point_by_distance(pl.get_start_plp(), pl.end, SPLIT_INTERVAL_DISTANCE, reached);
+      while (!reached) {
+        n++;
+        plp = pl.next_pl_point_by_distance(plp, pl.end, SPLIT_INTERVAL_DISTANCE, reached);
+      }
+    }
+  return n;
+}
+static inline void match_polyline_set(const Scene& sc, const std::vector<std::vector<ulong_t>>& compat,
+                                      uint32_t sample_base, std::vector<EdgePoint>& res, Stats* st) {
+  const int V = (int)sc.plgs.size();
+  uint32_t sample = sample_base;
+  for (int starting_plg_id = 0; starting_plg_id < V; starting_plg_id++)
+    for (ulong_t starting_polyline_id : compat[starting_plg_id]) {
+      const polyline& pl = sc.plgs[starting_plg_id].polylines[starting_polyline_id];
+      if (!pl.valid || pl.polyline_coords.size() < 2) continue;
+      bool reached_end;
+      pl_point plp = pl.next_pl_point_by_distance(pl.get_start_plp(), pl.end, SPLIT_INTERVAL_DISTANCE, reached_end);
+      while (!reached_end) {
+        const plg_point starting_plgp(starting_polyline_id, plp);
+        if (st) {
+          st->n_tasks++;
+          st->bytes_algorithmic += 8 + (uint64_t)V * 64 + (uint64_t)(V - 1) * 72;
+        }
+        // find_epipolar_correspondences
+        std::vector<std::vector<plg_point>> epc;
+        for (int other = 0; other < V; other++) {
+          std::vector<plg_point> filtered;
+          if (other == starting_plg_id) {
+            filtered.push_back(starting_plgp);
+          } else {
+            float epi[3];
+            if (computeCorrespondEpilineSinglePoint(sc.cams, starting_plg_id, other, starting_plgp.plp.coords, epi))
+              for (ulong_t other_pl : compat[other]) {
+                const polyline& opl = sc.plgs[other].polylines[other_pl];
+                if (st) st->bytes_algorithmic += 8ull * opl.polyline_coords.size();
+                std::vector<pl_point> pis = opl.intersect_line(epi);
+                for (auto& p : pis) filtered.push_back(plg_point(other_pl, p));
+              }
+          }
+          epc.push_back(filtered);
+        }
+        std::vector<P3> chain = compute_3D_point_multiple_views(sc, starting_plg_id, epc, st);
+        if (!chain.empty() && st) st->n_chains++;
+        for (size_t c = 0; c < chain.size(); c++) {
+          EdgePoint e;
+          e.p = chain[c];
+          e.key[0] = sample;
+          e.key[1] = (uint32_t)starting_plg_id;
+          e.key[2] = 0;
+          e.key[3] = (uint32_t)c;
+          if (st) st->bytes_algorithmic += 12 + (uint64_t)chain[c].obs.size() * 20;
+          res.push_back(e);
+        }
+        sample++;
+        plp = pl.next_pl_point_by_distance(plp, pl.end, SPLIT_INTERVAL_DISTANCE, reached_end);
+      }
+    }
+}
+
 }  // namespace orc

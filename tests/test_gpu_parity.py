@@ -162,3 +162,26 @@ def test_reference_surface_shim_on_gpu(have_gpu, tmp_path):
                            "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-L", "/opt/rocm/lib", "-lamdhip64", "-o", exe])
     out = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+def test_polyline_sets_extractor_parity(have_gpu, cfg):
+    """SURVEY N1 (pipelines 1-2): polyline sets -> 20 px samples -> epipolar hits on the set ->
+    3-view consensus + expand-all-views, against the oracle's restatement of
+    polyline_matching.cpp:45-73,153-208. Sets = the polylines of each synthetic 3-D curve."""
+    s = host.Synth(cfg)
+    n, row_off, ids = s.polyline_sets()
+    ctx = api.Context(s.scene)
+    got = ctx.match_polyline_sets(n, row_off, ids)
+    ref = _oracle(s.scene).match_polyline_sets(n, row_off, ids, nthreads=16)
+    rep = compare_edgepoints(ref, got, rel_tol=1e-4)
+    assert rep["ok"], rep["msgs"]
+    assert got["n_tasks"] == ref["stats"]["n_tasks"] and got["n_chains"] == ref["stats"]["n_chains"]
+    assert got["n_points"] > 0 and (got["flags"] & 7) == 0
+    assert got["times"]["bytes_algorithmic"] == ref["stats"]["bytes_algorithmic"]
+    # a sub-range of sets is the corresponding slice of the whole (sets are independent)
+    if n >= 4:
+        part = ctx.match_polyline_sets(n, row_off, ids, 1, 3)
+        refp = _oracle(s.scene).match_polyline_sets(n, row_off, ids, 1, 3, nthreads=8)
+        assert compare_edgepoints(refp, part, rel_tol=1e-4)["ok"]
+    ctx.close()
