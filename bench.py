@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=3,
                     help="independent steps kept in flight per GPU, each on its own context/HIP stream driven by its "
                          "own host thread (1 = strictly one step at a time)")
+    ap.add_argument("--path", choices=["refpoints", "sets"], default="refpoints",
+                    help="refpoints = pipeline 3 (the headline path); sets = the pipelines 1-2 extractor (SURVEY N1) on "
+                         "one synthetic polyline set per 3-D curve (single GPU only)")
     ap.add_argument("--cpu-runs", type=int, default=5)
     ap.add_argument("--cpu-seeds", type=int, default=0,
                     help="bound the CPU baseline to the first K seeds of the workload (0 = all); its rate is "
@@ -94,6 +97,9 @@ def main():
     cfg.n_seeds = per_gpu * world  # same scene on every rank; rank r owns seeds [r*per_gpu, (r+1)*per_gpu)
     synth = host.Synth(cfg)
     b, e = rank * per_gpu, (rank + 1) * per_gpu
+    sets = synth.polyline_sets() if args.path == "sets" else None
+    if sets is not None and world > 1:
+        raise SystemExit("bench.py --path sets is a single-GPU measurement")
     inflight = max(1, args.inflight)
 
     # One context (own HIP stream, own work buffers) + one host thread per step in flight: the
@@ -117,7 +123,10 @@ def main():
         def run(self):
             while self.todo.get() is not None:
                 try:
-                    self.done.put(self.ctx.match_resident(b, e, device_only=True))
+                    if sets is not None:
+                        self.done.put(self.ctx.match_polyline_sets(sets[0], sets[1], sets[2], device_only=True))
+                    else:
+                        self.done.put(self.ctx.match_resident(b, e, device_only=True))
                 except Exception as ex:  # surfaced by the main thread
                     self.done.put(ex)
 
@@ -219,8 +228,11 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "steps_in_flight": inflight,
             "config": {
-                "workload": "C%d synthetic: %d views / %d seeds per GPU / %.0f polyline segments per view"
-                            % (args.config, synth.n_views, per_gpu, synth.total_segments / synth.n_views),
+                "workload": ("C%d synthetic: %d views / %d seeds per GPU / %.0f polyline segments per view"
+                             % (args.config, synth.n_views, per_gpu, synth.total_segments / synth.n_views))
+                if sets is None else
+                ("C%d synthetic, pipelines 1-2 extractor: %d views / %d polyline sets (%d polylines) / %.0f segments "
+                 "per view" % (args.config, synth.n_views, sets[0], len(sets[2]), synth.total_segments / synth.n_views)),
                 "edge_points_per_step": int(total_points), "observations_per_step_rank0": int(last["n_obs"]),
                 "tasks": int(last["n_tasks"]), "hypotheses": int(last["n_hypotheses"]), "chains": int(last["n_chains"]),
                 "parallelism": "seed-shard x%d%s" % (world, " + RCCL all-gather of the cloud" if world > 1 else ""),
@@ -236,21 +248,31 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             from oracle import binding as ob   # cpu_baseline leg: the checker timed as the CPU port
             orc = ob.Oracle(synth.scene)
-            orc.match(synth.seeds, b, min(e, b + 200), 1)  # warm-up
+            if sets is not None:
+                def cpu_run(lo, hi, nthreads):
+                    return orc.match_polyline_sets(sets[0], sets[1], sets[2], lo, hi, nthreads)
+                b, e = 0, sets[0]
+                warm = min(e, 2)
+            else:
+                def cpu_run(lo, hi, nthreads):
+                    return orc.match(synth.seeds, lo, hi, nthreads)
+                warm = min(e, b + 200)
+            cpu_run(b, warm, 1)  # warm-up
             ce = e if not args.cpu_seeds else min(e, b + args.cpu_seeds)
             secs, pts = [], 0
             for _ in range(max(1, args.cpu_runs)):
-                r = orc.match(synth.seeds, b, ce, 1)
+                r = cpu_run(b, ce, 1)
                 secs.append(r["stats"]["seconds"])
                 pts = r["n_points"]
             med = statistics.median(secs)
             ncores = os.cpu_count() or 1
-            rall = orc.match(synth.seeds, b, ce, ncores)
+            rall = cpu_run(b, ce, ncores)
             line["cpu_baseline"] = {
                 "value": pts / med, "unit": "edge-points/s", "cores": 1, "kind": "port",
-                "sample": "%s of the N=1 workload (%d seeds, %d edge-points), oracle -O3, 1 thread, median of %d runs "
+                "sample": "%s of the N=1 workload (%d %s, %d edge-points), oracle -O3, 1 thread, median of %d runs "
                           "(%.2f s each); scene/grid construction excluded"
-                          % ("all" if ce == e else "first %d seeds" % (ce - b), ce - b, pts, len(secs), med),
+                          % ("all" if ce == e else "first %d" % (ce - b), ce - b, "sets" if sets is not None else "seeds",
+                             pts, len(secs), med),
                 "all_cores": {"value": rall["n_points"] / rall["stats"]["seconds"], "cores": ncores},
                 "same_point_count_as_gpu": (bool(pts == total_points) if ce == e else None),
                 "oracle_algorithmic_bytes": int(r["stats"]["bytes_algorithmic"]),

@@ -6,6 +6,8 @@
 //        include/edgegraph3d/matching/plg_matching/plg_matching_from_refpoints.hpp:53,55
 //   PLGEdgeManager(imgs, sfmd, F, plgs, 10, 3)  +  detect_nearby_intersections_and_correspondences_plgp(int)
 //        include/edgegraph3d/edge_managers/plg_edge_manager.hpp:74,80
+//   find_new_3d_points_from_compatible_polylines_expandallviews_parallel(sfmd, ..., potentially_compatible_polylines, ...)
+//        include/edgegraph3d/matching/plg_matching/polyline_matching.hpp:55-56
 //   gaussNewtonFiltering(SfMData&, std::vector<bool>&, float)
 //        include/edgegraph3d/filtering/gauss_newton.hpp:20
 //
@@ -18,6 +20,7 @@
 #include <array>
 #include <atomic>
 #include <cstdint>
+#include <set>
 #include <string>
 #include <thread>
 #include <tuple>
@@ -228,6 +231,40 @@ class PLGEdgeManager {
     return res;
   }
 
+  // find_new_3d_points_from_compatible_polylines_expandallviews_parallel for ONE set of potentially
+  // compatible polylines (per view: the reference's set<ulong> of polyline ids), as
+  // pipelines.cpp:98,144 call it once per polyline match.
+  std::vector<new_3dpoint_plgp_matches> match_polyline_set(const std::vector<std::set<unsigned long>>& compat) {
+    std::vector<new_3dpoint_plgp_matches> res;
+    if (!ctx_) return res;
+    std::vector<uint32_t> row_off(1, 0), ids;
+    for (const auto& per_view : compat) {
+      for (unsigned long id : per_view) ids.push_back((uint32_t)id);
+      row_off.push_back((uint32_t)ids.size());
+    }
+    if (ids.empty()) ids.push_back(0);
+    eg3d_polyline_sets ps;
+    ps.n_sets = 1;
+    ps.row_off = row_off.data();
+    ps.pl_ids = ids.data();
+    eg3d_edgepoints e;
+    status_ = eg3d_match_polyline_sets(ctx_, &ps, 0, 1, 0, &e, nullptr);
+    if (status_ == EG3D_OK) {
+      res.reserve(e.n_points);
+      for (uint64_t i = 0; i < e.n_points; i++) {
+        std::vector<PolyLineGraph2D::plg_point> obs;
+        std::vector<int> views;
+        for (uint32_t j = e.obs_off[i]; j < e.obs_off[i + 1]; j++) {
+          obs.push_back({e.obs_pl[j], {e.obs_seg[j], {e.obs_xy[2 * j], e.obs_xy[2 * j + 1]}}});
+          views.push_back(e.obs_view[j]);
+        }
+        res.emplace_back(vec3{e.X[3 * i], e.X[3 * i + 1], e.X[3 * i + 2]}, std::move(obs), std::move(views));
+      }
+      eg3d_free_edgepoints(&e);
+    }
+    return res;
+  }
+
  private:
   eg3d_seeds seeds_struct() {
     eg3d_seeds s;
@@ -269,6 +306,14 @@ inline std::vector<new_3dpoint_plgp_matches> plg_matching_from_refpoints_paralle
 }
 inline std::vector<new_3dpoint_plgp_matches> plg_matching_from_refpoints(const SfMData& s, PLGEdgeManager* em) {
   return plg_matching_from_refpoints_parallel(s, em);
+}
+
+// find_new_3d_points_from_compatible_polylines_expandallviews[_parallel]
+// (include/edgegraph3d/matching/plg_matching/polyline_matching.hpp:55-56): plgs, F, the matches
+// manager and the grid maps of the reference signature live in the edge manager.
+inline std::vector<new_3dpoint_plgp_matches> find_new_3d_points_from_compatible_polylines_expandallviews_parallel(
+    const SfMData&, PLGEdgeManager* em, const std::vector<std::set<unsigned long>>& potentially_compatible_polylines) {
+  return em->match_polyline_set(potentially_compatible_polylines);
 }
 
 // gaussNewtonFiltering(SfMData&, vector<bool>&, float): mutates points_ of the inliers in place.

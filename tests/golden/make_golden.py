@@ -39,5 +39,20 @@ def make(cfg_index, name):
     print(name, "points", r["n_points"], "obs", r["n_obs"])
 
 
+def make_sets(cfg_index, name, max_sets):
+    """Pipelines 1-2 extractor: the first `max_sets` synthetic polyline sets of the
+    scene `cfg_index` (the scene itself is pinned by synthetic_tiny_v1.npz) and the oracle's output."""
+    s = host.Synth(cfg_index)
+    n, row_off, ids = s.polyline_sets(max_sets)
+    r = ob.Oracle(s.scene).match_polyline_sets(n, row_off, ids, 0, n, 1)
+    out = {"n_sets": np.int64(n), "row_off": row_off, "pl_ids": ids}
+    for k in ("X", "obs_off", "obs_view", "obs_pl", "obs_seg", "obs_xy", "key"):
+        out["out_" + k] = r[k]
+    out["out_counts"] = np.array([r["stats"]["n_tasks"], r["stats"]["n_chains"], r["flags"]], np.int64)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(name, "sets", n, "points", r["n_points"], "obs", r["n_obs"])
+
+
 if __name__ == "__main__":
     make(0, "synthetic_tiny_v1.npz")
+    make_sets(0, "synthetic_tiny_sets_v1.npz", 3)

@@ -102,6 +102,35 @@ int main(int argc, char** argv) {
       }
     }
   }
+  // pipelines 1-2 extractor through the reference's signature: the polylines of curves 0 and 1
+  {
+    const uint32_t* curve = eg3d_synth_polyline_curve(syn);
+    for (uint32_t cid = 0; cid < 2 && !bad; cid++) {
+      std::vector<std::set<unsigned long>> compat(V);
+      std::vector<uint32_t> row_off(1, 0), ids;
+      for (int v = 0; v < V; v++) {
+        for (uint32_t p = sc->view_pl_off[v]; p < sc->view_pl_off[v + 1]; p++)
+          if (curve[p] == cid && sc->pl_valid[p] && sc->pl_vtx_off[p + 1] - sc->pl_vtx_off[p] >= 2) {
+            compat[v].insert(p - sc->view_pl_off[v]);
+            ids.push_back(p - sc->view_pl_off[v]);
+          }
+        row_off.push_back((uint32_t)ids.size());
+      }
+      auto via_shim = find_new_3d_points_from_compatible_polylines_expandallviews_parallel(sfm, &em, compat);
+      eg3d_polyline_sets ps{1, row_off.data(), ids.empty() ? row_off.data() : ids.data()};
+      eg3d_edgepoints d;
+      if (eg3d_match_polyline_sets(ctx, &ps, 0, 1, 0, &d, nullptr) != EG3D_OK || via_shim.size() != d.n_points) {
+        bad++;
+        break;
+      }
+      for (uint64_t i = 0; i < d.n_points; i++)
+        if (std::memcmp(&std::get<0>(via_shim[i]), d.X + 3 * i, 12) != 0 ||
+            std::get<1>(via_shim[i]).size() != d.obs_off[i + 1] - d.obs_off[i])
+          bad++;
+      std::printf("set %u: %llu points via shim and C ABI\n", cid, (unsigned long long)d.n_points);
+      eg3d_free_edgepoints(&d);
+    }
+  }
   // stage A through the reference's per-point entry
   auto cand = em.detect_nearby_intersections_and_correspondences_plgp(0);
   std::printf("%s points=%llu shim_batched=%zu shim_single=%zu track0_entries=%zu\n", bad ? "FAIL" : "OK",

