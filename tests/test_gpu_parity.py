@@ -185,3 +185,39 @@ def test_polyline_sets_extractor_parity(have_gpu, cfg):
         refp = _oracle(s.scene).match_polyline_sets(n, row_off, ids, 1, 3, nthreads=8)
         assert compare_edgepoints(refp, part, rel_tol=1e-4)["ok"]
     ctx.close()
+
+
+def test_full_size_properties_dtu006_shaped(have_gpu):
+    """BASELINE-size run (C3': 25 views / 6268 seeds / ~15k segments per view, 1.7 M edge-points) checked
+    through size-independent properties instead of the oracle: run-to-run determinism (bitwise),
+    seed-range concatenation, ordering of the emission keys, well-formed observation lists, and a
+    40-seed window of it against the oracle."""
+    s = host.Synth(3)
+    n = s.n_seeds
+    ctx = api.Context(s.scene)
+    ctx.upload_seeds(s.seeds)
+    full = ctx.match_resident(0, n)
+    again = ctx.match_resident(0, n)
+    for k in ("X", "obs_xy"):
+        assert np.array_equal(full[k].view(np.uint32), again[k].view(np.uint32)), k
+    for k in ("key", "obs_off", "obs_view", "obs_pl", "obs_seg"):
+        assert np.array_equal(full[k], again[k]), k
+    cut = n // 3
+    a, b = ctx.match_resident(0, cut), ctx.match_resident(cut, n)
+    assert a["n_points"] + b["n_points"] == full["n_points"] > 1000000
+    assert np.array_equal(np.concatenate([a["X"], b["X"]]).view(np.uint32), full["X"].view(np.uint32))
+    assert np.array_equal(np.concatenate([a["key"], b["key"]]), full["key"])
+    key = full["key"].astype(np.int64)
+    order = key[:, 0] * (1 << 40) + key[:, 1] * (1 << 30) + key[:, 2] * (1 << 20) + key[:, 3]
+    assert (np.diff(order) > 0).all(), "emission order (seed, entry, hit, index) is strictly increasing"
+    off = full["obs_off"].astype(np.int64)
+    m = np.diff(off)
+    assert (m >= 3).all()   # (a view may legitimately appear twice on a point: the oracle agrees on those)
+    assert np.isfinite(full["X"]).all()
+    assert ((full["obs_view"] >= 0) & (full["obs_view"] < s.n_views)).all()
+    assert (full["flags"] & 7) == 0
+    lo = 3000
+    ref = _oracle(s.scene).match(s.seeds, lo, lo + 40, nthreads=16)
+    win = ctx.match_resident(lo, lo + 40)
+    assert compare_edgepoints(ref, win, rel_tol=1e-4)["ok"]
+    ctx.close()
