@@ -425,7 +425,10 @@ struct HTeam4 {
 };
 
 template <class Team>
-__global__ void __launch_bounds__(256) k3a_hypotheses(DevScene s, StageAView a, const TaskDesc* tasks,
+#ifndef EG3D_K3A_WAVES
+#define EG3D_K3A_WAVES 3 /* waves/SIMD the register allocation of K3a aims at (3: co-resides better with K3b waves of other steps in flight; measured C3 81 -> 77 ms, neutral alone) */
+#endif
+__global__ void __launch_bounds__(256, EG3D_K3A_WAVES) k3a_hypotheses(DevScene s, StageAView a, const TaskDesc* tasks,
                                                      const uint32_t* hyp_off, uint32_t n_hyp, HypResult* res,
                                                      HPoint* scratch, uint32_t hyp_cap, HPoint* arena,
                                                      uint32_t arena_cap, Counters* ctr) {
