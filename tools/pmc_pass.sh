@@ -1,9 +1,10 @@
 #!/bin/bash
 # usage (GPU box): tools/pmc_pass.sh <name> "<bench args>" COUNTER [COUNTER...]   -> gpurun_out/pmc_<name>.txt
+# NOTE: one derived counter family per pass (FETCH_SIZE and WRITE_SIZE together exceed the hardware and rocprofv3 then hangs in its abort handler)
 name=$1; shift; args=$1; shift
 out=$PWD/gpurun_out; mkdir -p $out/tmp; export TMPDIR=$out/tmp
 rm -rf $out/prof_$name
-rocprofv3 --kernel-trace --pmc "$@" -d $out/prof_$name -o x -- python bench.py $args > $out/prof_$name.out 2> $out/prof_$name.err
+timeout -k 5 300 rocprofv3 --kernel-trace --pmc "$@" -d $out/prof_$name -o x -- python bench.py $args > $out/prof_$name.out 2> $out/prof_$name.err
 echo "rc=$?"
 python - <<PY
 import sqlite3,collections,glob

@@ -11,7 +11,7 @@ export TMPDIR=$out/tmp; mkdir -p $TMPDIR
 run() { # name, rocprof flags...
   local name=$1; shift
   rm -rf $out/prof_$name
-  rocprofv3 "$@" -d $out/prof_$name -o $tag -- python bench.py $args > $out/prof_$name.out 2> $out/prof_$name.err
+  timeout -k 5 600 rocprofv3 "$@" -d $out/prof_$name -o $tag -- python bench.py $args > $out/prof_$name.out 2> $out/prof_$name.err
   echo "pass $name rc=$?"
 }
 run kt --kernel-trace --stats
