@@ -9,11 +9,14 @@
 //   k2_epipolar_hits  1 WAVE / task         epiline x candidate polylines, ballot/popcount
 //                                           ordered compaction (count pass + fill pass)
 //   k_task_setup      1 lane / task         3-view selection, hypothesis count
-//   k3a_hypotheses    1 lane / hypothesis   orientation + following (wave-synchronous batches)
+//   k3a_hypotheses    1 or 4 lanes / hypothesis  orientation + following (4-lane teams when latency-bound)
 //   k3s_select        1 lane / task         uniqueness rule -> chain seeds
 //   k3b_expand        1 WAVE / chain        expand-all-views (wave-cooperative Gauss-Newton)
 //   k4_emit           1 WAVE / chain        ordered SoA output (wave prefix sum of obs counts)
 //   k5_gn_filter      1 lane / point        config 5, FP32 Gauss-Newton outlier filter
+// Pipelines 1-2 extractor, stage A' feeding the same task_setup..k4 stages:
+//   k_n1_samples      1 lane / polyline     a sample every 20 px (count pass + fill pass), 1 task each
+//   k_n1_hits         1 WAVE / (task, view) epiline x the set's polylines of that view, all hits
 // All arithmetic follows the contract in DESIGN.md (no FMA contraction: -ffp-contract=off).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
