@@ -446,10 +446,12 @@ EG3D_HD int follow_front(const Team& tm, const DevScene& s, Chain& c) {
 // points ci-1, ci-2, ... >= lo (towards_start) or ci+1, ... < hi; for each take the next hit of
 // the epipolar line of the point's FIRST observation. Walk positions do not depend on the
 // solver, so all candidates are generated first; returns how many walks succeeded.
-template <class PlT, class EpiPtr>
+// walk(pl, from, direction, a, b, c, out) = the unbounded next-hit walk (walk_by_line, or a team's
+// segment-parallel version of it).
+template <class PlT, class EpiPtr, class WalkFn>
 EG3D_HD int walk_side_candidates_core(const DevScene& s, Chain& c, const PlT& pl, EpiPtr epi, int n_epi, int view,
                                       const Obs& from, uint32_t direction, int lo, int ci, int hi, bool towards_start,
-                                      Pending* out) {
+                                      Pending* out, WalkFn walk) {
   int cnt = 0;
   int t = 0;
   PlPt actual;
@@ -475,7 +477,7 @@ EG3D_HD int walk_side_candidates_core(const DevScene& s, Chain& c, const PlT& pl
     }
     t++;
     PlPt nx;
-    uint32_t w = walk_by_line(pl, actual, direction, la, lb, lc, false, 0.0f, 0.0f, nx);
+    uint32_t w = walk(pl, actual, direction, la, lb, lc, nx);
     if (w & WALK_BAD_DIR) c.flags |= 8u;
     if (!(w & WALK_FOUND)) break;
     Pending& pd = out[cnt++];
@@ -497,7 +499,10 @@ EG3D_HD int TeamSeq::side_walk(const DevScene& s, Chain& c, int view, const Obs&
                                int ci, int hi, bool towards_start, Pending* out) const {
   const PlRef pl = polyline_of(s, view, from.pl);
   return walk_side_candidates_core(s, c, pl, (const float*)nullptr, 0, view, from, direction, lo, ci, hi,
-                                   towards_start, out);
+                                   towards_start, out,
+                                   [](const PlRef& p, const PlPt& a, uint32_t d, float la, float lb, float lc, PlPt& nx) {
+                                     return walk_by_line(p, a, d, la, lb, lc, false, 0.0f, 0.0f, nx);
+                                   });
 }
 
 // Side walk, phase 2 (PARALLEL over candidates): ADD-solve candidate j against chain point

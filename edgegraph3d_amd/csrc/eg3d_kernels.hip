@@ -556,15 +556,70 @@ struct TeamWave {
     }
     __syncthreads();
     const lds_fp epi = (lds_fp)&L->walk.epi[0][0];
+    // next hit of the line towards `direction`, SEGMENT-PARALLEL: lane 0 tests the partial segment
+    // from the current position, lane k the k-th whole segment beyond it; the first lane (walking
+    // order) whose test reports a hit or a quasi-parallel stop decides — exactly the sequential
+    // scan of walk_by_line, one test deep instead of one per segment
+    auto walk = [](const auto& p, const PlPt& from, uint32_t dir, float la, float lb, float lc, PlPt& nx) -> uint32_t {
+      const bool to_start = dir == p.start;
+      if (!to_start && dir != p.end) return WALK_BAD_DIR;  // Q15
+      const LineDir ld = line_dir(la, lb);
+      const uint32_t lane = threadIdx.x & 63u;
+      // candidates in walking order: towards start: 1 + from.seg ; towards end: 1 + (n - 2 - from.seg)
+      const uint32_t total = 1u + (to_start ? from.seg : (p.n - 2u - from.seg));
+      for (uint32_t k0 = 0; k0 < total; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        uint32_t r = 0, seg = 0;
+        float hx = 0.f, hy = 0.f;
+        if (k < total) {
+          float x1, y1, x2, y2;
+          if (k == 0) {
+            x1 = from.x;
+            y1 = from.y;
+            const uint32_t vi = to_start ? from.seg : from.seg + 1u;
+            x2 = p.v[vi].x;
+            y2 = p.v[vi].y;
+            seg = from.seg;
+          } else if (to_start) {
+            const uint32_t i = from.seg - (k - 1u);  // segment (v[i], v[i-1]), i >= 1
+            x1 = p.v[i].x;
+            y1 = p.v[i].y;
+            x2 = p.v[i - 1].x;
+            y2 = p.v[i - 1].y;
+            seg = i - 1u;
+          } else {
+            const uint32_t i = from.seg + k;  // segment (v[i], v[i+1]), i <= n-2
+            x1 = p.v[i].x;
+            y1 = p.v[i].y;
+            x2 = p.v[i + 1].x;
+            y2 = p.v[i + 1].y;
+            seg = i;
+          }
+          r = seg_line_hit_guarded(x1, y1, x2, y2, la, lb, lc, ld, hx, hy);
+        }
+        const unsigned long long any = __ballot(r != 0);
+        if (any) {
+          const int f = __ffsll((long long)any) - 1;
+          const uint32_t rf = (uint32_t)__shfl((int)r, f);
+          if (rf & 2u) return WALK_QUASIPARALLEL;
+          nx.seg = (uint32_t)__shfl((int)seg, f);
+          nx.x = __shfl(hx, f);
+          nx.y = __shfl(hy, f);
+          return WALK_FOUND;
+        }
+      }
+      return WALK_EXTREME;
+    };
     if (fits) {
       PlRefT<lds_f2p> pls;
       pls.v = (lds_f2p)&L->walk.vtx[0];
       pls.n = pl.n;
       pls.start = pl.start;
       pls.end = pl.end;
-      return walk_side_candidates_core(s, c, pls, epi, staged, view, from, direction, lo, ci, hi, towards_start, out);
+      return walk_side_candidates_core(s, c, pls, epi, staged, view, from, direction, lo, ci, hi, towards_start, out,
+                                       walk);
     }
-    return walk_side_candidates_core(s, c, pl, epi, staged, view, from, direction, lo, ci, hi, towards_start, out);
+    return walk_side_candidates_core(s, c, pl, epi, staged, view, from, direction, lo, ci, hi, towards_start, out, walk);
   }
   // uniform section: all lanes hold the same (a, n, X0) and receive the same answer
   __device__ __forceinline__ bool gn_array(const DevScene& s, const Obs* a, int n, const double X0[3],
