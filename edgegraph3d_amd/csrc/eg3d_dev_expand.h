@@ -169,6 +169,7 @@ EG3D_HD bool add_observation_solve(const DevScene& s, const Chain& c, const Chai
 // wavefront team spreads the observations of the solves over its lanes (eg3d_dev_coopgn.h).
 struct TeamSeq {
   static constexpr bool kSlotStep = false;  // N-view step: plain sequential candidates
+  static constexpr bool kSpecFollow = false; // chain following: one step at a time
   EG3D_HD int lane() const { return 0; }
   EG3D_HD int size() const { return 1; }
   EG3D_HD void sync() const {}
@@ -219,10 +220,8 @@ struct TeamSeqSlots : TeamSeq {
 // (5..20 px) epipolar walk — PARALLEL over the observations, the survivors compacted in
 // observation order. Returns the number of observations collected in sel (0 = candidate dead).
 template <class Team>
-EG3D_HD int stepn_walks(const Team& tm, const DevScene& s, const Chain& c, const ChainPt& cur, int st,
-                        const uint32_t* dirs, Obs* sel, int sel_cap, uint32_t& flags) {
-  const int n = (int)cur.nobs;
-  const Obs* co_all = c.pool + cur.off;
+EG3D_HD int stepn_walks(const Team& tm, const DevScene& s, const Obs* co_all, int n, int st, const uint32_t* dirs,
+                        Obs* sel, int sel_cap, uint32_t& flags) {
   const Obs so = co_all[st];
   PlRef ps = polyline_of(s, so.view, so.pl);
   PlPt p, q;
@@ -334,7 +333,7 @@ EG3D_HD int stepn_chain(const Team& tm, const DevScene& s, Chain& c, const Chain
   if (n > EG3D_STEP_OBS || !Team::kSlotStep) {
     for (int st = 0; st < n; st++) {
       const uint64_t tw0 = EG3D_TICK();
-      int m = stepn_walks(tm, s, c, cur, st, dirs, c.tmp_a, c.tmp_cap, c.flags);
+      int m = stepn_walks(tm, s, c.pool + cur.off, n, st, dirs, c.tmp_a, c.tmp_cap, c.flags);
       c.tsec[1] += EG3D_TICK() - tw0;
       if (!m) continue;
       if (triangulate_array_team(tm, s, c.tmp_a, m, Xout, c.flags, c.tsec)) return m;
@@ -347,7 +346,7 @@ EG3D_HD int stepn_chain(const Team& tm, const DevScene& s, Chain& c, const Chain
   for (int st = tm.lane(); st < n; st += tm.size()) {
     StepSlot& sl = c.slots[st];
     uint32_t fl = 0;
-    sl.m = stepn_walks(TeamSeq(), s, c, cur, st, dirs, sl.sel, EG3D_STEP_OBS, fl);
+    sl.m = stepn_walks(TeamSeq(), s, c.pool + cur.off, n, st, dirs, sl.sel, EG3D_STEP_OBS, fl);
     sl.flags = fl;
     sl.ok = 0;
   }
@@ -386,6 +385,16 @@ EG3D_HD int stepn_chain(const Team& tm, const DevScene& s, Chain& c, const Chain
   return 0;
 }
 
+EG3D_HD bool new_point_from_list(Chain& c, ChainPt& np, const Obs* list, int m, const float X[3]) {
+  np.X[0] = X[0];
+  np.X[1] = X[1];
+  np.X[2] = X[2];
+  point_init(np);
+  if (!point_reserve(c, np, (uint32_t)m + 1)) return false;
+  for (int i = 0; i < m; i++)
+    if (!pool_append(c, np, list[i])) return false;
+  return true;
+}
 EG3D_HD bool new_point_from_tmp(Chain& c, ChainPt& np, int m, const float X[3]) {
   np.X[0] = X[0];
   np.X[1] = X[1];
@@ -397,44 +406,29 @@ EG3D_HD bool new_point_from_tmp(Chain& c, ChainPt& np, int m, const float X[3]) 
   return true;
 }
 
-// Grow the chain at the back / at the front while steps succeed. Returns points added.
+// Grow the chain at its front (towards start_dirs) or back (towards end_dirs) while N-view steps
+// succeed (follow_direction_vector_start / _end, plg_matching.cpp:771-795). Returns points added.
 template <class Team>
-EG3D_HD int follow_back(const Team& tm, const DevScene& s, Chain& c) {
+EG3D_HD int follow_end(const Team& tm, const DevScene& s, Chain& c, bool front) {
+  if constexpr (Team::kSpecFollow) return tm.follow(s, c, front);
   int added = 0;
   for (;;) {
     float X[3];
-    int m = stepn_chain(tm, s, c, chain_at(c, c.len - 1), c.end_dirs, X);
+    int m = stepn_chain(tm, s, c, front ? chain_at(c, 0) : chain_at(c, c.len - 1), front ? c.start_dirs : c.end_dirs, X);
     if (m == 0) break;
-    if (c.head + c.len >= c.cap_pts) {
+    if (front ? (c.head <= 0) : (c.head + c.len >= c.cap_pts)) {
       c.flags |= 1u;
       break;
     }
     ChainPt np;
     const uint64_t tn0 = EG3D_TICK();
     if (!new_point_from_tmp(c, np, m, X)) break;
-    c.pts[c.head + c.len] = np;
-    c.tsec[11] += EG3D_TICK() - tn0;
-    c.len++;
-    added++;
-  }
-  return added;
-}
-template <class Team>
-EG3D_HD int follow_front(const Team& tm, const DevScene& s, Chain& c) {
-  int added = 0;
-  for (;;) {
-    float X[3];
-    int m = stepn_chain(tm, s, c, chain_at(c, 0), c.start_dirs, X);
-    if (m == 0) break;
-    if (c.head <= 0) {
-      c.flags |= 1u;
-      break;
+    if (front) {
+      c.head--;
+      c.pts[c.head] = np;
+    } else {
+      c.pts[c.head + c.len] = np;
     }
-    ChainPt np;
-    const uint64_t tn0 = EG3D_TICK();
-    if (!new_point_from_tmp(c, np, m, X)) break;
-    c.head--;
-    c.pts[c.head] = np;
     c.tsec[11] += EG3D_TICK() - tn0;
     c.len++;
     added++;
@@ -645,15 +639,21 @@ EG3D_HD bool attach_view(const Team& tm, const DevScene& s, Chain& c, const Obs&
   to_end = n2;
   uint64_t tf0 = EG3D_TICK();
   c.tsec[8] += tf0 - tcm0;
-  if (n1 > 0 && n1 == ci) {
-    c.start_dirs[view] = nd1;
-    int g = follow_front(tm, s, c);
-    to_start += g;
-    ci += g;
-  }
-  if (n2 > 0 && n2 == (c.len - ci - 1)) {
-    c.end_dirs[view] = nd2;
-    to_end += follow_back(tm, s, c);
+  // grow the chain at the front, then at the back (one call site: the following code is large)
+  for (int side = 0; side < 2; side++) {
+    const bool front = side == 0;
+    if (front ? !(n1 > 0 && n1 == ci) : !(n2 > 0 && n2 == (c.len - ci - 1))) continue;
+    if (front)
+      c.start_dirs[view] = nd1;
+    else
+      c.end_dirs[view] = nd2;
+    const int g = follow_end(tm, s, c, front);
+    if (front) {
+      to_start += g;
+      ci += g;
+    } else {
+      to_end += g;
+    }
   }
   c.tsec[4] += EG3D_TICK() - tf0;
   tm.sync();
