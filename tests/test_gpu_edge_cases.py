@@ -1,0 +1,116 @@
+"""-m gpu: edge cases of the C ABI against the oracle — empty and ragged inputs, tracks that are too
+short or repeat a view (Q2), seeds far from every edge, invalid F pairs, invalid arguments."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from edgegraph3d_amd import api, host
+from parity_util import compare_edgepoints
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(scene):
+    from oracle import binding as ob
+    return ob.Oracle(scene)
+
+
+def _both(scene_ptr, seeds_ptr, n):
+    ctx = api.Context(scene_ptr)
+    got = ctx.match_refpoints(seeds_ptr, 0, n)
+    ref = _oracle(scene_ptr).match(seeds_ptr, 0, n, nthreads=4)
+    ctx.close()
+    return got, ref
+
+
+def test_empty_ranges_and_zero_seeds():
+    s = host.Synth(0)
+    ctx = api.Context(s.scene)
+    ctx.upload_seeds(s.seeds)
+    r = ctx.match_resident(5, 5)
+    assert r["n_points"] == 0 and r["n_obs"] == 0 and len(r["obs_off"]) == 1
+    empty = host.SeedsArrays(np.zeros(1, np.uint32), np.zeros(0, np.int32), np.zeros((0, 2), np.float32))
+    r = ctx.match_refpoints(C.byref(empty.c), 0, 0)
+    assert r["n_points"] == 0
+    n, row_off, ids = s.polyline_sets()
+    r = ctx.match_polyline_sets(n, row_off, ids, 2, 2)
+    assert r["n_points"] == 0
+    # a set with no polylines at all
+    r = ctx.match_polyline_sets(1, np.zeros(s.n_views + 1, np.uint32), np.zeros(0, np.uint32))
+    assert r["n_points"] == 0 and r["n_tasks"] == 0
+    ctx.close()
+
+
+def test_ragged_tracks_short_duplicate_views_and_far_seeds():
+    """Mutated seed set: tracks cut to 1-2 views (no triple possible), a view repeated inside a track
+    (the LAST observation of a view wins, Q2), observations moved far from every polyline (no start
+    hits), and untouched seeds in between."""
+    s = host.Synth(1)
+    off, view, xy = s.seeds_np()
+    rng = np.random.default_rng(7)
+    noff, nview, nxy = [0], [], []
+    for i in range(len(off) - 1):
+        v = list(view[off[i]:off[i + 1]])
+        p = [tuple(q) for q in xy[off[i]:off[i + 1]]]
+        kind = i % 5
+        if kind == 1:
+            v, p = v[:1 + i % 2], p[:1 + i % 2]
+        elif kind == 2 and len(v) >= 3:
+            v.append(v[0])                       # repeat the first view with a shifted observation
+            p.append((p[0][0] + 3.0, p[0][1] - 2.0))
+        elif kind == 3:
+            p = [(float(rng.uniform(5, 40)), float(rng.uniform(5, 40))) for _ in p]   # image corner: nothing nearby
+        nview += v
+        nxy += p
+        noff.append(len(nview))
+    seeds = host.SeedsArrays(np.asarray(noff, np.uint32), np.asarray(nview, np.int32), np.asarray(nxy, np.float32))
+    got, ref = _both(s.scene, C.byref(seeds.c), len(noff) - 1)
+    rep = compare_edgepoints(ref, got, rel_tol=1e-4)
+    assert rep["ok"], rep["msgs"]
+    assert got["n_points"] > 0
+    keys = set(int(k) for k in got["key"][:, 0])
+    assert not any(k % 5 == 1 for k in keys), "a track of one or two views cannot yield a 3-view hypothesis"
+
+
+def test_invalid_fundamental_matrices_disable_their_pairs():
+    """F_valid = 0 (the reference's 1x1 Mat => computeCorrespondEpilineSinglePoint fails) for every
+    pair that involves view 1: the view drops out of all epipolar searches; oracle and GPU agree."""
+    s = host.Synth(1)
+    sc = s.scene_np()
+    Fv = sc["F_valid"].copy()
+    Fv[1, :] = 0
+    Fv[:, 1] = 0
+    sc["F_valid"] = Fv
+    sa = host.SceneArrays(sc)
+    got, ref = _both(C.byref(sa.c), s.seeds, s.n_seeds)
+    rep = compare_edgepoints(ref, got, rel_tol=1e-4)
+    assert rep["ok"], rep["msgs"]
+    full = api.Context(s.scene)
+    whole = full.match_refpoints(s.seeds, 0, s.n_seeds)
+    full.close()
+    assert got["n_points"] != whole["n_points"]
+
+
+def test_invalid_arguments_are_reported_not_crashing():
+    s = host.Synth(0)
+    ctx = api.Context(s.scene)
+    ctx.upload_seeds(s.seeds)
+    with pytest.raises(api.Eg3dError):
+        ctx.match_resident(0, s.n_seeds + 1)                      # range beyond the resident seeds
+    off, view, xy = s.seeds_np()
+    bad = view.copy()
+    bad[0] = s.n_views                                            # view id out of range
+    seeds = host.SeedsArrays(off, bad, xy)
+    with pytest.raises(api.Eg3dError):
+        ctx.upload_seeds(C.byref(seeds.c))
+    n, row_off, ids = s.polyline_sets()
+    bad_ids = ids.copy()
+    bad_ids[0] = 10 ** 6
+    with pytest.raises(api.Eg3dError):
+        ctx.match_polyline_sets(n, row_off, bad_ids)
+    assert b"polyline id out of range" in api.lib().eg3d_last_error()
+    # the context is still usable after the errors
+    ctx.upload_seeds(s.seeds)
+    assert ctx.match_resident(0, s.n_seeds)["n_points"] > 0
+    ctx.close()
