@@ -667,6 +667,7 @@ struct TeamWave {
       int mj[4] = {0, 0, 0, 0};
       uint32_t flj[4] = {0, 0, 0, 0};
       int Deff = 0;
+      const uint64_t tq0 = EG3D_TICK();
       {
         const Obs* prev = c.pool + endpt.off;
         int nprev = n_end;
@@ -688,6 +689,8 @@ struct TeamWave {
         return added;
       }
       // ---- stage 2: the Deff initial DLTs, list j on lane j
+      const uint64_t tq1 = EG3D_TICK();
+      c.tsec[1] += tq1 - tq0;
       double X0[3] = {0, 0, 0};
       uint32_t dfl = 0;
       if (lane() < Deff) {
@@ -706,6 +709,8 @@ struct TeamWave {
       }
       // ---- stage 3: Deff Gauss-Newton solves as groups of one cooperative batch (group j = rows
       // [j*n_end, j*n_end + m_j))
+      const uint64_t tq2 = EG3D_TICK();
+      c.tsec[5] += tq2 - tq1;
       {
         const int g = lane() / n_end, k = lane() - g * n_end;
         const int n = g == 0 ? mj[0] : g == 1 ? mj[1] : g == 2 ? mj[2] : g == 3 ? mj[3] : 0;
@@ -733,6 +738,7 @@ struct TeamWave {
         __syncthreads();
       }
       // ---- stage 4: accept in order
+      c.tsec[6] += EG3D_TICK() - tq2;
       bool redo = false, stop = false;
       for (int j = 0; j < Deff; j++) {
         const uint32_t dflj = (uint32_t)__shfl((int)dfl, j);
