@@ -55,6 +55,12 @@ void launch_task_setup(hipStream_t st, StageAView a, const int32_t* map_view, co
 void launch_k3a(hipStream_t st, bool team4, uint32_t n_blocks, DevScene s, StageAView a, const TaskDesc* tasks,
                 const uint32_t* hyp_off, uint32_t n_hyp, HypResult* res, HPoint* scratch, uint32_t hyp_cap, HPoint* arena,
                 uint32_t arena_cap, Counters* ctr);
+// K3a split: orientation phase (initial lists to the arena), following through a lane-level work
+// queue (follow_scratch: hyp_cap HPoints per lane of follow_blocks x 256), compatibility flags
+void launch_k3a_queue(hipStream_t st, bool team4, uint32_t n_blocks, uint32_t follow_blocks, DevScene s, StageAView a,
+                      const TaskDesc* tasks, const uint32_t* hyp_off, uint32_t n_hyp, HypResult* res, HPoint* scratch,
+                      HPoint* follow_scratch, uint32_t hyp_cap, HPoint* arena, uint32_t arena_cap, Counters* ctr,
+                      uint32_t* queue);
 void launch_k3s(hipStream_t st, uint32_t n_tasks, const uint32_t* hyp_off, const HypResult* res, ChainSeed* per_task,
                 uint32_t* valid);
 void launch_compact_chains(hipStream_t st, uint32_t n_tasks, const ChainSeed* per_task, const uint32_t* valid,
