@@ -114,3 +114,31 @@ def test_invalid_arguments_are_reported_not_crashing():
     ctx.upload_seeds(s.seeds)
     assert ctx.match_resident(0, s.n_seeds)["n_points"] > 0
     ctx.close()
+
+
+@pytest.mark.parametrize("rng_seed,n_views,n_curves,max_track", [(11, 5, 9, 5), (12, 12, 20, 12), (13, 31, 24, 31),
+                                                               (14, 70, 30, 70)])
+def test_random_scenes_parity(rng_seed, n_views, n_curves, max_track):
+    """Other scene shapes than the named configs (few views; tracks as long as the rig; more than 64
+    views so points outgrow a wavefront's 64 rows and the LDS candidate lists): both extractors
+    against the oracle, bit-exact, including with the K3a work queue forced on."""
+    cfg = host.default_config(1)
+    cfg.rng_seed = rng_seed
+    cfg.n_views = n_views
+    cfg.n_curves = n_curves
+    cfg.max_track = max_track
+    cfg.n_seeds = 160 if n_views < 40 else 60
+    s = host.Synth(cfg)
+    ctx = api.Context(s.scene)
+    o = _oracle(s.scene)
+    got = ctx.match_refpoints(s.seeds)
+    ref = o.match(s.seeds, 0, s.n_seeds, nthreads=16)
+    rep = compare_edgepoints(ref, got, rel_tol=1e-4)
+    assert rep["ok"] and rep["bitexact_X"], rep["msgs"]
+    assert (got["flags"] & 7) == 0 and got["n_points"] > 0
+    n, row_off, ids = s.polyline_sets(4)
+    gs = ctx.match_polyline_sets(n, row_off, ids)
+    rs = o.match_polyline_sets(n, row_off, ids, nthreads=16)
+    rep = compare_edgepoints(rs, gs, rel_tol=1e-4)
+    assert rep["ok"] and rep["bitexact_X"], rep["msgs"]
+    ctx.close()
