@@ -274,36 +274,49 @@ EG3D_HD void expand_chain(const Team& tm, const DevScene& s, const StageAView& a
     c.start_dirs[d.sel_view[k]] = w.dirs1[k];
     c.end_dirs[d.sel_view[k]] = w.dirs2[k];
   }
-  auto push_h = [&](const HPoint& hp) {
-    if (c.head + c.len >= c.cap_pts) {
-      c.flags |= 1u;
-      return;
-    }
-    ChainPt& p = c.pts[c.head + c.len];
-    p.X[0] = hp.X[0];
-    p.X[1] = hp.X[1];
-    p.X[2] = hp.X[2];
-    point_init(p);
-    point_reserve(c, p, hp.nobs + 1);
-    for (uint32_t i = 0; i < hp.nobs; i++) pool_append(c, p, hp.o[i]);
-    c.len++;
-  };
-  for (int i = (int)cs.n1 - 1; i >= 0; i--) push_h(arena[w.pts1_off + i]);
+  // initial chain = direction-1 points reversed, the central point, direction-2 points
+  // (new_3dpoint_and_sides_plgp_matches_to_vector, polyline_graph_2d.cpp:1298-1306). PARALLEL over
+  // the points: every hypothesis-stage point has three observations => a block of 4 pool slots each.
+  const int centre0 = (int)cs.n1;
   {
-    HPoint hc;
-    hypothesis_hits(a, d, cs.task, cs.winner - hyp_base, hc.o);
-    hc.X[0] = w.X[0];
-    hc.X[1] = w.X[1];
-    hc.X[2] = w.X[2];
-    hc.nobs = 3;
-    hc.pad = 0;
-    push_h(hc);
+    int L1 = L0;
+    if (c.head + L1 > c.cap_pts) {
+      c.flags |= 1u;
+      L1 = c.cap_pts - c.head;
+    }
+    if ((uint32_t)L1 * 4u > c.pool_cap) {
+      c.flags |= 2u;
+      L1 = (int)(c.pool_cap / 4u);
+    }
+    const uint32_t p2 = cs.pts2_src != 0xffffffffu ? res[cs.pts2_src].pts2_off : 0u;
+    for (int i = tm.lane(); i < L1; i += tm.size()) {
+      HPoint hp;
+      if (i < centre0) {
+        hp = arena[w.pts1_off + (uint32_t)(centre0 - 1 - i)];
+      } else if (i == centre0) {
+        hypothesis_hits(a, d, cs.task, cs.winner - hyp_base, hp.o);
+        hp.X[0] = w.X[0];
+        hp.X[1] = w.X[1];
+        hp.X[2] = w.X[2];
+        hp.nobs = 3;
+        hp.pad = 0;
+      } else {
+        hp = arena[p2 + (uint32_t)(i - centre0 - 1)];
+      }
+      ChainPt p;
+      p.X[0] = hp.X[0];
+      p.X[1] = hp.X[1];
+      p.X[2] = hp.X[2];
+      p.off = 4u * (uint32_t)i;
+      p.cap = 4;
+      p.nobs = hp.nobs;
+      for (uint32_t k = 0; k < hp.nobs; k++) c.pool[p.off + k] = hp.o[k];
+      c.pts[c.head + i] = p;
+    }
+    c.len = L1;
+    c.pool_used = 4u * (uint32_t)L1;
   }
-  int centre = (int)cs.n1;
-  if (cs.pts2_src != 0xffffffffu) {
-    const HypResult& r2 = res[cs.pts2_src];
-    for (uint32_t i = 0; i < cs.n2; i++) push_h(arena[r2.pts2_off + i]);
-  }
+  int centre = centre0;  // index of the central point; moves when the chain grows at the front
   tm.sync();
   c.tsec[9] = EG3D_TICK() - t_begin;
   // every view except the three selected, ascending; epc = the task's hits in that view
