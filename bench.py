@@ -278,6 +278,20 @@ def main():
                 "oracle_algorithmic_bytes": int(r["stats"]["bytes_algorithmic"]),
             }
             line["speedup_vs_cpu_1thread"] = value / (pts / med)
+            # "CPU-ref parity err" (the second half of BASELINE.json's metric): the step's output copied to the
+            # host and compared with the oracle's output on the same seeds / sets — relative error of the 3-D
+            # coordinates (north star: <= 1e-4) and exactness of every id / view list and of the order
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from parity_util import compare_edgepoints
+            if sets is not None:
+                gfull = workers[0].ctx.match_polyline_sets(sets[0], sets[1], sets[2], b, ce)
+            else:
+                gfull = workers[0].ctx.match_resident(b, ce)
+            rep = compare_edgepoints(r, gfull, rel_tol=1e-4)
+            line["parity"] = {"vs": "oracle (CPU restatement; parity unpinned, see DESIGN.md 3)", "points_compared": int(pts),
+                              "max_rel_err_X": rep.get("max_rel_X"), "X_bit_exact": rep.get("bitexact_X"),
+                              "ids_views_order_exact": bool(rep["ok"]), "obs_xy_bit_exact": rep.get("bitexact_xy"),
+                              "tolerance": 1e-4}
         print(json.dumps(line), flush=True)
     for w in workers:
         w.todo.put(None)
