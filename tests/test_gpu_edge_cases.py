@@ -142,3 +142,36 @@ def test_random_scenes_parity(rng_seed, n_views, n_curves, max_track):
     rep = compare_edgepoints(rs, gs, rel_tol=1e-4)
     assert rep["ok"] and rep["bitexact_X"], rep["msgs"]
     ctx.close()
+
+
+def test_very_long_polylines_parity():
+    """Polylines of more than 512 vertices (the side-walk LDS staging limit) and walks that test more
+    than 64 segments per step: the tiny scene with every segment split into 14 collinear pieces."""
+    s = host.Synth(0)
+    sc = s.scene_np()
+    K = 14
+    pvo, vtx = sc["pl_vtx_off"], sc["vtx_xy"]
+    new_off, new_vtx = [0], []
+    for p in range(len(pvo) - 1):
+        v = vtx[pvo[p]:pvo[p + 1]]
+        if len(v) >= 2:
+            for i in range(len(v) - 1):
+                for k in range(K):
+                    t = np.float32(k) / np.float32(K)
+                    new_vtx.append(v[i] + (v[i + 1] - v[i]) * t)
+            new_vtx.append(v[-1])
+        new_off.append(len(new_vtx))
+    sc["pl_vtx_off"] = np.asarray(new_off, np.uint32)
+    sc["vtx_xy"] = np.asarray(new_vtx, np.float32).reshape(-1, 2)
+    assert np.diff(sc["pl_vtx_off"]).max() > 512
+    sa = host.SceneArrays(sc)
+    got, ref = _both(C.byref(sa.c), s.seeds, s.n_seeds)
+    rep = compare_edgepoints(ref, got, rel_tol=1e-4)
+    assert rep["ok"] and rep["bitexact_X"], rep["msgs"]
+    assert got["n_points"] > 100 and (got["flags"] & 7) == 0
+    n, row_off, ids = s.polyline_sets(2)
+    ctx = api.Context(C.byref(sa.c))
+    gs = ctx.match_polyline_sets(n, row_off, ids)
+    rs = _oracle(C.byref(sa.c)).match_polyline_sets(n, row_off, ids, nthreads=8)
+    assert compare_edgepoints(rs, gs, rel_tol=1e-4)["ok"]
+    ctx.close()
