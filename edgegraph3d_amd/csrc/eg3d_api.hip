@@ -497,7 +497,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
   // ---- K3a
   BUF_TRY(c->b_res.ensure(sizeof(HypResult) * (B.n_hyp + 1)));
   // small batches are latency-bound by their slowest hypothesis: give each hypothesis a 4-lane team
-  static const int k3a_mode = getenv("EG3D_K3A_TEAM") ? atoi(getenv("EG3D_K3A_TEAM")) : -1;  // -1 auto, 0 lanes, 1 teams
+  const int k3a_mode = getenv("EG3D_K3A_TEAM") ? atoi(getenv("EG3D_K3A_TEAM")) : -1;  // -1 auto, 0 lanes, 1 teams
   const bool team4 = k3a_mode < 0 ? (B.n_hyp <= 131072u) : (k3a_mode != 0);
   const uint32_t k3a_lanes_needed = B.n_hyp * (team4 ? 4u : 1u);
   const uint32_t k3a_blocks =
@@ -506,7 +506,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
   // throughput mode (1 lane per hypothesis): the lists are followed through a lane-level work queue
   // (2 items per hypothesis) — C3' K3a 19.6 -> 17.0 ms; with 4-lane teams (small, latency-bound
   // batches) the team's own two-lane following is faster (C2 2.96 vs 3.34 ms). EG3D_K3A_QUEUE=0/1 forces.
-  static const int k3a_queue_mode = getenv("EG3D_K3A_QUEUE") ? atoi(getenv("EG3D_K3A_QUEUE")) : -1;
+  const int k3a_queue_mode = getenv("EG3D_K3A_QUEUE") ? atoi(getenv("EG3D_K3A_QUEUE")) : -1;
   const bool k3a_queue = k3a_queue_mode < 0 ? !team4 : (k3a_queue_mode != 0);
   const uint32_t follow_blocks =
       std::max<uint32_t>(1, std::min<uint32_t>(c->k3a_blocks * 2u, (uint32_t)(((uint64_t)B.n_hyp * 2 + 255) / 256)));
@@ -515,6 +515,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
     BUF_TRY(c->b_queue.ensure(sizeof(uint32_t)));
   }
   uint32_t arena_cap = std::max<uint32_t>(1u << 16, std::min<uint64_t>((uint64_t)B.n_hyp * (k3a_queue ? 32 : 24), 1ull << 26));
+  if (const char* e0 = getenv("EG3D_ARENA_CAP0")) arena_cap = std::max(16, atoi(e0));  // tests: force the overflow-and-retry path
   Counters hc;
   for (int attempt = 0;; attempt++) {
     BUF_TRY(c->b_arena.ensure(sizeof(HPoint) * (size_t)arena_cap));

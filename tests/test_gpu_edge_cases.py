@@ -175,3 +175,18 @@ def test_very_long_polylines_parity():
     rs = _oracle(C.byref(sa.c)).match_polyline_sets(n, row_off, ids, nthreads=8)
     assert compare_edgepoints(rs, gs, rel_tol=1e-4)["ok"]
     ctx.close()
+
+
+def test_hypothesis_arena_overflow_is_retried(monkeypatch):
+    """The bump-allocated arena of hypothesis point lists starts from an estimate; when a batch
+    outgrows it the kernels flag the overflow and the stage is rerun with a larger arena. Forced
+    here with a tiny initial arena (EG3D_ARENA_CAP0), in both K3a modes."""
+    s = host.Synth(1)
+    ref = _oracle(s.scene).match(s.seeds, 0, s.n_seeds, nthreads=8)
+    monkeypatch.setenv("EG3D_ARENA_CAP0", "64")
+    for team in ("0", "1"):
+        monkeypatch.setenv("EG3D_K3A_TEAM", team)
+        ctx = api.Context(s.scene)
+        got = ctx.match_refpoints(s.seeds)
+        ctx.close()
+        assert compare_edgepoints(ref, got, rel_tol=1e-4)["ok"]
