@@ -558,7 +558,8 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
                         c->b_chains.as<ChainSeed>());
   HIP_TRY(hipEventRecord(c->eb[4], st));
   // ---- K3b + K4 in chunks bounded by scratch size
-  const size_t max_scratch = (size_t)24 << 30;
+  size_t max_scratch = (size_t)24 << 30;
+  if (const char* e1 = getenv("EG3D_MAX_SCRATCH_MB")) max_scratch = (size_t)std::max(1, atoi(e1)) << 20;  // tests: force chunking
   float ms_expand = 0, ms_emit = 0;
   uint32_t chunk = 0;
   unsigned long long bytes_before_chunk = 0;
