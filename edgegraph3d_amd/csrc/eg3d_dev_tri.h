@@ -202,8 +202,8 @@ struct ArrayCursor {
 };
 
 // Observations gathered once into per-lane arrays (private memory is lane-interleaved on
-// gfx950, so these reads coalesce across the wave) — used when the source is a linked list in
-// HBM, whose dependent loads would otherwise be repeated in every pass of every iteration.
+// gfx950, so these reads coalesce across the wave) — used by the one-lane-per-solve batches so the
+// block of observations is fetched from HBM once, not in every pass of every iteration.
 #define EG3D_LOCAL_OBS 16
 struct LocalCursor {
   int32_t v[EG3D_LOCAL_OBS];
