@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the RCCL all-gather of the cloud even with one rank (exercises the N>1 code path)")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=4,
                     help="independent steps kept in flight per GPU, each on its own context/HIP stream driven by its "
                          "own host thread (1 = strictly one step at a time)")
     ap.add_argument("--path", choices=["refpoints", "sets"], default="refpoints",
