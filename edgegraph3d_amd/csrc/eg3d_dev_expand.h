@@ -180,6 +180,10 @@ struct TeamSeq {
     return 0;
   }
   EG3D_HD uint32_t or_reduce(uint32_t v) const { return v; }
+  // members that share one item of an n_items-wide parallel section (a power of two), and the
+  // merge of their partial closest-point results (smaller distance, then smaller segment index)
+  EG3D_HD int group_size(int) const { return 1; }
+  EG3D_HD void group_best(int, float&, PlPt&) const {}
   // exclusive prefix sum of v over the members (+ the total)
   EG3D_HD uint32_t excl_scan(uint32_t v, uint32_t& total) const {
     total = v;
@@ -690,8 +694,14 @@ template <class Team>
 EG3D_HD void view_candidates(const Team& tm, const DevScene& s, Chain& c, int v, int from) {
   const float* P = s.cam_P + (size_t)v * 16;
   uint64_t tc0 = EG3D_TICK();
-  for (int i = from + tm.lane(); i < c.len; i += tm.size()) {
-    const ChainPt& pt = chain_at(c, i);
+  // G members share a chain point when the chain is short: each scans 1/G of the polyline's segments
+  const int n_items = c.len - from;
+  const int G = tm.group_size(n_items);
+  const int per_pass = tm.size() / G;
+  for (int i0 = 0; i0 < n_items; i0 += per_pass) {
+    const int item = i0 + tm.lane() / G, part = tm.lane() % G;
+    const int i = from + item;
+    const bool act = item < n_items;
     ViewCand vc;
     vc.valid = 0;
     vc.pl = 0;
@@ -699,24 +709,44 @@ EG3D_HD void view_candidates(const Team& tm, const DevScene& s, Chain& c, int v,
     vc.x = vc.y = vc.d2 = 0.0f;
     vc.cok = 0;
     vc.cX[0] = vc.cX[1] = vc.cX[2] = 0.0f;
-    {
-      const Obs& first = c.pool[pt.off];
-      vc.eok = epiline(s.F, s.F_valid, s.n_views, first.view, v, first.x, first.y, vc.ea, vc.eb, vc.ec) ? 1u : 0u;
+    vc.eok = 0;
+    vc.ea = vc.eb = vc.ec = 0.0f;
+    float d2 = __builtin_inff();
+    PlPt cp;
+    cp.seg = 0xffffffffu;
+    cp.x = cp.y = 0.0f;
+    bool have = false;
+    if (act) {
+      const ChainPt& pt = chain_at(c, i);
+      if (part == 0) {
+        const Obs& first = c.pool[pt.off];
+        vc.eok = epiline(s.F, s.F_valid, s.n_views, first.view, v, first.x, first.y, vc.ea, vc.eb, vc.ec) ? 1u : 0u;
+      }
+      float u, w;
+      project_f32(P, pt.X[0], pt.X[1], pt.X[2], u, w);
+      uint32_t pl_id;
+      if (unique_polyline_4px(s, v, u, w, pl_id)) {
+        PlRef pl = polyline_of(s, v, pl_id);
+        const uint32_t nseg = pl.n - 1u;
+        const uint32_t chunk = (nseg + (uint32_t)G - 1u) / (uint32_t)G;
+        const uint32_t s0 = (uint32_t)part * chunk;
+        const uint32_t s1 = s0 + chunk < nseg ? s0 + chunk : nseg;
+        if (s0 < s1 || part == 0) d2 = polyline_closest_range(pl, u, w, s0 < nseg ? s0 : nseg, s1, cp);
+        have = true;
+        vc.pl = pl_id;
+      }
     }
-    float u, w;
-    project_f32(P, pt.X[0], pt.X[1], pt.X[2], u, w);
-    uint32_t pl_id;
-    if (unique_polyline_4px(s, v, u, w, pl_id)) {
-      PlRef pl = polyline_of(s, v, pl_id);
-      PlPt cp;
-      vc.d2 = polyline_closest(pl, u, w, cp);
-      vc.valid = 1;
-      vc.pl = pl_id;
-      vc.seg = cp.seg;
-      vc.x = cp.x;
-      vc.y = cp.y;
+    tm.group_best(G, d2, cp);
+    if (act && part == 0) {
+      if (have) {
+        vc.valid = 1;
+        vc.d2 = d2;
+        vc.seg = cp.seg;
+        vc.x = cp.x;
+        vc.y = cp.y;
+      }
+      c.cand[c.head + i] = vc;
     }
-    c.cand[c.head + i] = vc;
   }
   tm.sync();
   // speculative central ADD solve of every point whose candidate is within 4 px

@@ -371,6 +371,36 @@ EG3D_HD float polyline_closest(const PlRef& pl, float px, float py, PlPt& out) {
   return best;
 }
 
+// The same over the segments [s0, s1) only (s1 <= n-1): the range that starts at segment 0 takes
+// that segment as its initial best exactly like polyline_closest; later ranges start from +inf, so
+// that merging the ranges' results by (smaller distance, then smaller segment index) reproduces the
+// whole-polyline scan. Returns +inf with seg = 0xffffffff for an empty range.
+EG3D_HD float polyline_closest_range(const PlRef& pl, float px, float py, uint32_t s0, uint32_t s1, PlPt& out) {
+  float bx = 0.0f, by = 0.0f;
+  float best = __builtin_inff();
+  uint32_t bseg = 0xffffffffu;
+  uint32_t i = s0;
+  if (s0 == 0 && s1 > 0) {
+    best = seg_closest(px, py, pl.v[0].x, pl.v[0].y, pl.v[1].x, pl.v[1].y, bx, by);
+    bseg = 0;
+    i = 1;
+  }
+  for (; i < s1; i++) {
+    float cx, cy;
+    float d = seg_closest(px, py, pl.v[i].x, pl.v[i].y, pl.v[i + 1].x, pl.v[i + 1].y, cx, cy);
+    if (d < best) {
+      best = d;
+      bx = cx;
+      by = cy;
+      bseg = i;
+    }
+  }
+  out.seg = bseg;
+  out.x = bx;
+  out.y = by;
+  return best;
+}
+
 // ---------------------------------------------------------------- grid cells ---
 #if defined(__HIP_DEVICE_COMPILE__)
 #define EG3D_CEILF(x) __builtin_ceilf(x)

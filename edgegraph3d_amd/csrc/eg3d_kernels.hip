@@ -624,6 +624,24 @@ struct TeamWave {
     for (int d = 32; d >= 1; d >>= 1) v |= (uint32_t)__shfl_xor((int)v, d);
     return v;
   }
+  __device__ __forceinline__ int group_size(int n_items) const {
+    int g = 1;
+    while (g < 16 && g * 2 * n_items <= 64) g <<= 1;
+    return g;
+  }
+  __device__ __forceinline__ void group_best(int G, float& d, PlPt& p) const {
+    for (int o = 1; o < G; o <<= 1) {
+      const float od = __shfl_xor(d, o);
+      const uint32_t os = (uint32_t)__shfl_xor((int)p.seg, o);
+      const float ox = __shfl_xor(p.x, o), oy = __shfl_xor(p.y, o);
+      if (od < d || (od == d && os < p.seg)) {
+        d = od;
+        p.seg = os;
+        p.x = ox;
+        p.y = oy;
+      }
+    }
+  }
   __device__ __forceinline__ uint32_t excl_scan(uint32_t v, uint32_t& total) const {
     uint32_t pre = v;
 #pragma unroll
