@@ -43,8 +43,8 @@ class _DevArr:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--config", type=int, default=2, help="synthetic config index (2 = C2, BASELINE configs[1])")
     ap.add_argument("--seeds-per-gpu", type=int, default=0, help="override the per-GPU seed count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
