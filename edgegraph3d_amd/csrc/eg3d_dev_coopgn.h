@@ -29,6 +29,8 @@ struct CoopLds {
       float epi[EG3D_STAGE_EPI][4];
     } walk;
   };
+  int32_t la_m[8];               // look-ahead following: observations kept by step j
+  uint32_t la_fl[8];             //   and the diagnostic flags its walks raised
   Obs tmp_a[EG3D_COOP_ROWS];     // the N-view step's candidate observations (Chain::tmp_a) when they fit
   double sums[22][8];            // a group has >= 3 rows => <= 21 groups per round
   float x0[EG3D_COOP_ROWS][3];   // in: start point of request j; out: its result

@@ -601,6 +601,9 @@ __global__ void k_compact_chains(uint32_t n_tasks, const ChainSeed* per_task, co
 #ifndef EG3D_COOP_GN
 #define EG3D_COOP_GN 1 /* wave-cooperative Gauss-Newton (eg3d_dev_coopgn.h); 0 = one lane per solve */
 #endif
+#ifndef EG3D_LOOKAHEAD
+#define EG3D_LOOKAHEAD 8 /* steps walked ahead per round (<= 8, and <= 64 / observations of the end point) */
+#endif
 #ifndef EG3D_SPEC_FOLLOW
 #define EG3D_SPEC_FOLLOW 1 /* chain following: walk up to 4 steps ahead, then triangulate them together */
 #endif
@@ -759,7 +762,7 @@ struct TeamWave {
   }
   // Chain following (follow_direction_vector_start/_end, plg_matching.cpp:771-795) with LOOK-AHEAD.
   // The walks of step t+1 start from the observations step t FOUND, not from its triangulated X,
-  // so up to D = 4 steps are walked ahead first (each: the first starting observation whose walks
+  // so up to D = 8 steps are walked ahead first (each: the first starting observation whose walks
   // keep >= 3 observations — exactly the candidate the sequential N-view step triangulates first);
   // their D initial DLTs then run side by side on D lanes (one DLT's worth of instructions instead
   // of D) and their D all-observation Gauss-Newton solves as D groups of one cooperative batch.
@@ -775,13 +778,12 @@ struct TeamWave {
       const ChainPt& endpt = front ? chain_at(c, 0) : chain_at(c, c.len - 1);
       const int n_end = (int)endpt.nobs;
       int D = n_end > 0 ? EG3D_COOP_ROWS / n_end : 0;
-      if (D > 4) D = 4;
+      if (D > EG3D_LOOKAHEAD) D = EG3D_LOOKAHEAD;
       bool seq = !look_ahead || D < 2 || c.tmp_a != L->tmp_a;  // long observation lists (or lists not in LDS): plain steps
       if (!seq) {
       // ---- stage 1: walk ahead (lists of step j at tmp_a + j * n_end; a step keeps <= n_end obs)
-      int mj[4] = {0, 0, 0, 0};
-      uint32_t flj[4] = {0, 0, 0, 0};
       int Deff = 0;
+      uint32_t fl_dead = 0;  // walk flags of the step that died (merged when the following ends there)
       const uint64_t tq0 = EG3D_TICK();
       {
         const Obs* prev = c.pool + endpt.off;
@@ -791,18 +793,24 @@ struct TeamWave {
           uint32_t fl = 0;
           int m = 0;
           for (int st = 0; st < nprev && m == 0; st++) m = stepn_walks(*this, s, prev, nprev, st, dirs, sel, n_end, fl);
-          flj[j] = fl;
-          mj[j] = m;
-          if (m == 0) break;
+          if (m == 0) {
+            fl_dead = fl;
+            break;
+          }
+          if (lane() == 0) {
+            L->la_m[j] = m;
+            L->la_fl[j] = fl;
+          }
           Deff++;
           prev = sel;
           nprev = m;
         }
       }
       if (Deff == 0) {  // no starting observation survives its walks: the following ends here
-        c.flags |= flj[0];
+        c.flags |= fl_dead;
         return added;
       }
+      __syncthreads();  // la_m / la_fl
       // ---- stage 2: the Deff initial DLTs, list j on lane j
       const uint64_t tq1 = EG3D_TICK();
       c.tsec[1] += tq1 - tq0;
@@ -810,7 +818,7 @@ struct TeamWave {
       uint32_t dfl = 0;
       if (lane() < Deff) {
         const Obs* a = L->tmp_a + lane() * n_end;
-        const int n = lane() == 0 ? mj[0] : lane() == 1 ? mj[1] : lane() == 2 ? mj[2] : mj[3];
+        const int n = L->la_m[lane()];
         int mi = 0;
         int32_t mv = a[0].view;
         for (int i = 0; i < n; i++)
@@ -828,7 +836,7 @@ struct TeamWave {
       c.tsec[5] += tq2 - tq1;
       {
         const int g = lane() / n_end, k = lane() - g * n_end;
-        const int n = g == 0 ? mj[0] : g == 1 ? mj[1] : g == 2 ? mj[2] : g == 3 ? mj[3] : 0;
+        const int n = g < Deff ? L->la_m[g] : 0;
         const bool act = g < Deff && k < n;
         const int gs = g < Deff ? g : 0;
         double X[3];
@@ -859,8 +867,8 @@ struct TeamWave {
         const uint32_t dflj = (uint32_t)__shfl((int)dfl, j);
         if (L->res_ok[j]) {
           const float X[3] = {L->x0[j][0], L->x0[j][1], L->x0[j][2]};
-          c.flags |= flj[j] | dflj;
-          if (!follow_append(c, front, L->tmp_a + j * n_end, mj[j], X)) {
+          c.flags |= L->la_fl[j] | dflj;
+          if (!follow_append(c, front, L->tmp_a + j * n_end, L->la_m[j], X)) {
             stop = true;
             break;
           }
@@ -874,7 +882,7 @@ struct TeamWave {
       if (stop) return added;
       if (!redo) {
         if (Deff < D) {  // step Deff died in its walks after Deff accepted steps: the following ends
-          c.flags |= flj[Deff];
+          c.flags |= fl_dead;
           return added;
         }
         continue;
