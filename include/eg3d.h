@@ -178,7 +178,9 @@ int eg3d_match_refpoints(eg3d_ctx* ctx, const eg3d_seeds* seeds, uint32_t seed_b
  * hit. As in the reference's parallel build the PLGMatchesManager is not consulted
  * (is_matched() == false: it is empty when pipelines 1-2 run and never updated inside the loop).
  * Output as eg3d_match_refpoints, in the reference's order (set, start view, polyline id, sample);
- * key = (sample index of the call, start view, 0, index in chain). */
+ * key = (sample index of the call, start view, 0, index in chain); in the device view
+ * (eg3d_last_device_output after device_only) the sample index counts from the start of the last
+ * internal batch of sets. */
 typedef struct eg3d_polyline_sets {
   uint32_t n_sets;
   const uint32_t* row_off; /* [n_sets * n_views + 1] CSR over rows (set * n_views + view) */
