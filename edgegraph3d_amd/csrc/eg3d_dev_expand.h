@@ -182,6 +182,13 @@ struct TeamSeq {
   EG3D_HD uint32_t or_reduce(uint32_t v) const { return v; }
   // members that share one item of an n_items-wide parallel section (a power of two), and the
   // merge of their partial closest-point results (smaller distance, then smaller segment index)
+  // number of leading j in [0, m) for which pred(j) holds
+  template <class Pred>
+  EG3D_HD int leading_true(int m, Pred pred) const {
+    int k = 0;
+    while (k < m && pred(k)) k++;
+    return k;
+  }
   EG3D_HD int group_size(int) const { return 1; }
   EG3D_HD void group_best(int, float&, PlPt&) const {}
   // exclusive prefix sum of v over the members (+ the total)
@@ -224,7 +231,7 @@ struct TeamSeqSlots : TeamSeq {
 // (5..20 px) epipolar walk — PARALLEL over the observations, the survivors compacted in
 // observation order. Returns the number of observations collected in sel (0 = candidate dead).
 template <class Team>
-EG3D_HD int stepn_walks(const Team& tm, const DevScene& s, const Obs* co_all, int n, int st, const uint32_t* dirs,
+EG3D_HD_FLAT int stepn_walks(const Team& tm, const DevScene& s, const Obs* co_all, int n, int st, const uint32_t* dirs,
                         Obs* sel, int sel_cap, uint32_t& flags) {
   const Obs so = co_all[st];
   PlRef ps = polyline_of(s, so.view, so.pl);
@@ -331,7 +338,7 @@ EG3D_HD int stepn_fallback(const DevScene& s, Obs* sel, int m, Obs* tmp, uint8_t
 // it. Flags of candidates past the winner are dropped, as the sequential order never ran them.
 // The new point is returned in tmp_a[0..m) with its X.
 template <class Team>
-EG3D_HD int stepn_chain(const Team& tm, const DevScene& s, Chain& c, const ChainPt& cur, const uint32_t* dirs,
+EG3D_HD_FLAT int stepn_chain(const Team& tm, const DevScene& s, Chain& c, const ChainPt& cur, const uint32_t* dirs,
                         float Xout[3]) {
   const int n = (int)cur.nobs;
   if (n > EG3D_STEP_OBS || !Team::kSlotStep) {
@@ -413,7 +420,7 @@ EG3D_HD bool new_point_from_tmp(Chain& c, ChainPt& np, int m, const float X[3]) 
 // Grow the chain at its front (towards start_dirs) or back (towards end_dirs) while N-view steps
 // succeed (follow_direction_vector_start / _end, plg_matching.cpp:771-795). Returns points added.
 template <class Team>
-EG3D_HD int follow_end(const Team& tm, const DevScene& s, Chain& c, bool front) {
+EG3D_HD_FLAT int follow_end(const Team& tm, const DevScene& s, Chain& c, bool front) {
   if constexpr (Team::kSpecFollow) return tm.follow(s, c, front);
   int added = 0;
   for (;;) {
@@ -503,44 +510,56 @@ EG3D_HD int TeamSeq::side_walk(const DevScene& s, Chain& c, int view, const Obs&
                                    });
 }
 
-// Side walk, phase 2 (PARALLEL over candidates): ADD-solve candidate j against chain point
-// ci-1-j / ci+1+j; then (uniform) count the leading successes — the reference stops at the
-// first failed walk or solve (plg_matching.cpp:866-914).
+// The two side walks of one orientation (towards dS on the chain's start side, towards dE on its
+// end side) and their ADD solves as ONE batch: candidate j of the start side against chain point
+// ci-1-j, of the end side against ci+1+j; n1 / n2 = leading successes of each side — the reference
+// stops a side at its first failed walk or solve (plg_matching.cpp:866-914) and walks the end side
+// only when the start side attached something (:1345-1412). The end-side walk is made before the
+// start side's solves are known (its positions do not depend on them) whenever the start side
+// produced candidates at all; it is discarded if none of those survives its solve.
 template <class Team>
-EG3D_HD int walk_side(const Team& tm, const DevScene& s, Chain& c, int view, const Obs& from, uint32_t direction,
-                      int lo, int ci, int hi, bool towards_start, Pending* out) {
+EG3D_HD_FLAT void walk_sides(const Team& tm, const DevScene& s, Chain& c, int view, const Obs& from, uint32_t dS, uint32_t dE,
+                        int lo, int ci, int hi, int& n1, int& n2) {
   uint64_t t0 = EG3D_TICK();
-  const int m = tm.side_walk(s, c, view, from, direction, lo, ci, hi, towards_start, out);
+  const int m1 = tm.side_walk(s, c, view, from, dS, lo, ci, hi, true, c.pend1);
+  int m2 = 0;
+  if (m1 > 0 && ci < hi) m2 = tm.side_walk(s, c, view, from, dE, lo, ci, hi, false, c.pend2);
   tm.sync();
   uint64_t t1 = EG3D_TICK();
   c.tsec[2] += t1 - t0;
+  Pending* p1 = c.pend1;
+  Pending* p2 = c.pend2;
   tm.add_solves(
-      s, c, m,
+      s, c, m1 + m2,
       [&](int j, const ChainPt*& pt, Obs& o) {
-        pt = &chain_at(c, towards_start ? ci - 1 - j : ci + 1 + j);
-        o = out[j].o;
+        if (j < m1) {
+          pt = &chain_at(c, ci - 1 - j);
+          o = p1[j].o;
+        } else {
+          pt = &chain_at(c, ci + 1 + (j - m1));
+          o = p2[j - m1].o;
+        }
         return true;
       },
       [&](int j, bool ok, const float* X) {
-        if (ok) {
-          out[j].X[0] = X[0];
-          out[j].X[1] = X[1];
-          out[j].X[2] = X[2];
-          out[j].ok = 1;
-        }
+        if (!ok) return;
+        Pending& pd = j < m1 ? p1[j] : p2[j - m1];
+        pd.X[0] = X[0];
+        pd.X[1] = X[1];
+        pd.X[2] = X[2];
+        pd.ok = 1;
       });
   tm.sync();
+  n1 = tm.leading_true(m1, [&](int j) { return p1[j].ok != 0; });
+  n2 = n1 > 0 ? tm.leading_true(m2, [&](int j) { return p2[j].ok != 0; }) : 0;
   c.tsec[3] += EG3D_TICK() - t1;
-  int cnt = 0;
-  while (cnt < m && out[cnt].ok) cnt++;
-  return cnt;
 }
 
 // Try to attach observation `o` of view o.view to chain point ci, then to its neighbours within
 // [lo, hi). On success returns true with (to_start, to_end) = observations added on each side
 // including newly grown points. (add_view_to_3dpoint_and_sides_plgp_matches_vector, Q13.)
 template <class Team>
-EG3D_HD bool attach_view(const Team& tm, const DevScene& s, Chain& c, const Obs& o, int lo, int ci, int hi,
+EG3D_HD_FLAT bool attach_view(const Team& tm, const DevScene& s, Chain& c, const Obs& o, int lo, int ci, int hi,
                          int& to_start, int& to_end, const uint32_t* pre_ok, const float* pre_X) {
   to_start = 0;
   to_end = 0;
@@ -562,17 +581,15 @@ EG3D_HD bool attach_view(const Team& tm, const DevScene& s, Chain& c, const Obs&
   uint32_t nd1 = 0, nd2 = 0;
   int n1 = 0, n2 = 0;
   if (ci > lo) {
-    n1 = walk_side(tm, s, c, view, o, pl.start, lo, ci, hi, true, c.pend1);
+    walk_sides(tm, s, c, view, o, pl.start, pl.end, lo, ci, hi, n1, n2);
     if (n1 > 0) {
       nd1 = pl.start;
       nd2 = pl.end;
-      if (ci < hi) n2 = walk_side(tm, s, c, view, o, pl.end, lo, ci, hi, false, c.pend2);
     } else {
-      n1 = walk_side(tm, s, c, view, o, pl.end, lo, ci, hi, true, c.pend1);
+      walk_sides(tm, s, c, view, o, pl.end, pl.start, lo, ci, hi, n1, n2);
       if (n1 > 0) {
         nd1 = pl.end;
         nd2 = pl.start;
-        if (ci < hi) n2 = walk_side(tm, s, c, view, o, pl.start, lo, ci, hi, false, c.pend2);
       }
       // else: neither orientation reaches the lower neighbour; with ci > lo >= 0 the
       // attachment is rejected below whatever the upper side would give.
@@ -691,7 +708,7 @@ EG3D_HD bool unique_polyline_4px(const DevScene& s, int view, float x, float y, 
 // PARALLEL over chain points [from, len): project the point into view v, look up the unique
 // polyline of the 4 px grid and its closest point (triangulation.cpp:791-806).
 template <class Team>
-EG3D_HD void view_candidates(const Team& tm, const DevScene& s, Chain& c, int v, int from) {
+EG3D_HD_FLAT void view_candidates(const Team& tm, const DevScene& s, Chain& c, int v, int from) {
   const float* P = s.cam_P + (size_t)v * 16;
   uint64_t tc0 = EG3D_TICK();
   // G members share a chain point when the chain is short: each scans 1/G of the polyline's segments
@@ -776,7 +793,7 @@ EG3D_HD void view_candidates(const Team& tm, const DevScene& s, Chain& c, int v,
 
 // Offer the chain to view v. epc = the task's epipolar hits in v (may be empty).
 template <class Team>
-EG3D_HD void expand_to_view(const Team& tm, const DevScene& s, Chain& c, int v, const Obs* epc, int n_epc,
+EG3D_HD_FLAT void expand_to_view(const Team& tm, const DevScene& s, Chain& c, int v, const Obs* epc, int n_epc,
                             int& centre) {
   bool epc_matched = false;
   int idx_first = 0, idx_second = 0;

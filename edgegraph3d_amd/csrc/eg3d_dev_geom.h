@@ -18,8 +18,13 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define EG3D_HD __host__ __device__ inline
+// the large per-chain routines must stay inlined into the expand kernel: when the inliner outlines
+// one of them (it did, depending on unrelated code-size changes) the call ABI costs a third of the
+// kernel's speed (more scratch, registers saved around the call)
+#define EG3D_HD_FLAT __host__ __device__ inline __attribute__((always_inline))
 #else
 #define EG3D_HD inline
+#define EG3D_HD_FLAT inline
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -246,7 +246,7 @@ struct ChainOut {
 // three selected, ascending (triangulation.cpp:960-973). One lane, one chain.
 // hyp_base = global index of the task's first hypothesis.
 template <class Team>
-EG3D_HD void expand_chain(const Team& tm, const DevScene& s, const StageAView& a, const TaskDesc& d, const ChainSeed& cs,
+EG3D_HD_FLAT void expand_chain(const Team& tm, const DevScene& s, const StageAView& a, const TaskDesc& d, const ChainSeed& cs,
                           uint32_t hyp_base, const HypResult* res, const HPoint* arena, const int32_t* map_view,
                           const uint32_t* map_entry, const uint32_t* map_n, const ChainLayout& L,
                           unsigned char* slice, ChainOut& out) {

@@ -627,6 +627,19 @@ struct TeamWave {
     for (int d = 32; d >= 1; d >>= 1) v |= (uint32_t)__shfl_xor((int)v, d);
     return v;
   }
+  template <class Pred>
+  __device__ __forceinline__ int leading_true(int m, Pred pred) const {
+    int cnt = 0;
+    for (int j0 = 0; j0 < m; j0 += 64) {
+      const int j = j0 + lane();
+      const unsigned long long mask = __ballot(j < m && pred(j));
+      const unsigned long long inv = ~mask;
+      const int lead = inv ? (__ffsll((long long)inv) - 1) : 64;
+      cnt += lead;
+      if (lead < 64) break;
+    }
+    return cnt;
+  }
   __device__ __forceinline__ int group_size(int n_items) const {
     int g = 1;
     while (g < 16 && g * 2 * n_items <= 64) g <<= 1;
