@@ -705,6 +705,38 @@ EG3D_HD bool unique_polyline_4px(const DevScene& s, int view, float x, float y, 
   return have;
 }
 
+#ifndef EG3D_LAZY_PRESOLVE
+#define EG3D_LAZY_PRESOLVE 0 /* 1: central pre-solves a window at a time as the visit reaches them */
+#endif
+#ifndef EG3D_SPEC_WINDOW
+#define EG3D_SPEC_WINDOW 8
+#endif
+// speculative central ADD solve of the chain points [from, to) whose candidate is within 4 px
+template <class Team>
+EG3D_HD_FLAT void central_presolves(const Team& tm, const DevScene& s, Chain& c, int v, int from, int to) {
+  tm.add_solves(
+      s, c, to - from,
+      [&](int j, const ChainPt*& pt, Obs& o) {
+        const ViewCand& vc = c.cand[c.head + from + j];
+        if (!vc.valid || !(vc.d2 <= 16.0f)) return false;
+        pt = &chain_at(c, from + j);
+        o.view = v;
+        o.pl = vc.pl;
+        o.seg = vc.seg;
+        o.x = vc.x;
+        o.y = vc.y;
+        return true;
+      },
+      [&](int j, bool ok, const float* X) {
+        ViewCand& vc = c.cand[c.head + from + j];
+        vc.cok = ok ? 1u : 0u;
+        vc.cX[0] = X[0];
+        vc.cX[1] = X[1];
+        vc.cX[2] = X[2];
+      });
+  tm.sync();
+}
+
 // PARALLEL over chain points [from, len): project the point into view v, look up the unique
 // polyline of the 4 px grid and its closest point (triangulation.cpp:791-806).
 template <class Team>
@@ -766,28 +798,9 @@ EG3D_HD_FLAT void view_candidates(const Team& tm, const DevScene& s, Chain& c, i
     }
   }
   tm.sync();
-  // speculative central ADD solve of every point whose candidate is within 4 px
-  tm.add_solves(
-      s, c, c.len - from,
-      [&](int j, const ChainPt*& pt, Obs& o) {
-        const ViewCand& vc = c.cand[c.head + from + j];
-        if (!vc.valid || !(vc.d2 <= 16.0f)) return false;
-        pt = &chain_at(c, from + j);
-        o.view = v;
-        o.pl = vc.pl;
-        o.seg = vc.seg;
-        o.x = vc.x;
-        o.y = vc.y;
-        return true;
-      },
-      [&](int j, bool ok, const float* X) {
-        ViewCand& vc = c.cand[c.head + from + j];
-        vc.cok = ok ? 1u : 0u;
-        vc.cX[0] = X[0];
-        vc.cX[1] = X[1];
-        vc.cX[2] = X[2];
-      });
-  tm.sync();
+#if !EG3D_LAZY_PRESOLVE
+  central_presolves(tm, s, c, v, from, c.len);
+#endif
   c.tsec[0] += EG3D_TICK() - tc0;
 }
 
@@ -845,6 +858,9 @@ EG3D_HD_FLAT void expand_to_view(const Team& tm, const DevScene& s, Chain& c, in
   }
   int last_matched = -1;
   view_candidates(tm, s, c, v, 0);
+#if EG3D_LAZY_PRESOLVE
+  int spec_slot_hi = 0;  // pre-solves exist for the visited slots below this one
+#endif
   for (int cur = 0; cur < c.len; cur++) {
     if (epc_matched && cur == idx_first) {
       cur = idx_second;
@@ -855,6 +871,14 @@ EG3D_HD_FLAT void expand_to_view(const Team& tm, const DevScene& s, Chain& c, in
     if (!vc.valid) continue;
     c.bytes += 8ull * (s.pl_vtx_off[s.view_pl_off[v] + vc.pl + 1] - s.pl_vtx_off[s.view_pl_off[v] + vc.pl]);
     if (vc.d2 > 16.0f) return;  // abandons this view (Q4)
+#if EG3D_LAZY_PRESOLVE
+    if (c.head + cur >= spec_slot_hi) {
+      int to = cur + EG3D_SPEC_WINDOW;
+      if (to > c.len) to = c.len;
+      central_presolves(tm, s, c, v, cur, to);
+      spec_slot_hi = c.head + to;
+    }
+#endif
     Obs o;
     o.view = v;
     o.pl = vc.pl;
