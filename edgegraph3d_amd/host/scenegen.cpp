@@ -443,6 +443,17 @@ extern "C" const eg3d_seeds* eg3d_synth_seeds(const eg3d_synth* s) { return &s->
 extern "C" const float* eg3d_synth_seed_truth(const eg3d_synth* s) { return s->seed_truth.data(); }
 extern "C" const uint32_t* eg3d_synth_polyline_curve(const eg3d_synth* s) { return s->pl_curve.data(); }
 extern "C" int eg3d_synth_n_curves(const eg3d_synth* s) { return (int)s->curves.size(); }
+extern "C" int eg3d_synth_camera(const eg3d_synth* s, int view, float* focal, float* ppx, float* ppy, float* R9,
+                                 float* C3) {
+  if (!s || view < 0 || view >= (int)s->cams.size()) return -1;
+  const Cam& c = s->cams[view];
+  *focal = c.f;
+  *ppx = c.px;
+  *ppy = c.py;
+  memcpy(R9, c.R, sizeof(float) * 9);
+  memcpy(C3, c.C, sizeof(float) * 3);
+  return 0;
+}
 extern "C" uint64_t eg3d_synth_total_segments(const eg3d_synth* s) { return s->total_segments; }
 extern "C" void eg3d_synth_destroy(eg3d_synth* s) { delete s; }
 extern "C" void eg3d_host_free(void* p) { free(p); }

@@ -447,8 +447,59 @@ extern "C" int eg3d_sfm_write_json(const eg3d_sfm* s, const char* in_path, const
   empty_str.t = JVal::STR;
   copy_or("sfm_data_version", empty_str);
   copy_or("root_path", empty_str);
-  copy_or("views", empty_arr);
-  copy_or("intrinsics", empty_arr);
+  if (have_in && in.get("views") && in.get("intrinsics")) {
+    copy_or("views", empty_arr);
+    copy_or("intrinsics", empty_arr);
+  } else {
+    // no input file to pass through (a scene built with eg3d_sfm_create): write the views and one
+    // pinhole intrinsic per camera in the layout OpenMvgParser reads (OpenMvgParser.cpp:39-301)
+    auto jstr = [](const std::string& v) {
+      JVal j;
+      j.t = JVal::STR;
+      j.s = v;
+      return j;
+    };
+    JVal views, intr;
+    views.t = intr.t = JVal::ARR;
+    for (size_t i = 0; i < s->cams.size(); i++) {
+      const Cam& c = s->cams[i];
+      JVal v, val, pw, d;
+      v.t = val.t = pw.t = d.t = JVal::OBJ;
+      d.o.emplace_back("local_path", jstr("/"));
+      d.o.emplace_back("filename", jstr(c.path));
+      d.o.emplace_back("width", jint(s->width));
+      d.o.emplace_back("height", jint(s->height));
+      d.o.emplace_back("id_view", jint((long long)i));
+      d.o.emplace_back("id_intrinsic", jint((long long)i));
+      d.o.emplace_back("id_pose", jint((long long)i));
+      pw.o.emplace_back("id", jint(2147483649ll + (long long)i));
+      pw.o.emplace_back("data", d);
+      val.o.emplace_back("polymorphic_id", jint(1073741824ll));
+      val.o.emplace_back("ptr_wrapper", pw);
+      v.o.emplace_back("key", jint((long long)i));
+      v.o.emplace_back("value", val);
+      views.a.push_back(v);
+      JVal k, kval, kpw, kd, pp;
+      k.t = kval.t = kpw.t = kd.t = JVal::OBJ;
+      pp.t = JVal::ARR;
+      pp.a.push_back(jnum(c.ppx));
+      pp.a.push_back(jnum(c.ppy));
+      kd.o.emplace_back("width", jint(s->width));
+      kd.o.emplace_back("height", jint(s->height));
+      kd.o.emplace_back("focal_length", jnum(c.focal));
+      kd.o.emplace_back("principal_point", pp);
+      kpw.o.emplace_back("id", jint(2147484649ll + (long long)i));
+      kpw.o.emplace_back("data", kd);
+      kval.o.emplace_back("polymorphic_id", jint(2147483649ll));
+      kval.o.emplace_back("polymorphic_name", jstr("pinhole"));
+      kval.o.emplace_back("ptr_wrapper", kpw);
+      k.o.emplace_back("key", jint((long long)i));
+      k.o.emplace_back("value", kval);
+      intr.a.push_back(k);
+    }
+    root.o.emplace_back("views", views);
+    root.o.emplace_back("intrinsics", intr);
+  }
   JVal ex;
   ex.t = JVal::ARR;
   for (size_t i = 0; i < s->cams.size(); i++) {

@@ -1,0 +1,133 @@
+// examples/edge_matcher_refpoints.cpp — the reference's `edge_matcher` run for pipeline 3, end to end
+// in C++ over the C ABI (what src/edgegraph3d/edge_matcher.cpp:57-182 + pipelines.cpp:160-176 do):
+//
+//   OpenMVG JSON (cameras + SfM points)  +  polyline graphs of every view
+//     -> fundamental matrices            (edge_matcher.cpp:96; analytic here)
+//     -> plg_matching_from_refpoints     (pipelines.cpp:164)            GPU: eg3d_match_refpoints
+//     -> filter_3d_points_close_2d_array (edge_matcher.cpp:150)         host
+//     -> add_3dpoints_to_sfmd            (edge_matcher.cpp:158)         host
+//     -> [./filter -e] gaussNewtonFiltering + observation filter + removeOutliers   GPU + host
+//     -> output_sfm_data                 (edge_matcher.cpp:169)         OpenMVG JSON out
+//
+// Usage:
+//   edge_matcher_refpoints --make-synthetic <config 0..4> <dir>      writes <dir>/input.json, <dir>/plgs.bin
+//   edge_matcher_refpoints <dir>/input.json <dir>/plgs.bin <out.json> [--filter]
+//
+// The polyline graphs come from a container file because building them from edge images (SURVEY
+// N2) is outside this repository's scope. Build (see tests/test_gpu_edge_cases.py):
+//   g++ -std=c++17 -I include examples/edge_matcher_refpoints.cpp -Ledgegraph3d_amd -leg3d -leg3d_host ...
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "eg3d.h"
+#include "eg3d_host.h"
+
+static int fail(const char* what) {
+  std::fprintf(stderr, "edge_matcher_refpoints: %s (%s)\n", what, eg3d_last_error());
+  return 1;
+}
+
+static int make_synthetic(int cfg_index, const std::string& dir) {
+  eg3d_synth_config cfg;
+  eg3d_synth_default_config(&cfg, cfg_index);
+  eg3d_synth* syn = eg3d_synth_create(&cfg);
+  if (!syn) return fail("synthetic scene");
+  const eg3d_scene* sc = eg3d_synth_scene(syn);
+  const eg3d_seeds* sd = eg3d_synth_seeds(syn);
+  const float* truth = eg3d_synth_seed_truth(syn);
+  eg3d_sfm* sfm = eg3d_sfm_create(sc->n_views, sc->width, sc->height);
+  for (int v = 0; v < sc->n_views; v++) {
+    float f, px, py, R[9], C[3];
+    eg3d_synth_camera(syn, v, &f, &px, &py, R, C);
+    char name[64];
+    std::snprintf(name, sizeof(name), "%04d.png", v);
+    eg3d_sfm_set_camera(sfm, v, f, px, py, R, C, name);
+  }
+  for (uint32_t i = 0; i < sd->n_seeds; i++) {
+    const uint32_t a = sd->trk_off[i], b = sd->trk_off[i + 1];
+    eg3d_sfm_add_point(sfm, truth + 3 * i, (int)(b - a), sd->trk_view + a, sd->trk_xy + 2 * a);
+  }
+  int rc = eg3d_sfm_write_json(sfm, nullptr, (dir + "/input.json").c_str());
+  if (rc == 0) rc = eg3d_plg_write((dir + "/plgs.bin").c_str(), sc);
+  std::printf("wrote %s/input.json (%d views, %u points) and %s/plgs.bin (%u polylines)\n", dir.c_str(), sc->n_views,
+              sd->n_seeds, dir.c_str(), sc->view_pl_off[sc->n_views]);
+  eg3d_sfm_destroy(sfm);
+  eg3d_synth_destroy(syn);
+  return rc == 0 ? 0 : fail("writing the synthetic inputs");
+}
+
+int main(int argc, char** argv) {
+  if (argc >= 4 && std::strcmp(argv[1], "--make-synthetic") == 0) return make_synthetic(std::atoi(argv[2]), argv[3]);
+  if (argc < 4) {
+    std::fprintf(stderr, "usage: %s <input.json> <plgs.bin> <out.json> [--filter]\n", argv[0]);
+    return 2;
+  }
+  const bool do_filter = argc > 4 && std::strcmp(argv[4], "--filter") == 0;
+
+  // ---- inputs (edge_matcher.cpp:64-95)
+  eg3d_sfm* sfm = eg3d_sfm_read_json(argv[1]);
+  if (!sfm) return fail("reading the OpenMVG file");
+  eg3d_plg* plg = eg3d_plg_read(argv[2]);
+  if (!plg) return fail("reading the polyline graphs");
+  const int V = eg3d_sfm_n_views(sfm);
+  eg3d_scene sc = *eg3d_plg_scene(plg);
+  if (sc.n_views != V) return fail("views of the SfM file and of the polyline graphs differ");
+  std::vector<double> F((size_t)V * V * 9);
+  std::vector<uint8_t> Fv((size_t)V * V);
+  if (eg3d_sfm_analytic_F(sfm, F.data(), Fv.data()) != 0) return fail("fundamental matrices");
+  sc.cam_P = eg3d_sfm_cam_P(sfm);
+  sc.F = F.data();
+  sc.F_valid = Fv.data();
+  const uint64_t first_edgepoint = eg3d_sfm_n_points(sfm);
+
+  // ---- pipeline 3 on the GPU (pipelines.cpp:160-176)
+  eg3d_ctx* ctx = nullptr;
+  if (eg3d_create(&sc, 0, &ctx) != EG3D_OK) return fail("eg3d_create");
+  eg3d_seeds seeds;
+  eg3d_sfm_seeds(sfm, &seeds);
+  eg3d_edgepoints pts;
+  eg3d_stage_times tm;
+  if (eg3d_match_refpoints(ctx, &seeds, 0, seeds.n_seeds, 0, &pts, &tm) != EG3D_OK) return fail("eg3d_match_refpoints");
+  std::printf("matched %u reference points -> %llu edge-points (%llu observations) in %.2f ms on the GPU\n", seeds.n_seeds,
+              (unsigned long long)pts.n_points, (unsigned long long)pts.n_obs, tm.ms_total);
+
+  // ---- filter_3d_points_close_2d_array + add_3dpoints_to_sfmd (edge_matcher.cpp:150-158)
+  std::vector<uint8_t> keep(pts.n_points ? pts.n_points : 1);
+  if (eg3d_host_filter_close_2d(V, sc.width, sc.height, &pts, keep.data()) != 0) return fail("dedup");
+  uint64_t kept = 0;
+  for (uint64_t i = 0; i < pts.n_points; i++) kept += keep[i];
+  if (eg3d_sfm_add_edgepoints(sfm, &pts, keep.data()) != 0) return fail("adding the edge-points");
+  std::printf("kept %llu edge-points after the 3 px de-duplication; SfM data now holds %llu points\n",
+              (unsigned long long)kept, (unsigned long long)eg3d_sfm_n_points(sfm));
+  eg3d_free_edgepoints(&pts);
+
+  // ---- ./filter -e (src/utils/filter.cpp:48-115): Gauss-Newton refinement + observation-count filter
+  if (do_filter) {
+    eg3d_seeds all;
+    eg3d_sfm_seeds(sfm, &all);
+    const uint64_t n = all.n_seeds;
+    std::vector<float> Xo(3 * n);
+    std::vector<uint8_t> inl(n ? n : 1);
+    if (eg3d_gn_filter(ctx, eg3d_sfm_points(sfm), all.trk_off, all.trk_view, all.trk_xy, n, 2.25f, 0, Xo.data(),
+                       inl.data(), nullptr) != EG3D_OK)
+      return fail("eg3d_gn_filter");
+    eg3d_sfm_set_point_coords(sfm, Xo.data());   // inliers moved, outliers returned unchanged
+    const int thr = eg3d_host_observation_filter(V, all.trk_off, n, first_edgepoint, -1, inl.data());
+    uint64_t n_in = 0;
+    for (uint64_t i = 0; i < n; i++) n_in += inl[i];
+    eg3d_sfm_remove_outliers(sfm, inl.data());
+    std::printf("filter: %llu of %llu points kept (Gauss-Newton mse < 2.25, more than %d observations)\n",
+                (unsigned long long)n_in, (unsigned long long)n, thr);
+  }
+
+  // ---- output_sfm_data (edge_matcher.cpp:169)
+  if (eg3d_sfm_write_json(sfm, argv[1], argv[3]) != 0) return fail("writing the output");
+  std::printf("wrote %s (%llu points)\n", argv[3], (unsigned long long)eg3d_sfm_n_points(sfm));
+  eg3d_destroy(ctx);
+  eg3d_plg_destroy(plg);
+  eg3d_sfm_destroy(sfm);
+  return 0;
+}

@@ -49,6 +49,22 @@ int eg3d_synth_points(const eg3d_synth* s, uint64_t n_points, uint64_t rng_seed,
                       int32_t** obs_view, float** obs_xy);
 void eg3d_host_free(void* p);
 
+/* camera of the synthetic rig (for writing the scene as an OpenMVG file): K = (focal, ppx, ppy),
+ * R row-major, C = centre */
+int eg3d_synth_camera(const eg3d_synth* s, int view, float* focal, float* ppx, float* ppy, float* R9, float* C3);
+
+/* ------------------------------------------------------ polyline-graph file ---- */
+/* The reference builds its PolyLineGraph2DHMapImpl per view from the edge images at start-up
+ * (io/input/convert_edge_images_pixel_to_segment.cpp:868-892, SURVEY N2: out of scope); this
+ * container ("EG3DPLG1", layout in edgegraph3d_amd/host/plg_file.cpp) carries the polyline graphs
+ * of all views — ids = the reference's vector positions — from whatever built them to the path. */
+typedef struct eg3d_plg eg3d_plg;
+int eg3d_plg_write(const char* path, const eg3d_scene* scene);
+eg3d_plg* eg3d_plg_read(const char* path);
+/* polyline part of an eg3d_scene (cam_P / F / F_valid null: taken from the SfM data by the caller) */
+const eg3d_scene* eg3d_plg_scene(const eg3d_plg* g);
+void eg3d_plg_destroy(eg3d_plg* g);
+
 /* --------------------------------------------------------------- grid maps ---- */
 /* Uniform grid of one view (reference PolyLine2DMap ctor, polyLine_2d_map.cpp:40-58).
  * Outputs malloc'd CSR arrays (cell = row*ncols+col), free with eg3d_host_free. */

@@ -205,3 +205,43 @@ def test_chain_expansion_in_many_chunks(monkeypatch):
     rep = compare_edgepoints(whole, parts)
     assert rep["ok"] and rep["bitexact_X"], rep["msgs"]
     ctx.close()
+
+
+def test_cpp_end_to_end_example(tmp_path):
+    """examples/edge_matcher_refpoints.cpp: OpenMVG JSON + polyline-graph file in, pipeline 3 on the GPU
+    through the C ABI, dedup, add points, (optional) ./filter -e, OpenMVG JSON out — all from C++.
+    Its counts must equal the same steps driven from Python on the same synthetic scene."""
+    import json
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "edgegraph3d_amd")
+    exe = str(tmp_path / "edge_matcher_refpoints")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "edge_matcher_refpoints.cpp"), "-L", pkg, "-leg3d", "-leg3d_host",
+                           "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-L", "/opt/rocm/lib", "-lamdhip64", "-o", exe])
+    d = str(tmp_path)
+    subprocess.check_call([exe, "--make-synthetic", "1", d])
+    out = subprocess.run([exe, d + "/input.json", d + "/plgs.bin", d + "/out.json"], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = re.search(r"-> (\d+) edge-points \((\d+) observations\)", out.stdout)
+    k = re.search(r"kept (\d+) edge-points", out.stdout)
+    s = host.Synth(1)
+    ctx = api.Context(s.scene)
+    got = ctx.match_refpoints(s.seeds)
+    ctx.close()
+    assert int(m.group(1)) == got["n_points"] and int(m.group(2)) == got["n_obs"]
+    doc = json.load(open(d + "/out.json"))
+    assert len(doc["structure"]) == s.n_seeds + int(k.group(1)) and 0 < int(k.group(1)) < got["n_points"]
+    assert len(doc["views"]) == s.n_views == len(doc["extrinsics"])
+    # the appended points carry >= 3 observations with view keys inside the rig
+    last = doc["structure"][-1]["value"]["observations"]
+    assert len(last) >= 3 and all(0 <= o["key"] < s.n_views for o in last)
+    out2 = subprocess.run([exe, d + "/input.json", d + "/plgs.bin", d + "/out_f.json", "--filter"], capture_output=True,
+                          text=True, timeout=300)
+    assert out2.returncode == 0, out2.stdout + out2.stderr
+    f = re.search(r"filter: (\d+) of (\d+) points kept", out2.stdout)
+    assert int(f.group(2)) == len(doc["structure"]) and 0 < int(f.group(1)) <= int(f.group(2))
+    assert len(json.load(open(d + "/out_f.json"))["structure"]) == int(f.group(1))
