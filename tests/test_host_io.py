@@ -123,3 +123,38 @@ def test_reference_surface_shim_compiles():
         p = os.path.join(d, "t.cpp")
         open(p, "w").write(src)
         subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), p])
+
+
+def test_polyline_graph_container_round_trip():
+    """EG3DPLG1 container (edgegraph3d_amd/host/plg_file.cpp): the polyline graphs of all views
+    written and read back are identical, including invalid / empty polylines and node ids."""
+    L = host.lib()
+    L.eg3d_plg_write.argtypes = [C.c_char_p, C.POINTER(D.Scene)]
+    L.eg3d_plg_read.restype = C.c_void_p
+    L.eg3d_plg_read.argtypes = [C.c_char_p]
+    L.eg3d_plg_scene.restype = C.POINTER(D.Scene)
+    L.eg3d_plg_scene.argtypes = [C.c_void_p]
+    L.eg3d_plg_destroy.argtypes = [C.c_void_p]
+    s = host.Synth(1)
+    sc = s.scene_np()
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "plgs.bin").encode()
+        assert L.eg3d_plg_write(p, s.scene) == 0
+        g = L.eg3d_plg_read(p)
+        assert g
+        r = L.eg3d_plg_scene(g).contents
+        V = int(r.n_views)
+        assert V == sc["n_views"] and r.width == sc["width"] and r.height == sc["height"]
+        vpo = D.as_np(r.view_pl_off, V + 1, np.uint32)
+        NP = int(vpo[-1])
+        pvo = D.as_np(r.pl_vtx_off, NP + 1, np.uint32)
+        assert np.array_equal(vpo, sc["view_pl_off"]) and np.array_equal(pvo, sc["pl_vtx_off"])
+        assert np.array_equal(D.as_np(r.pl_start, NP, np.uint32), sc["pl_start"])
+        assert np.array_equal(D.as_np(r.pl_end, NP, np.uint32), sc["pl_end"])
+        assert np.array_equal(D.as_np(r.pl_valid, NP, np.uint8), sc["pl_valid"])
+        assert (sc["pl_valid"] == 0).any()                     # the generator emits some invalid polylines
+        got = D.as_np(r.vtx_xy, 2 * int(pvo[-1]), np.float32).reshape(-1, 2)
+        assert np.array_equal(got.view(np.uint32), sc["vtx_xy"].view(np.uint32))
+        L.eg3d_plg_destroy(g)
+        open(os.path.join(d, "bad.bin"), "wb").write(b"NOTAPLG!" + b"\0" * 12)
+        assert not L.eg3d_plg_read(os.path.join(d, "bad.bin").encode())
