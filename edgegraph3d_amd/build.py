@@ -66,6 +66,21 @@ def build_hip(force=False):
     return HIP_LIB
 
 
+RCCL_LIB = os.path.join(PKG, "libeg3d_rccl.so")
+
+
+def build_rccl(force=False):
+    """The RCCL all-gather of the edge-point cloud for C/C++ hosts (include/eg3d_rccl.h): its own
+    library so that libeg3d.so carries no communication dependency."""
+    src = os.path.join(PKG, "rccl", "eg3d_rccl.hip")
+    deps = [src] + _all_sources(INC_DIR, (".h",))
+    if force or _newer(RCCL_LIB, deps):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        _run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", INC_DIR, src,
+              "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-o", RCCL_LIB])
+    return RCCL_LIB
+
+
 def build_oracle(force=False):
     """Builds the CPU oracle (test infrastructure). Building the checker is not using it."""
     d = os.path.join(ROOT, "oracle")
@@ -78,6 +93,7 @@ def build_oracle(force=False):
 def build_all(force=False):
     build_host(force)
     build_hip(force)
+    build_rccl(force)
     build_oracle(force)
 
 

@@ -1,0 +1,165 @@
+// eg3d_rccl.hip — RCCL all-gather of the edge-point cloud (include/eg3d_rccl.h). One process per GPU;
+// xGMI is point-to-point, so the cloud travels as ONE large padded message per rank (every link
+// busy at once) instead of seven small ones, and is compacted on the device afterwards.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/eg3d_rccl.h"
+
+namespace {
+
+struct Buf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t n) {
+    if (n <= cap && p) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = std::max<size_t>(n + n / 4, 256);
+    if (hipMalloc(&p, want) != hipSuccess) return -1;
+    cap = want;
+    return 0;
+  }
+  ~Buf() {
+    if (p) (void)hipFree(p);
+  }
+};
+
+// packed layout of one rank's block, padded to the largest rank: field f starts at off[f]
+struct Layout {
+  uint64_t mp, mo;     // padded points / observations per rank
+  uint64_t off[7];     // X, obs_off, key | obs_view, obs_pl, obs_seg, obs_xy
+  uint64_t bytes;
+};
+static Layout make_layout(uint64_t mp, uint64_t mo) {
+  static const uint64_t per[7] = {12, 4, 16, 4, 4, 4, 8};
+  Layout L;
+  L.mp = mp;
+  L.mo = mo;
+  uint64_t o = 0;
+  for (int f = 0; f < 7; f++) {
+    L.off[f] = o;
+    o += per[f] * (f < 3 ? mp : mo);
+    o = (o + 15) & ~15ull;
+  }
+  L.bytes = std::max<uint64_t>(o, 16);
+  return L;
+}
+
+// one block per (rank, field): copy the rank's valid prefix to its place in the ordered cloud
+__global__ void k_unpack(const unsigned char* recv, Layout L, const uint64_t* counts /*[R][2]*/, int n_ranks,
+                         float* X, uint32_t* obs_off, uint32_t* key, int32_t* obs_view, uint32_t* obs_pl,
+                         uint32_t* obs_seg, float* obs_xy) {
+  const int r = blockIdx.y, f = blockIdx.z;
+  uint64_t pbase = 0, obase = 0;
+  for (int q = 0; q < r; q++) {
+    pbase += counts[2 * q];
+    obase += counts[2 * q + 1];
+  }
+  const uint64_t np = counts[2 * r], no = counts[2 * r + 1];
+  const unsigned char* src = recv + (size_t)r * L.bytes + L.off[f];
+  const uint64_t words = f == 0 ? np * 3 : f == 1 ? np : f == 2 ? np * 4 : f == 6 ? no * 2 : no;
+  uint32_t* dst = f == 0   ? (uint32_t*)X + pbase * 3
+                  : f == 1 ? obs_off + pbase
+                  : f == 2 ? key + pbase * 4
+                  : f == 3 ? (uint32_t*)obs_view + obase
+                  : f == 4 ? obs_pl + obase
+                  : f == 5 ? obs_seg + obase
+                           : (uint32_t*)obs_xy + obase * 2;
+  const uint32_t add = f == 1 ? (uint32_t)obase : 0u;  // observation offsets index the gathered arrays
+  const uint32_t* s32 = (const uint32_t*)src;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (uint64_t)gridDim.x * blockDim.x)
+    dst[i] = s32[i] + add;
+}
+
+}  // namespace
+
+struct eg3d_gather {
+  int device = 0;
+  Buf send, recv, cnt_dev, X, off, key, view, pl, seg, xy;
+};
+
+extern "C" eg3d_gather* eg3d_gather_create(int device) {
+  eg3d_gather* g = new eg3d_gather();
+  g->device = device;
+  return g;
+}
+extern "C" void eg3d_gather_destroy(eg3d_gather* g) {
+  if (!g) return;
+  (void)hipSetDevice(g->device);
+  delete g;
+}
+
+#define TRY_HIP(e)                   \
+  do {                               \
+    if ((e) != hipSuccess) return -2; \
+  } while (0)
+#define TRY_NCCL(e)                   \
+  do {                                \
+    if ((e) != ncclSuccess) return -5; \
+  } while (0)
+
+extern "C" int eg3d_allgather_edgepoints(eg3d_gather* g, void* nccl_comm, int n_ranks, int rank, void* hip_stream,
+                                         const eg3d_device_edgepoints* local, eg3d_device_edgepoints* out,
+                                         uint64_t* rank_points, uint64_t* rank_obs) {
+  if (!g || !nccl_comm || !local || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks || !local->complete) return -1;
+  ncclComm_t comm = (ncclComm_t)nccl_comm;
+  hipStream_t st = (hipStream_t)hip_stream;
+  TRY_HIP(hipSetDevice(g->device));
+  // ---- counts
+  if (g->cnt_dev.ensure(sizeof(uint64_t) * 2 * ((size_t)n_ranks + 1))) return -2;
+  uint64_t* cnt = (uint64_t*)g->cnt_dev.p;
+  const uint64_t mine[2] = {local->n_points, local->n_obs};
+  TRY_HIP(hipMemcpyAsync(cnt + 2 * (size_t)n_ranks, mine, sizeof(mine), hipMemcpyHostToDevice, st));
+  TRY_NCCL(ncclAllGather(cnt + 2 * (size_t)n_ranks, cnt, 2, ncclUint64, comm, st));
+  std::vector<uint64_t> h(2 * (size_t)n_ranks);
+  TRY_HIP(hipMemcpyAsync(h.data(), cnt, sizeof(uint64_t) * h.size(), hipMemcpyDeviceToHost, st));
+  TRY_HIP(hipStreamSynchronize(st));
+  uint64_t mp = 0, mo = 0, tp = 0, to = 0;
+  for (int r = 0; r < n_ranks; r++) {
+    mp = std::max(mp, h[2 * r]);
+    mo = std::max(mo, h[2 * r + 1]);
+    tp += h[2 * r];
+    to += h[2 * r + 1];
+    if (rank_points) rank_points[r] = h[2 * r];
+    if (rank_obs) rank_obs[r] = h[2 * r + 1];
+  }
+  if (to > 0xffffffffull) return -3;  // observation offsets are 32-bit
+  const Layout L = make_layout(mp, mo);
+  // ---- pack this rank's block and gather
+  if (g->send.ensure(L.bytes) || g->recv.ensure(L.bytes * (size_t)n_ranks)) return -2;
+  unsigned char* sb = (unsigned char*)g->send.p;
+  const uint64_t np = local->n_points, no = local->n_obs;
+  const void* src[7] = {local->X, local->obs_off, local->key, local->obs_view, local->obs_pl, local->obs_seg, local->obs_xy};
+  const uint64_t nbytes[7] = {np * 12, np * 4, np * 16, no * 4, no * 4, no * 4, no * 8};
+  for (int f = 0; f < 7; f++)
+    if (nbytes[f]) TRY_HIP(hipMemcpyAsync(sb + L.off[f], src[f], nbytes[f], hipMemcpyDeviceToDevice, st));
+  TRY_NCCL(ncclAllGather(sb, g->recv.p, L.bytes, ncclUint8, comm, st));
+  // ---- compaction into one ordered cloud
+  if (g->X.ensure(tp * 12 + 16) || g->off.ensure((tp + 1) * 4) || g->key.ensure(tp * 16 + 16) || g->view.ensure(to * 4 + 16) ||
+      g->pl.ensure(to * 4 + 16) || g->seg.ensure(to * 4 + 16) || g->xy.ensure(to * 8 + 16))
+    return -2;
+  hipLaunchKernelGGL(k_unpack, dim3(64, n_ranks, 7), dim3(256), 0, st, (const unsigned char*)g->recv.p, L,
+                     (const uint64_t*)cnt, n_ranks, (float*)g->X.p, (uint32_t*)g->off.p, (uint32_t*)g->key.p,
+                     (int32_t*)g->view.p, (uint32_t*)g->pl.p, (uint32_t*)g->seg.p, (float*)g->xy.p);
+  const uint32_t last = (uint32_t)to;
+  TRY_HIP(hipMemcpyAsync((uint32_t*)g->off.p + tp, &last, 4, hipMemcpyHostToDevice, st));
+  TRY_HIP(hipStreamSynchronize(st));
+  out->n_points = tp;
+  out->n_obs = to;
+  out->X = (const float*)g->X.p;
+  out->obs_off = (const uint32_t*)g->off.p;
+  out->obs_view = (const int32_t*)g->view.p;
+  out->obs_pl = (const uint32_t*)g->pl.p;
+  out->obs_seg = (const uint32_t*)g->seg.p;
+  out->obs_xy = (const float*)g->xy.p;
+  out->key = (const uint32_t*)g->key.p;
+  out->complete = 1;
+  return 0;
+}

@@ -1,0 +1,39 @@
+/*
+ * eg3d_rccl.h — the one exchange step of the path for a C/C++ host: the variable-length
+ * all-gather of the edge-point cloud over RCCL (SURVEY 8(b) `eg3d_allgather_edgepoints`, 8(e)).
+ * Seeds are sharded over ranks in contiguous ranges (rank order = seed order,
+ * plg_matching_from_refpoints.cpp:83-104 has no cross-seed state), every rank runs
+ * eg3d_match_resident(..., device_only=1) on its range, then all ranks call
+ * eg3d_allgather_edgepoints: counts first (16 B/rank), ONE padded ncclAllGather of the packed SoA
+ *   [X | obs_off | key | obs_view | obs_pl | obs_seg | obs_xy]
+ * read straight from the context's HBM buffers, then a compaction kernel that leaves the whole,
+ * globally ordered cloud on every rank (obs_off rebased). Lives in its own library
+ * (libeg3d_rccl.so, links librccl) so that libeg3d.so has no communication dependency.
+ * bench.py does the same through torch.distributed (edgegraph3d_amd/distributed.py).
+ */
+#ifndef EG3D_RCCL_H_
+#define EG3D_RCCL_H_
+#include "eg3d.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct eg3d_gather eg3d_gather; /* staging + result buffers of one rank (grow-only) */
+
+eg3d_gather* eg3d_gather_create(int device);
+void eg3d_gather_destroy(eg3d_gather* g);
+
+/* nccl_comm: an initialised ncclComm_t of n_ranks ranks (this process = `rank`); hip_stream: the
+ * stream the collective is enqueued on (NULL = the null stream). `local` = this rank's
+ * eg3d_last_device_output (must be `complete`). On return `out` views the gathered cloud in HBM
+ * (valid until the next call on `g`), rank_points / rank_obs (host arrays of n_ranks entries, may
+ * be NULL) receive the per-rank counts. Collective: every rank must call it. */
+int eg3d_allgather_edgepoints(eg3d_gather* g, void* nccl_comm, int n_ranks, int rank, void* hip_stream,
+                              const eg3d_device_edgepoints* local, eg3d_device_edgepoints* out,
+                              uint64_t* rank_points, uint64_t* rank_obs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EG3D_RCCL_H_ */

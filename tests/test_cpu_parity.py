@@ -69,10 +69,15 @@ def test_abi_library_exports_every_declared_symbol():
         assert hasattr(L, name), name
     H = host.lib()
     hhdr = open(os.path.join(root, "include", "eg3d_host.h")).read()
-    host_syms = set(re.findall(r"\b(eg3d_(?:synth|host|sfm)_[a-z_0-9A-Z]+)\s*\(", hhdr))
-    assert len(host_syms) > 20
+    host_syms = set(re.findall(r"\b(eg3d_(?:synth|host|sfm|plg)_[a-z_0-9A-Z]+)\s*\(", hhdr))
+    assert len(host_syms) > 24
     for name in host_syms:
         assert hasattr(H, name), name
+    # the RCCL gather library (include/eg3d_rccl.h); loading it needs librccl, not a GPU
+    R = C.CDLL(os.path.join(os.path.dirname(api.lib_path()), "libeg3d_rccl.so"))
+    rhdr = open(os.path.join(root, "include", "eg3d_rccl.h")).read()
+    for name in set(re.findall(r"\b(eg3d_(?:gather|allgather)_[a-z_0-9]+)\s*\(", rhdr)):
+        assert hasattr(R, name), name
 
 
 def test_no_gpu_means_loud_failure():
