@@ -73,11 +73,16 @@ def test_abi_library_exports_every_declared_symbol():
     assert len(host_syms) > 24
     for name in host_syms:
         assert hasattr(H, name), name
-    # the RCCL gather library (include/eg3d_rccl.h); loading it needs librccl, not a GPU
-    R = C.CDLL(os.path.join(os.path.dirname(api.lib_path()), "libeg3d_rccl.so"))
+    # the RCCL gather library (include/eg3d_rccl.h): symbol table only — loading it would pull
+    # /opt/rocm's librccl into a process that may already hold the torch wheel's ROCm runtime
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", os.path.join(os.path.dirname(api.lib_path()), "libeg3d_rccl.so")],
+                          capture_output=True, text=True, check=True).stdout
     rhdr = open(os.path.join(root, "include", "eg3d_rccl.h")).read()
-    for name in set(re.findall(r"\b(eg3d_(?:gather|allgather)_[a-z_0-9]+)\s*\(", rhdr)):
-        assert hasattr(R, name), name
+    rsyms = set(re.findall(r"\b(eg3d_(?:gather|allgather)_[a-z_0-9]+)\s*\(", rhdr))
+    assert len(rsyms) == 3
+    for name in rsyms:
+        assert re.search(r"\b%s\b" % name, syms), name
 
 
 def test_no_gpu_means_loud_failure():
