@@ -233,8 +233,11 @@ EG3D_HD bool gauss_newton_f64(const float* cam_P, Cursor& cur, const double X0[3
   // Jacobian rows and residuals of the first pass are kept in lane-private memory (8 doubles per
   // observation, lane-interleaved => coalesced) so the update pass does not redo the projection
   // and its 8 FP64 divisions; same values, same order => same bits. Larger n recomputes.
-  double keep[EG3D_LOCAL_OBS][8];
-  const bool stored = n <= EG3D_LOCAL_OBS;
+#ifndef EG3D_KEEP_OBS
+#define EG3D_KEEP_OBS EG3D_LOCAL_OBS
+#endif
+  double keep[EG3D_KEEP_OBS > 0 ? EG3D_KEEP_OBS : 1][8];
+  const bool stored = EG3D_KEEP_OBS > 0 && n <= EG3D_KEEP_OBS;
   for (int it = 0; it < 30; it++) {
     double mse = 0;
     double H00 = 0, H01 = 0, H02 = 0, H11 = 0, H12 = 0, H22 = 0;

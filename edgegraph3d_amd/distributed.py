@@ -1,7 +1,8 @@
 """Multi-GPU plumbing of the path: seed sharding and the all-gather of the edge-point cloud.
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI; "gloo" on CPU for
-tests). Seeds are independent units, so rank r owns the contiguous range shard_range(...)[r]
+tests). Seeds are independent units, so rank r owns the contiguous range
+shard_ranges_balanced(...)[r] (balanced by the sum of track lengths; shard_range = by count)
 and the concatenation of the per-rank outputs in rank order IS the single-process output. The
 only exchange step is the variable-length all-gather of the cloud: counts first (16 B/rank),
 then ONE padded all_gather_into_tensor of the packed SoA
@@ -25,6 +26,90 @@ def shard_range(n_seeds, world):
         out.append((b, e))
         b = e
     return out
+
+
+def shard_ranges_balanced(trk_off, begin, end, world):
+    """Contiguous seed ranges of [begin, end) per rank, balanced by the sum of the track lengths k
+    (the loop being split, plg_matching_from_refpoints.cpp:83-104, costs ~k candidate searches and
+    ~k start views per seed) instead of by seed count. trk_off = the seeds' CSR offsets, so the
+    weight of a range is one subtraction. Every rank computes the same split from the same array."""
+    import numpy as np
+    off = np.asarray(trk_off, dtype=np.int64)
+    lo, hi = int(off[begin]), int(off[end])
+    cuts = [begin]
+    for r in range(1, world):
+        target = lo + (hi - lo) * r // world
+        c = int(np.searchsorted(off[begin:end + 1], target, side="left")) + begin
+        cuts.append(min(max(c, cuts[-1]), end))
+    cuts.append(end)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+class RcclCloudGather:
+    """The C-ABI exchange step (include/eg3d_rccl.h: eg3d_allgather_edgepoints in libeg3d_rccl.so) on an
+    RCCL communicator created with ncclCommInitRank; the unique id travels through the caller's
+    existing torch.distributed group (any backend). librccl is resolved by SONAME, so a process that
+    has imported torch shares torch's copy instead of loading a second one."""
+
+    def __init__(self, dist, world, rank, device_index, stream_ptr=None):
+        import ctypes as C
+        import os
+        import torch as _t
+        from . import _cdefs as D
+        self.C, self.D = C, D
+        self.world, self.rank = world, rank
+        self.nccl = C.CDLL("librccl.so.1")
+        pkg = os.path.dirname(os.path.abspath(__file__))
+        self.G = C.CDLL(os.path.join(pkg, "libeg3d_rccl.so"))
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_char * 128)]
+
+        uid = UniqueId()
+        if rank == 0:
+            rc = self.nccl.ncclGetUniqueId(C.byref(uid))
+            if rc != 0:
+                raise RuntimeError("ncclGetUniqueId failed (%d)" % rc)
+        if world > 1:
+            dev = _t.device("cuda", device_index) if dist.get_backend() == "nccl" else _t.device("cpu")
+            t = _t.frombuffer(bytearray(bytes(uid)), dtype=_t.uint8).clone().to(dev)
+            dist.broadcast(t, src=0)
+            C.memmove(C.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+        self.comm = C.c_void_p()
+        self.nccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        rc = self.nccl.ncclCommInitRank(C.byref(self.comm), world, uid, rank)
+        if rc != 0:
+            raise RuntimeError("ncclCommInitRank failed (%d)" % rc)
+        self.G.eg3d_gather_create.restype = C.c_void_p
+        self.G.eg3d_gather_create.argtypes = [C.c_int]
+        self.G.eg3d_gather_destroy.argtypes = [C.c_void_p]
+        self.G.eg3d_allgather_edgepoints.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                                     C.POINTER(D.DeviceEdgePoints), C.POINTER(D.DeviceEdgePoints),
+                                                     C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        self.g = self.G.eg3d_gather_create(device_index)
+        if not self.g:
+            raise RuntimeError("eg3d_gather_create failed")
+        self.stream = C.c_void_p(stream_ptr) if stream_ptr else None
+        self.rank_points = (C.c_uint64 * world)()
+        self.rank_obs = (C.c_uint64 * world)()
+
+    def allgather(self, local_dev):
+        """local_dev = Context.last_device_output(). Returns (DeviceEdgePoints of the whole cloud, rc);
+        every rank gets the same rc (see include/eg3d_rccl.h)."""
+        C = self.C
+        out = self.D.DeviceEdgePoints()
+        rc = self.G.eg3d_allgather_edgepoints(self.g, self.comm, self.world, self.rank, self.stream,
+                                              C.byref(local_dev), C.byref(out), self.rank_points, self.rank_obs)
+        return out, rc
+
+    def close(self):
+        if self.g:
+            self.G.eg3d_gather_destroy(self.g)
+            self.g = None
+        if self.comm:
+            self.nccl.ncclCommDestroy.argtypes = [self.C.c_void_p]
+            self.nccl.ncclCommDestroy(self.comm)
+            self.comm = self.C.c_void_p()
 
 
 class CloudGather:
@@ -96,6 +181,9 @@ class CloudGather:
                 o += mo * per
             obs_base += no_
         out = {n: torch.cat(v) for n, v in parts.items()}
+        # n_obs sentinel, as the C ABI (eg3d_edgepoints.obs_off[n_points]) and the RCCL path return it
+        out["obs_off"] = torch.cat([out["obs_off"], torch.tensor([obs_base], dtype=out["obs_off"].dtype,
+                                                                  device=out["obs_off"].device)])
         out["X"] = out["X"].view(-1, 3)
         out["key"] = out["key"].view(-1, 4)
         out["obs_xy"] = out["obs_xy"].view(-1, 2)

@@ -53,16 +53,16 @@ static Layout make_layout(uint64_t mp, uint64_t mo) {
 }
 
 // one block per (rank, field): copy the rank's valid prefix to its place in the ordered cloud
-__global__ void k_unpack(const unsigned char* recv, Layout L, const uint64_t* counts /*[R][2]*/, int n_ranks,
+__global__ void k_unpack(const unsigned char* recv, Layout L, const uint64_t* counts /*[R][3]: points, observations, status*/, int n_ranks,
                          float* X, uint32_t* obs_off, uint32_t* key, int32_t* obs_view, uint32_t* obs_pl,
                          uint32_t* obs_seg, float* obs_xy) {
   const int r = blockIdx.y, f = blockIdx.z;
   uint64_t pbase = 0, obase = 0;
   for (int q = 0; q < r; q++) {
-    pbase += counts[2 * q];
-    obase += counts[2 * q + 1];
+    pbase += counts[3 * q];
+    obase += counts[3 * q + 1];
   }
-  const uint64_t np = counts[2 * r], no = counts[2 * r + 1];
+  const uint64_t np = counts[3 * r], no = counts[3 * r + 1];
   const unsigned char* src = recv + (size_t)r * L.bytes + L.off[f];
   const uint64_t words = f == 0 ? np * 3 : f == 1 ? np : f == 2 ? np * 4 : f == 6 ? no * 2 : no;
   uint32_t* dst = f == 0   ? (uint32_t*)X + pbase * 3
@@ -83,68 +83,97 @@ __global__ void k_unpack(const unsigned char* recv, Layout L, const uint64_t* co
 struct eg3d_gather {
   int device = 0;
   Buf send, recv, cnt_dev, X, off, key, view, pl, seg, xy;
+  hipEvent_t pack_done = nullptr;
 };
 
 extern "C" eg3d_gather* eg3d_gather_create(int device) {
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
   eg3d_gather* g = new eg3d_gather();
   g->device = device;
+  if (hipEventCreateWithFlags(&g->pack_done, hipEventDisableTiming) != hipSuccess) g->pack_done = nullptr;
   return g;
 }
 extern "C" void eg3d_gather_destroy(eg3d_gather* g) {
   if (!g) return;
   (void)hipSetDevice(g->device);
+  if (g->pack_done) (void)hipEventDestroy(g->pack_done);
   delete g;
 }
 
 #define TRY_HIP(e)                   \
   do {                               \
-    if ((e) != hipSuccess) return -2; \
+    if ((e) != hipSuccess) return EG3D_GATHER_ERR_HIP; \
   } while (0)
 #define TRY_NCCL(e)                   \
   do {                                \
-    if ((e) != ncclSuccess) return -5; \
+    if ((e) != ncclSuccess) return EG3D_GATHER_ERR_NCCL; \
   } while (0)
 
 extern "C" int eg3d_allgather_edgepoints(eg3d_gather* g, void* nccl_comm, int n_ranks, int rank, void* hip_stream,
                                          const eg3d_device_edgepoints* local, eg3d_device_edgepoints* out,
                                          uint64_t* rank_points, uint64_t* rank_obs) {
-  if (!g || !nccl_comm || !local || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks || !local->complete) return -1;
+  // Argument errors that every rank sees identically (same call on every rank) may return at once;
+  // anything RANK-LOCAL (an incomplete local result, a failed allocation) must not: the other ranks
+  // would block in the next collective. Such conditions travel as a status word inside the first
+  // (counts) all-gather and in a second 8-byte all-gather after the allocations, so that all ranks
+  // agree to abort BEFORE the payload collective.
+  if (!g || !nccl_comm || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return EG3D_GATHER_ERR_ARG;
   ncclComm_t comm = (ncclComm_t)nccl_comm;
   hipStream_t st = (hipStream_t)hip_stream;
   TRY_HIP(hipSetDevice(g->device));
-  // ---- counts
-  if (g->cnt_dev.ensure(sizeof(uint64_t) * 2 * ((size_t)n_ranks + 1))) return -2;
-  uint64_t* cnt = (uint64_t*)g->cnt_dev.p;
-  const uint64_t mine[2] = {local->n_points, local->n_obs};
-  TRY_HIP(hipMemcpyAsync(cnt + 2 * (size_t)n_ranks, mine, sizeof(mine), hipMemcpyHostToDevice, st));
-  TRY_NCCL(ncclAllGather(cnt + 2 * (size_t)n_ranks, cnt, 2, ncclUint64, comm, st));
-  std::vector<uint64_t> h(2 * (size_t)n_ranks);
+  // ---- counts + status: [n_points, n_obs, status] per rank. The one allocation made before any
+  // collective is this call's 32*(R+1)-byte control block; a rank that cannot even get that has no
+  // way of telling its peers (documented in the header as the unrecoverable case).
+  const size_t R = (size_t)n_ranks;
+  if (g->cnt_dev.ensure(sizeof(uint64_t) * (4 * R + 4))) return EG3D_GATHER_ERR_HIP;
+  uint64_t* cnt = (uint64_t*)g->cnt_dev.p;      // [R][3] gathered counts + status
+  uint64_t* mine_dev = cnt + 3 * R;             // [3] this rank's entry / [1] its allocation flag
+  uint64_t* flags_dev = cnt + 3 * R + 3;        // [R] gathered allocation flags
+  const uint64_t my_status = (local && local->complete) ? 0u : 1u;
+  const uint64_t mine[3] = {my_status ? 0 : local->n_points, my_status ? 0 : local->n_obs, my_status};
+  TRY_HIP(hipMemcpyAsync(mine_dev, mine, sizeof(mine), hipMemcpyHostToDevice, st));
+  TRY_NCCL(ncclAllGather(mine_dev, cnt, 3, ncclUint64, comm, st));
+  std::vector<uint64_t> h(3 * R);
   TRY_HIP(hipMemcpyAsync(h.data(), cnt, sizeof(uint64_t) * h.size(), hipMemcpyDeviceToHost, st));
   TRY_HIP(hipStreamSynchronize(st));
-  uint64_t mp = 0, mo = 0, tp = 0, to = 0;
+  uint64_t mp = 0, mo = 0, tp = 0, to = 0, bad = 0;
   for (int r = 0; r < n_ranks; r++) {
-    mp = std::max(mp, h[2 * r]);
-    mo = std::max(mo, h[2 * r + 1]);
-    tp += h[2 * r];
-    to += h[2 * r + 1];
-    if (rank_points) rank_points[r] = h[2 * r];
-    if (rank_obs) rank_obs[r] = h[2 * r + 1];
+    mp = std::max(mp, h[3 * r]);
+    mo = std::max(mo, h[3 * r + 1]);
+    tp += h[3 * r];
+    to += h[3 * r + 1];
+    bad |= h[3 * r + 2];
+    if (rank_points) rank_points[r] = h[3 * r];
+    if (rank_obs) rank_obs[r] = h[3 * r + 1];
   }
-  if (to > 0xffffffffull) return -3;  // observation offsets are 32-bit
+  if (bad) return EG3D_GATHER_ERR_INCOMPLETE;  // same verdict on every rank
+  if (to > 0xffffffffull) return EG3D_GATHER_ERR_RANGE;  // observation offsets are 32-bit (same on every rank)
   const Layout L = make_layout(mp, mo);
+  // ---- every allocation of this call, then agree on their success
+  uint64_t alloc_fail = 0;
+  if (g->send.ensure(L.bytes) || g->recv.ensure(L.bytes * R) || g->X.ensure(tp * 12 + 16) || g->off.ensure((tp + 1) * 4) ||
+      g->key.ensure(tp * 16 + 16) || g->view.ensure(to * 4 + 16) || g->pl.ensure(to * 4 + 16) ||
+      g->seg.ensure(to * 4 + 16) || g->xy.ensure(to * 8 + 16))
+    alloc_fail = 1;
+  {
+    TRY_HIP(hipMemcpyAsync(mine_dev, &alloc_fail, sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    TRY_NCCL(ncclAllGather(mine_dev, flags_dev, 1, ncclUint64, comm, st));
+    std::vector<uint64_t> hf(R);
+    TRY_HIP(hipMemcpyAsync(hf.data(), flags_dev, sizeof(uint64_t) * R, hipMemcpyDeviceToHost, st));
+    TRY_HIP(hipStreamSynchronize(st));
+    for (size_t r = 0; r < R; r++)
+      if (hf[r]) return EG3D_GATHER_ERR_HIP;  // same verdict on every rank
+  }
   // ---- pack this rank's block and gather
-  if (g->send.ensure(L.bytes) || g->recv.ensure(L.bytes * (size_t)n_ranks)) return -2;
   unsigned char* sb = (unsigned char*)g->send.p;
   const uint64_t np = local->n_points, no = local->n_obs;
   const void* src[7] = {local->X, local->obs_off, local->key, local->obs_view, local->obs_pl, local->obs_seg, local->obs_xy};
   const uint64_t nbytes[7] = {np * 12, np * 4, np * 16, no * 4, no * 4, no * 4, no * 8};
   for (int f = 0; f < 7; f++)
     if (nbytes[f]) TRY_HIP(hipMemcpyAsync(sb + L.off[f], src[f], nbytes[f], hipMemcpyDeviceToDevice, st));
+  if (g->pack_done) TRY_HIP(hipEventRecord(g->pack_done, st));  // `local` may be overwritten once this has fired
   TRY_NCCL(ncclAllGather(sb, g->recv.p, L.bytes, ncclUint8, comm, st));
   // ---- compaction into one ordered cloud
-  if (g->X.ensure(tp * 12 + 16) || g->off.ensure((tp + 1) * 4) || g->key.ensure(tp * 16 + 16) || g->view.ensure(to * 4 + 16) ||
-      g->pl.ensure(to * 4 + 16) || g->seg.ensure(to * 4 + 16) || g->xy.ensure(to * 8 + 16))
-    return -2;
   hipLaunchKernelGGL(k_unpack, dim3(64, n_ranks, 7), dim3(256), 0, st, (const unsigned char*)g->recv.p, L,
                      (const uint64_t*)cnt, n_ranks, (float*)g->X.p, (uint32_t*)g->off.p, (uint32_t*)g->key.p,
                      (int32_t*)g->view.p, (uint32_t*)g->pl.p, (uint32_t*)g->seg.p, (float*)g->xy.p);
@@ -162,4 +191,9 @@ extern "C" int eg3d_allgather_edgepoints(eg3d_gather* g, void* nccl_comm, int n_
   out->key = (const uint32_t*)g->key.p;
   out->complete = 1;
   return 0;
+}
+
+extern "C" int eg3d_gather_wait_pack(eg3d_gather* g) {
+  if (!g || !g->pack_done) return EG3D_GATHER_ERR_ARG;
+  return hipEventSynchronize(g->pack_done) == hipSuccess ? 0 : EG3D_GATHER_ERR_HIP;
 }

@@ -9,7 +9,8 @@
  * read straight from the context's HBM buffers, then a compaction kernel that leaves the whole,
  * globally ordered cloud on every rank (obs_off rebased). Lives in its own library
  * (libeg3d_rccl.so, links librccl) so that libeg3d.so has no communication dependency.
- * bench.py does the same through torch.distributed (edgegraph3d_amd/distributed.py).
+ * bench.py --gpus N calls this entry point (through ctypes) on a communicator created with
+ * ncclCommInitRank; tests/rccl_two_rank_check.py is the 2-process check for a node with >= 2 GPUs.
  */
 #ifndef EG3D_RCCL_H_
 #define EG3D_RCCL_H_
@@ -29,9 +30,23 @@ void eg3d_gather_destroy(eg3d_gather* g);
  * eg3d_last_device_output (must be `complete`). On return `out` views the gathered cloud in HBM
  * (valid until the next call on `g`), rank_points / rank_obs (host arrays of n_ranks entries, may
  * be NULL) receive the per-rank counts. Collective: every rank must call it. */
+#define EG3D_GATHER_ERR_ARG -1        /* bad arguments (identical on every rank) */
+#define EG3D_GATHER_ERR_HIP -2        /* a HIP call or a device allocation failed on SOME rank */
+#define EG3D_GATHER_ERR_RANGE -3      /* more than 2^32-1 observations in the gathered cloud */
+#define EG3D_GATHER_ERR_INCOMPLETE -4 /* SOME rank's local result is missing or spans several chunks */
+#define EG3D_GATHER_ERR_NCCL -5       /* an RCCL call failed */
+/* Rank-local failures (incomplete local output, allocation failure) are exchanged as status words
+ * in the counts all-gather and in one 8-byte all-gather after the allocations: every rank returns
+ * the same error code before the payload collective instead of leaving its peers blocked. (Only a
+ * rank that cannot allocate the call's 32*(n_ranks+1)-byte control block returns alone.) */
 int eg3d_allgather_edgepoints(eg3d_gather* g, void* nccl_comm, int n_ranks, int rank, void* hip_stream,
                               const eg3d_device_edgepoints* local, eg3d_device_edgepoints* out,
                               uint64_t* rank_points, uint64_t* rank_obs);
+
+/* Blocks the host until the last eg3d_allgather_edgepoints on `g` has copied `local` into its send
+ * buffer: from then on the producing context may overwrite its output buffers (next step) while
+ * the collective itself is still in flight on the gather stream. */
+int eg3d_gather_wait_pack(eg3d_gather* g);
 
 #ifdef __cplusplus
 }

@@ -82,7 +82,7 @@ def test_two_rank_gloo_allgather_reproduces_single_process_output():
         assert c["n_points"] == ref["n_points"] and c["n_obs"] == ref["n_obs"]
         assert np.array_equal(c["X"].view(np.uint32), ref["X"].view(np.uint32))
         assert np.array_equal(c["key"].astype(np.uint32), ref["key"])
-        assert np.array_equal(c["obs_off"].astype(np.uint32), ref["obs_off"][:-1])
+        assert np.array_equal(c["obs_off"].astype(np.uint32), ref["obs_off"])  # incl. the n_obs sentinel
         assert np.array_equal(c["obs_view"], ref["obs_view"])
         assert np.array_equal(c["obs_pl"].astype(np.uint32), ref["obs_pl"])
         assert np.array_equal(c["obs_seg"].astype(np.uint32), ref["obs_seg"])

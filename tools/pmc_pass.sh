@@ -20,3 +20,4 @@ for db in glob.glob("$out/prof_$name/**/*.db", recursive=True):
                 print(line); f.write(line+"\n")
 PY
 tail -3 $out/prof_$name.err
+rm -rf $out/prof_$name $out/tmp/*  # keep gpurun_out under the 64 MiB copy-back limit
