@@ -17,11 +17,22 @@
 namespace eg3d {
 
 #define EG3D_COOP_ROWS 64
+#ifndef EG3D_GN_GROUPS
+#define EG3D_GN_GROUPS 1 /* 1: every Gauss-Newton solve of the expand stage through coop_gn_groups */
+#endif
+#ifndef EG3D_GN_PACK_MAX
+#define EG3D_GN_PACK_MAX 32      /* requests of up to this many rows are packed side by side, one chunk each */
+#define EG3D_GN_ROW_CYCLES 1400  /* cost model of the longer ones: one row's projection + Jacobian (8 FP64 divisions) */
+#define EG3D_GN_SUM_CYCLES 44    /*   and one row's share of the in-order sums of both passes */
+#endif
 #define EG3D_STAGE_VTX 512
 #define EG3D_STAGE_EPI 192
+#if EG3D_GN_GROUPS
+// 12 784 bytes: gfx950 allocates LDS in 1 280-byte units, 10 units per wave = 12 single-wave
+// workgroups per CU (3 per SIMD) in 160 KiB.
 struct CoopLds {
   union {
-    double prod[14][EG3D_COOP_ROWS + 1];
+    double prod[14][EG3D_COOP_ROWS + 1];  // the rows' products of one chunk (odd stride)
     // side-walk staging (never live at the same time as a solve): the polyline being walked and
     // the epipolar lines of the chain points ahead
     struct {
@@ -32,8 +43,31 @@ struct CoopLds {
   int32_t la_m[8];               // look-ahead following: observations kept by step j
   uint32_t la_fl[8];             //   and the diagnostic flags its walks raised
   Obs tmp_a[EG3D_COOP_ROWS];     // the N-view step's candidate observations (Chain::tmp_a) when they fit
-  double sums[22][8];            // a group has >= 3 rows => <= 21 groups per round
   float x0[EG3D_COOP_ROWS][3];   // in: start point of request j; out: its result
+  const Obs* gbase[EG3D_COOP_ROWS];  // observation array of request j
+  double gsum[32][7];            // per-group sums (G >= 2 => <= 32 groups)
+  int32_t ex_view[EG3D_COOP_ROWS];   // the extra (ADD) observation of request j
+  float ex_x[EG3D_COOP_ROWS], ex_y[EG3D_COOP_ROWS];
+  uint16_t n16[EG3D_COOP_ROWS];  // rows of request j | has-extra << 15
+  uint8_t row_req[EG3D_COOP_ROWS];   // row (short rounds) / group slot (long rounds) -> request lane
+  uint8_t row_k[EG3D_COOP_ROWS];     // row -> its index in the request
+  uint8_t res_ok[EG3D_COOP_ROWS];
+};
+static_assert(sizeof(CoopLds) <= 12800, "CoopLds must fit 10 LDS allocation units (3 waves per SIMD)");
+#else
+struct CoopLds {
+  union {
+    double prod[14][EG3D_COOP_ROWS + 1];
+    struct {
+      f2 vtx[EG3D_STAGE_VTX];
+      float epi[EG3D_STAGE_EPI][4];
+    } walk;
+  };
+  int32_t la_m[8];
+  uint32_t la_fl[8];
+  Obs tmp_a[EG3D_COOP_ROWS];
+  double sums[22][8];            // a group has >= 3 rows => <= 21 groups per round
+  float x0[EG3D_COOP_ROWS][3];
   uint32_t off[EG3D_COOP_ROWS];  // first observation of request j in the chain's pool
   int32_t n[EG3D_COOP_ROWS];     // rows of request j (block observations + the extra one), 0 = none
   int32_t start[EG3D_COOP_ROWS]; // exclusive prefix of n over the window
@@ -42,7 +76,9 @@ struct CoopLds {
   uint8_t row_req[EG3D_COOP_ROWS], row_k[EG3D_COOP_ROWS], row_g[EG3D_COOP_ROWS];
   uint8_t res_ok[EG3D_COOP_ROWS];
 };
+#endif
 
+#if !EG3D_GN_GROUPS
 // Iterations of all groups currently mapped onto the wave. A row lane passes act=true, its group
 // ordinal g (index into sums), its row k within the group, the group's row count n and first
 // lane gb, its observation and the start point X (identical on the rows of a group). Returns the
@@ -453,5 +489,383 @@ __device__ __forceinline__ bool coop_gn_window(const float* cam_P, const Obs* po
   __syncthreads();  // the table may be rewritten by the next window
   return r;
 }
+
+
+#endif  // !EG3D_GN_GROUPS
+
+// ---------------------------------------------------------------------------------------------
+// Lane-GROUP Gauss-Newton: the one solver of the expand stage. A window of up to 64 requests
+// (request j held by lane j: observation array `base`, nblock observations, an optional extra one,
+// start point X0) is solved in ROUNDS; in a round every member request owns a GROUP of G adjacent
+// lanes and its rows (observations) are dealt to them in chunks of G: a lane computes the
+// projection, residuals and Jacobian rows of ITS row of the chunk, the products go to LDS and the
+// group's first lanes add them to the request's accumulators in observation order, carrying the
+// accumulators from chunk to chunk — every accumulator sees exactly the additions, in exactly the
+// order, of the sequential solver (eg3d_dev_tri.h gauss_newton_f64) => bit-identical results
+// whatever the grouping.
+//   * requests of <= 64 rows: G = the request's row count (one chunk; the rows stay in registers
+//     between the two passes of an iteration), requests packed side by side in lane order until
+//     the 64 lanes are full;
+//   * longer requests (V = 200 scenes: points carry ~74 observations): G = the largest power of
+//     two with G * #long requests <= 64, several chunks per pass, the update pass recomputes the
+//     rows (measured as fast as keeping 8 doubles per observation in lane-private scratch memory,
+//     which is what the retired one-lane-per-solve path did — at 1 KB of scratch per lane, the
+//     main source of the expand kernel's former HBM write traffic).
+// Each round iterates until all of its groups have converged.
+struct GnRow {
+  double j00, j01, j02, j10, j11, j12, r0, r1;
+};
+__device__ __forceinline__ void gn_row(const float* __restrict__ P, float ox, float oy, const double X[3], GnRow& w) {
+  const double p00 = P[0], p01 = P[1], p02 = P[2], p03 = P[3];
+  const double p10 = P[4], p11 = P[5], p12 = P[6], p13 = P[7];
+  const double p20 = P[8], p21 = P[9], p22 = P[10], p23 = P[11];
+  const double xH = ((p00 * X[0] + p01 * X[1]) + p02 * X[2]) + p03 * 1.0;
+  const double yH = ((p10 * X[0] + p11 * X[1]) + p12 * X[2]) + p13 * 1.0;
+  const double zH = ((p20 * X[0] + p21 * X[1]) + p22 * X[2]) + p23 * 1.0;
+  w.r0 = (double)ox - xH / zH;
+  w.r1 = (double)oy - yH / zH;
+  const double zz = zH * zH;
+  w.j00 = (p00 * zH - p20 * xH) / zz;
+  w.j10 = (p10 * zH - p20 * yH) / zz;
+  w.j01 = (p01 * zH - p21 * xH) / zz;
+  w.j11 = (p11 * zH - p21 * yH) / zz;
+  w.j02 = (p02 * zH - p22 * xH) / zz;
+  w.j12 = (p12 * zH - p22 * yH) / zz;
+}
+
+#if EG3D_GN_GROUPS
+// One round. Lane state: act (member of a group), l = index in its group of G >= 2 lanes starting
+// at lane gb, the request's n rows (the first nb from a[], the last one the extra observation),
+// start point X (identical on the lanes of a group). cmax = chunks per pass (wave-uniform maximum).
+// Returns the accept flag; X holds the solution.
+__device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool act, int l, int G, int gb, int n, int nb,
+                                         const Obs* a, int32_t xv, float xx, float xy, int cmax, double X[3]) {
+  const int lane = (int)(threadIdx.x & 63u);
+  const int gs = gb >> 1;  // slot of the group's sums (G >= 2 => distinct)
+  bool done = !act, ok = false;
+  double last_mse = 0;
+  const double two_n = (double)(n * 2);
+  for (int it = 0; it < 30; it++) {
+    if (!__any(!done)) break;
+    // ---- pass 1: H (6) and mse; accumulator e lives in group lane e % G, slot e / G
+    double acc[4] = {0, 0, 0, 0};
+    GnRow w;
+    w.j00 = w.j01 = w.j02 = w.j10 = w.j11 = w.j12 = w.r0 = w.r1 = 0;
+    for (int c = 0; c < cmax; c++) {
+      const int r = c * G + l;
+      const bool rowact = !done && r < n;
+      if (rowact) {
+        int32_t view;
+        float ox, oy;
+        if (r < nb) {
+          view = a[r].view;
+          ox = a[r].x;
+          oy = a[r].y;
+        } else {
+          view = xv;
+          ox = xx;
+          oy = xy;
+        }
+        gn_row(cam_P + (size_t)view * 16, ox, oy, X, w);
+        L.prod[0][lane] = w.j00 * w.j00;
+        L.prod[1][lane] = w.j10 * w.j10;
+        L.prod[2][lane] = w.j00 * w.j01;
+        L.prod[3][lane] = w.j10 * w.j11;
+        L.prod[4][lane] = w.j00 * w.j02;
+        L.prod[5][lane] = w.j10 * w.j12;
+        L.prod[6][lane] = w.j01 * w.j01;
+        L.prod[7][lane] = w.j11 * w.j11;
+        L.prod[8][lane] = w.j01 * w.j02;
+        L.prod[9][lane] = w.j11 * w.j12;
+        L.prod[10][lane] = w.j02 * w.j02;
+        L.prod[11][lane] = w.j12 * w.j12;
+        L.prod[12][lane] = w.r0 * w.r0;
+        L.prod[13][lane] = w.r1 * w.r1;
+      }
+      __syncthreads();
+      if (!done) {
+        int rows = n - c * G;
+        rows = rows > G ? G : rows;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {  // G >= 2 => at most 4 of the 7 accumulators per lane
+          const int e = l + t * G;
+          if (e < 7 && rows > 0) {
+            const double* A = &L.prod[2 * e][gb];
+            const double* Bp = &L.prod[2 * e + 1][gb];
+            double s = acc[t];
+            for (int m = 0; m < rows; m++) {
+              s += A[m];
+              s += Bp[m];
+            }
+            acc[t] = s;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (!done) {
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int e = l + t * G;
+        if (e < 7) L.gsum[gs][e] = acc[t];
+      }
+    }
+    __syncthreads();
+    double I00 = 0, I01 = 0, I02 = 0, I10 = 0, I11 = 0, I12 = 0, I20 = 0, I21 = 0, I22 = 0;
+    if (!done) {
+      const double H00 = L.gsum[gs][0], H01 = L.gsum[gs][1], H02 = L.gsum[gs][2];
+      const double H11 = L.gsum[gs][3], H12 = L.gsum[gs][4], H22 = L.gsum[gs][5];
+      const double mse = L.gsum[gs][6];
+      if (absd(mse / two_n - last_mse) < 0.0000005) {
+        done = true;
+        ok = last_mse < 9;
+      } else {
+        last_mse = mse / two_n;
+        const double H10 = H01, H20 = H02, H21 = H12;
+        const double d = H00 * (H11 * H22 - H12 * H21) - H01 * (H10 * H22 - H12 * H20) + H02 * (H10 * H21 - H11 * H20);
+        if (d < 0.00001) {
+          done = true;
+          ok = false;
+        } else {
+          const double id = 1. / d;
+          I00 = (H11 * H22 - H12 * H21) * id;
+          I01 = (H02 * H21 - H01 * H22) * id;
+          I02 = (H01 * H12 - H02 * H11) * id;
+          I10 = (H12 * H20 - H10 * H22) * id;
+          I11 = (H00 * H22 - H02 * H20) * id;
+          I12 = (H02 * H10 - H00 * H12) * id;
+          I20 = (H10 * H21 - H11 * H20) * id;
+          I21 = (H01 * H20 - H00 * H21) * id;
+          I22 = (H00 * H11 - H01 * H10) * id;
+        }
+      }
+    }
+    __syncthreads();  // the sums are rewritten by pass 2
+    if (!__any(!done)) break;
+    // ---- pass 2: the update (H^-1 J^T) r, 3 accumulators; rows recomputed unless there is one chunk
+    double dac[2] = {0, 0};
+    for (int c = 0; c < cmax; c++) {
+      const int r = c * G + l;
+      const bool rowact = !done && r < n;
+      if (rowact) {
+        if (cmax > 1) {
+          int32_t view;
+          float ox, oy;
+          if (r < nb) {
+            view = a[r].view;
+            ox = a[r].x;
+            oy = a[r].y;
+          } else {
+            view = xv;
+            ox = xx;
+            oy = xy;
+          }
+          gn_row(cam_P + (size_t)view * 16, ox, oy, X, w);
+        }
+        L.prod[0][lane] = ((I00 * w.j00 + I01 * w.j01) + I02 * w.j02) * w.r0;
+        L.prod[1][lane] = ((I00 * w.j10 + I01 * w.j11) + I02 * w.j12) * w.r1;
+        L.prod[2][lane] = ((I10 * w.j00 + I11 * w.j01) + I12 * w.j02) * w.r0;
+        L.prod[3][lane] = ((I10 * w.j10 + I11 * w.j11) + I12 * w.j12) * w.r1;
+        L.prod[4][lane] = ((I20 * w.j00 + I21 * w.j01) + I22 * w.j02) * w.r0;
+        L.prod[5][lane] = ((I20 * w.j10 + I21 * w.j11) + I22 * w.j12) * w.r1;
+      }
+      __syncthreads();
+      if (!done) {
+        int rows = n - c * G;
+        rows = rows > G ? G : rows;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {  // G >= 2 => at most 2 of the 3 accumulators per lane
+          const int e = l + t * G;
+          if (e < 3 && rows > 0) {
+            const double* A = &L.prod[2 * e][gb];
+            const double* Bp = &L.prod[2 * e + 1][gb];
+            double s = dac[t];
+            for (int m = 0; m < rows; m++) {
+              s += A[m];
+              s += Bp[m];
+            }
+            dac[t] = s;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (!done) {
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const int e = l + t * G;
+        if (e < 3) L.gsum[gs][e] = dac[t];
+      }
+    }
+    __syncthreads();
+    if (!done) {
+      X[0] += L.gsum[gs][0];
+      X[1] += L.gsum[gs][1];
+      X[2] += L.gsum[gs][2];
+    }
+    __syncthreads();
+  }
+  if (act && !done) ok = last_mse < 9;
+  return ok;
+}
+
+// Must be called by all 64 lanes of the (single-wave) block; every request must have >= 2 rows. On
+// return lane j holds the verdict and solution of ITS request (false when !want); the request
+// table keeps them too (L.res_ok[j], L.x0[j]) until the next call.
+__device__ __forceinline__ bool coop_gn_groups(const float* cam_P, CoopLds& L, bool want, const Obs* base, int nblock,
+                                               bool has_extra, int32_t ex_view, float ex_x, float ex_y,
+                                               const float X0[3], float Xout[3]) {
+  const int lane = (int)(threadIdx.x & 63u);
+  const int n_req = want ? nblock + (has_extra ? 1 : 0) : 0;
+  const bool is_short = want && n_req <= EG3D_GN_PACK_MAX;
+  const bool is_long = want && n_req > EG3D_GN_PACK_MAX;
+  const unsigned long long m_short = __ballot(is_short), m_long = __ballot(is_long);
+  if ((m_short | m_long) == 0ull) return false;
+  L.gbase[lane] = base;
+  L.n16[lane] = (uint16_t)(n_req | (has_extra ? 0x8000 : 0));
+  L.ex_view[lane] = ex_view;
+  L.ex_x[lane] = ex_x;
+  L.ex_y[lane] = ex_y;
+  L.x0[lane][0] = X0[0];
+  L.x0[lane][1] = X0[1];
+  L.x0[lane][2] = X0[2];
+  L.res_ok[lane] = 0;
+  __syncthreads();
+  // ---- short requests: rounds of whole requests packed into <= 64 rows, in lane order
+  if (m_short) {
+    const int ns = is_short ? n_req : 0;
+    int pre = ns;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(pre, d);
+      if (lane >= d) pre += t;
+    }
+    const int excl = pre - ns;
+    unsigned long long todo = m_short;
+    while (todo) {
+      const int q0 = __ffsll((long long)todo) - 1;
+      const int rbase = __shfl(excl, q0);
+      const unsigned long long in_round = __ballot(is_short && lane >= q0 && (excl + ns - rbase) <= EG3D_COOP_ROWS);
+      // contiguity: stop at the first short request >= q0 that does not fit
+      const unsigned long long nofit = todo & ~in_round & ~((1ull << q0) - 1ull);
+      const unsigned long long upto = nofit ? ((1ull << (__ffsll((long long)nofit) - 1)) - 1ull) : ~0ull;
+      const unsigned long long members = in_round & upto & todo;
+      const bool mine = (members >> lane) & 1ull;
+      if (mine)
+        for (int k = 0; k < ns; k++) {
+          L.row_req[excl - rbase + k] = (uint8_t)lane;
+          L.row_k[excl - rbase + k] = (uint8_t)k;
+        }
+      const int last = 63 - __builtin_clzll(members);
+      const int rows = __shfl(excl + ns, last) - rbase;
+      __syncthreads();
+      const bool act = lane < rows;
+      int rq = 0, l = 0, n = 2, nb = 0;
+      const Obs* a = nullptr;
+      int32_t xv = 0;
+      float xx = 0.f, xy = 0.f;
+      double X[3] = {0, 0, 0};
+      if (act) {
+        rq = L.row_req[lane];
+        l = L.row_k[lane];
+        n = L.n16[rq] & 0x7fff;
+        nb = n - (L.n16[rq] >> 15);
+        a = L.gbase[rq];
+        xv = L.ex_view[rq];
+        xx = L.ex_x[rq];
+        xy = L.ex_y[rq];
+        X[0] = (double)L.x0[rq][0];
+        X[1] = (double)L.x0[rq][1];
+        X[2] = (double)L.x0[rq][2];
+      }
+      const bool ok = gn_round(cam_P, L, act, l, n, lane - l, n, nb, a, xv, xx, xy, 1, X);
+      if (act && l == 0) {
+        L.res_ok[rq] = ok ? 1 : 0;
+        L.x0[rq][0] = (float)X[0];
+        L.x0[rq][1] = (float)X[1];
+        L.x0[rq][2] = (float)X[2];
+      }
+      __syncthreads();
+      todo &= ~members;
+    }
+  }
+  // ---- long requests: power-of-two groups, several chunks per pass
+  if (m_long) {
+    unsigned long long todo = m_long;
+    while (todo) {
+      const int Bl = __popcll(todo);
+      int mxl = ((todo >> lane) & 1ull) ? n_req : 0;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        const int t = __shfl_xor(mxl, d);
+        mxl = t > mxl ? t : mxl;
+      }
+      // group size G = 1 << lg (2..64) by a cost model in cycles: rounds x chunks x (row work, twice
+      // when the update pass must recompute, + the in-order sums of a chunk's G rows in both passes)
+      int lg = 6;
+      {
+        unsigned best = 0xffffffffu;
+        for (int cand = 1; cand <= 6; cand++) {
+          const int Gc = 1 << cand;
+          const int k = (mxl + Gc - 1) >> cand;
+          const int rounds = (Bl + (64 >> cand) - 1) / (64 >> cand);
+          const unsigned cost = (unsigned)(rounds * k) * (unsigned)((k > 1 ? 2 : 1) * EG3D_GN_ROW_CYCLES + EG3D_GN_SUM_CYCLES * Gc);
+          if (cost < best) {
+            best = cost;
+            lg = cand;
+          }
+        }
+      }
+      const int per_round = 64 >> lg;
+      // the first per_round requests of todo
+      const int rank = __popcll(todo & ((1ull << lane) - 1ull));
+      const bool mine = ((todo >> lane) & 1ull) && rank < per_round;
+      const unsigned long long members = __ballot(mine);
+      if (mine) L.row_req[rank] = (uint8_t)lane;
+      int mxn = mine ? n_req : 0;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        const int t = __shfl_xor(mxn, d);
+        mxn = t > mxn ? t : mxn;
+      }
+      __syncthreads();
+      const int G = 1 << lg, g = lane >> lg, l = lane & (G - 1);
+      const bool act = g < __popcll(members);
+      int rq = 0, n = 2, nb = 0;
+      const Obs* a = nullptr;
+      int32_t xv = 0;
+      float xx = 0.f, xy = 0.f;
+      double X[3] = {0, 0, 0};
+      if (act) {
+        rq = L.row_req[g];
+        n = L.n16[rq] & 0x7fff;
+        nb = n - (L.n16[rq] >> 15);
+        a = L.gbase[rq];
+        xv = L.ex_view[rq];
+        xx = L.ex_x[rq];
+        xy = L.ex_y[rq];
+        X[0] = (double)L.x0[rq][0];
+        X[1] = (double)L.x0[rq][1];
+        X[2] = (double)L.x0[rq][2];
+      }
+      const bool ok = gn_round(cam_P, L, act, l, G, lane - l, n, nb, a, xv, xx, xy, (mxn + G - 1) >> lg, X);
+      if (act && l == 0) {
+        L.res_ok[rq] = ok ? 1 : 0;
+        L.x0[rq][0] = (float)X[0];
+        L.x0[rq][1] = (float)X[1];
+        L.x0[rq][2] = (float)X[2];
+      }
+      __syncthreads();
+      todo &= ~members;
+    }
+  }
+  Xout[0] = L.x0[lane][0];
+  Xout[1] = L.x0[lane][1];
+  Xout[2] = L.x0[lane][2];
+  const bool res = want && L.res_ok[lane] != 0;
+  __syncthreads();  // the table may be rewritten by the next window
+  return res;
+}
+#endif
 
 }  // namespace eg3d

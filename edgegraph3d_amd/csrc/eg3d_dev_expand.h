@@ -208,6 +208,10 @@ struct TeamSeq {
     cur.i = 0;
     return gauss_newton_f64(s.cam_P, cur, X0, Xout);
   }
+  // one ADD solve inside a uniform section
+  EG3D_HD bool add_one(const DevScene& s, const Chain& c, const ChainPt& p, const Obs& extra, float Xout[3]) const {
+    return add_observation_solve(s, c, p, extra, Xout);
+  }
   template <class Get, class Put>
   EG3D_HD void add_solves(const DevScene& s, Chain& c, int B, Get get, Put put) const {
     for (int j = 0; j < B; j++) {
@@ -323,7 +327,7 @@ EG3D_HD bool triangulate_array_team(const Team& tm, const DevScene& s, const Obs
 // + greedy ADD (triangulation.cpp:1105-1158); compacts sel to the kept observations.
 EG3D_HD int stepn_fallback(const DevScene& s, Obs* sel, int m, Obs* tmp, uint8_t* mask, float Xout[3], uint32_t& flags) {
   if (m <= 3) return 0;
-  if (!triangulate_combinations(s.cam_P, sel, m, tmp, mask, Xout, flags)) return 0;
+  if (!triangulate_combinations<0>(s.cam_P, sel, m, tmp, mask, Xout, flags)) return 0;
   int k = 0;
   for (int i = 0; i < m; i++)
     if (mask[i]) sel[k++] = sel[i];
@@ -572,7 +576,7 @@ EG3D_HD_FLAT bool attach_view(const Team& tm, const DevScene& s, Chain& c, const
     Xc[2] = pre_X[2];
   } else {
     uint64_t t0 = EG3D_TICK();
-    bool okc = add_observation_solve(s, c, chain_at(c, ci), o, Xc);
+    bool okc = tm.add_one(s, c, chain_at(c, ci), o, Xc);
     c.tsec[1] += EG3D_TICK() - t0;
     if (!okc) return false;
   }

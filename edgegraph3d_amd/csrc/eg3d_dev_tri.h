@@ -224,7 +224,10 @@ struct LocalCursor {
 // FP64 Gauss-Newton over the cursor's observations from X0 (triangulation.cpp:105-176):
 // <=30 iterations; stop when |mse/(2n) - last| < 5e-7; fail when det(H) < 1e-5; accept iff
 // last mse < 9. H and the update are accumulated in observation order (rows 2m, 2m+1).
-template <class Cursor>
+#ifndef EG3D_KEEP_OBS
+#define EG3D_KEEP_OBS EG3D_LOCAL_OBS
+#endif
+template <class Cursor, int KEEP = EG3D_KEEP_OBS>
 EG3D_HD bool gauss_newton_f64(const float* cam_P, Cursor& cur, const double X0[3], float Xout[3]) {
   const int n = cur.count();
   double X[3] = {X0[0], X0[1], X0[2]};
@@ -233,11 +236,10 @@ EG3D_HD bool gauss_newton_f64(const float* cam_P, Cursor& cur, const double X0[3
   // Jacobian rows and residuals of the first pass are kept in lane-private memory (8 doubles per
   // observation, lane-interleaved => coalesced) so the update pass does not redo the projection
   // and its 8 FP64 divisions; same values, same order => same bits. Larger n recomputes.
-#ifndef EG3D_KEEP_OBS
-#define EG3D_KEEP_OBS EG3D_LOCAL_OBS
-#endif
-  double keep[EG3D_KEEP_OBS > 0 ? EG3D_KEEP_OBS : 1][8];
-  const bool stored = EG3D_KEEP_OBS > 0 && n <= EG3D_KEEP_OBS;
+  // (KEEP = 0: always recompute — the expand kernel's rare per-lane fallback, which must not add a
+  // kilobyte of scratch per lane to that kernel)
+  double keep[KEEP > 0 ? KEEP : 1][8];
+  const bool stored = KEEP > 0 && n <= KEEP;
   for (int it = 0; it < 30; it++) {
     double mse = 0;
     double H00 = 0, H01 = 0, H02 = 0, H11 = 0, H12 = 0, H22 = 0;
@@ -362,6 +364,7 @@ EG3D_HD bool gauss_newton_f64(const float* cam_P, Cursor& cur, const double X0[3
 
 // TRI on an observation array: DLT on (first minimal view id, LAST entry) — Q1/Q11 — then GN.
 // flags gets EG3D_FLAG_DEGENERATE_DLT (16) when both DLT views coincide.
+template <int KEEP = EG3D_KEEP_OBS>
 EG3D_HD bool triangulate_array(const float* cam_P, const Obs* a, int n, float Xout[3], uint32_t& flags) {
   int mi = 0;
   int32_t mv = a[0].view;
@@ -379,12 +382,13 @@ EG3D_HD bool triangulate_array(const float* cam_P, const Obs* a, int n, float Xo
   c.n = n;
   c.extra = nullptr;
   c.i = 0;
-  return gauss_newton_f64(cam_P, c, X0, Xout);
+  return gauss_newton_f64<ArrayCursor, KEEP>(cam_P, c, X0, Xout);
 }
 
 // First 3-subset (std::prev_permutation order of the selection mask) that triangulates, then
 // greedy ADD of the remaining observations in list order (triangulation.cpp:1105-1158).
 // `sel` receives the final mask; `tmp` must hold n observations.
+template <int KEEP = EG3D_KEEP_OBS>
 EG3D_HD bool triangulate_combinations(const float* cam_P, const Obs* a, int n, Obs* tmp, uint8_t* sel,
                                       float Xout[3], uint32_t& flags) {
   // enumerate 3-subsets i<j<k in the order prev_permutation visits {1,1,1,0,...}:
@@ -397,7 +401,7 @@ EG3D_HD bool triangulate_combinations(const float* cam_P, const Obs* a, int n, O
         tmp[0] = a[i];
         tmp[1] = a[j];
         tmp[2] = a[k];
-        if (triangulate_array(cam_P, tmp, 3, Xout, flags)) {
+        if (triangulate_array<KEEP>(cam_P, tmp, 3, Xout, flags)) {
           valid = true;
           bi = i;
           bj = j;
@@ -419,7 +423,7 @@ EG3D_HD bool triangulate_combinations(const float* cam_P, const Obs* a, int n, O
       c.i = 0;
       double X0[3] = {(double)Xout[0], (double)Xout[1], (double)Xout[2]};
       float Xn[3];
-      if (gauss_newton_f64(cam_P, c, X0, Xn)) {
+      if (gauss_newton_f64<ArrayCursor, KEEP>(cam_P, c, X0, Xn)) {
         sel[i] = 1;
         Xout[0] = Xn[0];
         Xout[1] = Xn[1];

@@ -843,10 +843,21 @@ struct TeamWave {
         if (a[mi].view == a[la].view) dfl = 16u;
         dlt2(s.cam_P + (size_t)a[mi].view * 16, a[mi].x, a[mi].y, s.cam_P + (size_t)a[la].view * 16, a[la].x, a[la].y, X0);
       }
-      // ---- stage 3: Deff Gauss-Newton solves as groups of one cooperative batch (group j = rows
-      // [j*n_end, j*n_end + m_j))
+      // ---- stage 3: the Deff Gauss-Newton solves as one batch (request j on lane j)
       const uint64_t tq2 = EG3D_TICK();
       c.tsec[5] += tq2 - tq1;
+#if EG3D_GN_GROUPS
+      {
+        const bool want = lane() < Deff;
+        const float X0f[3] = {(float)X0[0], (float)X0[1], (float)X0[2]};  // DLT results are float-valued
+        float Xr[3];
+        const bool ok = coop_gn_groups(s.cam_P, *L, want, L->tmp_a + (want ? lane() : 0) * n_end,
+                                       want ? L->la_m[lane()] : 0, false, 0, 0.f, 0.f, X0f, Xr);
+        // results stay in the request table: L->res_ok[j], L->x0[j]
+        (void)ok;
+        (void)Xr;
+      }
+#else
       {
         const int g = lane() / n_end, k = lane() - g * n_end;
         const int n = g < Deff ? L->la_m[g] : 0;
@@ -873,6 +884,7 @@ struct TeamWave {
         }
         __syncthreads();
       }
+#endif
       // ---- stage 4: accept in order
       c.tsec[6] += EG3D_TICK() - tq2;
       bool redo = false, stop = false;
@@ -916,8 +928,34 @@ struct TeamWave {
   // uniform section: all lanes hold the same (a, n, X0) and receive the same answer
   __device__ __forceinline__ bool gn_array(const DevScene& s, const Obs* a, int n, const double X0[3],
                                            float Xout[3]) const {
+#if EG3D_GN_GROUPS
+    // one request (lane 0), the whole wave on its rows
+    const float X0f[3] = {(float)X0[0], (float)X0[1], (float)X0[2]};  // callers pass float-valued starts
+    float Xr[3];
+    const bool ok = coop_gn_groups(s.cam_P, *L, lane() == 0, a, n, false, 0, 0.f, 0.f, X0f, Xr);
+    Xout[0] = __shfl(Xr[0], 0);
+    Xout[1] = __shfl(Xr[1], 0);
+    Xout[2] = __shfl(Xr[2], 0);
+    return __shfl(ok ? 1 : 0, 0) != 0;
+#else
     if (EG3D_COOP_GN && n <= EG3D_COOP_ROWS) return coop_gn_single(s.cam_P, *L, a, n, X0, Xout);
     return coop_gn_big(s.cam_P, *L, a, n, false, 0, 0.f, 0.f, X0, Xout);
+#endif
+  }
+  __device__ __forceinline__ bool add_one(const DevScene& s, const Chain& c, const ChainPt& p, const Obs& extra,
+                                          float Xout[3]) const {
+#if EG3D_GN_GROUPS
+    const float X0f[3] = {p.X[0], p.X[1], p.X[2]};
+    float Xr[3];
+    const bool ok = coop_gn_groups(s.cam_P, *L, lane() == 0, c.pool + p.off, (int)p.nobs, true, extra.view, extra.x,
+                                   extra.y, X0f, Xr);
+    Xout[0] = __shfl(Xr[0], 0);
+    Xout[1] = __shfl(Xr[1], 0);
+    Xout[2] = __shfl(Xr[2], 0);
+    return __shfl(ok ? 1 : 0, 0) != 0;
+#else
+    return add_observation_solve(s, c, p, extra, Xout);
+#endif
   }
   // B independent ADD solves, 64 per window, request j on lane j. A window goes cooperative
   // (rows = observations) when that needs fewer row-passes than the longest single solve;
@@ -932,6 +970,17 @@ struct TeamWave {
       o.pl = o.seg = 0;
       o.x = o.y = 0.f;
       const bool want = j < B && get(j, pt, o);
+#if EG3D_GN_GROUPS
+      float X[3] = {0.f, 0.f, 0.f};
+      float X0[3] = {0.f, 0.f, 0.f};
+      if (want) {
+        X0[0] = pt->X[0];
+        X0[1] = pt->X[1];
+        X0[2] = pt->X[2];
+      }
+      const bool ok = coop_gn_groups(s.cam_P, *L, want, want ? c.pool + pt->off : nullptr, want ? (int)pt->nobs : 0, true,
+                                     o.view, o.x, o.y, X0, X);
+#else
       const int n = want ? (int)pt->nobs + 1 : 0;
       int tot = n, mx = n, chunks_total = (n + 63) >> 6;
 #pragma unroll
@@ -980,6 +1029,7 @@ struct TeamWave {
       } else if (want) {
         ok = add_observation_solve(s, c, *pt, o, X);
       }
+#endif
       if (want) put(j, ok, X);
     }
   }
