@@ -1112,13 +1112,22 @@ extern "C" int eg3d_probe_sections(eg3d_ctx* c, double* sum, double* slowest, ui
   if (!c || !sum || !slowest) return EG3D_ERR_ARG;
   std::vector<ChainOut> co(c->last_nc ? c->last_nc : 1);
   if (c->last_nc) HIP_TRY(hipMemcpy(co.data(), c->b_couts.p, sizeof(ChainOut) * c->last_nc, hipMemcpyDeviceToHost));
-  for (int k = 0; k < 12; k++) sum[k] = slowest[k] = 0;
+  // sum / slowest hold 16 doubles: 0..11 the section ticks, 12..14 the follow diagnostics packed in
+  // tsec[11] (sequential N-view steps, look-ahead steps accepted, look-ahead rounds redone)
+  for (int k = 0; k < 16; k++) sum[k] = slowest[k] = 0;
   uint64_t worst = 0;
   for (uint32_t j = 0; j < c->last_nc; j++) {
     for (int k = 0; k < 12; k++) sum[k] += (double)co[j].tsec[k];
+    sum[12] += (double)(co[j].tsec[11] & 0xffffu);
+    sum[13] += (double)((co[j].tsec[11] >> 16) & 0xffffu);
+    sum[14] += (double)(co[j].tsec[11] >> 32);
     if (co[j].tsec[7] >= worst) {
       worst = co[j].tsec[7];
       for (int k = 0; k < 12; k++) slowest[k] = (double)co[j].tsec[k];
+      slowest[12] = (double)(co[j].tsec[11] & 0xffffu);
+      slowest[13] = (double)((co[j].tsec[11] >> 16) & 0xffffu);
+      slowest[14] = (double)(co[j].tsec[11] >> 32);
+      slowest[15] = (double)co[j].n_points;
     }
   }
   if (n_chains) *n_chains = c->last_nc;

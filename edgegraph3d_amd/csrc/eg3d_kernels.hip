@@ -604,6 +604,9 @@ __global__ void k_compact_chains(uint32_t n_tasks, const ChainSeed* per_task, co
 #ifndef EG3D_LOOKAHEAD
 #define EG3D_LOOKAHEAD 8 /* steps walked ahead per round (<= 8, and <= 64 / observations of the end point) */
 #endif
+#ifndef EG3D_LA_RESUME
+#define EG3D_LA_RESUME 0 /* look-ahead depth after a redone round (0 = off for the rest of the following call) */
+#endif
 #ifndef EG3D_SPEC_FOLLOW
 #define EG3D_SPEC_FOLLOW 1 /* chain following: walk up to 4 steps ahead, then triangulate them together */
 #endif
@@ -786,12 +789,16 @@ struct TeamWave {
   __device__ __forceinline__ int follow(const DevScene& s, Chain& c, bool front) const {
     const uint32_t* dirs = front ? c.start_dirs : c.end_dirs;
     int added = 0;
-    bool look_ahead = true;  // switched off for the rest of the call once a look-ahead step had to be redone
+    // look-ahead depth limit: EG3D_LOOKAHEAD to start with; after a round whose step had to be redone
+    // the sequential step runs once, then look-ahead resumes at depth EG3D_LA_RESUME (0 = stays off for
+    // the rest of the call) and doubles with every round that is accepted whole
+    int d_cap = EG3D_LOOKAHEAD;
+    bool look_ahead = true;
     for (;;) {
       const ChainPt& endpt = front ? chain_at(c, 0) : chain_at(c, c.len - 1);
       const int n_end = (int)endpt.nobs;
       int D = n_end > 0 ? EG3D_COOP_ROWS / n_end : 0;
-      if (D > EG3D_LOOKAHEAD) D = EG3D_LOOKAHEAD;
+      if (D > d_cap) D = d_cap;
       bool seq = !look_ahead || D < 2 || c.tmp_a != L->tmp_a;  // long observation lists (or lists not in LDS): plain steps
       if (!seq) {
       // ---- stage 1: walk ahead (lists of step j at tmp_a + j * n_end; a step keeps <= n_end obs)
@@ -898,7 +905,13 @@ struct TeamWave {
             break;
           }
           added++;
+#ifdef EG3D_SECTION_TIMING
+          c.tsec[11] += 1ull << 16;  // diagnostic: steps accepted from a look-ahead round
+#endif
         } else {
+#ifdef EG3D_SECTION_TIMING
+          c.tsec[11] += 1ull << 32;  // diagnostic: look-ahead rounds that ended in a redo
+#endif
           redo = true;  // sequential N-view step from the chain's current end (same walks, then the
           break;        // 3-subset fallback and the later candidates)
         }
@@ -910,15 +923,20 @@ struct TeamWave {
           c.flags |= fl_dead;
           return added;
         }
+        if (d_cap < EG3D_LOOKAHEAD) d_cap *= 2;
         continue;
       }
       seq = true;  // redo the failed step with the sequential N-view step; where the first candidate's
-      look_ahead = false;  // triangulation fails once it tends to keep failing (measured on C2's slowest chain)
+      look_ahead = EG3D_LA_RESUME >= 2;  // where a first candidate's triangulation fails it tends to fail again
+      d_cap = EG3D_LA_RESUME;
       }
       if (seq) {
         const ChainPt& e2 = front ? chain_at(c, 0) : chain_at(c, c.len - 1);
         float X[3];
         const int m = stepn_chain(*this, s, c, e2, dirs, X);
+#ifdef EG3D_SECTION_TIMING
+        c.tsec[11] += 1ull;  // diagnostic: sequential N-view steps
+#endif
         if (m == 0) return added;
         if (!follow_append(c, front, c.tmp_a, m, X)) return added;
         added++;

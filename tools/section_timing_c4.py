@@ -10,7 +10,7 @@ for _ in range(2):
     r = ctx.match_resident(0, n, device_only=True)
 L = api.lib()
 L.eg3d_probe_sections.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
-sm, sl, nc = (C.c_double * 12)(), (C.c_double * 12)(), C.c_uint32()
+sm, sl, nc = (C.c_double * 16)(), (C.c_double * 16)(), C.c_uint32()
 assert L.eg3d_probe_sections(ctx._h, sm, sl, C.byref(nc)) == 0
 names = ["candidates", "stepwalks", "sidewalks", "batchGN", "follow", "stepDLT", "stepGN", "whole", "commit", "init", "epc-pre", "newpoint"]
 print("chains", nc.value, "points", r["n_points"], "obs", r["n_obs"], "ms_expand", r["times"]["ms_expand"])
