@@ -70,6 +70,53 @@ def np_ptr(a, ctype):
     return a.ctypes.data_as(C.POINTER(ctype))
 
 
+class Graph3D(C.Structure):
+    """eg3d_graph3d (include/eg3d_host.h): the PLGMatchesManager replay (row a17)."""
+    _fields_ = [("n_nodes", C.c_uint64), ("n_real_nodes", C.c_uint64), ("node_X", f32p),
+                ("node_point", C.POINTER(C.c_uint64)), ("n_polylines", C.c_uint64), ("pl_start", u32p),
+                ("pl_end", u32p), ("conn_off", C.POINTER(C.c_uint64)), ("conn_pl", u32p),
+                ("n_scene_polylines", C.c_uint64), ("iv_off", C.POINTER(C.c_uint64)), ("iv_start_seg", u32p),
+                ("iv_start_xy", f32p), ("iv_end_seg", u32p), ("iv_end_xy", f32p)]
+
+
+def graph3d_to_dict(g):
+    nn, npl, nsp = int(g.n_nodes), int(g.n_polylines), int(g.n_scene_polylines)
+    conn_off = as_np(g.conn_off, nn + 1, np.uint64)
+    iv_off = as_np(g.iv_off, nsp + 1, np.uint64)
+    ni = int(iv_off[-1]) if nsp else 0
+    nc = int(conn_off[-1]) if nn else 0
+    return {
+        "n_nodes": nn, "n_real_nodes": int(g.n_real_nodes), "n_polylines": npl,
+        "node_X": as_np(g.node_X, 3 * nn, np.float32).reshape(nn, 3),
+        "node_point": as_np(g.node_point, nn, np.uint64),
+        "pl_start": as_np(g.pl_start, npl, np.uint32), "pl_end": as_np(g.pl_end, npl, np.uint32),
+        "conn_off": conn_off, "conn_pl": as_np(g.conn_pl, nc, np.uint32),
+        "iv_off": iv_off, "iv_start_seg": as_np(g.iv_start_seg, ni, np.uint32),
+        "iv_start_xy": as_np(g.iv_start_xy, 2 * ni, np.float32).reshape(ni, 2),
+        "iv_end_seg": as_np(g.iv_end_seg, ni, np.uint32),
+        "iv_end_xy": as_np(g.iv_end_xy, 2 * ni, np.float32).reshape(ni, 2),
+    }
+
+
+class EdgePointsArrays:
+    """Owns numpy copies of an edge-point cloud (a dict as returned by edgepoints_to_dict) and
+    exposes an EdgePoints struct over them, for the host steps that consume a cloud."""
+
+    def __init__(self, d):
+        self.a = {"X": np.ascontiguousarray(d["X"], np.float32), "obs_off": np.ascontiguousarray(d["obs_off"], np.uint32),
+                  "obs_view": np.ascontiguousarray(d["obs_view"], np.int32),
+                  "obs_pl": np.ascontiguousarray(d["obs_pl"], np.uint32),
+                  "obs_seg": np.ascontiguousarray(d["obs_seg"], np.uint32),
+                  "obs_xy": np.ascontiguousarray(d["obs_xy"], np.float32),
+                  "key": np.ascontiguousarray(d["key"], np.uint32)}
+        a = self.a
+        n = len(a["obs_off"]) - 1
+        self.c = EdgePoints(n, int(a["obs_off"][-1]) if n >= 0 else 0, np_ptr(a["X"], C.c_float),
+                            np_ptr(a["obs_off"], C.c_uint32), np_ptr(a["obs_view"], C.c_int32),
+                            np_ptr(a["obs_pl"], C.c_uint32), np_ptr(a["obs_seg"], C.c_uint32),
+                            np_ptr(a["obs_xy"], C.c_float), np_ptr(a["key"], C.c_uint32), 0, 0, 0, 0, None)
+
+
 def edgepoints_to_dict(e):
     n, m = int(e.n_points), int(e.n_obs)
     return {

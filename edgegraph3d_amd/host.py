@@ -38,6 +38,8 @@ def lib():
                                            C.POINTER(D.u32p), C.POINTER(D.u32p), D.u32p]
         L.eg3d_host_filter_close_2d.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(D.EdgePoints), D.u8p]
         L.eg3d_host_observation_filter.argtypes = [C.c_int, D.u32p, C.c_uint64, C.c_uint64, C.c_int, D.u8p]
+        L.eg3d_host_replay_matches.argtypes = [C.POINTER(D.Scene), C.POINTER(D.EdgePoints), C.POINTER(D.Graph3D)]
+        L.eg3d_host_free_graph3d.argtypes = [C.POINTER(D.Graph3D)]
         _LIB = L
     return _LIB
 
@@ -144,6 +146,19 @@ class Synth:
         for p in (X, off, view, xy):
             lib().eg3d_host_free(p)
         return out
+
+
+def replay_matches(scene_ptr, cloud):
+    """Row a17: the 3-D polyline graph and matched 2-D intervals PLGMatchesManager would hold after
+    the path emitted `cloud` (a dict as returned by Context.match_refpoints)."""
+    ep = D.EdgePointsArrays(cloud)
+    g = D.Graph3D()
+    rc = lib().eg3d_host_replay_matches(scene_ptr, C.byref(ep.c), C.byref(g))
+    if rc != 0:
+        raise RuntimeError("eg3d_host_replay_matches failed (%d)" % rc)
+    d = D.graph3d_to_dict(g)
+    lib().eg3d_host_free_graph3d(C.byref(g))
+    return d
 
 
 def build_grid(scene_ptr, view, cell_dim):

@@ -78,6 +78,36 @@ int eg3d_host_filter_close_2d(int n_views, int width, int height, const eg3d_edg
 int eg3d_host_observation_filter(int n_cameras, const uint32_t* obs_off, uint64_t n_points, uint64_t first_edgepoint,
                                  int forced_min_filter, uint8_t* inlier_inout);
 
+/* ------------------------------------------- PLGMatchesManager replay (row a17) -- */
+/* What plgmm.add_matched_3dpolyline(chain) leaves behind when the reference runs the path
+ * (plg_matching_from_refpoints.cpp:74-77 -> plg_matches_manager.cpp:99-180): the 3-D polyline graph
+ * (PolyLineGraph3DHMapImpl: nodes keyed by exact coordinates, one 2-point polyline per distinct
+ * consecutive pair of chain points, polyline_graph_3d_hmap_impl.cpp:47-68,99-141) and the matched
+ * 2-D intervals per (view, polyline). Rebuilt on the host from the ordered edge-point cloud of
+ * eg3d_match_refpoints / eg3d_match_polyline_sets (chains = runs of equal key[0..2] with key[3]
+ * counting up). Node and polyline ids are the reference's (creation order), narrowed to 32 bits. */
+typedef struct eg3d_graph3d {
+  uint64_t n_nodes;          /* nodes_amount, invalidated nodes included */
+  uint64_t n_real_nodes;     /* real_nodes_amount */
+  float* node_X;             /* [n_nodes][3] nodes_coords; an invalidated node holds (-1,-1,-1) */
+  uint64_t* node_point;      /* [n_nodes] edge-point whose observations the node carries (set_observations /
+                                p3d_to_matches_map: last writer), ~0 if none */
+  uint64_t n_polylines;      /* 2-point polylines = direct connections, duplicates suppressed */
+  uint32_t* pl_start;        /* [n_polylines] node ids */
+  uint32_t* pl_end;
+  uint64_t* conn_off;        /* [n_nodes+1] connections[node]: polyline ids in insertion order */
+  uint32_t* conn_pl;
+  uint64_t n_scene_polylines;/* = view_pl_off[V] */
+  uint64_t* iv_off;          /* [n_scene_polylines+1] matched_polyline_intervals[view][polyline] as a CSR over
+                                the scene's global polyline index, ascending start segment */
+  uint32_t* iv_start_seg;
+  float* iv_start_xy;        /* [..][2] */
+  uint32_t* iv_end_seg;
+  float* iv_end_xy;
+} eg3d_graph3d;
+int eg3d_host_replay_matches(const eg3d_scene* scene, const eg3d_edgepoints* pts, eg3d_graph3d* out);
+void eg3d_host_free_graph3d(eg3d_graph3d* g);
+
 /* -------------------------------------------------------------- OpenMVG JSON --- */
 typedef struct eg3d_sfm eg3d_sfm; /* host mirror of SfMData (SfMData.h:16-30) */
 eg3d_sfm* eg3d_sfm_read_json(const char* path);          /* OpenMvgParser::parse, OpenMvgParser.cpp:39-301 */

@@ -20,6 +20,7 @@
 #include <array>
 #include <atomic>
 #include <cstdint>
+#include <cstring>
 #include <set>
 #include <string>
 #include <thread>
@@ -28,6 +29,7 @@
 #include <vector>
 
 #include "eg3d.h"
+#include "eg3d_host.h" /* eg3d_host_replay_matches (libeg3d_host.so) */
 
 namespace eg3d_ref {
 
@@ -79,6 +81,55 @@ using FundamentalMatrices = std::vector<std::vector<std::array<double, 9>>>;  //
 
 using new_3dpoint_plgp_matches = std::tuple<vec3, std::vector<PolyLineGraph2D::plg_point>, std::vector<int>>;
 
+// PLGMatchesManager of the path (plg_matches_manager.hpp:99-141): what add_matched_3dpolyline leaves
+// behind — the 3-D polyline graph (get_plg3d()) and the matched 2-D intervals — rebuilt by
+// eg3d_host_replay_matches (include/eg3d_host.h, row a17) from the ordered output of a run.
+class PLGMatchesManager {
+ public:
+  PLGMatchesManager() { std::memset(&g_, 0, sizeof(g_)); }
+  ~PLGMatchesManager() { eg3d_host_free_graph3d(&g_); }
+  PLGMatchesManager(const PLGMatchesManager&) = delete;
+  PLGMatchesManager& operator=(const PLGMatchesManager&) = delete;
+  const eg3d_graph3d& get_plg3d() const { return g_; }
+  // matched_polyline_intervals[plg_id][polyline_id] as [begin, end) into the iv_* arrays of get_plg3d()
+  std::pair<uint64_t, uint64_t> matched_intervals(const eg3d_scene& sc, int plg_id, unsigned long polyline_id) const {
+    const uint64_t gpl = sc.view_pl_off[plg_id] + polyline_id;
+    return {g_.iv_off[gpl], g_.iv_off[gpl + 1]};
+  }
+  // concatenates the batches of a run (seed order) and replays them
+  int replay(const eg3d_scene& sc, const std::vector<eg3d_edgepoints>& parts) {
+    eg3d_host_free_graph3d(&g_);
+    std::vector<float> X, xy;
+    std::vector<uint32_t> off(1, 0), pl, seg, key;
+    std::vector<int32_t> view;
+    for (const eg3d_edgepoints& e : parts) {
+      const uint32_t base = (uint32_t)view.size();
+      X.insert(X.end(), e.X, e.X + 3 * e.n_points);
+      key.insert(key.end(), e.key, e.key + 4 * e.n_points);
+      for (uint64_t i = 0; i < e.n_points; i++) off.push_back(base + e.obs_off[i + 1]);
+      view.insert(view.end(), e.obs_view, e.obs_view + e.n_obs);
+      pl.insert(pl.end(), e.obs_pl, e.obs_pl + e.n_obs);
+      seg.insert(seg.end(), e.obs_seg, e.obs_seg + e.n_obs);
+      xy.insert(xy.end(), e.obs_xy, e.obs_xy + 2 * e.n_obs);
+    }
+    eg3d_edgepoints all;
+    std::memset(&all, 0, sizeof(all));
+    all.n_points = off.size() - 1;
+    all.n_obs = view.size();
+    all.X = X.data();
+    all.obs_off = off.data();
+    all.obs_view = view.data();
+    all.obs_pl = pl.data();
+    all.obs_seg = seg.data();
+    all.obs_xy = xy.data();
+    all.key = key.data();
+    return eg3d_host_replay_matches(&sc, &all, &g_);
+  }
+
+ private:
+  eg3d_graph3d g_;
+};
+
 // Owns the flattened scene and the GPU context: the PLGEdgeManager + PLGPCM3ViewsPLGFollowing
 // pair of the reference collapsed into one object (edge_matcher.cpp:101-115).
 class PLGEdgeManager {
@@ -119,7 +170,7 @@ class PLGEdgeManager {
       }
       vpo_.push_back((uint32_t)pls_.size());
     }
-    eg3d_scene sc;
+    eg3d_scene& sc = scene_;
     sc.n_views = V;
     sc.width = sfmd.imageWidth_;
     sc.height = sfmd.imageHeight_;
@@ -143,6 +194,7 @@ class PLGEdgeManager {
 
   int last_status() const { return status_; }
   eg3d_ctx* ctx() const { return ctx_; }
+  const eg3d_scene& scene() const { return scene_; }
 
   // pair(starting intersections, [per starting intersection][per track entry] correspondences), per track entry
   using per_view_result = std::pair<std::vector<PolyLineGraph2D::plg_point>,
@@ -181,7 +233,7 @@ class PLGEdgeManager {
     batch_ = seeds_per_batch ? seeds_per_batch : 2048;
     n_ctx_ = contexts < 1 ? 1 : contexts;
   }
-  std::vector<new_3dpoint_plgp_matches> match_all() {
+  std::vector<new_3dpoint_plgp_matches> match_all(PLGMatchesManager* plgmm = nullptr) {
     std::vector<new_3dpoint_plgp_matches> res;
     if (!ctx_) return res;
     const uint32_t n = (uint32_t)sfmd_.numPoints_;
@@ -225,6 +277,9 @@ class PLGEdgeManager {
           res.emplace_back(vec3{e.X[3 * i], e.X[3 * i + 1], e.X[3 * i + 2]}, std::move(obs), std::move(views));
         }
       }
+      // plgmm.add_matched_3dpolyline(chain) for every emitted chain, in emission order
+      // (plg_matching_from_refpoints.cpp:74-77): replayed on the host from the ordered cloud
+      if (plgmm) status_ = plgmm->replay(scene_, parts);
     }
     for (uint32_t i = 0; i < nb; i++)
       if (rc[i] == EG3D_OK) eg3d_free_edgepoints(&parts[i]);
@@ -293,6 +348,7 @@ class PLGEdgeManager {
   std::vector<uint8_t> Fv_, plv_;
   std::vector<uint32_t> vpo_, pvo_, pls_, ple_, toff_;
   std::vector<int32_t> tview_;
+  eg3d_scene scene_;
   eg3d_ctx* ctx_ = nullptr;
   int status_ = EG3D_OK;
   uint32_t batch_ = 2048;
@@ -303,6 +359,12 @@ class PLGEdgeManager {
 // reference signature are folded into the edge manager / replayable from the ordered output.
 inline std::vector<new_3dpoint_plgp_matches> plg_matching_from_refpoints_parallel(const SfMData&, PLGEdgeManager* em) {
   return em->match_all();
+}
+// ... and with the matches manager of the reference signature (sfmd, em, cm, plgmm): the consensus
+// manager lives in the edge manager; plgmm receives what add_matched_3dpolyline would have recorded
+inline std::vector<new_3dpoint_plgp_matches> plg_matching_from_refpoints_parallel(const SfMData&, PLGEdgeManager* em,
+                                                                                  PLGMatchesManager& plgmm) {
+  return em->match_all(&plgmm);
 }
 inline std::vector<new_3dpoint_plgp_matches> plg_matching_from_refpoints(const SfMData& s, PLGEdgeManager* em) {
   return plg_matching_from_refpoints_parallel(s, em);

@@ -43,6 +43,8 @@ def lib():
                                     C.c_int, D.f32p, D.u8p]
         L.orc_filter_close_2d.argtypes = [C.c_void_p, C.POINTER(D.EdgePoints), D.u8p]
         L.orc_observation_filter.argtypes = [C.c_int, D.u32p, C.c_uint64, C.c_uint64, C.c_int, D.u8p]
+        L.orc_replay_matches.argtypes = [C.c_void_p, C.POINTER(D.EdgePoints), C.POINTER(D.Graph3D)]
+        L.orc_free_graph3d.argtypes = [C.POINTER(D.Graph3D)]
         L.orc_squared_2d_distance.restype = C.c_float
         L.orc_squared_2d_distance.argtypes = [C.c_float] * 4
         L.orc_minimum_distancesq.restype = C.c_float
@@ -114,6 +116,15 @@ class Oracle:
         d = D.edgepoints_to_dict(e)
         lib().orc_free_edgepoints(C.byref(e))
         d["stats"] = {f[0]: getattr(st, f[0]) for f in Stats._fields_}
+        return d
+
+    def replay_matches(self, cloud):
+        """Row a17 (plg_matches_manager.cpp:99-180) over the chains of `cloud` (an edge-point dict)."""
+        ep = D.EdgePointsArrays(cloud)
+        g = D.Graph3D()
+        assert lib().orc_replay_matches(self._h, C.byref(ep.c), C.byref(g)) == 0
+        d = D.graph3d_to_dict(g)
+        lib().orc_free_graph3d(C.byref(g))
         return d
 
     def candidates(self, seeds_ptr, begin, end):

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "oracle_plg.hpp"
+#include "oracle_replay.hpp"
 
 using namespace orc;
 
@@ -358,10 +359,22 @@ extern "C" int orc_filter_close_2d(orc_ctx* c, const eg3d_edgepoints* pts, uint8
   const int w = int(std::ceil((float)c->sc.width / CELL)), h = int(std::ceil((float)c->sc.height / CELL));
   const int V = c->sc.cams.n_views;
   std::vector<std::vector<uint8_t>> bmaps(V, std::vector<uint8_t>((size_t)w * h, 0));
+  // An observation outside the maps (coordinates at/past the border, negative beyond one cell, NaN,
+  // view id out of range) indexes out of bounds in the reference — undefined behaviour. The rule
+  // adopted by oracle and product alike: it never makes a point new and marks nothing.
+  auto inside = [&](uint32_t j, int& cx, int& cy) {
+    const int v = pts->obs_view[j];
+    const float fx = pts->obs_xy[2 * j] / CELL, fy = pts->obs_xy[2 * j + 1] / CELL;
+    if (v < 0 || v >= V || !(fx > -1.0f) || !(fy > -1.0f) || !(fx < (float)w) || !(fy < (float)h)) return false;
+    cx = int(fx);
+    cy = int(fy);
+    return cx >= 0 && cy >= 0 && cx < w && cy < h;
+  };
   for (uint64_t i = 0; i < pts->n_points; i++) {
     bool is_new = false;
     for (uint32_t j = pts->obs_off[i]; j < pts->obs_off[i + 1]; j++) {
-      int cx = int(pts->obs_xy[2 * j] / CELL), cy = int(pts->obs_xy[2 * j + 1] / CELL);
+      int cx, cy;
+      if (!inside(j, cx, cy)) continue;
       if (!bmaps[pts->obs_view[j]][(size_t)cy * w + cx]) {
         is_new = true;
         break;
@@ -370,11 +383,109 @@ extern "C" int orc_filter_close_2d(orc_ctx* c, const eg3d_edgepoints* pts, uint8
     keep[i] = is_new ? 1 : 0;
     if (is_new)
       for (uint32_t j = pts->obs_off[i]; j < pts->obs_off[i + 1]; j++) {
-        int cx = int(pts->obs_xy[2 * j] / CELL), cy = int(pts->obs_xy[2 * j + 1] / CELL);
-        bmaps[pts->obs_view[j]][(size_t)cy * w + cx] = 1;
+        int cx, cy;
+        if (inside(j, cx, cy)) bmaps[pts->obs_view[j]][(size_t)cy * w + cx] = 1;
       }
   }
   return 0;
+}
+
+// Row a17: replay of plgmm.add_matched_3dpolyline over the chains of an edge-point cloud
+// (plg_matching_from_refpoints.cpp:74-77). Output in the eg3d_graph3d layout of include/eg3d_host.h.
+extern "C" int orc_replay_matches(orc_ctx* c, const eg3d_edgepoints* pts, eg3d_graph3d* out) {
+  if (!c || !pts || !out) return -1;
+  memset(out, 0, sizeof(*out));
+  MatchesManager mm(c->sc);
+  std::vector<MatchesManager::P3> chain;
+  auto flush = [&]() {
+    if (!chain.empty()) mm.add_matched_3dpolyline(chain);
+    chain.clear();
+  };
+  for (uint64_t i = 0; i < pts->n_points; i++) {
+    const uint32_t* k = pts->key + 4 * i;
+    if (i > 0) {
+      const uint32_t* kp = pts->key + 4 * (i - 1);
+      if (!(kp[0] == k[0] && kp[1] == k[1] && kp[2] == k[2] && k[3] == kp[3] + 1)) flush();
+    }
+    MatchesManager::P3 p;
+    p.X = vec3r{pts->X[3 * i], pts->X[3 * i + 1], pts->X[3 * i + 2]};
+    p.index = i;
+    for (uint32_t o = pts->obs_off[i]; o < pts->obs_off[i + 1]; o++) {
+      p.obs.push_back(plg_point(pts->obs_pl[o], pts->obs_seg[o], vec2(pts->obs_xy[2 * o], pts->obs_xy[2 * o + 1])));
+      p.views.push_back(pts->obs_view[o]);
+    }
+    chain.push_back(std::move(p));
+  }
+  flush();
+  const PLG3D& g = mm.plg3d;
+  const uint64_t NN = g.nodes_coords.size();
+  out->n_nodes = NN;
+  out->n_real_nodes = g.real_nodes_amount;
+  out->n_polylines = g.polylines.size();
+  out->node_X = (float*)malloc(sizeof(float) * 3 * (NN + 1));
+  out->node_point = (uint64_t*)malloc(sizeof(uint64_t) * (NN + 1));
+  out->conn_off = (uint64_t*)malloc(sizeof(uint64_t) * (NN + 1));
+  uint64_t nconn = 0;
+  for (uint64_t n = 0; n < NN; n++) nconn += g.connections[n].size();
+  out->conn_pl = (uint32_t*)malloc(sizeof(uint32_t) * (nconn + 1));
+  uint64_t w = 0;
+  for (uint64_t n = 0; n < NN; n++) {
+    out->node_X[3 * n] = g.nodes_coords[n].x;
+    out->node_X[3 * n + 1] = g.nodes_coords[n].y;
+    out->node_X[3 * n + 2] = g.nodes_coords[n].z;
+    out->node_point[n] = g.node_point[n];
+    out->conn_off[n] = w;
+    for (auto p : g.connections[n]) out->conn_pl[w++] = (uint32_t)p;
+  }
+  out->conn_off[NN] = w;
+  out->pl_start = (uint32_t*)malloc(sizeof(uint32_t) * (g.polylines.size() + 1));
+  out->pl_end = (uint32_t*)malloc(sizeof(uint32_t) * (g.polylines.size() + 1));
+  for (size_t p = 0; p < g.polylines.size(); p++) {
+    out->pl_start[p] = (uint32_t)g.polylines[p].start;
+    out->pl_end[p] = (uint32_t)g.polylines[p].end;
+  }
+  uint64_t NP = 0, NI = 0;
+  for (auto& v : mm.matched) {
+    NP += v.size();
+    for (auto& S : v) NI += S.size();
+  }
+  out->n_scene_polylines = NP;
+  out->iv_off = (uint64_t*)malloc(sizeof(uint64_t) * (NP + 1));
+  out->iv_start_seg = (uint32_t*)malloc(sizeof(uint32_t) * (NI + 1));
+  out->iv_end_seg = (uint32_t*)malloc(sizeof(uint32_t) * (NI + 1));
+  out->iv_start_xy = (float*)malloc(sizeof(float) * 2 * (NI + 1));
+  out->iv_end_xy = (float*)malloc(sizeof(float) * 2 * (NI + 1));
+  uint64_t gp = 0, k = 0;
+  for (auto& v : mm.matched)
+    for (auto& S : v) {
+      out->iv_off[gp++] = k;
+      for (auto& iv : S) {
+        out->iv_start_seg[k] = (uint32_t)iv.start.segment_index;
+        out->iv_end_seg[k] = (uint32_t)iv.end.segment_index;
+        out->iv_start_xy[2 * k] = iv.start.coords.x;
+        out->iv_start_xy[2 * k + 1] = iv.start.coords.y;
+        out->iv_end_xy[2 * k] = iv.end.coords.x;
+        out->iv_end_xy[2 * k + 1] = iv.end.coords.y;
+        k++;
+      }
+    }
+  out->iv_off[NP] = k;
+  return 0;
+}
+extern "C" void orc_free_graph3d(eg3d_graph3d* g) {
+  if (!g) return;
+  free(g->node_X);
+  free(g->node_point);
+  free(g->pl_start);
+  free(g->pl_end);
+  free(g->conn_off);
+  free(g->conn_pl);
+  free(g->iv_off);
+  free(g->iv_start_seg);
+  free(g->iv_end_seg);
+  free(g->iv_start_xy);
+  free(g->iv_end_xy);
+  memset(g, 0, sizeof(*g));
 }
 
 // compute_ray_stats + compute_inliers tail, outliers_filtering.cpp:14-35,37-64

@@ -4,7 +4,7 @@
  * __graft_entry__.smoke() and by bench.py's cpu_baseline leg. Never linked into the product. */
 #ifndef EG3D_ORACLE_H_
 #define EG3D_ORACLE_H_
-#include "../include/eg3d.h"
+#include "../include/eg3d_host.h" /* eg3d.h + the eg3d_graph3d layout */
 
 #ifdef __cplusplus
 extern "C" {
@@ -44,6 +44,11 @@ int orc_filter_close_2d(orc_ctx*, const eg3d_edgepoints* pts, uint8_t* keep);
 /* compute_inliers tail (outliers_filtering.cpp:37-64) given GN inliers: returns threshold used */
 int orc_observation_filter(int n_cameras, const uint32_t* obs_off, uint64_t n_points, uint64_t first_edgepoint,
                            int forced_min_filter, uint8_t* inlier_inout);
+
+/* row a17: PLGMatchesManager::add_matched_3dpolyline replayed over the chains of a cloud
+ * (plg_matches_manager.cpp:99-180); release with orc_free_graph3d */
+int orc_replay_matches(orc_ctx*, const eg3d_edgepoints* pts, eg3d_graph3d* out);
+void orc_free_graph3d(eg3d_graph3d* g);
 
 /* primitive probes for known-answer tests */
 float orc_squared_2d_distance(float ax, float ay, float bx, float by);

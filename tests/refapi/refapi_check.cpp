@@ -67,7 +67,8 @@ int main(int argc, char** argv) {
     return 1;
   }
   em.set_batching(37, 3);  // ragged batches, three contexts in flight
-  auto many = plg_matching_from_refpoints_parallel(sfm, &em);
+  PLGMatchesManager plgmm;   // row a17: filled by the replay of the batched run
+  auto many = plg_matching_from_refpoints_parallel(sfm, &em, plgmm);
   if (em.last_status() != EG3D_OK) {
     std::printf("FAIL match_all: %s\n", eg3d_last_error());
     return 1;
@@ -101,6 +102,20 @@ int main(int argc, char** argv) {
           bad++;
       }
     }
+  }
+  // row a17: the matches manager filled from the batched run equals the replay of the direct cloud
+  {
+    eg3d_graph3d g;
+    if (eg3d_host_replay_matches(sc, &e, &g) != 0) bad++;
+    const eg3d_graph3d& h = plgmm.get_plg3d();
+    if (g.n_nodes != h.n_nodes || g.n_polylines != h.n_polylines || g.n_nodes == 0 || g.n_polylines == 0 ||
+        std::memcmp(g.node_X, h.node_X, 12 * g.n_nodes) != 0 || std::memcmp(g.pl_start, h.pl_start, 4 * g.n_polylines) != 0 ||
+        std::memcmp(g.pl_end, h.pl_end, 4 * g.n_polylines) != 0 ||
+        g.iv_off[g.n_scene_polylines] != h.iv_off[h.n_scene_polylines] || g.iv_off[g.n_scene_polylines] == 0)
+      bad++;
+    std::printf("replay: %llu nodes, %llu 3-D connections, %llu matched 2-D intervals\n", (unsigned long long)g.n_nodes,
+                (unsigned long long)g.n_polylines, (unsigned long long)g.iv_off[g.n_scene_polylines]);
+    eg3d_host_free_graph3d(&g);
   }
   // pipelines 1-2 extractor through the reference's signature: the polylines of curves 0 and 1
   {
