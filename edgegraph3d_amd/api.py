@@ -36,6 +36,7 @@ def lib():
         L = C.CDLL(path)
         L.eg3d_last_error.restype = C.c_char_p
         L.eg3d_device_count.restype = C.c_int
+        L.eg3d_dlt_rows.restype = C.c_int
         L.eg3d_create.argtypes = [C.POINTER(D.Scene), C.c_int, C.POINTER(C.c_void_p)]
         L.eg3d_destroy.argtypes = [C.c_void_p]
         L.eg3d_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
@@ -59,7 +60,7 @@ def lib():
 
 # every symbol include/eg3d.h declares (checked by tests/test_abi.py without a GPU)
 EXPORTED_SYMBOLS = [
-    "eg3d_last_error", "eg3d_device_count", "eg3d_create", "eg3d_clone", "eg3d_destroy", "eg3d_get_grid", "eg3d_candidates_run",
+    "eg3d_last_error", "eg3d_device_count", "eg3d_dlt_rows", "eg3d_create", "eg3d_clone", "eg3d_destroy", "eg3d_get_grid", "eg3d_candidates_run",
     "eg3d_free_candidates", "eg3d_match_refpoints", "eg3d_free_edgepoints", "eg3d_upload_seeds",
     "eg3d_match_resident", "eg3d_gn_filter", "eg3d_last_device_output", "eg3d_match_polyline_sets",
 ]

@@ -55,15 +55,28 @@ def build_host(force=False):
     return HOST_LIB
 
 
-def build_hip(force=False):
+def build_hip(force=False, out=None, defines=()):
+    out = out or HIP_LIB
     srcs = _all_sources(CSRC_DIR, (".hip",))
     host_srcs = [os.path.join(HOST_DIR, "grid_build.cpp")]
     deps = srcs + host_srcs + _all_sources(CSRC_DIR, (".h", ".hpp")) + _all_sources(INC_DIR, (".h",))
-    if force or _newer(HIP_LIB, deps):
+    if force or _newer(out, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         extra = os.environ.get("EG3D_EXTRA_HIPFLAGS", "").split()
-        _run([hipcc] + HIP_FLAGS + extra + ["-I", INC_DIR, "-I", CSRC_DIR, "-I", HOST_DIR, "-o", HIP_LIB] + srcs + host_srcs)
-    return HIP_LIB
+        _run([hipcc] + HIP_FLAGS + extra + list(defines) + ["-I", INC_DIR, "-I", CSRC_DIR, "-I", HOST_DIR, "-o", out]
+             + srcs + host_srcs)
+    return out
+
+
+# The same library with the OTHER form of cv::triangulatePoints' system (three rows per view, 6x4:
+# OpenCV 2.4-3.1 — the release the reference names; the default build follows the later 4x4 form).
+# The reference pins no OpenCV version, so both are kept bit-exact against the oracle in the
+# matching mode (tests/test_gpu_dlt_forms.py). Selected with EG3D_LIB=<this file>.
+HIP_LIB_DLT6X4 = os.path.join(PKG, "libeg3d_dlt6x4.so")
+
+
+def build_hip_dlt6x4(force=False):
+    return build_hip(force, HIP_LIB_DLT6X4, ("-DEG3D_DLT_ROWS=3",))
 
 
 RCCL_LIB = os.path.join(PKG, "libeg3d_rccl.so")
@@ -93,6 +106,7 @@ def build_oracle(force=False):
 def build_all(force=False):
     build_host(force)
     build_hip(force)
+    build_hip_dlt6x4(force)
     build_rccl(force)
     build_oracle(force)
 

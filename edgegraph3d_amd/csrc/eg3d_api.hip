@@ -137,6 +137,8 @@ static int read_u32(eg3d_ctx* c, const uint32_t* dptr, uint32_t& v) {
   return EG3D_OK;
 }
 
+extern "C" int eg3d_dlt_rows(void) { return EG3D_DLT_ROWS; }
+
 extern "C" int eg3d_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1096,7 +1098,7 @@ extern "C" int eg3d_gn_filter(eg3d_ctx* c, const float* X, const uint32_t* obs_o
   BUF_TRY(c->f_Xo.ensure(sizeof(float) * 3 * (n + 1)));
   BUF_TRY(c->f_inl.ensure(n + 1));
   HIP_TRY(hipEventRecord(c->ea[0], st));
-  launch_k5(st, c->ds.cam_P, c->f_X.as<float>(), c->f_off.as<uint32_t>(), c->f_view.as<int32_t>(), c->f_xy.as<float>(),
+  launch_k5(st, c->ds.cam_P, c->V, c->f_X.as<float>(), c->f_off.as<uint32_t>(), c->f_view.as<int32_t>(), c->f_xy.as<float>(),
             n, gn_max_mse, legacy_abs, c->f_Xo.as<float>(), c->f_inl.as<uint8_t>());
   HIP_TRY(hipEventRecord(c->eb[0], st));
   if (n) {

@@ -54,20 +54,28 @@ EG3D_HD void project_f32(const float* P, float X, float Y, float Z, float& u, fl
 
 EG3D_HD double absd(double v) { return v < 0.0 ? -v : v; }
 
-// Smallest right singular vector of a 4x4 double matrix by one-sided Jacobi (the algorithm
-// OpenCV's SVD uses inside cv::triangulatePoints); rotation order (i<j ascending), the
-// 30-sweep cap and the 10*DBL_EPSILON skip test are part of the arithmetic contract.
-EG3D_HD void svd4_smallest_v(const double A[4][4], double out[4]) {
-  double At[4][4], Vt[4][4], W[4];
+// Which system cv::triangulatePoints builds depends on the OpenCV release (the reference pins
+// none: "OpenCV >= 3.1, tested 3.1"): EG3D_DLT_ROWS = 3 is the legacy cvTriangulatePoints of OpenCV
+// 2.4-3.1 (6x4: rows x*P2-P0, y*P2-P1, x*P1-y*P0 per view), 2 the later 4x4 rewrite. Compile-time
+// here (register budget), run-time in the oracle (orc_set_dlt_rows); eg3d_dlt_rows() reports it.
+#ifndef EG3D_DLT_ROWS
+#define EG3D_DLT_ROWS 2
+#endif
+#define EG3D_DLT_M (2 * EG3D_DLT_ROWS)
+
+// Smallest right singular vector of an M x 4 double matrix (given transposed: 4 rows of length M)
+// by one-sided Jacobi (the algorithm OpenCV's SVD uses inside cv::triangulatePoints); rotation
+// order (i<j ascending), the 30-sweep cap and the 10*DBL_EPSILON skip test are part of the
+// arithmetic contract.
+EG3D_HD void svd4_smallest_v(double At[4][EG3D_DLT_M], double out[4]) {
+  constexpr int M = EG3D_DLT_M;
+  double Vt[4][4], W[4];
   for (int i = 0; i < 4; i++)
-    for (int k = 0; k < 4; k++) {
-      At[i][k] = A[k][i];
-      Vt[i][k] = (i == k) ? 1.0 : 0.0;
-    }
+    for (int k = 0; k < 4; k++) Vt[i][k] = (i == k) ? 1.0 : 0.0;
   const double eps = 2.2204460492503131e-16 * 10;
   for (int i = 0; i < 4; i++) {
     double sd = 0;
-    for (int k = 0; k < 4; k++) sd += At[i][k] * At[i][k];
+    for (int k = 0; k < M; k++) sd += At[i][k] * At[i][k];
     W[i] = sd;
   }
   for (int iter = 0; iter < 30; iter++) {
@@ -75,7 +83,7 @@ EG3D_HD void svd4_smallest_v(const double A[4][4], double out[4]) {
     for (int i = 0; i < 3; i++)
       for (int j = i + 1; j < 4; j++) {
         double a = W[i], p = 0, b = W[j];
-        for (int k = 0; k < 4; k++) p += At[i][k] * At[j][k];
+        for (int k = 0; k < M; k++) p += At[i][k] * At[j][k];
         // skip test |p| <= eps*sqrt(a*b): decided on the squares whenever that is unambiguous
         // (relative margin 1e-7 >> the few-ulp error of either form), so the FP64 sqrt is only
         // evaluated in the knife-edge band — same decisions, same bits
@@ -103,7 +111,7 @@ EG3D_HD void svd4_smallest_v(const double A[4][4], double out[4]) {
         }
         a = 0;
         b = 0;
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < M; k++) {
           double t0 = c * At[i][k] + s * At[j][k];
           double t1 = c * At[j][k] - s * At[i][k];
           At[i][k] = t0;
@@ -125,7 +133,7 @@ EG3D_HD void svd4_smallest_v(const double A[4][4], double out[4]) {
   }
   for (int i = 0; i < 4; i++) {
     double sd = 0;
-    for (int k = 0; k < 4; k++) sd += At[i][k] * At[i][k];
+    for (int k = 0; k < M; k++) sd += At[i][k] * At[i][k];
     W[i] = EG3D_SQRT(sd);
   }
   // descending selection sort; track which row ends up last
@@ -147,26 +155,33 @@ EG3D_HD void svd4_smallest_v(const double A[4][4], double out[4]) {
   for (int k = 0; k < 4; k++) out[k] = Vt[last][k];
 }
 
-// 2-view DLT: rows x*P(2,:)-P(0,:), y*P(2,:)-P(1,:) per view in double; the homogeneous
-// solution is rounded to float before the float division by w (triangulation.cpp:216-224).
+// 2-view DLT: per view the rows x*P(2,:)-P(0,:), y*P(2,:)-P(1,:) [, x*P(1,:)-y*P(0,:)] in double;
+// the homogeneous solution is rounded to float before the float division by w
+// (triangulation.cpp:216-224).
 EG3D_HD void dlt2(const float* P1, float x1, float y1, const float* P2, float x2, float y2, double X0[3]) {
-  double A[4][4];
+  double At[4][EG3D_DLT_M];  // At[k][row] = A[row][k]
   {
     double x = x1, y = y1;
     for (int k = 0; k < 4; k++) {
-      A[0][k] = x * (double)P1[8 + k] - (double)P1[k];
-      A[1][k] = y * (double)P1[8 + k] - (double)P1[4 + k];
+      At[k][0] = x * (double)P1[8 + k] - (double)P1[k];
+      At[k][1] = y * (double)P1[8 + k] - (double)P1[4 + k];
+#if EG3D_DLT_ROWS == 3
+      At[k][2] = x * (double)P1[4 + k] - y * (double)P1[k];
+#endif
     }
   }
   {
     double x = x2, y = y2;
     for (int k = 0; k < 4; k++) {
-      A[2][k] = x * (double)P2[8 + k] - (double)P2[k];
-      A[3][k] = y * (double)P2[8 + k] - (double)P2[4 + k];
+      At[k][EG3D_DLT_ROWS + 0] = x * (double)P2[8 + k] - (double)P2[k];
+      At[k][EG3D_DLT_ROWS + 1] = y * (double)P2[8 + k] - (double)P2[4 + k];
+#if EG3D_DLT_ROWS == 3
+      At[k][EG3D_DLT_ROWS + 2] = x * (double)P2[4 + k] - y * (double)P2[k];
+#endif
     }
   }
   double v[4];
-  svd4_smallest_v(A, v);
+  svd4_smallest_v(At, v);
   float h0 = (float)v[0], h1 = (float)v[1], h2 = (float)v[2], h3 = (float)v[3];
   X0[0] = (double)(h0 / h3);
   X0[1] = (double)(h1 / h3);
@@ -439,15 +454,19 @@ EG3D_HD bool triangulate_combinations(const float* cam_P, const Obs* a, int n, O
 // One point of gaussNewtonFiltering (src/edgegraph3d/filtering/gauss_newton.cpp:83-134):
 // FP32 state, products of the normal equations accumulated in double and rounded to float
 // per element (OpenCV float GEMM), determinant/inverse of the 3x3 in double.
-EG3D_HD bool gauss_newton_f32(const float* cam_P, const int32_t* views, const float* xy, int n, const float X0[3],
-                              float gn_max_mse, bool legacy_abs, float Xout[3]) {
+// Pointer types are template parameters so that the filter kernel can run it on operands staged in
+// LDS (address_space(3) pointers => ds_read) as well as on HBM arrays; pstride = floats per camera
+// matrix in cam_P (16 in HBM, 12 in the kernel's LDS copy: the last row is never read).
+template <class PP, class VP, class XYP>
+EG3D_HD bool gauss_newton_f32_t(PP cam_P, int pstride, VP views, XYP xy, int n, const float X0[3], float gn_max_mse,
+                                bool legacy_abs, float Xout[3]) {
   float X[3] = {X0[0], X0[1], X0[2]};
   float last_mse = 0;
   for (int it = 0; it < 30; it++) {
     float mse = 0;
     double H00 = 0, H01 = 0, H02 = 0, H11 = 0, H12 = 0, H22 = 0;
     for (int m = 0; m < n; m++) {
-      const float* P = cam_P + (size_t)views[m] * 16;
+      const PP P = cam_P + (size_t)views[m] * pstride;
       float xH = ((P[0] * X[0] + P[1] * X[1]) + P[2] * X[2]) + P[3] * 1.0f;
       float yH = ((P[4] * X[0] + P[5] * X[1]) + P[6] * X[2]) + P[7] * 1.0f;
       float zH = ((P[8] * X[0] + P[9] * X[1]) + P[10] * X[2]) + P[11] * 1.0f;
@@ -506,7 +525,7 @@ EG3D_HD bool gauss_newton_f32(const float* cam_P, const int32_t* views, const fl
     }
     double d0 = 0, d1 = 0, d2 = 0;
     for (int m = 0; m < n; m++) {
-      const float* P = cam_P + (size_t)views[m] * 16;
+      const PP P = cam_P + (size_t)views[m] * pstride;
       float xH = ((P[0] * X[0] + P[1] * X[1]) + P[2] * X[2]) + P[3] * 1.0f;
       float yH = ((P[4] * X[0] + P[5] * X[1]) + P[6] * X[2]) + P[7] * 1.0f;
       float zH = ((P[8] * X[0] + P[9] * X[1]) + P[10] * X[2]) + P[11] * 1.0f;
@@ -543,6 +562,11 @@ EG3D_HD bool gauss_newton_f32(const float* cam_P, const int32_t* views, const fl
     return true;
   }
   return false;
+}
+
+EG3D_HD bool gauss_newton_f32(const float* cam_P, const int32_t* views, const float* xy, int n, const float X0[3],
+                              float gn_max_mse, bool legacy_abs, float Xout[3]) {
+  return gauss_newton_f32_t(cam_P, 16, views, xy, n, X0, gn_max_mse, legacy_abs, Xout);
 }
 
 }  // namespace eg3d

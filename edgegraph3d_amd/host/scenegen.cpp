@@ -134,6 +134,11 @@ extern "C" void eg3d_synth_default_config(eg3d_synth_config* c, int idx) {
       c->n_seeds = 100000;
       c->n_curves = 295;
       break;
+    case 5:  // C5 rig: 16 views so that k ~ U[3,10] of the 1 M-point filter workload (eg3d_synth_points) is real
+      c->n_views = 16;
+      c->n_seeds = 200;
+      c->n_curves = 82;
+      break;
     case 1:  // small: used by the CPU parity tests
       c->n_views = 6;
       c->n_seeds = 120;

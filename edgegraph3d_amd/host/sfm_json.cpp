@@ -42,16 +42,22 @@ struct Parser {
   const char* p;
   const char* e;
   bool ok = true;
+  int depth = 0;  // nesting of the value being parsed (a hostile file must not overflow the stack)
   void ws() {
     while (p < e && (*p == ' ' || *p == '\n' || *p == '\t' || *p == '\r')) p++;
   }
   JVal parse() {
     ws();
     JVal v;
-    if (p >= e) {
+    if (p >= e || depth > 64) {
       ok = false;
       return v;
     }
+    struct Depth {
+      int& d;
+      explicit Depth(int& x) : d(x) { d++; }
+      ~Depth() { d--; }
+    } guard(depth);
     if (*p == '{') {
       v.t = JVal::OBJ;
       p++;
@@ -184,8 +190,15 @@ void write_val(std::ostream& os, const JVal& v, int ind) {
 }
 
 // shortest decimal text that round-trips a float widened to double (rapidjson writes doubles)
+// a NaN / infinity has no JSON text (rapidjson's writer refuses it): the writer emits null and
+// eg3d_sfm_write_json reports the file as invalid (-2)
+thread_local bool g_nonfinite_written = false;
 std::string num_text(float f) {
   double d = (double)f;
+  if (!(d == d) || d > 1.7e308 || d < -1.7e308) {
+    g_nonfinite_written = true;
+    return "null";
+  }
   char buf[40];
   for (int prec = 1; prec <= 17; prec++) {
     snprintf(buf, sizeof(buf), "%.*g", prec, d);
@@ -351,88 +364,123 @@ static bool load_json(const char* path, JVal& root) {
   return p.ok && root.t == JVal::OBJ;
 }
 
+// Checked access for the reader: a missing key, a wrong type or a short array makes the whole
+// read fail (nullptr) instead of dereferencing a null / out-of-range element.
+struct Bad {};
+static const JVal& need(const JVal* v, const char* k) {
+  const JVal* r = (v && v->t == JVal::OBJ) ? v->get(k) : nullptr;
+  if (!r) throw Bad();
+  return *r;
+}
+static const JVal& at(const JVal& v, size_t i) {
+  if (v.t != JVal::ARR || i >= v.a.size()) throw Bad();
+  return v.a[i];
+}
+static double numv(const JVal& v) {
+  if (v.t != JVal::NUM) throw Bad();
+  return strtod(v.s.c_str(), nullptr);
+}
+static const std::string& strv(const JVal& v) {
+  if (v.t != JVal::STR) throw Bad();
+  return v.s;
+}
+static const JVal* data_of(const JVal& item) {  // item.value.ptr_wrapper.data, or null (entry skipped as in the reference)
+  const JVal* d = item.t == JVal::OBJ ? item.get("value") : nullptr;
+  d = (d && d->t == JVal::OBJ) ? d->get("ptr_wrapper") : nullptr;
+  d = (d && d->t == JVal::OBJ) ? d->get("data") : nullptr;
+  return (d && d->t == JVal::OBJ) ? d : nullptr;
+}
+
 extern "C" eg3d_sfm* eg3d_sfm_read_json(const char* path) {
   JVal root;
-  if (!load_json(path, root)) return nullptr;
+  if (!path || !load_json(path, root)) return nullptr;
   const JVal *views = root.get("views"), *intr = root.get("intrinsics"), *extr = root.get("extrinsics"),
              *structure = root.get("structure"), *rp = root.get("root_path");
-  if (!views || !intr || !extr || !structure) return nullptr;
-  std::string base = rp ? rp->s : "";
-  struct K {
-    float f, px, py;
-  };
-  std::map<int, K> intrinsics;
-  for (const JVal& it : intr->a) {
-    const JVal* d = it.get("value");
-    d = d ? d->get("ptr_wrapper") : nullptr;
-    d = d ? d->get("data") : nullptr;
-    if (!d) continue;
-    K k;
-    k.f = (float)d->get("focal_length")->num();
-    k.px = (float)d->get("principal_point")->a[0].num();
-    k.py = (float)d->get("principal_point")->a[1].num();
-    intrinsics[(int)it.get("key")->num()] = k;
-  }
-  struct E {
-    float R[9], C[3];
-  };
-  std::map<int, E> extrinsics;
-  std::map<int, int> map_pos;
-  int pos = 0;
-  for (const JVal& it : extr->a) {
-    E e;
-    const JVal* v = it.get("value");
-    for (int r = 0; r < 3; r++)
-      for (int c = 0; c < 3; c++) e.R[3 * r + c] = (float)v->get("rotation")->a[r].a[c].num();
-    for (int r = 0; r < 3; r++) e.C[r] = (float)v->get("center")->a[r].num();
-    const int key = (int)it.get("key")->num();
-    extrinsics[key] = e;
-    map_pos[key] = pos++;
-  }
-  eg3d_sfm* s = new eg3d_sfm();
-  s->cams.resize(views->a.size());
-  for (size_t i = 0; i < views->a.size(); i++) {
-    const JVal* d = views->a[i].get("value");
-    d = d ? d->get("ptr_wrapper") : nullptr;
-    d = d ? d->get("data") : nullptr;
-    if (!d) continue;
-    Cam& c = s->cams[i];
-    c.path = base + d->get("local_path")->s + d->get("filename")->s;
-    s->width = (int)d->get("width")->num();
-    s->height = (int)d->get("height")->num();
-    const int ii = (int)d->get("id_intrinsic")->num(), ie = (int)d->get("id_pose")->num();
-    auto ki = intrinsics.find(ii);
-    auto ke = extrinsics.find(ie);
-    if (ki == intrinsics.end() || ke == extrinsics.end()) continue;  // reference prints and leaves zeros
-    c.focal = ki->second.f;
-    c.ppx = ki->second.px;
-    c.ppy = ki->second.py;
-    memcpy(c.R, ke->second.R, sizeof(c.R));
-    memcpy(c.C, ke->second.C, sizeof(c.C));
-    eg3dh::translation_from_center(c.R, c.C, c.t);
-    eg3dh::camera_matrix(c.focal, c.ppx, c.ppy, c.R, c.t, c.P);
-  }
-  s->refresh_P();
-  for (const JVal& pt : structure->a) {
-    const JVal* v = pt.get("value");
-    float X[3] = {(float)v->get("X")->a[0].num(), (float)v->get("X")->a[1].num(), (float)v->get("X")->a[2].num()};
-    std::vector<int32_t> vw;
-    std::vector<float> xy;
-    for (const JVal& ob : v->get("observations")->a) {
-      auto it = map_pos.find((int)ob.get("key")->num());
-      if (it == map_pos.end()) continue;
-      vw.push_back(it->second);
-      const JVal* x = ob.get("value")->get("x");
-      xy.push_back((float)x->a[0].num());
-      xy.push_back((float)x->a[1].num());
+  if (!views || !intr || !extr || !structure || views->t != JVal::ARR || intr->t != JVal::ARR || extr->t != JVal::ARR ||
+      structure->t != JVal::ARR)
+    return nullptr;
+  eg3d_sfm* s = nullptr;
+  try {
+    std::string base = (rp && rp->t == JVal::STR) ? rp->s : "";
+    struct K {
+      float f, px, py;
+    };
+    std::map<int, K> intrinsics;
+    for (const JVal& it : intr->a) {
+      const JVal* d = data_of(it);
+      if (!d) continue;
+      K k;
+      k.f = (float)numv(need(d, "focal_length"));  // a non-pinhole intrinsic (no focal_length) fails the read
+      k.px = (float)numv(at(need(d, "principal_point"), 0));
+      k.py = (float)numv(at(need(d, "principal_point"), 1));
+      intrinsics[(int)numv(need(&it, "key"))] = k;
     }
-    eg3d_sfm_add_point(s, X, (int)vw.size(), vw.data(), xy.data());
+    struct E {
+      float R[9], C[3];
+    };
+    std::map<int, E> extrinsics;
+    std::map<int, int> map_pos;
+    int pos = 0;
+    for (const JVal& it : extr->a) {
+      E e;
+      const JVal& v = need(&it, "value");
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) e.R[3 * r + c] = (float)numv(at(at(need(&v, "rotation"), r), c));
+      for (int r = 0; r < 3; r++) e.C[r] = (float)numv(at(need(&v, "center"), r));
+      const int key = (int)numv(need(&it, "key"));
+      extrinsics[key] = e;
+      map_pos[key] = pos++;
+    }
+    s = new eg3d_sfm();
+    s->cams.resize(views->a.size());
+    for (size_t i = 0; i < views->a.size(); i++) {
+      const JVal* d = data_of(views->a[i]);
+      if (!d) continue;
+      Cam& c = s->cams[i];
+      c.path = base + strv(need(d, "local_path")) + strv(need(d, "filename"));
+      s->width = (int)numv(need(d, "width"));
+      s->height = (int)numv(need(d, "height"));
+      const int ii = (int)numv(need(d, "id_intrinsic")), ie = (int)numv(need(d, "id_pose"));
+      auto ki = intrinsics.find(ii);
+      auto ke = extrinsics.find(ie);
+      if (ki == intrinsics.end() || ke == extrinsics.end()) continue;  // reference prints and leaves zeros
+      c.focal = ki->second.f;
+      c.ppx = ki->second.px;
+      c.ppy = ki->second.py;
+      memcpy(c.R, ke->second.R, sizeof(c.R));
+      memcpy(c.C, ke->second.C, sizeof(c.C));
+      eg3dh::translation_from_center(c.R, c.C, c.t);
+      eg3dh::camera_matrix(c.focal, c.ppx, c.ppy, c.R, c.t, c.P);
+    }
+    s->refresh_P();
+    for (const JVal& pt : structure->a) {
+      const JVal& v = need(&pt, "value");
+      const JVal& Xj = need(&v, "X");
+      float X[3] = {(float)numv(at(Xj, 0)), (float)numv(at(Xj, 1)), (float)numv(at(Xj, 2))};
+      std::vector<int32_t> vw;
+      std::vector<float> xy;
+      const JVal& obs = need(&v, "observations");
+      if (obs.t != JVal::ARR) throw Bad();
+      for (const JVal& ob : obs.a) {
+        auto it = map_pos.find((int)numv(need(&ob, "key")));
+        if (it == map_pos.end()) continue;
+        vw.push_back(it->second);
+        const JVal& x = need(&need(&ob, "value"), "x");
+        xy.push_back((float)numv(at(x, 0)));
+        xy.push_back((float)numv(at(x, 1)));
+      }
+      eg3d_sfm_add_point(s, X, (int)vw.size(), vw.data(), xy.data());
+    }
+  } catch (const Bad&) {
+    delete s;
+    return nullptr;
   }
   return s;
 }
 
 extern "C" int eg3d_sfm_write_json(const eg3d_sfm* s, const char* in_path, const char* out_path) {
   if (!s || !out_path) return -1;
+  g_nonfinite_written = false;
   JVal in;
   bool have_in = in_path && load_json(in_path, in);
   JVal root;
@@ -552,5 +600,6 @@ extern "C" int eg3d_sfm_write_json(const eg3d_sfm* s, const char* in_path, const
   std::ofstream f(out_path, std::ios::binary);
   if (!f) return -1;
   write_val(f, root, 0);
+  if (g_nonfinite_written) return -2;  // a NaN / infinite coordinate was written as null: not a valid SfM file
   return f.good() ? 0 : -1;
 }

@@ -141,6 +141,11 @@ typedef struct eg3d_stage_times {
 
 const char* eg3d_last_error(void);
 int eg3d_device_count(void);
+/* Form of the 2-view DLT that initialises every triangulation (cv::triangulatePoints,
+ * triangulation.cpp:216,290), fixed when the library is built: 2 = rows x*P2-P0, y*P2-P1 per view
+ * (4x4 system, later OpenCV releases), 3 = those plus x*P1-y*P0 (6x4, OpenCV 2.4-3.1, the release
+ * the reference names). The reference pins no OpenCV version; see DESIGN.md 3. */
+int eg3d_dlt_rows(void);
 
 int eg3d_create(const eg3d_scene* scene, int device, eg3d_ctx** out);
 void eg3d_destroy(eg3d_ctx* ctx);

@@ -62,6 +62,15 @@ def lib():
         L.orc_next_by_line.argtypes = [D.f32p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float,
                                        C.c_uint32, D.f32p, C.c_int, C.c_float, C.c_float, D.u32p, D.f32p,
                                        C.POINTER(C.c_int)]
+        # the checker follows the DLT form the product library was built with (include/eg3d.h eg3d_dlt_rows)
+        rows = os.environ.get("EG3D_ORACLE_DLT_ROWS")
+        if rows is None:
+            try:
+                from edgegraph3d_amd import api
+                rows = api.lib().eg3d_dlt_rows()
+            except Exception:
+                rows = 2
+        assert L.orc_set_dlt_rows(int(rows)) == 0
         _LIB = L
     return _LIB
 

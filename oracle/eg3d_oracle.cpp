@@ -90,6 +90,16 @@ extern "C" orc_ctx* orc_create(const eg3d_scene* s) {
 
 extern "C" void orc_destroy(orc_ctx* c) { delete c; }
 
+// DLT form of cv::triangulatePoints: 2 rows per view (4x4, later OpenCV) or 3 (6x4, OpenCV <= 3.1)
+extern "C" int orc_set_dlt_rows(int rows) {
+  if (rows != 2 && rows != 3) return -1;
+  orc::g_dlt_rows = rows;
+  return 0;
+}
+extern "C" int orc_get_dlt_rows(void) { return orc::g_dlt_rows; }
+// test hook (tests/test_quirks.py): bit q makes the restatement "fix" quirk Qq (4, 12, 13); 0 = reference behaviour
+extern "C" void orc_set_quirk_fixes(unsigned mask) { orc::g_quirk_fix = mask; }
+
 extern "C" int orc_get_grid(orc_ctx* c, int view, int which, uint32_t* ncols, uint32_t* nrows,
                             const uint32_t** cell_off, const uint32_t** ids) {
   if (!c || view < 0 || view >= c->sc.cams.n_views || which < 0 || which > 1) return -1;

@@ -21,6 +21,12 @@ typedef struct orc_stats {
   double seconds; /* wall time of the call, scene/grid construction excluded */
 } orc_stats;
 
+/* which system cv::triangulatePoints builds (process-wide): 2 rows per view = 4x4 (later OpenCV), 3 = 6x4
+ * (OpenCV 2.4-3.1, incl. the x*P1 - y*P0 row); must match the product's eg3d_dlt_rows() */
+int orc_set_dlt_rows(int rows);
+int orc_get_dlt_rows(void);
+/* test hook: bit q = behave as a "corrected" implementation of quirk Qq would (q = 4, 12, 13); 0 = reference */
+void orc_set_quirk_fixes(unsigned mask);
 orc_ctx* orc_create(const eg3d_scene* scene);
 void orc_destroy(orc_ctx*);
 int orc_get_grid(orc_ctx*, int view, int which, uint32_t* ncols, uint32_t* nrows, const uint32_t** cell_off,

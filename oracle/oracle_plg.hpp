@@ -254,6 +254,12 @@ static inline void follow_direction_vector_start(const Scene& sc, const std::vec
   }
 }
 
+// Test hook: bits of g_quirk_fix make the restatement behave as a "corrected" implementation would
+// at one quirk of SURVEY 9 (bit 4 = Q4, 12 = Q12, 13 = Q13). 0 = the reference's behaviour. Only
+// tests/test_quirks.py sets it: the committed fixtures and the HIP path must match mask 0 and must
+// NOT match the corrected variants (which shows the seeded scenes exercise each quirk).
+static unsigned g_quirk_fix = 0;
+
 // ---- hypothesis: compatible_new_plg_point -> follow_plgs_from_match4 -> find_directions_all_views
 // -> find_directions_3view_firstlast (vector form), plg_matching.cpp:1276-1287, 1249-1270, 1060-1076, 325-370.
 // The out vectors keep their previous content when the corresponding direction is not
@@ -285,6 +291,7 @@ static inline bool compatible_new_plg_point(const Scene& sc, const P3& matches, 
       }
       directions2 = std::vector<ulong_t>(sc.plgs.size());
       for (int k = 0; k < 3; k++) directions2[ids[k]] = d2[k];
+      if (!direction2_valid && (g_quirk_fix & (1u << 12))) pts2.clear();  // what a "fixed" Q12 would do
       if (direction2_valid) {
         pts2.clear();
         for (auto& v : p2t) {
@@ -435,6 +442,21 @@ static inline std::pair<int, int> add_view_vector(const Scene& sc, std::vector<P
   {
     const polyline& pl = sc.plgs[current_plg_id].polylines[current_plgp.polyline_id];
     const ulong_t start = pl.start, end = pl.end;
+    if (cur_point_index == start_interval_index && (g_quirk_fix & (1u << 13))) {
+      // what a "fixed" Q13 would do: with no lower neighbour in the interval, still orient on the upper side
+      if (cur_point_index < end_interval_index) {
+        if (compatible_direction_noupdate_vector(sc, current_plg_id, current_plgp, end, cur_pts, nd2,
+                                                 start_interval_index, cur_point_index, end_interval_index, false, st)) {
+          new_direction2 = end;
+          new_direction1 = start;
+        } else if (compatible_direction_noupdate_vector(sc, current_plg_id, current_plgp, start, cur_pts, nd2,
+                                                        start_interval_index, cur_point_index, end_interval_index,
+                                                        false, st)) {
+          new_direction2 = start;
+          new_direction1 = end;
+        }
+      }
+    }
     if (cur_point_index > start_interval_index) {
       if (compatible_direction_noupdate_vector(sc, current_plg_id, current_plgp, start, cur_pts, nd1,
                                                start_interval_index, cur_point_index, end_interval_index, true, st)) {
@@ -545,8 +567,10 @@ static inline void expand_allpoints_to_other_view_using_plmap(const Scene& sc, c
       if (st) st->bytes_algorithmic += 8 * pl.polyline_coords.size();
       pl_point init_ppl;
       if (pl.compute_distancesq(start_coords, init_ppl.segment_index, init_ppl.coords) >
-          MAX_3DPOINT_PROJECTIONDISTSQ_EXPANDALLVIEWS)
+          MAX_3DPOINT_PROJECTIONDISTSQ_EXPANDALLVIEWS) {
+        if (g_quirk_fix & (1u << 4)) continue;  // what a "fixed" Q4 would do: skip the point, keep the view
         return;  // "return false" in a void function: abandons this view (Q4)
+      }
       plg_point init_plgp(cur_pl_id, init_ppl);
       if (epc_matched)
         cur_interval_end = central_point <= epc_idx.first ? epc_idx.first : (int)cur_p3ds.size();

@@ -55,16 +55,27 @@ static inline vec2 compute_projection(const float* P, const vec3& X) {
   return vec2(u0 / u2, u1 / u2);
 }
 
-// One-sided (Hestenes) Jacobi SVD of a 4x4 double matrix, restating OpenCV's
-// JacobiSVDImpl_<double> as reached from cvSVD(A, W, U, V) inside cvTriangulatePoints.
-// At holds A transposed (rows of At = columns of A). Returns the right singular vector of
-// the smallest singular value = last row of Vt. hypot() is replaced by sqrt(p*p+beta*beta)
-// (documented deviation: libm hypot is not available to the device code).
-static inline void jacobi_svd4_last_v(const double A[4][4], double out[4]) {
-  const int m = 4, n = 4;
-  double At[4][4], Vt[4][4], W[4];
+// Which linear system cv::triangulatePoints builds depends on the OpenCV release, and the
+// reference does not pin one ("OpenCV >= 3.1, tested 3.1", README.md:23,32):
+//   rows per view = 3 : OpenCV 2.4 .. 3.1 (legacy cvTriangulatePoints, `double matrA_dat[24]`): a 6x4
+//       system, rows x*P2-P0, y*P2-P1, x*P1-y*P0 per view, cvSVD on the 6x4 matrix;
+//   rows per view = 2 : the later rewrite (Matx<double,4,4>): a 4x4 system without the third row.
+// Both are restated (from knowledge of the sources — none are in this container); the switch is
+// orc_set_dlt_rows(), the product's compile-time EG3D_DLT_ROWS. Only the Gauss-Newton START changes.
+static int g_dlt_rows = 2;
+
+// One-sided (Hestenes) Jacobi SVD of an m x 4 double matrix (m = 4 or 6), restating OpenCV's
+// JacobiSVDImpl_<double> as reached from cvSVD / SVD::compute inside cvTriangulatePoints: for
+// m >= n the routine works on At = A transposed (n = 4 rows of length m), W[i] = |row i|^2, and
+// rotates row pairs (i < j ascending) until no pair changes (at most max(m,30) = 30 sweeps).
+// Returns the right singular vector of the smallest singular value = last row of Vt after the
+// descending sort. hypot() is replaced by sqrt(p*p+beta*beta) (documented deviation: libm hypot
+// is not available to the device code).
+static inline void jacobi_svd_last_v(const double At_in[4][6], int m, double out[4]) {
+  const int n = 4;
+  double At[4][6], Vt[4][4], W[4];
   for (int i = 0; i < 4; i++)
-    for (int k = 0; k < 4; k++) At[i][k] = A[k][i];
+    for (int k = 0; k < m; k++) At[i][k] = At_in[i][k];
   const double eps = DBL_EPSILON * 10;
   for (int i = 0; i < n; i++) {
     double sd = 0;
@@ -141,24 +152,26 @@ static inline void jacobi_svd4_last_v(const double A[4][4], double out[4]) {
   for (int k = 0; k < 4; k++) out[k] = Vt[3][k];
 }
 
-// cv::triangulatePoints for one point pair (triangulate.cpp cvTriangulatePoints):
-// A[2j+0][k] = x_j*P_j(2,k) - P_j(0,k); A[2j+1][k] = y_j*P_j(2,k) - P_j(1,k) in double,
-// solution = V[:,3]; the 4x1 output Mat is CV_32F (same type as the input points), so
-// each homogeneous component is rounded to float before the caller divides by w in float
-// (triangulation.cpp:216-224).
+// cv::triangulatePoints for one point pair (triangulate.cpp cvTriangulatePoints): per view j the
+// rows x_j*P_j(2,:) - P_j(0,:), y_j*P_j(2,:) - P_j(1,:) [and x_j*P_j(1,:) - y_j*P_j(0,:) in the
+// three-row form] in double, solution = V[:,3]; the 4x1 output Mat is CV_32F (same type as the
+// input points), so each homogeneous component is rounded to float before the caller divides by w
+// in float (triangulation.cpp:216-224).
 static inline void dlt2_init(const float* P1, const vec2& p1, const float* P2, const vec2& p2, double X0[3]) {
-  double A[4][4];
+  double At[4][6];  // At[k][row] = A[row][k]
   const float* Ps[2] = {P1, P2};
   const vec2 pts[2] = {p1, p2};
+  const int R = g_dlt_rows;
   for (int j = 0; j < 2; j++) {
     double x = pts[j].x, y = pts[j].y;
     for (int k = 0; k < 4; k++) {
-      A[j * 2 + 0][k] = x * (double)Ps[j][8 + k] - (double)Ps[j][0 + k];
-      A[j * 2 + 1][k] = y * (double)Ps[j][8 + k] - (double)Ps[j][4 + k];
+      At[k][j * R + 0] = x * (double)Ps[j][8 + k] - (double)Ps[j][0 + k];
+      At[k][j * R + 1] = y * (double)Ps[j][8 + k] - (double)Ps[j][4 + k];
+      if (R == 3) At[k][j * R + 2] = x * (double)Ps[j][4 + k] - y * (double)Ps[j][0 + k];
     }
   }
   double v[4];
-  jacobi_svd4_last_v(A, v);
+  jacobi_svd_last_v(At, 2 * R, v);
   float h0 = (float)v[0], h1 = (float)v[1], h2 = (float)v[2], h3 = (float)v[3];
   X0[0] = (double)(h0 / h3);
   X0[1] = (double)(h1 / h3);

@@ -53,6 +53,21 @@ def make_sets(cfg_index, name, max_sets):
     print(name, "sets", n, "points", r["n_points"], "obs", r["n_obs"])
 
 
+def make_dlt6x4(cfg_index, name):
+    """Outputs of the same scene with the three-rows-per-view (6x4, OpenCV <= 3.1) DLT system; the
+    inputs are those of synthetic_tiny_v1.npz."""
+    assert ob.lib().orc_set_dlt_rows(3) == 0
+    s = host.Synth(cfg_index)
+    r = ob.Oracle(s.scene).match(s.seeds, 0, s.n_seeds, 1)
+    assert ob.lib().orc_set_dlt_rows(2) == 0
+    out = {"out_" + k: r[k] for k in ("X", "obs_off", "obs_view", "obs_pl", "obs_seg", "obs_xy", "key")}
+    out["out_counts"] = np.array([r["n_tasks"], r["stats"]["n_chains"], r["flags"]], np.int64)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(name, "points", r["n_points"], "obs", r["n_obs"])
+
+
 if __name__ == "__main__":
+    os.environ["EG3D_ORACLE_DLT_ROWS"] = "2"  # the v1 fixtures are the default (4x4) form
     make(0, "synthetic_tiny_v1.npz")
     make_sets(0, "synthetic_tiny_sets_v1.npz", 3)
+    make_dlt6x4(0, "synthetic_tiny_v1_dlt6x4.npz")

@@ -88,6 +88,30 @@ def test_gn_filter_parity(have_gpu):
     assert np.array_equal(Xo.view(np.uint32), Xr.view(np.uint32))
     assert 0.5 < inl.mean() < 1.0
     ctx.close()
+    # the 16-view C5 rig (k really spans 3..10), both abs() behaviours of Q9, and lists long enough that
+    # a block's observation slice does NOT fit its LDS staging area (the HBM-operand fallback)
+    s = host.Synth(5)
+    X, off, view, xy = s.points(60000)
+    assert (np.diff(off) == 10).any() and (np.diff(off) == 3).any()
+    ctx = api.Context(s.scene)
+    for legacy in (False, True):
+        Xo, inl, ms = ctx.gn_filter(X, off, view, xy, 2.25, legacy_abs=legacy)
+        Xr, ir = _oracle(s.scene).gn_filter(X, off, view, xy, 2.25, legacy_abs=legacy, nthreads=8)
+        assert np.array_equal(inl, ir) and np.array_equal(Xo.view(np.uint32), Xr.view(np.uint32))
+    # 300 points x 16 observations (every view twice over would exceed the rig: reuse views) > 2816 per block
+    n = 600
+    big_off = np.arange(n + 1, dtype=np.uint32) * 16
+    big_view = np.tile(np.arange(16, dtype=np.int32), n)
+    P = s.scene_np()["cam_P"].reshape(16, 4, 4)[:, :3, :].astype(np.float64)
+    rng = np.random.default_rng(3)
+    Xt = rng.uniform(-100, 100, (n, 3))
+    h = np.einsum("vij,nj->nvi", P, np.concatenate([Xt, np.ones((n, 1))], 1))
+    big_xy = (h[:, :, :2] / h[:, :, 2:3] + rng.normal(0, 0.5, (n, 16, 2))).astype(np.float32).reshape(-1, 2)
+    Xs = (Xt + rng.normal(0, 2.0, Xt.shape)).astype(np.float32)
+    Xo, inl, ms = ctx.gn_filter(Xs, big_off, big_view, big_xy, 2.25)
+    Xr, ir = _oracle(s.scene).gn_filter(Xs, big_off, big_view, big_xy, 2.25, nthreads=8)
+    assert np.array_equal(inl, ir) and np.array_equal(Xo.view(np.uint32), Xr.view(np.uint32)) and inl.mean() > 0.5
+    ctx.close()
 
 
 def test_c4_shaped_subset_parity_and_capacity_growth(have_gpu):
@@ -235,3 +259,32 @@ def test_rccl_allgather_c_abi_single_rank(have_gpu):
     out = subprocess.run([sys.executable, os.path.join(here, "rccl_single_rank_check.py")], capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0 and "RCCL-GATHER-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_quirks_q4_q12_q13_on_the_device():
+    """The HIP path follows the reference at the three stale-state / early-return quirks: it equals
+    the oracle's reference behaviour bit for bit on scenes where a "corrected" Q4 / Q12 / Q13
+    (oracle test hook orc_set_quirk_fixes) gives a different cloud (tests/test_quirks.py)."""
+    from oracle import binding as ob
+    L = ob.lib()
+    for cfg, lo, hi, bits in ((0, 0, None, (4, 13)), (2, 80, 90, (12,))):
+        s = host.Synth(cfg)
+        hi = s.n_seeds if hi is None else hi
+        ctx = api.Context(s.scene)
+        ctx.upload_seeds(s.seeds)
+        got = ctx.match_resident(lo, hi)
+        o = ob.Oracle(s.scene)
+        ref = o.match(s.seeds, lo, hi, 4)
+        rep = compare_edgepoints(ref, got)
+        assert rep["ok"] and rep["bitexact_X"], rep
+        for q in bits:
+            try:
+                L.orc_set_quirk_fixes(1 << q)
+                fixed = o.match(s.seeds, lo, hi, 4)
+            finally:
+                L.orc_set_quirk_fixes(0)
+            same = (fixed["n_points"] == got["n_points"] and fixed["n_obs"] == got["n_obs"] and
+                    np.array_equal(fixed["X"].view(np.uint32), got["X"].view(np.uint32)))
+            assert not same, "Q%d: the device output equals the corrected variant" % q
+        ctx.close()

@@ -158,3 +158,87 @@ def test_polyline_graph_container_round_trip():
         L.eg3d_plg_destroy(g)
         open(os.path.join(d, "bad.bin"), "wb").write(b"NOTAPLG!" + b"\0" * 12)
         assert not L.eg3d_plg_read(os.path.join(d, "bad.bin").encode())
+
+
+def test_openmvg_reader_rejects_malformed_files_instead_of_crashing():
+    """A variant / truncated OpenMVG file (non-pinhole intrinsic without focal_length, short
+    rotation, missing observation coordinates, absurd nesting) makes eg3d_sfm_read_json return NULL."""
+    L = _sfm_lib()
+    import copy
+
+    def reads(doc, raw=None):
+        with tempfile.TemporaryDirectory() as d:
+            p = os.path.join(d, "x.json")
+            open(p, "w").write(raw if raw is not None else json.dumps(doc))
+            h = L.eg3d_sfm_read_json(p.encode())
+            if h:
+                L.eg3d_sfm_destroy(h)
+            return bool(h)
+
+    good = _openmvg_doc()
+    assert reads(good)
+    bad = copy.deepcopy(good)
+    del bad["intrinsics"][0]["value"]["ptr_wrapper"]["data"]["focal_length"]
+    assert not reads(bad)
+    bad = copy.deepcopy(good)
+    bad["intrinsics"][0]["value"]["ptr_wrapper"]["data"]["principal_point"] = [823.0]
+    assert not reads(bad)
+    bad = copy.deepcopy(good)
+    bad["extrinsics"][1]["value"]["rotation"] = [[1, 0, 0], [0, 1, 0]]
+    assert not reads(bad)
+    bad = copy.deepcopy(good)
+    del bad["structure"][0]["value"]["observations"][0]["value"]["x"]
+    assert not reads(bad)
+    bad = copy.deepcopy(good)
+    bad["views"][0]["value"]["ptr_wrapper"]["data"]["width"] = "wide"
+    assert not reads(bad)
+    assert not reads(None, raw="[" * 5000 + "]" * 5000)        # nesting limit, no stack overflow
+    assert not reads(None, raw='{"views": [')                  # truncated
+
+
+def test_analytic_fundamental_matrices_satisfy_the_epipolar_constraint():
+    """N4: eg3d_sfm_analytic_F from the cameras of an SfM scene. F[i][j] maps a point of view i to
+    its line in view j (the convention of computeCorrespondEpilineSinglePoint,
+    geometric_utilities.cpp:824-843): the projection of any 3-D point into j lies on the line of its
+    projection into i. Checked in float64 from the float camera matrices, through the oracle's
+    epiline primitive, and against the synthetic generator's own F (same rig => same matrices)."""
+    L = _sfm_lib()
+    L.eg3d_sfm_create.restype = C.c_void_p
+    L.eg3d_sfm_create.argtypes = [C.c_int, C.c_int, C.c_int]
+    L.eg3d_sfm_set_camera.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, D.f32p, D.f32p, C.c_char_p]
+    L.eg3d_sfm_analytic_F.argtypes = [C.c_void_p, D.f64p, D.u8p]
+    L.eg3d_synth_camera.argtypes = [C.c_void_p, C.c_int, D.f32p, D.f32p, D.f32p, D.f32p, D.f32p]
+    s = host.Synth(1)
+    sc = s.scene_np()
+    V = sc["n_views"]
+    h = L.eg3d_sfm_create(V, sc["width"], sc["height"])
+    for v in range(V):
+        f, px, py = C.c_float(), C.c_float(), C.c_float()
+        R, Cc = np.zeros(9, np.float32), np.zeros(3, np.float32)
+        assert L.eg3d_synth_camera(s._h, v, C.byref(f), C.byref(px), C.byref(py), D.np_ptr(R, C.c_float), D.np_ptr(Cc, C.c_float)) == 0
+        assert L.eg3d_sfm_set_camera(h, v, f, px, py, D.np_ptr(R, C.c_float), D.np_ptr(Cc, C.c_float), b"v.png") == 0
+    P = D.as_np(L.eg3d_sfm_cam_P(h), V * 16, np.float32).reshape(V, 4, 4).astype(np.float64)
+    assert np.array_equal(P.astype(np.float32).reshape(V, 16), sc["cam_P"])      # the same rig as the generator's scene
+    F = np.zeros((V, V, 9), np.float64)
+    Fv = np.zeros((V, V), np.uint8)
+    assert L.eg3d_sfm_analytic_F(h, D.np_ptr(F, C.c_double), D.np_ptr(Fv, C.c_uint8)) == 0
+    assert np.array_equal(Fv, 1 - np.eye(V, dtype=np.uint8))
+    assert np.array_equal(F, sc["F"]) and np.array_equal(Fv, sc["F_valid"])       # generator F == analytic F of its cameras
+    rng = np.random.default_rng(11)
+    line = np.zeros(3, np.float32)
+    worst = 0.0
+    for _ in range(200):
+        i, j = rng.choice(V, 2, replace=False)
+        X = np.append(rng.uniform(-180, 180, 3), 1.0)
+        xi, xj = P[i][:3] @ X, P[j][:3] @ X
+        xi, xj = xi[:2] / xi[2], xj[:2] / xj[2]
+        l = F[i, j].reshape(3, 3) @ np.append(xi, 1.0)
+        d = abs(l @ np.append(xj, 1.0)) / np.hypot(l[0], l[1])
+        worst = max(worst, d)
+        # the oracle's epiline (f64 accumulate, normalised, rounded to f32) of the float-rounded point
+        Fij = np.ascontiguousarray(F[i, j])
+        assert ob.lib().orc_epiline(D.np_ptr(Fij, C.c_double), np.float32(xi[0]), np.float32(xi[1]), D.np_ptr(line, C.c_float)) == 1
+        assert abs(float(line[0]) ** 2 + float(line[1]) ** 2 - 1) < 1e-5
+        assert abs(line.astype(np.float64) @ np.append(xj, 1.0)) < 0.05           # px; f32 line coefficients at ~1000 px
+    assert worst < 1e-3, worst                                                    # px, float camera matrices
+    L.eg3d_sfm_destroy(h)

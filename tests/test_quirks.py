@@ -208,3 +208,60 @@ def test_q3_uniqueness_and_emission_order_keys_are_sorted():
     # every emitted point has >= 3 observations with distinct... (views may repeat only through re-attachment)
     nobs = np.diff(r["obs_off"].astype(np.int64))
     assert nobs.min() >= 3
+
+
+# ---- Q4, Q12, Q13: stale-state / early-return quirks of the consensus stage ---------------------
+# These cannot be isolated in a three-polyline toy scene (they need a chain that has already been
+# expanded, or two hypotheses of one start hit), so they are pinned differently: the oracle has a
+# test hook that makes it behave as a "corrected" implementation of ONE quirk would
+# (orc_set_quirk_fixes, oracle_plg.hpp g_quirk_fix). On the seeded scenes below the corrected
+# variants produce a DIFFERENT cloud than the reference behaviour, and the reference behaviour is
+# what the committed fixture (and, in tests/test_gpu_parity.py, the HIP path) holds — so an
+# implementation that "fixes" the quirk fails.
+def _run_with_fix(cfg, lo, hi, mask):
+    L = ob.lib()
+    s = host.Synth(cfg)
+    o = ob.Oracle(s.scene)
+    try:
+        L.orc_set_quirk_fixes(mask)
+        return o.match(s.seeds, lo, hi if hi is not None else s.n_seeds, 4)
+    finally:
+        L.orc_set_quirk_fixes(0)
+
+
+def _same_cloud(a, b):
+    return (a["n_points"] == b["n_points"] and a["n_obs"] == b["n_obs"] and
+            np.array_equal(a["X"].view(np.uint32), b["X"].view(np.uint32)) and np.array_equal(a["obs_view"], b["obs_view"]))
+
+
+def test_q4_abandoning_the_view_is_pinned_by_the_fixture():
+    """Q4 (triangulation.cpp:807-808): a chain point whose projection is > 4 px from its unique
+    polyline ABANDONS the whole view (`return false` in a void function), it does not just skip the
+    point. Config 0 = the scene of tests/golden/synthetic_tiny_v1.npz."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "synthetic_tiny_v1.npz"))
+    ref = _run_with_fix(0, 0, None, 0)
+    assert np.array_equal(ref["X"].view(np.uint32), z["out_X"].view(np.uint32)) and np.array_equal(ref["obs_view"], z["out_obs_view"])
+    fixed = _run_with_fix(0, 0, None, 1 << 4)
+    assert not _same_cloud(ref, fixed)
+    assert fixed["n_obs"] > ref["n_obs"]  # a corrected version keeps attaching the view to later chain points
+
+
+def test_q13_lower_bound_attachment_is_pinned_by_the_fixture():
+    """Q13 (plg_matching.cpp:1017, :1364-1368): attaching a view at the lower bound of its interval
+    runs no direction search at all, so it fails unless the chain has a single point."""
+    ref = _run_with_fix(0, 0, None, 0)
+    fixed = _run_with_fix(0, 0, None, 1 << 13)
+    assert not _same_cloud(ref, fixed)
+
+
+def test_q12_stale_direction2_points_are_exercised():
+    """Q12 (triangulation.cpp:559-561, plg_matching.cpp:355-368): a compatible triple whose direction
+    2 is invalid inherits the direction-2 points an earlier, rejected triple of the same start hit
+    left in the shared buffer. C2 seeds 80..90 contain such a start hit (seed 85)."""
+    ref = _run_with_fix(2, 80, 90, 0)
+    fixed = _run_with_fix(2, 80, 90, 1 << 12)
+    assert not _same_cloud(ref, fixed)
+    per_seed_ref = np.bincount(ref["key"][:, 0], minlength=90)
+    per_seed_fix = np.bincount(fixed["key"][:, 0], minlength=90)
+    assert list(np.nonzero(per_seed_ref != per_seed_fix)[0]) == [85]
