@@ -79,6 +79,20 @@ def build_hip_dlt6x4(force=False):
     return build_hip(force, HIP_LIB_DLT6X4, ("-DEG3D_DLT_ROWS=3",))
 
 
+PROBE_LIB = os.path.join(ROOT, "tests", "probe", "libeg3d_probe.so")
+
+
+def build_probe(force=False):
+    """TEST-ONLY: device primitives of the product's headers behind a tiny C interface
+    (tests/probe/eg3d_probe.h) for the bit-for-bit arithmetic checks; never linked into libeg3d.so."""
+    src = os.path.join(ROOT, "tests", "probe", "eg3d_probe.hip")
+    deps = [src] + _all_sources(CSRC_DIR, (".h", ".hpp"))
+    if force or _newer(PROBE_LIB, deps):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        _run([hipcc] + HIP_FLAGS + ["-I", INC_DIR, "-I", CSRC_DIR, "-I", os.path.dirname(src), "-o", PROBE_LIB, src])
+    return PROBE_LIB
+
+
 RCCL_LIB = os.path.join(PKG, "libeg3d_rccl.so")
 
 
@@ -107,6 +121,7 @@ def build_all(force=False):
     build_host(force)
     build_hip(force)
     build_hip_dlt6x4(force)
+    build_probe(force)
     build_rccl(force)
     build_oracle(force)
 

@@ -82,8 +82,32 @@ struct HostGrids {
   std::vector<std::vector<uint32_t>> h_off[2], h_ids[2];
 };
 
+// Test / tuning knobs, read from the environment ONCE when a context is created (eg3d_create; clones
+// inherit them) — the hot path never calls getenv:
+//   EG3D_K3A_TEAM=0|1      force 1-lane / 4-lane hypothesis teams (default: by batch size)
+//   EG3D_K3A_QUEUE=0|1     force the lane-level following queue off / on
+//   EG3D_ARENA_CAP0=n      initial hypothesis arena capacity (tests: forces the overflow-and-retry path)
+//   EG3D_MAX_SCRATCH_MB=n  chain scratch budget per K3b launch (tests: forces chunking)
+//   EG3D_NO_LPT=1          launch chains in identity order instead of longest-first (diagnostic)
+struct Tunables {
+  int k3a_team = -1, k3a_queue = -1;
+  uint32_t arena_cap0 = 0;
+  size_t max_scratch = (size_t)24 << 30;
+  bool use_lpt = true;
+  static Tunables from_env() {
+    Tunables t;
+    if (const char* e = getenv("EG3D_K3A_TEAM")) t.k3a_team = atoi(e);
+    if (const char* e = getenv("EG3D_K3A_QUEUE")) t.k3a_queue = atoi(e);
+    if (const char* e = getenv("EG3D_ARENA_CAP0")) t.arena_cap0 = (uint32_t)std::max(16, atoi(e));
+    if (const char* e = getenv("EG3D_MAX_SCRATCH_MB")) t.max_scratch = (size_t)std::max(1, atoi(e)) << 20;
+    if (const char* e = getenv("EG3D_NO_LPT")) t.use_lpt = !(e[0] == '1');
+    return t;
+  }
+};
+
 struct eg3d_ctx {
   int device = 0;
+  Tunables tune;
   hipStream_t stream = nullptr;
   int V = 0, W = 0, H = 0;
   DevScene ds;
@@ -167,6 +191,7 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
   HIP_TRY(hipSetDevice(device));
   eg3d_ctx* c = new eg3d_ctx();
   c->device = device;
+  c->tune = Tunables::from_env();
   c->hg = std::make_shared<HostGrids>();
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   for (int i = 0; i < 8; i++) {
@@ -273,6 +298,7 @@ extern "C" int eg3d_clone(eg3d_ctx* parent, eg3d_ctx** out) {
   HIP_TRY(hipSetDevice(parent->device));
   eg3d_ctx* c = new eg3d_ctx();
   c->device = parent->device;
+  c->tune = parent->tune;
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   for (int i = 0; i < 8; i++) {
     HIP_TRY(hipEventCreate(&c->ea[i]));
@@ -499,7 +525,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
   // ---- K3a
   BUF_TRY(c->b_res.ensure(sizeof(HypResult) * (B.n_hyp + 1)));
   // small batches are latency-bound by their slowest hypothesis: give each hypothesis a 4-lane team
-  const int k3a_mode = getenv("EG3D_K3A_TEAM") ? atoi(getenv("EG3D_K3A_TEAM")) : -1;  // -1 auto, 0 lanes, 1 teams
+  const int k3a_mode = c->tune.k3a_team;  // -1 auto, 0 lanes, 1 teams
   const bool team4 = k3a_mode < 0 ? (B.n_hyp <= 131072u) : (k3a_mode != 0);
   const uint32_t k3a_lanes_needed = B.n_hyp * (team4 ? 4u : 1u);
   const uint32_t k3a_blocks =
@@ -508,7 +534,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
   // throughput mode (1 lane per hypothesis): the lists are followed through a lane-level work queue
   // (2 items per hypothesis) — C3' K3a 19.6 -> 17.0 ms; with 4-lane teams (small, latency-bound
   // batches) the team's own two-lane following is faster (C2 2.96 vs 3.34 ms). EG3D_K3A_QUEUE=0/1 forces.
-  const int k3a_queue_mode = getenv("EG3D_K3A_QUEUE") ? atoi(getenv("EG3D_K3A_QUEUE")) : -1;
+  const int k3a_queue_mode = c->tune.k3a_queue;
   const bool k3a_queue = k3a_queue_mode < 0 ? !team4 : (k3a_queue_mode != 0);
   const uint32_t follow_blocks =
       std::max<uint32_t>(1, std::min<uint32_t>(c->k3a_blocks * 2u, (uint32_t)(((uint64_t)B.n_hyp * 2 + 255) / 256)));
@@ -517,7 +543,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
     BUF_TRY(c->b_queue.ensure(sizeof(uint32_t)));
   }
   uint32_t arena_cap = std::max<uint32_t>(1u << 16, std::min<uint64_t>((uint64_t)B.n_hyp * (k3a_queue ? 32 : 24), 1ull << 26));
-  if (const char* e0 = getenv("EG3D_ARENA_CAP0")) arena_cap = std::max(16, atoi(e0));  // tests: force the overflow-and-retry path
+  if (c->tune.arena_cap0) arena_cap = c->tune.arena_cap0;  // tests: force the overflow-and-retry path
   Counters hc;
   for (int attempt = 0;; attempt++) {
     BUF_TRY(c->b_arena.ensure(sizeof(HPoint) * (size_t)arena_cap));
@@ -560,8 +586,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
                         c->b_chains.as<ChainSeed>());
   HIP_TRY(hipEventRecord(c->eb[4], st));
   // ---- K3b + K4 in chunks bounded by scratch size
-  size_t max_scratch = (size_t)24 << 30;
-  if (const char* e1 = getenv("EG3D_MAX_SCRATCH_MB")) max_scratch = (size_t)std::max(1, atoi(e1)) << 20;  // tests: force chunking
+  const size_t max_scratch = c->tune.max_scratch;  // tests shrink it to force chunking
   float ms_expand = 0, ms_emit = 0;
   uint32_t chunk = 0;
   unsigned long long bytes_before_chunk = 0;
@@ -586,7 +611,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
     BUF_TRY(c->b_cidx.ensure(sizeof(uint32_t) * (nc + 1)));
     BUF_TRY(c->b_cost2.ensure(sizeof(uint32_t) * (nc + 1)));
     BUF_TRY(c->b_order.ensure(sizeof(uint32_t) * (nc + 1)));
-    static const bool use_lpt = !(getenv("EG3D_NO_LPT") && getenv("EG3D_NO_LPT")[0] == '1');
+    const bool use_lpt = c->tune.use_lpt;
     launch_chain_cost(st, B.a, c->b_tasks.as<TaskDesc>(), c->b_chains.as<ChainSeed>() + c0, nc, c->b_cost.as<uint32_t>(),
                       c->b_cidx.as<uint32_t>());
     {
@@ -1110,6 +1135,10 @@ extern "C" int eg3d_gn_filter(eg3d_ctx* c, const float* X, const uint32_t* obs_o
   return EG3D_OK;
 }
 
+#ifdef EG3D_SECTION_TIMING
+// Tuning diagnostics, present only in builds made with -DEG3D_SECTION_TIMING (tools/section_timing*.py):
+// per-section shader-clock ticks of the most recent k3b_expand launch, summed over the chains
+// (sum[16]) and of the slowest chain (slowest[16]).
 extern "C" int eg3d_probe_sections(eg3d_ctx* c, double* sum, double* slowest, uint32_t* n_chains) {
   if (!c || !sum || !slowest) return EG3D_ERR_ARG;
   std::vector<ChainOut> co(c->last_nc ? c->last_nc : 1);
@@ -1160,6 +1189,4 @@ extern "C" int eg3d_probe_hyp_sections(eg3d_ctx* c, double* sum, double* slowest
   return EG3D_OK;
 }
 
-// accessors for the diagnostic probes (eg3d_probe.hip)
-extern "C" const float* eg3d_internal_cam_P(eg3d_ctx* c) { return c->ds.cam_P; }
-extern "C" hipStream_t eg3d_internal_stream(eg3d_ctx* c) { return c->stream; }
+#endif  // EG3D_SECTION_TIMING

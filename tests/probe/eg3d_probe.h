@@ -1,0 +1,21 @@
+/*
+ * eg3d_probe.h — TEST-ONLY entry points of tests/probe/libeg3d_probe.so: single device primitives of
+ * the product's headers run on the GPU, for the bit-for-bit arithmetic checks of
+ * tests/test_gpu_arith.py. Not part of the product and not linked into libeg3d.so.
+ */
+#ifndef EG3D_PROBE_H_
+#define EG3D_PROBE_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* out_d[5][n]: a/b, sqrt(|a|), a*b+c (two roundings), (double)(float)a, 1/sqrt; out_f likewise in float */
+int eg3d_probe_arith(uint64_t n, const double* a, const double* b, const double* c, double* out_d, const float* fa,
+                     const float* fb, const float* fc, float* out_f);
+/* n_cases triangulations of k observations each; cam_P = [n_views][16] host array */
+int eg3d_probe_triangulate(const float* cam_P, int n_views, uint64_t n_cases, int k, const int32_t* views, const float* xy,
+                           float* X, uint8_t* valid, double* dlt_X0);
+#ifdef __cplusplus
+}
+#endif
+#endif

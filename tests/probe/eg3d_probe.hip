@@ -1,10 +1,12 @@
-// Diagnostic probes (include/eg3d_probe.h): run device primitives in isolation so tests can
-// verify the arithmetic contract bit-for-bit on the GPU.
+// TEST-ONLY library (tests/probe/libeg3d_probe.so, built by edgegraph3d_amd.build.build_probe): runs
+// single device primitives of the product's headers (IEEE arithmetic, DLT, triangulation) on the
+// GPU so that tests/test_gpu_arith.py can check the arithmetic contract bit-for-bit against x86 and
+// the oracle. Nothing of this is linked into libeg3d.so.
 #include <hip/hip_runtime.h>
 
 #include <string>
 
-#include "../../include/eg3d_probe.h"
+#include "eg3d_probe.h"
 #include "eg3d_dev_pipeline.h"
 
 using namespace eg3d;
@@ -56,19 +58,13 @@ __global__ void k_probe_tri(const float* cam_P, uint64_t n, int k, const int32_t
   dlt[3 * i + 2] = X0[2];
 }
 
-// the context layout is private to eg3d_api.hip; probes only need the camera table, fetched
-// through this accessor
-extern "C" const float* eg3d_internal_cam_P(eg3d_ctx* c);
-extern "C" hipStream_t eg3d_internal_stream(eg3d_ctx* c);
-
 #define PT(expr)                         \
   do {                                   \
     if ((expr) != hipSuccess) return -2; \
   } while (0)
 
-extern "C" int eg3d_probe_arith(eg3d_ctx* ctx, uint64_t n, const double* a, const double* b, const double* c, double* od,
+extern "C" int eg3d_probe_arith(uint64_t n, const double* a, const double* b, const double* c, double* od,
                                 const float* fa, const float* fb, const float* fc, float* of) {
-  if (!ctx) return -1;
   double *da, *db, *dc, *dod;
   float *dfa, *dfb, *dfc, *dof;
   PT(hipMalloc(&da, n * 8));
@@ -101,11 +97,13 @@ extern "C" int eg3d_probe_arith(eg3d_ctx* ctx, uint64_t n, const double* a, cons
   return 0;
 }
 
-extern "C" int eg3d_probe_triangulate(eg3d_ctx* ctx, uint64_t n, int k, const int32_t* views, const float* xy, float* X,
-                                      uint8_t* valid, double* dlt) {
-  if (!ctx || k < 2 || k > 16) return -1;
+extern "C" int eg3d_probe_triangulate(const float* cam_P, int n_views, uint64_t n, int k, const int32_t* views,
+                                      const float* xy, float* X, uint8_t* valid, double* dlt) {
+  if (!cam_P || n_views < 1 || k < 2 || k > 16) return -1;
   int32_t* dv;
-  float *dxy, *dX;
+  float *dxy, *dX, *dP;
+  PT(hipMalloc(&dP, (size_t)n_views * 64));
+  PT(hipMemcpy(dP, cam_P, (size_t)n_views * 64, hipMemcpyHostToDevice));
   uint8_t* dval;
   double* ddlt;
   PT(hipMalloc(&dv, n * k * 4));
@@ -115,12 +113,12 @@ extern "C" int eg3d_probe_triangulate(eg3d_ctx* ctx, uint64_t n, int k, const in
   PT(hipMalloc(&ddlt, n * 24));
   PT(hipMemcpy(dv, views, n * k * 4, hipMemcpyHostToDevice));
   PT(hipMemcpy(dxy, xy, n * k * 8, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_probe_tri, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, eg3d_internal_cam_P(ctx), n, k, dv, dxy,
-                     dX, dval, ddlt);
+  hipLaunchKernelGGL(k_probe_tri, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, dP, n, k, dv, dxy, dX, dval, ddlt);
   PT(hipDeviceSynchronize());
   PT(hipMemcpy(X, dX, n * 12, hipMemcpyDeviceToHost));
   PT(hipMemcpy(valid, dval, n, hipMemcpyDeviceToHost));
   PT(hipMemcpy(dlt, ddlt, n * 24, hipMemcpyDeviceToHost));
+  (void)hipFree(dP);
   (void)hipFree(dv);
   (void)hipFree(dxy);
   (void)hipFree(dX);

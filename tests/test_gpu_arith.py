@@ -1,7 +1,9 @@
 """-m gpu: the arithmetic contract on the device, bit-for-bit. Runs single
-primitives through the diagnostic probes of libeg3d.so and compares with IEEE results from
-numpy (x86) and with the oracle."""
+primitives of the product's device headers through the TEST-ONLY probe library
+(tests/probe/libeg3d_probe.so, tests/probe/eg3d_probe.h) and compares with IEEE results from numpy
+(x86) and with the oracle."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -15,13 +17,13 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def ctx():
     assert api.device_count() >= 1, "no HIP device: the product path has no CPU fallback"
-    L = api.lib()
-    L.eg3d_probe_arith.argtypes = [C.c_void_p, C.c_uint64, D.f64p, D.f64p, D.f64p, D.f64p, D.f32p, D.f32p, D.f32p, D.f32p]
-    L.eg3d_probe_triangulate.argtypes = [C.c_void_p, C.c_uint64, C.c_int, D.i32p, D.f32p, D.f32p, D.u8p, D.f64p]
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe", "libeg3d_probe.so")
+    assert os.path.exists(path), "tests/probe/libeg3d_probe.so is not built (python -m edgegraph3d_amd.build)"
+    L = C.CDLL(path)
+    L.eg3d_probe_arith.argtypes = [C.c_uint64, D.f64p, D.f64p, D.f64p, D.f64p, D.f32p, D.f32p, D.f32p, D.f32p]
+    L.eg3d_probe_triangulate.argtypes = [D.f32p, C.c_int, C.c_uint64, C.c_int, D.i32p, D.f32p, D.f32p, D.u8p, D.f64p]
     s = host.Synth(1)
-    c = api.Context(s.scene)
-    yield c, s
-    c.close()
+    yield L, s
 
 
 def test_ieee_primitives_match_x86_bit_for_bit(ctx):
@@ -33,7 +35,7 @@ def test_ieee_primitives_match_x86_bit_for_bit(ctx):
     cc = rng.standard_normal(n) * 10 ** rng.uniform(-8, 8, n)
     fa, fb, fc = a.astype(np.float32), b.astype(np.float32), cc.astype(np.float32)
     od, of = np.zeros((5, n)), np.zeros((5, n), np.float32)
-    rc = api.lib().eg3d_probe_arith(c._h, n, D.np_ptr(a, C.c_double), D.np_ptr(b, C.c_double), D.np_ptr(cc, C.c_double),
+    rc = c.eg3d_probe_arith(n, D.np_ptr(a, C.c_double), D.np_ptr(b, C.c_double), D.np_ptr(cc, C.c_double),
                                     D.np_ptr(od, C.c_double), D.np_ptr(fa, C.c_float), D.np_ptr(fb, C.c_float),
                                     D.np_ptr(fc, C.c_float), D.np_ptr(of, C.c_float))
     assert rc == 0
@@ -59,10 +61,10 @@ def test_triangulation_matches_oracle_including_degenerate_dlt(ctx):
     cv = np.ascontiguousarray(np.array(cv, np.int32)); cxy = np.ascontiguousarray(np.array(cxy, np.float32))
     m = len(cv)
     X, val, dlt = np.zeros((m, 3), np.float32), np.zeros(m, np.uint8), np.zeros((m, 3))
-    rc = api.lib().eg3d_probe_triangulate(c._h, m, 3, D.np_ptr(cv, C.c_int32), D.np_ptr(cxy, C.c_float),
-                                          D.np_ptr(X, C.c_float), D.np_ptr(val, C.c_uint8), D.np_ptr(dlt, C.c_double))
+    P = np.ascontiguousarray(s.scene_np()["cam_P"])
+    rc = c.eg3d_probe_triangulate(D.np_ptr(P, C.c_float), len(P), m, 3, D.np_ptr(cv, C.c_int32), D.np_ptr(cxy, C.c_float),
+                                  D.np_ptr(X, C.c_float), D.np_ptr(val, C.c_uint8), D.np_ptr(dlt, C.c_double))
     assert rc == 0
-    P = s.scene_np()["cam_P"]
     OL = ob.lib()
     n_deg = 0
     for i in range(m):

@@ -198,10 +198,12 @@ def test_chain_expansion_in_many_chunks(monkeypatch):
     s = host.Synth(1)
     ctx = api.Context(s.scene)
     whole = ctx.match_refpoints(s.seeds)
-    monkeypatch.setenv("EG3D_MAX_SCRATCH_MB", "48")
+    ctx.close()
+    monkeypatch.setenv("EG3D_MAX_SCRATCH_MB", "48")     # the knobs are read once, when a context is created
+    ctx = api.Context(s.scene)
+    monkeypatch.delenv("EG3D_MAX_SCRATCH_MB")
     parts = ctx.match_refpoints(s.seeds)
     assert not ctx.last_device_output().complete        # the device view only holds the last chunk
-    monkeypatch.delenv("EG3D_MAX_SCRATCH_MB")
     rep = compare_edgepoints(whole, parts)
     assert rep["ok"] and rep["bitexact_X"], rep["msgs"]
     ctx.close()

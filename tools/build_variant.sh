@@ -8,4 +8,4 @@ mkdir -p edgegraph3d_amd/variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math \
   -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-rdc -Wno-unused-function -I include -I edgegraph3d_amd/csrc -I edgegraph3d_amd/host \
   "$@" -o edgegraph3d_amd/variants/libeg3d_$name.so edgegraph3d_amd/csrc/eg3d_api.hip edgegraph3d_amd/csrc/eg3d_kernels.hip \
-  edgegraph3d_amd/csrc/eg3d_probe.hip edgegraph3d_amd/host/grid_build.cpp
+  edgegraph3d_amd/host/grid_build.cpp
