@@ -126,12 +126,12 @@ struct eg3d_ctx {
   DevBuf b_sv_seed, b_map_view, b_map_entry, b_map_n, b_raw_cnt, b_raw_off, b_cand_pl, b_start_hits, b_cand_cnt,
       b_start_cnt, b_task_off, b_task_seed, b_task_entry, b_task_hit, b_task_k, b_task_list_off, b_list_cnt, b_list_ptr,
       b_hits, b_tasks, b_nhyp, b_hyp_off, b_res, b_hscratch, b_arena, b_ctr, b_cs_task, b_valid, b_chain_off, b_chains,
-      b_cscratch, b_couts, b_cpts, b_cobs, b_cpoff, b_cooff, b_scan_tmp, b_cost, b_cidx, b_cost2, b_order;
+      b_cscratch, b_couts, b_cpts, b_cobs, b_cpoff, b_cooff, b_scan_tmp, b_scanchk, b_cost, b_cidx, b_cost2, b_order;
   DevBuf o_X, o_off, o_view, o_pl, o_seg, o_xy, o_key;
   DevBuf f_X, f_off, f_view, f_xy, f_Xo, f_inl;
   DevBuf b_sets_off, b_sets_ids;  // polyline sets of the current eg3d_match_polyline_sets call
   DevBuf b_fscratch, b_queue;     // K3a following: per-lane staging lists, work-queue head
-  hipEvent_t ea[8], eb[8];  // begin/end events per stage: 1 K1, 2 K2, 3 K3a, 4 K3s, 5 K3b, 6 K4, 0 misc
+  hipEvent_t ea[8], eb[8];  // begin/end events per stage: 1 K1, 2 K2, 3 K3a, 4 K3s, 5 K3b, 6 K4, 0 misc, 7 whole call
   uint32_t chain_cap = 384, pool_cap = 0, hyp_cap = 160;
   uint32_t k3a_blocks = 0;
   uint64_t last_np = 0, last_no = 0;
@@ -155,9 +155,23 @@ static int scan_exclusive_u32(eg3d_ctx* c, const uint32_t* in, uint32_t* out, si
   HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->b_scan_tmp.p, tmp_bytes, in, out, (int)n_plus_one, c->stream));
   return EG3D_OK;
 }
-static int read_u32(eg3d_ctx* c, const uint32_t* dptr, uint32_t& v) {
-  HIP_TRY(hipMemcpyAsync(&v, dptr, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+// Exclusive scan + its total on the host, with overflow detection: phase totals (candidate slots,
+// tasks, lists, hits, hypotheses) are 32-bit; a batch whose total does not fit is refused with
+// EG3D_ERR_CAPACITY instead of sizing buffers from a wrapped number.
+static int scan_total_u32(eg3d_ctx* c, const uint32_t* in, uint32_t* out, size_t n_plus_one, uint32_t& total,
+                          const char* what) {
+  BUF_TRY(scan_exclusive_u32(c, in, out, n_plus_one));
+  BUF_TRY(c->b_scanchk.ensure(2 * sizeof(uint32_t)));
+  HIP_TRY(hipMemsetAsync(c->b_scanchk.p, 0, 2 * sizeof(uint32_t), c->stream));
+  launch_scan_check(c->stream, out, n_plus_one, c->b_scanchk.as<uint32_t>());
+  uint32_t h[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(h, c->b_scanchk.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  if (h[1]) {
+    g_err = std::string("eg3d: the number of ") + what + " of this batch exceeds 2^32-1; use smaller seed / set ranges";
+    return EG3D_ERR_CAPACITY;
+  }
+  total = h[0];
   return EG3D_OK;
 }
 
@@ -203,7 +217,30 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
   c->W = sc->width;
   c->H = sc->height;
   const uint32_t NP = sc->view_pl_off[V];
-  const uint32_t NV = sc->pl_vtx_off[NP];
+  // An invalid polyline (pl_valid == 0) is one the reference has invalidated: it keeps its id but its
+  // coordinates are cleared (polyline_graph_2d.cpp:1047-1058, Q8). The ABI tolerates a caller that
+  // leaves vertices on such a polyline; the device must not see them (the polyline-sets path takes
+  // raw polyline ids), so they are dropped here: compacted vertex array, zero-length slices.
+  std::vector<uint32_t> pvo_c;
+  std::vector<float> vtx_c;
+  const uint32_t* pvo_up = sc->pl_vtx_off;
+  const float* vtx_up = sc->vtx_xy;
+  {
+    bool stray = false;
+    for (uint32_t p = 0; p < NP && !stray; p++) stray = !sc->pl_valid[p] && sc->pl_vtx_off[p + 1] > sc->pl_vtx_off[p];
+    if (stray) {
+      pvo_c.assign(1, 0);
+      for (uint32_t p = 0; p < NP; p++) {
+        if (sc->pl_valid[p])
+          vtx_c.insert(vtx_c.end(), sc->vtx_xy + 2 * (size_t)sc->pl_vtx_off[p], sc->vtx_xy + 2 * (size_t)sc->pl_vtx_off[p + 1]);
+        pvo_c.push_back((uint32_t)(vtx_c.size() / 2));
+      }
+      if (vtx_c.empty()) vtx_c.assign(2, 0.f);
+      pvo_up = pvo_c.data();
+      vtx_up = vtx_c.data();
+    }
+  }
+  const uint32_t NV = pvo_up[NP];
   int rc;
 #define UP(buf, ptr, n)                                        \
   if ((rc = upload(c->buf, ptr, (size_t)(n), c->stream)) != EG3D_OK) { \
@@ -214,8 +251,8 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
   UP(b_F, sc->F, (size_t)V * V * 9);
   UP(b_Fv, sc->F_valid, (size_t)V * V);
   UP(b_vpo, sc->view_pl_off, V + 1);
-  UP(b_pvo, sc->pl_vtx_off, NP + 1);
-  UP(b_vtx, sc->vtx_xy, (size_t)NV * 2);
+  UP(b_pvo, pvo_up, NP + 1);
+  UP(b_vtx, vtx_up, (size_t)NV * 2);
   UP(b_pls, sc->pl_start, NP);
   UP(b_ple, sc->pl_end, NP);
   // grids: built on the host (row a3), one CSR over (view, cell) per cell size
@@ -347,7 +384,7 @@ extern "C" void eg3d_destroy(eg3d_ctx* c) {
                    &c->b_task_k, &c->b_task_list_off, &c->b_list_cnt, &c->b_list_ptr, &c->b_hits, &c->b_tasks,
                    &c->b_nhyp, &c->b_hyp_off, &c->b_res, &c->b_hscratch, &c->b_arena, &c->b_ctr, &c->b_cs_task,
                    &c->b_valid, &c->b_chain_off, &c->b_chains, &c->b_cscratch, &c->b_couts, &c->b_cpts, &c->b_cobs,
-                   &c->b_cpoff, &c->b_cooff, &c->b_scan_tmp, &c->b_cost, &c->b_cidx, &c->b_cost2, &c->b_order, &c->o_X, &c->o_off, &c->o_view, &c->o_pl, &c->o_seg,
+                   &c->b_cpoff, &c->b_cooff, &c->b_scan_tmp, &c->b_scanchk, &c->b_cost, &c->b_cidx, &c->b_cost2, &c->b_order, &c->o_X, &c->o_off, &c->o_view, &c->o_pl, &c->o_seg,
                    &c->o_xy, &c->o_key, &c->f_X, &c->f_off, &c->f_view, &c->f_xy, &c->f_Xo, &c->f_inl, &c->b_sets_off, &c->b_sets_ids, &c->b_fscratch, &c->b_queue};
   for (DevBuf* b : all) b->release();
   for (int i = 0; i < 8; i++) {
@@ -440,8 +477,7 @@ int run_stage_a(eg3d_ctx* c, BatchState& B, eg3d_stage_times* tm) {
                    c->b_map_entry.as<uint32_t>(), c->b_map_n.as<uint32_t>());
   HIP_TRY(hipMemsetAsync(c->b_raw_cnt.as<uint32_t>() + n_sv, 0, sizeof(uint32_t), st));
   launch_k1_count_raw(st, c->ds, B.sd, B.sv_base, n_sv, c->b_sv_seed.as<uint32_t>(), c->b_raw_cnt.as<uint32_t>());
-  BUF_TRY(scan_exclusive_u32(c, c->b_raw_cnt.as<uint32_t>(), c->b_raw_off.as<uint32_t>(), n_sv + 1));
-  BUF_TRY(read_u32(c, c->b_raw_off.as<uint32_t>() + n_sv, B.total_raw));
+  BUF_TRY(scan_total_u32(c, c->b_raw_cnt.as<uint32_t>(), c->b_raw_off.as<uint32_t>(), n_sv + 1, B.total_raw, "candidate slots"));
   BUF_TRY(c->b_cand_pl.ensure(sizeof(uint32_t) * (B.total_raw + 1)));
   BUF_TRY(c->b_start_hits.ensure(sizeof(Obs) * (B.total_raw + 1)));
   HIP_TRY(hipMemsetAsync(c->b_start_cnt.as<uint32_t>() + n_sv, 0, sizeof(uint32_t), st));
@@ -450,8 +486,7 @@ int run_stage_a(eg3d_ctx* c, BatchState& B, eg3d_stage_times* tm) {
             c->b_cand_pl.as<uint32_t>(), c->b_start_hits.as<Obs>(), c->b_cand_cnt.as<uint32_t>(),
             c->b_start_cnt.as<uint32_t>(), c->b_ctr.as<Counters>());
   HIP_TRY(hipEventRecord(c->eb[1], st));
-  BUF_TRY(scan_exclusive_u32(c, c->b_start_cnt.as<uint32_t>(), c->b_task_off.as<uint32_t>(), n_sv + 1));
-  BUF_TRY(read_u32(c, c->b_task_off.as<uint32_t>() + n_sv, B.n_tasks));
+  BUF_TRY(scan_total_u32(c, c->b_start_cnt.as<uint32_t>(), c->b_task_off.as<uint32_t>(), n_sv + 1, B.n_tasks, "tasks"));
   const uint32_t nt = B.n_tasks;
   BUF_TRY(c->b_task_seed.ensure(sizeof(uint32_t) * (nt + 1)));
   BUF_TRY(c->b_task_entry.ensure(sizeof(uint32_t) * (nt + 1)));
@@ -462,8 +497,7 @@ int run_stage_a(eg3d_ctx* c, BatchState& B, eg3d_stage_times* tm) {
   launch_task_fill(st, B.sd, B.sv_base, n_sv, c->b_sv_seed.as<uint32_t>(), c->b_start_cnt.as<uint32_t>(),
                    c->b_task_off.as<uint32_t>(), c->b_task_seed.as<uint32_t>(), c->b_task_entry.as<uint32_t>(),
                    c->b_task_hit.as<uint32_t>(), c->b_task_k.as<uint32_t>());
-  BUF_TRY(scan_exclusive_u32(c, c->b_task_k.as<uint32_t>(), c->b_task_list_off.as<uint32_t>(), nt + 1));
-  BUF_TRY(read_u32(c, c->b_task_list_off.as<uint32_t>() + nt, B.n_lists));
+  BUF_TRY(scan_total_u32(c, c->b_task_k.as<uint32_t>(), c->b_task_list_off.as<uint32_t>(), nt + 1, B.n_lists, "hit lists"));
   BUF_TRY(c->b_list_cnt.ensure(sizeof(uint32_t) * (B.n_lists + 1)));
   BUF_TRY(c->b_list_ptr.ensure(sizeof(uint32_t) * (B.n_lists + 1)));
   HIP_TRY(hipMemsetAsync(c->b_list_cnt.as<uint32_t>() + B.n_lists, 0, sizeof(uint32_t), st));
@@ -472,8 +506,7 @@ int run_stage_a(eg3d_ctx* c, BatchState& B, eg3d_stage_times* tm) {
             c->b_task_hit.as<uint32_t>(), c->b_task_list_off.as<uint32_t>(), c->b_raw_off.as<uint32_t>(),
             c->b_cand_pl.as<uint32_t>(), c->b_cand_cnt.as<uint32_t>(), c->b_start_hits.as<Obs>(),
             c->b_list_cnt.as<uint32_t>(), nullptr, nullptr);
-  BUF_TRY(scan_exclusive_u32(c, c->b_list_cnt.as<uint32_t>(), c->b_list_ptr.as<uint32_t>(), B.n_lists + 1));
-  BUF_TRY(read_u32(c, c->b_list_ptr.as<uint32_t>() + B.n_lists, B.n_hits));
+  BUF_TRY(scan_total_u32(c, c->b_list_cnt.as<uint32_t>(), c->b_list_ptr.as<uint32_t>(), B.n_lists + 1, B.n_hits, "epipolar hits"));
   BUF_TRY(c->b_hits.ensure(sizeof(Obs) * (B.n_hits + 1)));
   launch_k2(st, true, c->ds, B.sd, B.sv_base, nt, c->b_task_seed.as<uint32_t>(), c->b_task_entry.as<uint32_t>(),
             c->b_task_hit.as<uint32_t>(), c->b_task_list_off.as<uint32_t>(), c->b_raw_off.as<uint32_t>(),
@@ -520,8 +553,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
   HIP_TRY(hipMemsetAsync(c->b_nhyp.as<uint32_t>() + nt, 0, sizeof(uint32_t), st));
   launch_task_setup(st, B.a, c->b_map_view.as<int32_t>(), c->b_map_entry.as<uint32_t>(), c->b_map_n.as<uint32_t>(),
                     c->b_tasks.as<TaskDesc>(), c->b_nhyp.as<uint32_t>());
-  BUF_TRY(scan_exclusive_u32(c, c->b_nhyp.as<uint32_t>(), c->b_hyp_off.as<uint32_t>(), nt + 1));
-  BUF_TRY(read_u32(c, c->b_hyp_off.as<uint32_t>() + nt, B.n_hyp));
+  BUF_TRY(scan_total_u32(c, c->b_nhyp.as<uint32_t>(), c->b_hyp_off.as<uint32_t>(), nt + 1, B.n_hyp, "hypotheses"));
   // ---- K3a
   BUF_TRY(c->b_res.ensure(sizeof(HypResult) * (B.n_hyp + 1)));
   // small batches are latency-bound by their slowest hypothesis: give each hypothesis a 4-lane team
@@ -579,8 +611,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
   HIP_TRY(hipEventRecord(c->ea[4], st));
   launch_k3s(st, nt, c->b_hyp_off.as<uint32_t>(), c->b_res.as<HypResult>(), c->b_cs_task.as<ChainSeed>(),
              c->b_valid.as<uint32_t>());
-  BUF_TRY(scan_exclusive_u32(c, c->b_valid.as<uint32_t>(), c->b_chain_off.as<uint32_t>(), nt + 1));
-  BUF_TRY(read_u32(c, c->b_chain_off.as<uint32_t>() + nt, B.n_chains));
+  BUF_TRY(scan_total_u32(c, c->b_valid.as<uint32_t>(), c->b_chain_off.as<uint32_t>(), nt + 1, B.n_chains, "chains"));
   BUF_TRY(c->b_chains.ensure(sizeof(ChainSeed) * (B.n_chains + 1)));
   launch_compact_chains(st, nt, c->b_cs_task.as<ChainSeed>(), c->b_valid.as<uint32_t>(), c->b_chain_off.as<uint32_t>(),
                         c->b_chains.as<ChainSeed>());
@@ -650,11 +681,13 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
         continue;
       }
     }
-    BUF_TRY(scan_exclusive_u32(c, c->b_cpts.as<uint32_t>(), c->b_cpoff.as<uint32_t>(), nc + 1));
-    BUF_TRY(scan_exclusive_u32(c, c->b_cobs.as<uint32_t>(), c->b_cooff.as<uint32_t>(), nc + 1));
     uint32_t np = 0, no = 0;
-    BUF_TRY(read_u32(c, c->b_cpoff.as<uint32_t>() + nc, np));
-    BUF_TRY(read_u32(c, c->b_cooff.as<uint32_t>() + nc, no));
+    BUF_TRY(scan_total_u32(c, c->b_cpts.as<uint32_t>(), c->b_cpoff.as<uint32_t>(), nc + 1, np, "edge-points of one chunk"));
+    BUF_TRY(scan_total_u32(c, c->b_cobs.as<uint32_t>(), c->b_cooff.as<uint32_t>(), nc + 1, no, "observations of one chunk"));
+    if (H.n_obs + no > 0xffffffffull) {  // obs_off is 32-bit (include/eg3d.h)
+      g_err = "eg3d: more than 2^32-1 observations in one call; use smaller seed / set ranges";
+      return EG3D_ERR_CAPACITY;
+    }
     HIP_TRY(hipMemcpyAsync(&hc, c->b_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
     BUF_TRY(c->o_X.ensure(sizeof(float) * 3 * ((size_t)np + 1)));
     BUF_TRY(c->o_off.ensure(sizeof(uint32_t) * ((size_t)np + 1)));
@@ -760,8 +793,7 @@ int run_sets_batch(eg3d_ctx* c, const SetsDev& sets, const uint32_t* h_row_off, 
   HIP_TRY(hipEventRecord(c->ea[1], st));
   launch_n1_samples(st, false, c->ds, sets, n_rows_total, item_b, n_items, c->b_raw_cnt.as<uint32_t>(), nullptr, nullptr,
                     nullptr, nullptr, nullptr, nullptr, nullptr, c->b_ctr.as<Counters>());
-  BUF_TRY(scan_exclusive_u32(c, c->b_raw_cnt.as<uint32_t>(), c->b_raw_off.as<uint32_t>(), n_items + 1));
-  BUF_TRY(read_u32(c, c->b_raw_off.as<uint32_t>() + n_items, B.n_tasks));
+  BUF_TRY(scan_total_u32(c, c->b_raw_cnt.as<uint32_t>(), c->b_raw_off.as<uint32_t>(), n_items + 1, B.n_tasks, "samples"));
   const uint32_t nt = B.n_tasks;
   if ((uint64_t)nt * V > 0x7fffffffull) {
     g_err = "eg3d_match_polyline_sets: too many samples in one batch of sets";
@@ -790,8 +822,8 @@ int run_sets_batch(eg3d_ctx* c, const SetsDev& sets, const uint32_t* h_row_off, 
   HIP_TRY(hipEventRecord(c->ea[2], st));
   launch_n1_hits(st, false, c->ds, sets, nt, c->b_start_hits.as<Obs>(), c->b_task_k.as<uint32_t>(),
                  c->b_list_cnt.as<uint32_t>(), nullptr, nullptr, c->b_ctr.as<Counters>());
-  BUF_TRY(scan_exclusive_u32(c, c->b_list_cnt.as<uint32_t>(), c->b_list_ptr.as<uint32_t>(), (size_t)B.n_lists + 1));
-  BUF_TRY(read_u32(c, c->b_list_ptr.as<uint32_t>() + B.n_lists, B.n_hits));
+  BUF_TRY(scan_total_u32(c, c->b_list_cnt.as<uint32_t>(), c->b_list_ptr.as<uint32_t>(), (size_t)B.n_lists + 1, B.n_hits,
+                         "epipolar hits"));
   BUF_TRY(c->b_hits.ensure(sizeof(Obs) * ((size_t)B.n_hits + 1)));
   launch_n1_hits(st, true, c->ds, sets, nt, c->b_start_hits.as<Obs>(), c->b_task_k.as<uint32_t>(),
                  c->b_list_cnt.as<uint32_t>(), c->b_list_ptr.as<uint32_t>(), c->b_hits.as<Obs>(), c->b_ctr.as<Counters>());
@@ -840,6 +872,7 @@ T* dup_to_malloc(const std::vector<T>& v, size_t extra = 0) {
 
 }  // namespace
 
+extern "C" void eg3d_free_edgepoints(eg3d_edgepoints* e);
 static int finish_match(HostOut& H, int device_only, float total, eg3d_edgepoints* out, eg3d_stage_times* times) {
   out->n_points = H.n_points;
   out->n_obs = H.n_obs;
@@ -870,6 +903,9 @@ static int finish_match(HostOut& H, int device_only, float total, eg3d_edgepoint
   }
   if (H.flags & (EG3D_FLAG_CHAIN_OVERFLOW | EG3D_FLAG_OBS_OVERFLOW | EG3D_FLAG_HYP_OVERFLOW)) {
     g_err = "eg3d: a device-side capacity was exceeded (flags in out->flags)";
+    const uint32_t flags = out->flags;
+    eg3d_free_edgepoints(out);  // an error return owns nothing the caller would have to free
+    out->flags = flags;
     return EG3D_ERR_CAPACITY;
   }
   return EG3D_OK;
@@ -888,20 +924,15 @@ extern "C" int eg3d_match_resident(eg3d_ctx* c, uint32_t b, uint32_t e, int devi
   c->last_np = c->last_no = 0;
   c->last_chunks = 0;
   const uint32_t SEED_BATCH = 16384;
-  hipEvent_t t0, t1;
-  HIP_TRY(hipEventCreate(&t0));
-  HIP_TRY(hipEventCreate(&t1));
-  HIP_TRY(hipEventRecord(t0, c->stream));
+  HIP_TRY(hipEventRecord(c->ea[7], c->stream));  // the context's own events: nothing to leak on an error path
   for (uint32_t s = b; s < e; s += SEED_BATCH) {
     int rc = run_batch(c, s, std::min(e, s + SEED_BATCH), device_only, H);
     if (rc != EG3D_OK) return rc;
   }
-  HIP_TRY(hipEventRecord(t1, c->stream));
-  HIP_TRY(hipEventSynchronize(t1));
+  HIP_TRY(hipEventRecord(c->eb[7], c->stream));
+  HIP_TRY(hipEventSynchronize(c->eb[7]));
   float total = 0;
-  HIP_TRY(hipEventElapsedTime(&total, t0, t1));
-  (void)hipEventDestroy(t0);
-  (void)hipEventDestroy(t1);
+  HIP_TRY(hipEventElapsedTime(&total, c->ea[7], c->eb[7]));
   return finish_match(H, device_only, total, out, times);
 }
 
@@ -966,10 +997,7 @@ extern "C" int eg3d_match_polyline_sets(eg3d_ctx* c, const eg3d_polyline_sets* p
   HostOut H;
   c->last_np = c->last_no = 0;
   c->last_chunks = 0;
-  hipEvent_t t0, t1;
-  HIP_TRY(hipEventCreate(&t0));
-  HIP_TRY(hipEventCreate(&t1));
-  HIP_TRY(hipEventRecord(t0, c->stream));
+  HIP_TRY(hipEventRecord(c->ea[7], c->stream));
   // batches of whole sets, bounded by the number of polylines (every sample owns V lists)
   const uint32_t max_items = V >= 64 ? 2048u : 16384u;
   uint32_t sample_base = 0;
@@ -984,12 +1012,10 @@ extern "C" int eg3d_match_polyline_sets(eg3d_ctx* c, const eg3d_polyline_sets* p
     sample_base += (uint32_t)(H.n_tasks - tasks_before);
     s0 = s1;
   }
-  HIP_TRY(hipEventRecord(t1, c->stream));
-  HIP_TRY(hipEventSynchronize(t1));
+  HIP_TRY(hipEventRecord(c->eb[7], c->stream));
+  HIP_TRY(hipEventSynchronize(c->eb[7]));
   float total = 0;
-  HIP_TRY(hipEventElapsedTime(&total, t0, t1));
-  (void)hipEventDestroy(t0);
-  (void)hipEventDestroy(t1);
+  HIP_TRY(hipEventElapsedTime(&total, c->ea[7], c->eb[7]));
   return finish_match(H, device_only, total, out, times);
 }
 

@@ -76,6 +76,8 @@ void launch_k4(hipStream_t st, const TaskDesc* tasks, const ChainSeed* chains, u
                const unsigned char* scratch, const ChainOut* outs, const uint32_t* point_off, const uint32_t* obs_off_in,
                uint64_t point_base, uint64_t obs_base, float* X, uint32_t* obs_off, int32_t* obs_view, uint32_t* obs_pl,
                uint32_t* obs_seg, float* obs_xy, uint32_t* key);
+// {out[n], 1 if the scan wrapped} -> total_and_flag[0..1] (flag word must be zero before the launch)
+void launch_scan_check(hipStream_t st, const uint32_t* out, uint64_t n_plus_one, uint32_t* total_and_flag);
 void launch_k5(hipStream_t st, const float* cam_P, int n_views, const float* X, const uint32_t* obs_off,
                const int32_t* obs_view, const float* obs_xy, uint64_t n, float gn_max_mse, int legacy_abs, float* X_out,
                uint8_t* inlier);

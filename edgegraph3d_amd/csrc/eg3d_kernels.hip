@@ -1204,6 +1204,19 @@ __global__ void __launch_bounds__(K5_BLOCK) k5_gn_filter(const float* cam_P, int
   X_out[3 * i + 2] = ok ? o[2] : x0[2];
 }
 
+// Exclusive scans of 32-bit counts wrap silently when the total passes 2^32. The counts are
+// non-negative, so a wrapped scan is exactly one whose output decreases somewhere: this check runs
+// after every scan and hands the host {total, wrapped} in one 8-byte read.
+__global__ void k_scan_check(const uint32_t* out, uint64_t n_plus_one, uint32_t* total_and_flag) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) total_and_flag[0] = out[n_plus_one - 1];
+  if (i + 1 < n_plus_one && out[i + 1] < out[i]) atomicOr(&total_and_flag[1], 1u);
+}
+void launch_scan_check(hipStream_t st, const uint32_t* out, uint64_t n_plus_one, uint32_t* total_and_flag) {
+  hipLaunchKernelGGL(k_scan_check, dim3((unsigned)((n_plus_one + 255) / 256)), dim3(256), 0, st, out, n_plus_one,
+                     total_and_flag);
+}
+
 // ------------------------------------------------------------ launch wrappers --
 static inline dim3 blocks_for(uint64_t n, uint32_t per_block) { return dim3((unsigned)((n + per_block - 1) / per_block)); }
 

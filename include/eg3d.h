@@ -64,7 +64,9 @@ typedef struct eg3d_scene {
   const float* vtx_xy;        /* [NV][2] polyline_coords */
   const uint32_t* pl_start;   /* [NP] node id `start` */
   const uint32_t* pl_end;     /* [NP] node id `end`   */
-  const uint8_t* pl_valid;    /* [NP] PolyLineGraph2D::is_valid_polyline (polyline_graph_2d.cpp:1141-1147) */
+  const uint8_t* pl_valid;    /* [NP] PolyLineGraph2D::is_valid_polyline (polyline_graph_2d.cpp:1141-1147); the vertices of an
+                                 invalid polyline, if the caller left any, are ignored (an invalidated polyline of the
+                                 reference has none) */
 } eg3d_scene;
 
 /* Seeds = SfM reference points: camViewingPointN_ + point2DoncamViewingPoint_ as CSR. */

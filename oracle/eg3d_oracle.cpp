@@ -67,6 +67,7 @@ extern "C" orc_ctx* orc_create(const eg3d_scene* s) {
       pl.valid = s->pl_valid[p] != 0;
       pl.dir_mismatch_counter = &c->sc.dir_mismatch;
       uint32_t a = s->pl_vtx_off[p], b = s->pl_vtx_off[p + 1];
+      if (!pl.valid) b = a;  // an invalidated polyline has no coordinates (polyline_graph_2d.cpp:1047-1058)
       pl.polyline_coords.resize(b - a);
       for (uint32_t i = a; i < b; i++) pl.polyline_coords[i - a] = vec2(s->vtx_xy[2 * i], s->vtx_xy[2 * i + 1]);
     }

@@ -247,3 +247,30 @@ def test_cpp_end_to_end_example(tmp_path):
     f = re.search(r"filter: (\d+) of (\d+) points kept", out2.stdout)
     assert int(f.group(2)) == len(doc["structure"]) and 0 < int(f.group(1)) <= int(f.group(2))
     assert len(json.load(open(d + "/out_f.json"))["structure"]) == int(f.group(1))
+
+
+def test_invalid_polyline_that_kept_its_vertices_is_ignored():
+    """include/eg3d.h allows pl_valid == 0 on a polyline whose vertex slice is not empty (the reference
+    clears the coordinates of an invalidated polyline, polyline_graph_2d.cpp:1047-1058). Such
+    vertices must be invisible to every path — including the polyline-sets path, which takes raw
+    polyline ids: the result equals the oracle's and equals the scene with the slice removed."""
+    s = host.Synth(1)
+    sc = s.scene_np()
+    n_sets, row_off, ids = s.polyline_sets(3)
+    victims = [int(i) for i in ids[:4]]                      # view-0 polylines of the first set
+    sc["pl_valid"] = sc["pl_valid"].copy()
+    v0 = int(sc["view_pl_off"][0])
+    for p in victims:
+        assert sc["pl_vtx_off"][v0 + p + 1] - sc["pl_vtx_off"][v0 + p] >= 2
+        sc["pl_valid"][v0 + p] = 0                           # invalid, vertices still there
+    sa = host.SceneArrays(sc)
+    ctx = api.Context(C.byref(sa.c))
+    got = ctx.match_polyline_sets(n_sets, row_off, ids)
+    ref = _oracle(C.byref(sa.c)).match_polyline_sets(n_sets, row_off, ids, nthreads=8)
+    rep = compare_edgepoints(ref, got)
+    assert rep["ok"] and rep["bitexact_X"], rep["msgs"]
+    assert not np.isin(got["obs_pl"][got["obs_view"] == 0], victims).any()
+    seeds_got = ctx.match_refpoints(s.seeds)
+    seeds_ref = _oracle(C.byref(sa.c)).match(s.seeds, 0, s.n_seeds, nthreads=8)
+    assert compare_edgepoints(seeds_ref, seeds_got)["ok"]
+    ctx.close()
