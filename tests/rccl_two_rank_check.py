@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""Two-rank check of the C-ABI exchange step (include/eg3d_rccl.h: eg3d_allgather_edgepoints) for a
+node with >= 2 GPUs — the single-GPU boxes of the round cannot run it, tests/test_gpu_parity.py
+skips it there. No torch: the communicator comes from ncclGetUniqueId / ncclCommInitRank, the
+unique id travels through a file.
+
+    python tests/rccl_two_rank_check.py            # spawns ranks 0 and 1 (GPUs 0 and 1), prints RCCL-2RANK-OK
+    python tests/rccl_two_rank_check.py --world 4  # more ranks if the node has them
+
+Cases, on the small synthetic scene:
+  1. unequal shards (sum-of-track-length balanced split of a skewed seed range): the gathered
+     cloud on EVERY rank equals the single-process result bit for bit, obs_off rebased;
+  2. a rank with ZERO seeds;
+  3. a rank whose local result is marked incomplete: every rank returns EG3D_GATHER_ERR_INCOMPLETE
+     (-4) from the same call instead of blocking in the payload collective.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+class UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+def worker(rank, world, idfile):
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from edgegraph3d_amd import _cdefs as D
+    from edgegraph3d_amd import api, host
+    from edgegraph3d_amd.distributed import shard_ranges_balanced
+    pkg = os.path.dirname(os.path.abspath(api.__file__))
+    G = C.CDLL(os.path.join(pkg, "libeg3d_rccl.so"))
+    nccl = C.CDLL("librccl.so.1")
+    hip = C.CDLL("libamdhip64.so")
+    uid = UniqueId()
+    if rank == 0:
+        assert nccl.ncclGetUniqueId(C.byref(uid)) == 0
+        with open(idfile + ".tmp", "wb") as f:
+            f.write(bytes(uid))
+        os.rename(idfile + ".tmp", idfile)
+    else:
+        for _ in range(600):
+            if os.path.exists(idfile):
+                break
+            time.sleep(0.1)
+        C.memmove(C.byref(uid), open(idfile, "rb").read(), 128)
+    assert hip.hipSetDevice(rank) == 0
+    comm = C.c_void_p()
+    nccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert nccl.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0
+    G.eg3d_gather_create.restype = C.c_void_p
+    G.eg3d_gather_create.argtypes = [C.c_int]
+    G.eg3d_allgather_edgepoints.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                            C.POINTER(D.DeviceEdgePoints), C.POINTER(D.DeviceEdgePoints),
+                                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    G.eg3d_gather_destroy.argtypes = [C.c_void_p]
+    g = G.eg3d_gather_create(rank)
+    assert g
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def fetch(ptr, n, dtype):
+        a = np.empty(n, dtype)
+        if n:
+            assert hip.hipMemcpy(a.ctypes.data, C.cast(ptr, C.c_void_p), a.nbytes, 2) == 0
+        return a
+
+    s = host.Synth(1)
+    ctx = api.Context(s.scene, rank)
+    ctx.upload_seeds(s.seeds)
+    whole = ctx.match_resident(0, s.n_seeds)            # the single-process answer, computed on every rank
+    off = s.seeds_np()[0]
+    rp, ro = (C.c_uint64 * world)(), (C.c_uint64 * world)()
+
+    def gather_and_check(ranges, label):
+        b, e = ranges[rank]
+        ctx.match_resident(b, e, device_only=True)
+        local = ctx.last_device_output()
+        out = D.DeviceEdgePoints()
+        rc = G.eg3d_allgather_edgepoints(g, comm, world, rank, None, C.byref(local), C.byref(out), rp, ro)
+        assert rc == 0, (label, rc)
+        lo, hi = ranges[0][0], ranges[-1][1]
+        sel = (whole["key"][:, 0] >= lo) & (whole["key"][:, 0] < hi)
+        n, m = int(out.n_points), int(out.n_obs)
+        assert n == int(sel.sum()), (label, n, int(sel.sum()))
+        first = int(np.argmax(sel)) if n else 0
+        o0 = int(whole["obs_off"][first]) if n else 0
+        assert m == int(whole["obs_off"][first + n]) - o0
+        assert np.array_equal(fetch(out.X, 3 * n, np.uint32), whole["X"][first:first + n].view(np.uint32).ravel())
+        assert np.array_equal(fetch(out.key, 4 * n, np.uint32), whole["key"][first:first + n].ravel())
+        assert np.array_equal(fetch(out.obs_off, n + 1, np.uint32), whole["obs_off"][first:first + n + 1] - o0)
+        assert np.array_equal(fetch(out.obs_view, m, np.int32), whole["obs_view"][o0:o0 + m])
+        assert np.array_equal(fetch(out.obs_pl, m, np.uint32), whole["obs_pl"][o0:o0 + m])
+        assert np.array_equal(fetch(out.obs_seg, m, np.uint32), whole["obs_seg"][o0:o0 + m])
+        assert np.array_equal(fetch(out.obs_xy, 2 * m, np.uint32), whole["obs_xy"][o0:o0 + m].view(np.uint32).ravel())
+        assert sum(rp) == n and sum(ro) == m
+        print("rank %d: %s ok (%d points, per rank %s)" % (rank, label, n, list(rp)), flush=True)
+
+    # 1. unequal shards
+    gather_and_check(shard_ranges_balanced(off, 0, s.n_seeds, world), "balanced shards")
+    uneven = [(0, 5)] + [(5 + (s.n_seeds - 5) * (r - 1) // (world - 1), 5 + (s.n_seeds - 5) * r // (world - 1))
+                         for r in range(1, world)]
+    gather_and_check(uneven, "uneven shards")
+    # 2. a rank with zero seeds
+    zero = [(0, 0)] + [(s.n_seeds * (r - 1) // (world - 1), s.n_seeds * r // (world - 1)) for r in range(1, world)]
+    gather_and_check(zero, "empty rank 0")
+    # 3. an incomplete local result on the LAST rank only: every rank gets the same error code
+    b, e = shard_ranges_balanced(off, 0, s.n_seeds, world)[rank]
+    ctx.match_resident(b, e, device_only=True)
+    local = ctx.last_device_output()
+    if rank == world - 1:
+        local.complete = 0
+    out = D.DeviceEdgePoints()
+    rc = G.eg3d_allgather_edgepoints(g, comm, world, rank, None, C.byref(local), C.byref(out), rp, ro)
+    assert rc == -4, rc
+    print("rank %d: incomplete rank reported to every rank (rc -4)" % rank, flush=True)
+    G.eg3d_gather_destroy(g)
+    nccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    nccl.ncclCommDestroy(comm)
+    ctx.close()
+
+
+def main():
+    if "--rank" in sys.argv:
+        i = sys.argv.index("--rank")
+        worker(int(sys.argv[i + 1]), int(sys.argv[i + 2]), sys.argv[i + 3])
+        return
+    world = int(sys.argv[sys.argv.index("--world") + 1]) if "--world" in sys.argv else 2
+    with tempfile.TemporaryDirectory() as d:
+        idfile = os.path.join(d, "nccl_id")
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--rank", str(r), str(world), idfile])
+                 for r in range(world)]
+        rcs = [p.wait(timeout=600) for p in procs]
+    if any(rcs):
+        raise SystemExit("rccl two-rank check failed: %s" % rcs)
+    print("RCCL-2RANK-OK")
+
+
+if __name__ == "__main__":
+    main()

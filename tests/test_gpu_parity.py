@@ -1,6 +1,8 @@
 """-m gpu: the parity tests proper. The HIP path is called through the C ABI and compared with
 the CPU oracle on the same seeded inputs (exact structure; X within 1e-4 relative as
 BASELINE.json's north_star states — in practice the arithmetic contract makes it bit-exact)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -288,3 +290,18 @@ def test_quirks_q4_q12_q13_on_the_device():
                     np.array_equal(fixed["X"].view(np.uint32), got["X"].view(np.uint32)))
             assert not same, "Q%d: the device output equals the corrected variant" % q
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_rccl_allgather_c_abi_two_ranks():
+    """include/eg3d_rccl.h with TWO ranks (unequal, empty and incomplete shards): needs >= 2 GPUs, so it
+    is skipped on the single-GPU boxes; tests/rccl_two_rank_check.py is the script the driver can run
+    on a multi-GPU node."""
+    import subprocess
+    import sys
+    if api.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_two_rank_check.py")],
+                       capture_output=True, text=True)
+    assert p.returncode == 0 and "RCCL-2RANK-OK" in p.stdout, p.stdout + p.stderr

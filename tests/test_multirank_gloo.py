@@ -1,7 +1,9 @@
-"""N>1 path on CPU: world_size-2 gloo. Each rank computes its contiguous seed shard (with the
-oracle standing in for the GPU kernels — this test is about the sharding, packing and ordering
-logic of edgegraph3d_amd/distributed.py, which bench.py runs over RCCL), all-gathers the
-edge-point cloud and must reproduce the single-process output exactly, on every rank."""
+"""N>1 path on CPU: world_size-2 gloo. Each rank computes its contiguous, sum-of-track-length
+balanced seed shard with the HOST SIMULATION of the device code (tests/hostsim: the kernels'
+per-lane bodies of stage B compiled for the host; stage A from the oracle, as the hostsim takes
+it), all-gathers the edge-point cloud with the packing / ordering logic of
+edgegraph3d_amd/distributed.py and must reproduce the single-process oracle output exactly, on
+every rank. (The RCCL exchange itself — include/eg3d_rccl.h — needs GPUs: tests/rccl_two_rank_check.py.)"""
 import os
 import socket
 
@@ -12,7 +14,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from edgegraph3d_amd import host
-from edgegraph3d_amd.distributed import CloudGather, shard_range
+from edgegraph3d_amd.distributed import CloudGather, shard_range, shard_ranges_balanced
 
 
 def _free_port():
@@ -30,13 +32,15 @@ def _worker(rank, world, port, cfg, q):
         if p not in sys.path:
             sys.path.insert(0, p)
     from oracle import binding as ob
+    import hostsim_binding as hs
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     s = host.Synth(cfg)
     o = ob.Oracle(s.scene)
-    b, e = shard_range(s.n_seeds, world)[rank]
-    r = o.match(s.seeds, b, e, 1)
+    b, e = shard_ranges_balanced(s.seeds_np()[0], 0, s.n_seeds, world)[rank]
+    # stage B = the device code run on the host; its keys carry the global seed index, as the GPU's do
+    r = hs.match(s.scene, s.seeds, b, e, o.candidates_raw(s.seeds, b, e))
     dev = torch.device("cpu")
 
     def raw(a):
@@ -50,6 +54,24 @@ def _worker(rank, world, port, cfg, q):
     q.put((rank, {k: (v.numpy().copy() if torch.is_tensor(v) else v) for k, v in cloud.items()}))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_balanced_shards_cover_and_balance_by_track_length():
+    s = host.Synth(1)
+    off = s.seeds_np()[0].astype(np.int64)
+    for w in (1, 2, 3, 8, 200):
+        r = shard_ranges_balanced(off, 0, s.n_seeds, w)
+        assert len(r) == w and r[0][0] == 0 and r[-1][1] == s.n_seeds
+        assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+        if w <= 8:
+            weights = [off[e] - off[b] for b, e in r]
+            assert max(weights) - min(weights) <= 2 * int(np.diff(off).max())
+    r = shard_ranges_balanced(off, 10, 50, 4)                      # a sub-range (one bench step's batch)
+    assert r[0][0] == 10 and r[-1][1] == 50
+    # a skewed set: one very long track — count-balanced shards would be 4x off, these are not
+    skew = np.concatenate([[0], np.cumsum([300] + [3] * 99)])
+    r = shard_ranges_balanced(skew, 0, 100, 2)
+    assert r[0] == (0, 1) or (skew[r[0][1]] - skew[r[0][0]]) <= 303
 
 
 def test_shard_ranges_cover_and_balance():
