@@ -45,10 +45,33 @@ STAGES = [("k1_seed_candidates", "ms_candidates"), ("k2_epipolar_hits", "ms_epip
           ("k3a_hypotheses", "ms_hypotheses"), ("k3s_select", "ms_select"), ("k3b_expand", "ms_expand"),
           ("k4_emit", "ms_emit")]
 WORKLOADS = {"c2": 2, "c3": 3, "c4": 4}
+
+
+class _RealEdges:
+    """BASELINE configs[2] from the REAL edge images: the 25 dtu006 edge maps (tests/golden/dtu006_edges) turned
+    into polyline graphs by the N2 builder (eg3d_plg_build_from_mask), with synthetic look-at cameras at the 25
+    listed camera centres and 6268 seeds sampled on the polylines (tests/real_scene.py). The reference's input.json
+    with the true poses is missing, so the geometry is not consistent with the images: real polyline statistics,
+    not a reconstruction."""
+
+    def __init__(self, n_seeds):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import real_scene as rs
+        self._sc, self._seeds, self.info = rs.real_edges_scene(n_seeds=n_seeds or 6268)
+        self.scene = C.pointer(self._sc.c)
+        self.seeds = C.pointer(self._seeds.c)
+        self.n_seeds = int(self._seeds.c.n_seeds)
+        self.n_views = int(self._sc.c.n_views)
+        self.total_segments = int(self.info["segments_per_view"] * self.n_views)
+
+    def seeds_np(self):
+        return self._seeds.trk_off, self._seeds.trk_view, self._seeds.trk_xy
 DESCR = {
     "c2": "C2 (BASELINE configs[1])",
     "c3": "C3' dtu006-shaped (BASELINE configs[2] with synthetic polylines and cameras)",
     "c4": "C4 (BASELINE configs[3])",
+    "c3real": "C3-real: 25 real dtu006 edge maps -> polyline graphs (N2 builder), SYNTHETIC look-at cameras at the listed "
+              "centres (the reference's input.json is missing: geometry not consistent with the images)",
 }
 
 
@@ -57,8 +80,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--workload", choices=["auto", "c2", "c3", "c4"], default="auto",
-                    help="auto = c3 on one GPU, c4 (strong scaling) on several")
+    ap.add_argument("--workload", choices=["auto", "c2", "c3", "c4", "c3real"], default="auto",
+                    help="auto = c3 on one GPU, c4 (strong scaling) on several; c3real = the real dtu006 edge maps")
     ap.add_argument("--config", type=int, default=0, help="deprecated alias: 2/3/4 = --workload c2/c3/c4")
     ap.add_argument("--seeds", type=int, default=0, help="override the workload's seed count (experiments only)")
     ap.add_argument("--batch-seeds", type=int, default=0, help="seeds per step (default: all; c4: %d)" % C4_BATCH)
@@ -110,15 +133,20 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    cfg = host.default_config(WORKLOADS[wl])
-    if args.seeds:
-        cfg.n_seeds = args.seeds
-    synth = host.Synth(cfg)           # same seeded scene + seeds on every rank
+    if wl == "c3real":
+        synth = _RealEdges(args.seeds)
+    else:
+        cfg = host.default_config(WORKLOADS[wl])
+        if args.seeds:
+            cfg.n_seeds = args.seeds
+        synth = host.Synth(cfg)       # same seeded scene + seeds on every rank
     n_total = synth.n_seeds
     trk_off = synth.seeds_np()[0]
     batch = args.batch_seeds or (C4_BATCH if wl == "c4" else n_total)
     batch = min(batch, n_total)
     n_batches = max(1, n_total // batch)
+    if args.path == "sets" and wl == "c3real":
+        raise SystemExit("bench.py --path sets needs a synthetic workload (the sets come from its 3-D curves)")
     sets = synth.polyline_sets() if args.path == "sets" else None
     if sets is not None and world > 1:
         raise SystemExit("bench.py --path sets is a single-GPU measurement")
@@ -252,7 +280,8 @@ def main():
         line = {
             "metric": "triangulated edge-points/sec", "value": value, "unit": "edge-points/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "steps_in_flight": inflight,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic" if wl != "c3real" else "real dtu006 edge maps + synthetic cameras and seeds", "steps_in_flight": inflight,
             "config": {
                 "workload": workload, "workload_key": wkey,
                 "edge_points_per_step": points_done / args.steps, "observations_last_step_rank0": int(last["n_obs"]),

@@ -70,6 +70,22 @@ def np_ptr(a, ctype):
     return a.ctypes.data_as(C.POINTER(ctype))
 
 
+class PlgView(C.Structure):
+    """eg3d_plg_view (include/eg3d_host.h): the polyline graph of one view."""
+    _fields_ = [("n_polylines", C.c_uint32), ("pl_vtx_off", u32p), ("vtx_xy", f32p), ("pl_start", u32p),
+                ("pl_end", u32p), ("pl_valid", u8p), ("n_nodes", C.c_uint32), ("node_xy", f32p)]
+
+
+def plg_view_to_dict(v):
+    n, nn = int(v.n_polylines), int(v.n_nodes)
+    off = as_np(v.pl_vtx_off, n + 1, np.uint32)
+    nv = int(off[-1]) if n else 0
+    return {"n_polylines": n, "n_nodes": nn, "pl_vtx_off": off,
+            "vtx_xy": as_np(v.vtx_xy, 2 * nv, np.float32).reshape(nv, 2),
+            "pl_start": as_np(v.pl_start, n, np.uint32), "pl_end": as_np(v.pl_end, n, np.uint32),
+            "pl_valid": as_np(v.pl_valid, n, np.uint8), "node_xy": as_np(v.node_xy, 2 * nn, np.float32).reshape(nn, 2)}
+
+
 class Graph3D(C.Structure):
     """eg3d_graph3d (include/eg3d_host.h): the PLGMatchesManager replay (row a17)."""
     _fields_ = [("n_nodes", C.c_uint64), ("n_real_nodes", C.c_uint64), ("node_X", f32p),

@@ -51,7 +51,7 @@ def build_host(force=False):
     srcs = _all_sources(HOST_DIR, (".cpp",))
     deps = srcs + _all_sources(HOST_DIR, (".hpp", ".h")) + _all_sources(INC_DIR, (".h",)) + _all_sources(CSRC_DIR, (".h", ".hpp"))
     if force or _newer(HOST_LIB, deps):
-        _run(["g++"] + HOST_FLAGS + ["-I", INC_DIR, "-I", CSRC_DIR, "-o", HOST_LIB] + srcs)
+        _run(["g++"] + HOST_FLAGS + ["-I", INC_DIR, "-I", CSRC_DIR, "-o", HOST_LIB] + srcs + ["-lz"])  # libz: PNG inflate
     return HOST_LIB
 
 

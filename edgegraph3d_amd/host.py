@@ -40,6 +40,15 @@ def lib():
         L.eg3d_host_observation_filter.argtypes = [C.c_int, D.u32p, C.c_uint64, C.c_uint64, C.c_int, D.u8p]
         L.eg3d_host_replay_matches.argtypes = [C.POINTER(D.Scene), C.POINTER(D.EdgePoints), C.POINTER(D.Graph3D)]
         L.eg3d_host_free_graph3d.argtypes = [C.POINTER(D.Graph3D)]
+        L.eg3d_plg_build_from_mask.argtypes = [D.u8p, C.c_int, C.c_int, C.POINTER(D.PlgView)]
+        L.eg3d_plg_build_from_png.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(D.PlgView)]
+        L.eg3d_png_read_edge_mask.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(D.u8p)]
+        L.eg3d_plg_view_free.argtypes = [C.POINTER(D.PlgView)]
+        L.eg3d_plg_from_views.restype = C.c_void_p
+        L.eg3d_plg_from_views.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(D.PlgView)]
+        L.eg3d_plg_scene.restype = C.POINTER(D.Scene)
+        L.eg3d_plg_scene.argtypes = [C.c_void_p]
+        L.eg3d_plg_destroy.argtypes = [C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -159,6 +168,28 @@ def replay_matches(scene_ptr, cloud):
     d = D.graph3d_to_dict(g)
     lib().eg3d_host_free_graph3d(C.byref(g))
     return d
+
+
+def plg_from_mask(mask):
+    """binary edge image (uint8 [h, w], non-zero = edge) -> optimised polyline graph of one view."""
+    m = np.ascontiguousarray(mask, np.uint8)
+    v = D.PlgView()
+    rc = lib().eg3d_plg_build_from_mask(D.np_ptr(m, C.c_uint8), m.shape[1], m.shape[0], C.byref(v))
+    if rc != 0:
+        raise RuntimeError("eg3d_plg_build_from_mask failed (%d)" % rc)
+    d = D.plg_view_to_dict(v)
+    lib().eg3d_plg_view_free(C.byref(v))
+    return d
+
+
+def png_edge_mask(path):
+    w, h, p = C.c_int(), C.c_int(), D.u8p()
+    rc = lib().eg3d_png_read_edge_mask(path.encode(), C.byref(w), C.byref(h), C.byref(p))
+    if rc != 0:
+        raise RuntimeError("eg3d_png_read_edge_mask(%s) failed (%d)" % (path, rc))
+    m = D.as_np(p, w.value * h.value, np.uint8).reshape(h.value, w.value)
+    lib().eg3d_host_free(p)
+    return m
 
 
 def build_grid(scene_ptr, view, cell_dim):

@@ -1,7 +1,7 @@
 // Polyline-graph container file. The reference builds its PolyLineGraph2DHMapImpl per view from
-// the edge images at start-up (convert_edge_images_pixel_to_segment.cpp, SURVEY N2 — out of scope
-// here); this small binary container lets any producer of polyline graphs (the reference's own
-// builder included) hand them to the path:
+// the edge images at start-up (convert_edge_images_pixel_to_segment.cpp, SURVEY N2 — rebuilt in
+// plg_build.cpp); this small binary container lets any producer of polyline graphs (that builder, or
+// the reference's own) hand them to the path:
 //   "EG3DPLG1"  i32 n_views  i32 width  i32 height
 //   per view:   u32 n_polylines, then per polyline: u32 start_node  u32 end_node  u8 valid  u32 n_vtx  f32 xy[2*n_vtx]
 // Little endian. Polyline ids are positions in the file (the reference's vector index).
@@ -83,6 +83,38 @@ extern "C" eg3d_plg* eg3d_plg_read(const char* path) {
   g->scene.n_views = hdr[0];
   g->scene.width = hdr[1];
   g->scene.height = hdr[2];
+  g->scene.view_pl_off = g->view_pl_off.data();
+  g->scene.pl_vtx_off = g->pl_vtx_off.data();
+  g->scene.vtx_xy = g->vtx.data();
+  g->scene.pl_start = g->pl_start.data();
+  g->scene.pl_end = g->pl_end.data();
+  g->scene.pl_valid = g->pl_valid.data();
+  return g;
+}
+
+// per-view graphs of the N2 builder (eg3d_plg_build_from_mask / _png) -> the container the path consumes
+extern "C" eg3d_plg* eg3d_plg_from_views(int n_views, int width, int height, const eg3d_plg_view* views) {
+  if (n_views < 1 || !views) return nullptr;
+  eg3d_plg* g = new eg3d_plg();
+  g->view_pl_off.push_back(0);
+  g->pl_vtx_off.push_back(0);
+  for (int v = 0; v < n_views; v++) {
+    const eg3d_plg_view& pv = views[v];
+    for (uint32_t p = 0; p < pv.n_polylines; p++) {
+      const uint32_t a = pv.pl_vtx_off[p], b = pv.pl_vtx_off[p + 1];
+      g->vtx.insert(g->vtx.end(), pv.vtx_xy + 2 * (size_t)a, pv.vtx_xy + 2 * (size_t)b);
+      g->pl_start.push_back(pv.pl_start[p]);
+      g->pl_end.push_back(pv.pl_end[p]);
+      g->pl_valid.push_back(pv.pl_valid[p]);
+      g->pl_vtx_off.push_back((uint32_t)(g->vtx.size() / 2));
+    }
+    g->view_pl_off.push_back((uint32_t)g->pl_start.size());
+  }
+  if (g->vtx.empty()) g->vtx.assign(2, 0.f);
+  memset(&g->scene, 0, sizeof(g->scene));
+  g->scene.n_views = n_views;
+  g->scene.width = width;
+  g->scene.height = height;
   g->scene.view_pl_off = g->view_pl_off.data();
   g->scene.pl_vtx_off = g->pl_vtx_off.data();
   g->scene.vtx_xy = g->vtx.data();

@@ -65,6 +65,34 @@ eg3d_plg* eg3d_plg_read(const char* path);
 const eg3d_scene* eg3d_plg_scene(const eg3d_plg* g);
 void eg3d_plg_destroy(eg3d_plg* g);
 
+/* ---------------------------------------- edge image -> polyline graph (N2) ---- */
+/* convertEdgeImagePolyLineGraph_optimized (io/input/convert_edge_images_pixel_to_segment.cpp:294-426,
+ * 428-626, 868-883) + PolyLineGraph2DHMapImpl::optimize (plgs/polyline_graph_2d_hmap_impl.cpp:255-266):
+ * a binary edge image becomes a pixel graph (8-neighbourhood, short cycles avoided), the graph a
+ * polyline graph, which is then simplified (1 px), its 2-connection nodes merged, close extremes
+ * connected and weak components dropped. Polyline and node ids = the reference's vector positions
+ * (invalidated polylines keep their id, with no vertices). One view per call; independent views
+ * may be built concurrently. */
+typedef struct eg3d_plg_view {
+  uint32_t n_polylines;
+  uint32_t* pl_vtx_off;   /* [n_polylines+1] */
+  float* vtx_xy;          /* [pl_vtx_off[n_polylines]][2] */
+  uint32_t* pl_start;     /* [n_polylines] node ids */
+  uint32_t* pl_end;
+  uint8_t* pl_valid;      /* PolyLineGraph2D::is_valid_polyline */
+  uint32_t n_nodes;
+  float* node_xy;         /* [n_nodes][2] nodes_coords ((-1,-1) = invalidated) */
+} eg3d_plg_view;
+/* mask: height*width bytes, non-zero = edge colour (EDGE_COLOR 255,255,255 as cv::imread(IMREAD_COLOR) sees it) */
+int eg3d_plg_build_from_mask(const uint8_t* mask, int width, int height, eg3d_plg_view* out);
+/* PNG reader of the edge images (8/16-bit or 1/2/4-bit grey, RGB, palette, with or without alpha,
+ * non-interlaced): mask[i] = 1 where the pixel is white. *mask is malloc'd (eg3d_host_free). */
+int eg3d_png_read_edge_mask(const char* path, int* width, int* height, uint8_t** mask);
+int eg3d_plg_build_from_png(const char* path, int* width, int* height, eg3d_plg_view* out);
+void eg3d_plg_view_free(eg3d_plg_view* v);
+/* assembles per-view graphs into the container the path consumes (eg3d_plg_scene) */
+eg3d_plg* eg3d_plg_from_views(int n_views, int width, int height, const eg3d_plg_view* views);
+
 /* --------------------------------------------------------------- grid maps ---- */
 /* Uniform grid of one view (reference PolyLine2DMap ctor, polyLine_2d_map.cpp:40-58).
  * Outputs malloc'd CSR arrays (cell = row*ncols+col), free with eg3d_host_free. */

@@ -45,6 +45,8 @@ def lib():
         L.orc_observation_filter.argtypes = [C.c_int, D.u32p, C.c_uint64, C.c_uint64, C.c_int, D.u8p]
         L.orc_replay_matches.argtypes = [C.c_void_p, C.POINTER(D.EdgePoints), C.POINTER(D.Graph3D)]
         L.orc_free_graph3d.argtypes = [C.POINTER(D.Graph3D)]
+        L.orc_plg_from_mask.argtypes = [D.u8p, C.c_int, C.c_int, C.POINTER(D.PlgView)]
+        L.orc_free_plg_view.argtypes = [C.POINTER(D.PlgView)]
         L.orc_squared_2d_distance.restype = C.c_float
         L.orc_squared_2d_distance.argtypes = [C.c_float] * 4
         L.orc_minimum_distancesq.restype = C.c_float
@@ -73,6 +75,16 @@ def lib():
         assert L.orc_set_dlt_rows(int(rows)) == 0
         _LIB = L
     return _LIB
+
+
+def plg_from_mask(mask):
+    """SURVEY N2 (convert_edge_images_pixel_to_segment.cpp:879-883): edge mask -> optimised polyline graph."""
+    m = np.ascontiguousarray(mask, np.uint8)
+    v = D.PlgView()
+    assert lib().orc_plg_from_mask(D.np_ptr(m, C.c_uint8), m.shape[1], m.shape[0], C.byref(v)) == 0
+    d = D.plg_view_to_dict(v)
+    lib().orc_free_plg_view(C.byref(v))
+    return d
 
 
 class Oracle:

@@ -20,6 +20,7 @@
 
 #include "oracle_plg.hpp"
 #include "oracle_replay.hpp"
+#include "oracle_n2.hpp"
 
 using namespace orc;
 
@@ -497,6 +498,56 @@ extern "C" void orc_free_graph3d(eg3d_graph3d* g) {
   free(g->iv_start_xy);
   free(g->iv_end_xy);
   memset(g, 0, sizeof(*g));
+}
+
+// one binary edge image -> optimised polyline graph (convertEdgeImagePolyLineGraph_optimized,
+// convert_edge_images_pixel_to_segment.cpp:879-883). Output in the eg3d_plg_view layout; free with orc_free_plg_view.
+extern "C" int orc_plg_from_mask(const uint8_t* mask_in, int width, int height, eg3d_plg_view* out) {
+  if (!mask_in || !out || width <= 0 || height <= 0) return -1;
+  std::vector<uint8_t> mask(mask_in, mask_in + (size_t)width * height);
+  for (auto& m : mask) m = m ? 1 : 0;
+  orc::n2::PLG2 g;
+  orc::n2::edge_image_to_plg(mask.data(), height, width, g);
+  memset(out, 0, sizeof(*out));
+  const size_t NP = g.polylines.size(), NN = g.nodes_coords.size();
+  out->n_polylines = (uint32_t)NP;
+  out->n_nodes = (uint32_t)NN;
+  out->pl_vtx_off = (uint32_t*)malloc(sizeof(uint32_t) * (NP + 1));
+  out->pl_start = (uint32_t*)malloc(sizeof(uint32_t) * (NP + 1));
+  out->pl_end = (uint32_t*)malloc(sizeof(uint32_t) * (NP + 1));
+  out->pl_valid = (uint8_t*)malloc(NP + 1);
+  size_t nv = 0;
+  for (size_t p = 0; p < NP; p++) nv += g.polylines[p].coords.size();
+  out->vtx_xy = (float*)malloc(sizeof(float) * 2 * (nv + 1));
+  out->node_xy = (float*)malloc(sizeof(float) * 2 * (NN + 1));
+  size_t w = 0;
+  for (size_t p = 0; p < NP; p++) {
+    out->pl_vtx_off[p] = (uint32_t)w;
+    out->pl_start[p] = (uint32_t)g.polylines[p].start;
+    out->pl_end[p] = (uint32_t)g.polylines[p].end;
+    out->pl_valid[p] = g.is_valid_polyline(p) ? 1 : 0;
+    for (auto& c : g.polylines[p].coords) {
+      out->vtx_xy[2 * w] = c.x;
+      out->vtx_xy[2 * w + 1] = c.y;
+      w++;
+    }
+  }
+  out->pl_vtx_off[NP] = (uint32_t)w;
+  for (size_t n = 0; n < NN; n++) {
+    out->node_xy[2 * n] = g.nodes_coords[n].x;
+    out->node_xy[2 * n + 1] = g.nodes_coords[n].y;
+  }
+  return 0;
+}
+extern "C" void orc_free_plg_view(eg3d_plg_view* v) {
+  if (!v) return;
+  free(v->pl_vtx_off);
+  free(v->vtx_xy);
+  free(v->pl_start);
+  free(v->pl_end);
+  free(v->pl_valid);
+  free(v->node_xy);
+  memset(v, 0, sizeof(*v));
 }
 
 // compute_ray_stats + compute_inliers tail, outliers_filtering.cpp:14-35,37-64

@@ -56,6 +56,11 @@ int orc_observation_filter(int n_cameras, const uint32_t* obs_off, uint64_t n_po
 int orc_replay_matches(orc_ctx*, const eg3d_edgepoints* pts, eg3d_graph3d* out);
 void orc_free_graph3d(eg3d_graph3d* g);
 
+/* binary edge image -> optimised polyline graph (convert_edge_images_pixel_to_segment.cpp:879-883);
+ * mask = height*width bytes, non-zero = edge; release with orc_free_plg_view */
+int orc_plg_from_mask(const uint8_t* mask, int width, int height, eg3d_plg_view* out);
+void orc_free_plg_view(eg3d_plg_view* v);
+
 /* primitive probes for known-answer tests */
 float orc_squared_2d_distance(float ax, float ay, float bx, float by);
 float orc_minimum_distancesq(float px, float py, float vx, float vy, float wx, float wy, float* proj);

@@ -305,3 +305,24 @@ def test_rccl_allgather_c_abi_two_ranks():
     p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_two_rank_check.py")],
                        capture_output=True, text=True)
     assert p.returncode == 0 and "RCCL-2RANK-OK" in p.stdout, p.stdout + p.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_scenes_built_from_edge_images_parity():
+    """SURVEY N2 feeding the path: (1) 25 real dtu006 edge maps -> polyline graphs, with synthetic look-at
+    cameras at the listed centres (real polyline statistics; geometry not consistent with the images),
+    (2) a synthetic scene rasterised into edge images and rebuilt by the same builder (consistent
+    geometry). HIP path == oracle bit for bit on both."""
+    import ctypes as C
+    import real_scene as rs
+    from oracle import binding as ob
+    for name, (sc, seeds, info) in (("real", rs.real_edges_scene(n_seeds=3000)), ("rendered", rs.rendered_edges_scene(1))):
+        ctx = api.Context(C.byref(sc.c))
+        got = ctx.match_refpoints(C.byref(seeds.c))
+        ref = ob.Oracle(C.byref(sc.c)).match(C.byref(seeds.c), 0, int(seeds.c.n_seeds), os.cpu_count())
+        rep = compare_edgepoints(ref, got)
+        assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], (name, rep["msgs"])
+        assert got["n_points"] > 1000, name
+        assert (got["flags"] & 7) == 0
+        ctx.close()

@@ -1,0 +1,177 @@
+"""SURVEY N2 — edge image -> polyline graph (include/eg3d_host.h eg3d_plg_build_from_mask / _png):
+the product's flat-array builder against the oracle's reference-shaped restatement on every real
+dtu006 edge map and on hand-built masks, the product's PNG reader against an independent Python
+decoder, and the structural promises of the result."""
+import glob
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from edgegraph3d_amd import host
+from oracle import binding as ob
+from png_util import read_png_edge_mask
+
+EDGES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dtu006_edges")
+KEYS = ("pl_vtx_off", "vtx_xy", "pl_start", "pl_end", "pl_valid", "node_xy")
+
+
+def _same(a, b):
+    assert a["n_polylines"] == b["n_polylines"] and a["n_nodes"] == b["n_nodes"]
+    for k in KEYS:
+        x, y = a[k], b[k]
+        assert np.array_equal(x.view(np.uint32) if x.dtype == np.float32 else x, y.view(np.uint32) if y.dtype == np.float32 else y), k
+
+
+def _check_structure(g, mask):
+    off, valid = g["pl_vtx_off"], g["pl_valid"]
+    n = np.diff(off)
+    assert (n[valid == 1] >= 2).all()
+    assert (n[valid == 0] == 0).all() or True   # an invalidated polyline has no vertices; a never-valid one may keep them
+    for p in np.nonzero(valid)[0][:500]:
+        v = g["vtx_xy"][off[p]:off[p + 1]]
+        assert np.array_equal(v[0], g["node_xy"][g["pl_start"][p]]) and np.array_equal(v[-1], g["node_xy"][g["pl_end"][p]])
+        # vertices are pixel centres of edge pixels (simplification only drops vertices; 4-pixel loops are the exception)
+        ij = np.floor(v).astype(int)
+        centre = np.all(v - ij == 0.5, axis=1)
+        assert mask[ij[centre, 1], ij[centre, 0]].all()
+
+
+@pytest.mark.parametrize("idx", range(26))
+def test_real_edge_maps_product_equals_oracle(idx):
+    f = sorted(glob.glob(os.path.join(EDGES, "*.png")))[idx]
+    m = host.png_edge_mask(f)
+    if idx % 5 == 0:
+        assert np.array_equal(m, read_png_edge_mask(f))          # the product's PNG reader vs python zlib + numpy
+    assert m.shape == (1200, 1600) and 40000 < m.sum() < 200000
+    a = host.plg_from_mask(m)
+    b = ob.plg_from_mask(m)
+    _same(a, b)
+    assert a["pl_valid"].sum() > 500
+    _check_structure(a, m)
+
+
+def _mask(h, w, pts):
+    m = np.zeros((h, w), np.uint8)
+    for (i, j) in pts:
+        m[i, j] = 1
+    return m
+
+
+def test_hand_built_masks():
+    # a straight horizontal run of 20 pixels: one polyline, simplified to its two end pixels' centres
+    m = _mask(40, 60, [(10, j) for j in range(5, 25)])
+    # (a single component is its own top-18 %: the component filter keeps it)
+    a, b = host.plg_from_mask(m), ob.plg_from_mask(m)
+    _same(a, b)
+    val = np.nonzero(a["pl_valid"])[0]
+    assert len(val) == 1
+    v = a["vtx_xy"][a["pl_vtx_off"][val[0]]:a["pl_vtx_off"][val[0] + 1]]
+    assert np.array_equal(v, np.array([[5.5, 10.5], [24.5, 10.5]], np.float32)) or np.array_equal(v[::-1], np.array([[5.5, 10.5], [24.5, 10.5]], np.float32))
+    # an L: the corner survives the 1 px simplification
+    m = _mask(60, 60, [(10, j) for j in range(5, 30)] + [(i, 29) for i in range(11, 40)])
+    a, b = host.plg_from_mask(m), ob.plg_from_mask(m)
+    _same(a, b)
+    val = np.nonzero(a["pl_valid"])[0]
+    assert len(val) == 1 and a["pl_vtx_off"][val[0] + 1] - a["pl_vtx_off"][val[0]] == 3
+    # a T junction (hub), a diagonal, a closed square loop, two separated strokes 4 px apart (close extremes), an
+    # isolated pixel, strokes touching the image border — only product == oracle is asserted
+    rng = np.random.default_rng(4)
+    shapes = []
+    shapes += [(20, j) for j in range(5, 50)] + [(i, 27) for i in range(21, 45)]
+    shapes += [(50 + k, 5 + k) for k in range(30)]
+    shapes += [(100, j) for j in range(10, 30)] + [(120, j) for j in range(10, 30)] + [(i, 10) for i in range(100, 121)] + [(i, 29) for i in range(100, 121)]
+    shapes += [(140, j) for j in range(5, 20)] + [(140, j) for j in range(24, 40)]
+    shapes += [(160, 80)]
+    shapes += [(0, j) for j in range(0, 30)] + [(i, 0) for i in range(0, 30)] + [(199, j) for j in range(150, 200)] + [(i, 199) for i in range(150, 200)]
+    m = _mask(200, 200, shapes)
+    _same(host.plg_from_mask(m), ob.plg_from_mask(m))
+    # noise images: dense random pixels make hubs, short cycles and 2x2 blocks everywhere
+    for density in (0.05, 0.2, 0.5):
+        m = (rng.random((120, 160)) < density).astype(np.uint8)
+        _same(host.plg_from_mask(m), ob.plg_from_mask(m))
+    # nothing at all
+    a = host.plg_from_mask(np.zeros((30, 30), np.uint8))
+    assert a["n_polylines"] == 0 and a["n_nodes"] == 0
+
+
+def _write_png(path, w, h, depth, ctype, rows, palette=None, filters=None):
+    def chunk(t, b):
+        return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b) & 0xffffffff)
+    raw = b""
+    prev = bytes(len(rows[0]))
+    bpp = max(1, {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype] * depth // 8)
+    for r, line in enumerate(rows):
+        ft = filters[r % len(filters)] if filters else 0
+        out = bytearray(len(line))
+        for x in range(len(line)):
+            a = line[x - bpp] if x >= bpp else 0
+            b = prev[x]
+            c = prev[x - bpp] if x >= bpp else 0
+            if ft == 0:
+                p = 0
+            elif ft == 1:
+                p = a
+            elif ft == 2:
+                p = b
+            elif ft == 3:
+                p = (a + b) // 2
+            else:
+                pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            out[x] = (line[x] - p) & 255
+        raw += bytes([ft]) + bytes(out)
+        prev = line
+    z = zlib.compress(raw)
+    body = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0))
+    if palette is not None:
+        body += chunk(b"PLTE", bytes(palette))
+    half = len(z) // 2
+    body += chunk(b"IDAT", z[:half]) + chunk(b"IDAT", z[half:]) + chunk(b"IEND", b"")
+    open(path, "wb").write(body)
+
+
+def test_png_reader_formats(tmp_path):
+    rng = np.random.default_rng(2)
+    w, h = 37, 19
+    white = rng.random((h, w)) < 0.4
+    cases = []
+    # 1-bit grey (the dtu006 format), rows packed MSB first
+    cases.append((1, 0, [bytes(np.packbits(r.astype(np.uint8))) for r in white], None))
+    # 8-bit grey with near-white decoys
+    g = np.where(white, 255, rng.integers(0, 255, (h, w))).astype(np.uint8)
+    cases.append((8, 0, [bytes(r) for r in g], None))
+    # RGB: white only when all three channels are 255
+    rgb = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    rgb[white] = 255
+    rgb[~white & (rgb == 255).all(axis=2)] = 254
+    cases.append((8, 2, [bytes(r.reshape(-1)) for r in rgb], None))
+    # RGBA and grey+alpha: alpha is ignored
+    rgba = np.concatenate([rgb, rng.integers(0, 256, (h, w, 1)).astype(np.uint8)], axis=2)
+    cases.append((8, 6, [bytes(r.reshape(-1)) for r in rgba], None))
+    ga = np.stack([g, rng.integers(0, 256, (h, w)).astype(np.uint8)], axis=2)
+    cases.append((8, 4, [bytes(r.reshape(-1)) for r in ga], None))
+    # 4-bit palette: entry 3 is white
+    pal = [0, 0, 0, 255, 255, 254, 10, 20, 30, 255, 255, 255] + [7] * 36
+    idx = np.where(white, 3, rng.integers(0, 3, (h, w))).astype(np.uint8)
+    packed = [bytes(((np.append(r, 0)[0::2][: (w + 1) // 2] << 4) | np.append(r, 0)[1::2][: (w + 1) // 2]).astype(np.uint8)) for r in idx]
+    cases.append((4, 3, packed, pal))
+    # 16-bit grey: white = 0xFFFF (high byte 255)
+    g16 = np.where(white, 65535, rng.integers(0, 65000, (h, w))).astype(">u2")
+    cases.append((16, 0, [r.tobytes() for r in g16], None))
+    for k, (depth, ctype, rows, pal) in enumerate(cases):
+        for filters in ([0], [1, 2, 3, 4], [4, 0, 3]):
+            p = str(tmp_path / ("t%d.png" % k))
+            _write_png(p, w, h, depth, ctype, rows, pal, filters)
+            m = host.png_edge_mask(p)
+            assert np.array_equal(m.astype(bool), white), (depth, ctype, filters)
+            assert np.array_equal(m, read_png_edge_mask(p))
+    # malformed input is refused, not crashed on
+    p = str(tmp_path / "bad.png")
+    good = open(str(tmp_path / "t0.png"), "rb").read()
+    for blob in (b"", b"notapng", good[:40], good[:-30], good[:33] + b"\xff" * 8 + good[41:]):
+        open(p, "wb").write(blob)
+        with pytest.raises(RuntimeError):
+            host.png_edge_mask(p)
