@@ -319,7 +319,7 @@ def test_scenes_built_from_edge_images_parity():
     from oracle import binding as ob
     for name, (sc, seeds, info) in (("real", rs.real_edges_scene(n_seeds=3000)), ("rendered", rs.rendered_edges_scene(1))):
         ctx = api.Context(C.byref(sc.c))
-        got = ctx.match_refpoints(C.byref(seeds.c))
+        got = ctx.match_refpoints(C.byref(seeds.c), 0, int(seeds.c.n_seeds))
         ref = ob.Oracle(C.byref(sc.c)).match(C.byref(seeds.c), 0, int(seeds.c.n_seeds), os.cpu_count())
         rep = compare_edgepoints(ref, got)
         assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], (name, rep["msgs"])
