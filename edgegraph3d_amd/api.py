@@ -125,6 +125,19 @@ class Context:
         d["times"] = {f[0]: getattr(tm, f[0]) for f in D.StageTimes._fields_}
         return d
 
+    def time_match_to_host(self, begin, end):
+        """Wall seconds of ONE eg3d_match_resident(..., device_only=0) call at the C ABI (kernels + D2H of the
+        cloud into caller-owned arrays), without this wrapper's conversion to numpy; returns (seconds, n_points)."""
+        import time
+        e, tm = D.EdgePoints(), D.StageTimes()
+        t0 = time.perf_counter()
+        rc = lib().eg3d_match_resident(self._h, begin, end, 0, C.byref(e), C.byref(tm))
+        dt = time.perf_counter() - t0
+        _check(rc, "eg3d_match_resident")
+        n = int(e.n_points)
+        lib().eg3d_free_edgepoints(C.byref(e))
+        return dt, n
+
     def match_refpoints(self, seeds_ptr, begin=0, end=None, device_only=False):
         if end is None:
             end = int(seeds_ptr.contents.n_seeds) if hasattr(seeds_ptr, "contents") else int(seeds_ptr.n_seeds)
