@@ -86,6 +86,9 @@ def main():
     ap.add_argument("--seeds", type=int, default=0, help="override the workload's seed count (experiments only)")
     ap.add_argument("--batch-seeds", type=int, default=0, help="seeds per step (default: all; c4: %d)" % C4_BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed side measurements (one step at a time, end to end): profiling passes want "
+                         "exactly max(warmup, inflight) + steps passes of the hot path in the process")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the RCCL all-gather of the cloud even with one rank (exercises the N>1 code path)")
     ap.add_argument("--inflight", type=int, default=4,
@@ -240,7 +243,7 @@ def main():
     # the same steps strictly one at a time, and end to end (with the D2H copy of the cloud): untimed
     # side measurements reported beside the value
     single = e2e = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_extras:
         ns = max(3, min(10, args.steps))
         torch.cuda.synchronize()
         ts = time.perf_counter()

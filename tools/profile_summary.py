@@ -49,6 +49,15 @@ def counter_stats(path):
     return {k: {c: (sum(v) / len(v), len(v)) for c, v in d.items()} for k, d in agg.items()}
 
 
+def counter_sums(path):
+    db = sqlite3.connect(path)
+    rows = db.execute("select kernel_name, counter_name, value from counters_collection").fetchall()
+    agg = defaultdict(lambda: defaultdict(float))
+    for n, c, v in rows:
+        agg[short(n)][c] += v
+    return agg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tag", required=True)
@@ -58,6 +67,11 @@ def main():
     ap.add_argument("--sq", nargs="*")
     ap.add_argument("--cmd", default="python bench.py --steps 20 --warmup 3 --no-cpu-baseline")
     ap.add_argument("--out", default="profiles")
+    ap.add_argument("--workload", default=None, help="key under which the traffic is stored in pmc_traffic.json (c2, c3, c4, ...)")
+    ap.add_argument("--pmc-steps", type=int, default=0,
+                    help="hot-path passes executed by the PMC runs (max(warmup, inflight) + steps with --no-extras): "
+                         "traffic per step = sum over the launches / this")
+    ap.add_argument("--pmc-cmd", default="")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     lines = []
@@ -87,7 +101,23 @@ def main():
             f, w = d.get("FETCH_SIZE", 0.0), d.get("WRITE_SIZE", 0.0)
             out[k] = {"fetch_bytes_raw": f, "write_bytes_raw": w, "hbm_bytes_per_launch": 2.0 * f + w,
                       "note": "FETCH_SIZE x2 (gfx950 wide-read correction, upper bound) + WRITE_SIZE"}
-        json.dump(out, open(os.path.join(a.out, "pmc_traffic.json"), "w"), indent=1)
+        if a.workload and a.pmc_steps and a.fetch and a.write:
+            fs, ws = counter_sums(a.fetch), counter_sums(a.write)
+            for k in out:
+                tot = 2.0 * fs.get(k, {}).get("FETCH_SIZE", 0.0) * 1024.0 + ws.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0
+                out[k]["hbm_bytes_per_step"] = tot / a.pmc_steps
+            path = os.path.join(a.out, "pmc_traffic.json")
+            allw = json.load(open(path)) if os.path.exists(path) else {}
+            if not isinstance(allw, dict) or any(isinstance(v, dict) and "hbm_bytes_per_launch" in v for v in allw.values()):
+                allw = {}  # round-1 layout (one flat workload): start over
+            ent = dict(out)
+            ent["provenance"] = ("profiles/%s_rocprof_summary.txt: separate rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE "
+                                 "passes of `%s` (%d passes of the hot path each); bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> B), "
+                                 "summed over the kernel's launches / passes" % (a.tag, a.pmc_cmd, a.pmc_steps))
+            allw[a.workload] = ent
+            json.dump(allw, open(path, "w"), indent=1)
+        else:
+            json.dump(out, open(os.path.join(a.out, "pmc_traffic.json"), "w"), indent=1)
         lines.append("")
         lines.append("# HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (guide's gfx950 correction; upper bound)")
         for k, d in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:8]:
