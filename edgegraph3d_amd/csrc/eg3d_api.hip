@@ -205,6 +205,15 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
     g_err = "eg3d_create: device index out of range";
     return EG3D_ERR_ARG;
   }
+  if (sc->n_views > EG3D_MAX_VIEWS) {
+    g_err = "eg3d_create: more than " + std::to_string(EG3D_MAX_VIEWS) + " views";
+    return EG3D_ERR_CAPACITY;
+  }
+  for (int v = 0; v < sc->n_views; v++)
+    if (sc->view_pl_off[v + 1] - sc->view_pl_off[v] > (uint32_t)EG3D_MAX_POLYLINES_PER_VIEW) {
+      g_err = "eg3d_create: a view has more than " + std::to_string(EG3D_MAX_POLYLINES_PER_VIEW) + " polylines";
+      return EG3D_ERR_CAPACITY;
+    }
   HIP_TRY(hipSetDevice(device));
   eg3d_ctx* c = new eg3d_ctx();
   c->device = device;

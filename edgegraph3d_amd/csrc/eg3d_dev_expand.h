@@ -709,12 +709,18 @@ EG3D_HD bool unique_polyline_4px(const DevScene& s, int view, float x, float y, 
   return have;
 }
 
-#ifndef EG3D_LAZY_PRESOLVE
-#define EG3D_LAZY_PRESOLVE 0 /* 1: central pre-solves a window at a time as the visit reaches them */
+// The speculative central ADD solves of a view's candidates: all chain points at once after the
+// candidate pass ("eager": one big batch, ~1/4 of the solves end up used), or a window of
+// EG3D_SPEC_WINDOW points at a time as the visit reaches them ("lazy"). Eager wins where the solves
+// are short (C2, C3': 8 / 25 views), lazy where points carry dozens of observations and a wasted solve
+// is expensive (C4, 200 views: K3b -9 %). Chosen per scene by the number of views.
+#ifndef EG3D_LAZY_PRESOLVE_MIN_VIEWS
+#define EG3D_LAZY_PRESOLVE_MIN_VIEWS 64
 #endif
 #ifndef EG3D_SPEC_WINDOW
 #define EG3D_SPEC_WINDOW 8
 #endif
+EG3D_HD bool lazy_presolve(const DevScene& s) { return s.n_views >= EG3D_LAZY_PRESOLVE_MIN_VIEWS; }
 // speculative central ADD solve of the chain points [from, to) whose candidate is within 4 px
 template <class Team>
 EG3D_HD_FLAT void central_presolves(const Team& tm, const DevScene& s, Chain& c, int v, int from, int to) {
@@ -802,9 +808,7 @@ EG3D_HD_FLAT void view_candidates(const Team& tm, const DevScene& s, Chain& c, i
     }
   }
   tm.sync();
-#if !EG3D_LAZY_PRESOLVE
-  central_presolves(tm, s, c, v, from, c.len);
-#endif
+  if (!lazy_presolve(s)) central_presolves(tm, s, c, v, from, c.len);
   c.tsec[0] += EG3D_TICK() - tc0;
 }
 
@@ -862,9 +866,7 @@ EG3D_HD_FLAT void expand_to_view(const Team& tm, const DevScene& s, Chain& c, in
   }
   int last_matched = -1;
   view_candidates(tm, s, c, v, 0);
-#if EG3D_LAZY_PRESOLVE
-  int spec_slot_hi = 0;  // pre-solves exist for the visited slots below this one
-#endif
+  int spec_slot_hi = 0;  // lazy mode: pre-solves exist for the visited slots below this one
   for (int cur = 0; cur < c.len; cur++) {
     if (epc_matched && cur == idx_first) {
       cur = idx_second;
@@ -875,14 +877,12 @@ EG3D_HD_FLAT void expand_to_view(const Team& tm, const DevScene& s, Chain& c, in
     if (!vc.valid) continue;
     c.bytes += 8ull * (s.pl_vtx_off[s.view_pl_off[v] + vc.pl + 1] - s.pl_vtx_off[s.view_pl_off[v] + vc.pl]);
     if (vc.d2 > 16.0f) return;  // abandons this view (Q4)
-#if EG3D_LAZY_PRESOLVE
-    if (c.head + cur >= spec_slot_hi) {
+    if (lazy_presolve(s) && c.head + cur >= spec_slot_hi) {
       int to = cur + EG3D_SPEC_WINDOW;
       if (to > c.len) to = c.len;
       central_presolves(tm, s, c, v, cur, to);
       spec_slot_hi = c.head + to;
     }
-#endif
     Obs o;
     o.view = v;
     o.pl = vc.pl;

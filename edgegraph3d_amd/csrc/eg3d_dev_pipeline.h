@@ -178,12 +178,12 @@ EG3D_HD bool select_task(const HypResult* res, uint32_t h0, uint32_t h1, ChainSe
   return true;
 }
 
-// Scratch slice layout of one chain (bytes); all sub-arrays 8-byte aligned.
+// Scratch slice layout of one chain (bytes); all sub-arrays 16-byte aligned (Obs is one 128-bit word).
 struct ChainLayout {
   uint32_t cap_pts, pool_cap, tmp_cap, n_views;
   size_t off_pts, off_pool, off_sdir, off_edir, off_p1, off_p2, off_cand, off_slots, off_epc, off_ta, off_tb, off_tm, total;
 };
-EG3D_HD size_t align8(size_t v) { return (v + 7) & ~(size_t)7; }
+EG3D_HD size_t align8(size_t v) { return (v + 15) & ~(size_t)15; }  // (name kept: 16-byte alignment)
 EG3D_HD ChainLayout chain_layout(uint32_t cap_pts, uint32_t pool_cap, uint32_t n_views) {
   ChainLayout L;
   L.cap_pts = cap_pts;

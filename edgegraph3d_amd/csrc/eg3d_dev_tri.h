@@ -14,12 +14,21 @@
 
 namespace eg3d {
 
-struct Obs {
-  int32_t view;
-  uint32_t pl;
+// One observation of an edge-point: 16 bytes, so that a lane fetches it with ONE 128-bit load (it was
+// 20: five dword loads, and a fifth more HBM traffic wherever chains do not fit the caches — the
+// expand stage of the 200-view scenes moves ~1 TB per 2048 seeds). View id and polyline id share a
+// word: scenes are limited to EG3D_MAX_VIEWS views and EG3D_MAX_POLYLINES_PER_VIEW polylines per view,
+// checked by eg3d_create. (Bit-fields: `o.view`, `o.pl` read and assign as before.)
+#define EG3D_VIEW_BITS 13
+#define EG3D_MAX_VIEWS (1 << EG3D_VIEW_BITS)
+#define EG3D_MAX_POLYLINES_PER_VIEW (1 << (32 - EG3D_VIEW_BITS))
+struct alignas(16) Obs {
+  uint32_t view : EG3D_VIEW_BITS;
+  uint32_t pl : 32 - EG3D_VIEW_BITS;
   uint32_t seg;
   float x, y;
 };
+static_assert(sizeof(Obs) == 16, "Obs must be one 128-bit word");
 
 // l = F_ij * (x,y,1), normalised so a^2+b^2 = 1; double accumulate, float result
 // (geometric_utilities.cpp:824-843 -> cv::computeCorrespondEpilines).

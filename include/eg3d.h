@@ -54,7 +54,7 @@ extern "C" {
  * vector<PolyLineGraph2DHMapImpl> (reference: SfMData.h:16-30,
  * types_reconstructor.hpp:68-82, polyline_graph_2d.hpp:85-119,278-294). */
 typedef struct eg3d_scene {
-  int32_t n_views;
+  int32_t n_views;            /* <= 8192; a view holds <= 524 288 polylines (EG3D_ERR_CAPACITY otherwise) */
   int32_t width, height;      /* image size, identical for all views (imgs[0].size()) */
   const float* cam_P;         /* [V][16] cameraMatrix[r][c], row-major 4x4, last row 0 (Q6) */
   const double* F;            /* [V][V][9] row-major; F[i][j] maps a point of view i to its line in view j */

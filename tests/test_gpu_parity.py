@@ -133,6 +133,34 @@ def test_c4_shaped_subset_parity_and_capacity_growth(have_gpu):
     ctx.close()
 
 
+@pytest.mark.timeout(1200)
+def test_c4_1200_seeds_parity(have_gpu):
+    """BASELINE configs[3] shape at a size the oracle finishes in about a minute on the box's cores: the
+    first 1200 seeds of the 200-view / 20k-segments-per-view scene (~0.7 M edge-points carrying ~70
+    observations each: the regime of the lane-group solver's chunked long lists). Bit-exact, ids and
+    order included; plus the properties that hold at any size (chains are runs of one key, obs_off is a
+    prefix sum, every observation's view is unique within its point)."""
+    cfg = host.default_config(4)
+    cfg.n_seeds = 1200
+    s = host.Synth(cfg)
+    ctx = api.Context(s.scene)
+    got = ctx.match_refpoints(s.seeds)
+    ref = _oracle(s.scene).match(s.seeds, 0, s.n_seeds, nthreads=os.cpu_count())
+    rep = compare_edgepoints(ref, got, rel_tol=1e-4)
+    assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], rep["msgs"]
+    assert (got["flags"] & 7) == 0 and got["n_points"] > 300000
+    off = got["obs_off"].astype(np.int64)
+    assert (np.diff(off) >= 3).all() and off[-1] == got["n_obs"]
+    k = got["key"]
+    new_chain = np.any(k[1:, :3] != k[:-1, :3], axis=1)
+    assert ((k[1:, 3] == k[:-1, 3] + 1) | new_chain).all() and (k[1:, 3][new_chain] == 0).all()
+    # views are unique within a point (checked on a sample of points)
+    for i in np.random.default_rng(0).integers(0, got["n_points"], 2000):
+        v = got["obs_view"][off[i]:off[i + 1]]
+        assert len(np.unique(v)) == len(v)
+    ctx.close()
+
+
 def test_contexts_in_concurrent_threads(have_gpu):
     """bench.py keeps several steps in flight: one context per host thread on the same device.
     Concurrent contexts must give exactly what one context gives alone."""
