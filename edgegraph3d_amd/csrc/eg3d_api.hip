@@ -515,14 +515,14 @@ int run_stage_a(eg3d_ctx* c, BatchState& B, eg3d_stage_times* tm) {
   BUF_TRY(c->b_list_ptr.ensure(sizeof(uint32_t) * (B.n_lists + 1)));
   HIP_TRY(hipMemsetAsync(c->b_list_cnt.as<uint32_t>() + B.n_lists, 0, sizeof(uint32_t), st));
   HIP_TRY(hipEventRecord(c->ea[2], st));
-  launch_k2(st, false, c->ds, B.sd, B.sv_base, nt, c->b_task_seed.as<uint32_t>(), c->b_task_entry.as<uint32_t>(),
-            c->b_task_hit.as<uint32_t>(), c->b_task_list_off.as<uint32_t>(), c->b_raw_off.as<uint32_t>(),
+  launch_k2(st, false, c->ds, B.sd, B.b, B.n_seeds, B.sv_base, nt, c->b_task_off.as<uint32_t>(),
+            c->b_task_seed.as<uint32_t>(), c->b_task_entry.as<uint32_t>(), c->b_task_hit.as<uint32_t>(), c->b_task_list_off.as<uint32_t>(), c->b_raw_off.as<uint32_t>(),
             c->b_cand_pl.as<uint32_t>(), c->b_cand_cnt.as<uint32_t>(), c->b_start_hits.as<Obs>(),
             c->b_list_cnt.as<uint32_t>(), nullptr, nullptr);
   BUF_TRY(scan_total_u32(c, c->b_list_cnt.as<uint32_t>(), c->b_list_ptr.as<uint32_t>(), B.n_lists + 1, B.n_hits, "epipolar hits"));
   BUF_TRY(c->b_hits.ensure(sizeof(Obs) * (B.n_hits + 1)));
-  launch_k2(st, true, c->ds, B.sd, B.sv_base, nt, c->b_task_seed.as<uint32_t>(), c->b_task_entry.as<uint32_t>(),
-            c->b_task_hit.as<uint32_t>(), c->b_task_list_off.as<uint32_t>(), c->b_raw_off.as<uint32_t>(),
+  launch_k2(st, true, c->ds, B.sd, B.b, B.n_seeds, B.sv_base, nt, c->b_task_off.as<uint32_t>(),
+            c->b_task_seed.as<uint32_t>(), c->b_task_entry.as<uint32_t>(), c->b_task_hit.as<uint32_t>(), c->b_task_list_off.as<uint32_t>(), c->b_raw_off.as<uint32_t>(),
             c->b_cand_pl.as<uint32_t>(), c->b_cand_cnt.as<uint32_t>(), c->b_start_hits.as<Obs>(),
             c->b_list_cnt.as<uint32_t>(), c->b_list_ptr.as<uint32_t>(), c->b_hits.as<Obs>());
   HIP_TRY(hipEventRecord(c->eb[2], st));

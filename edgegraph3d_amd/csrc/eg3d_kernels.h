@@ -30,10 +30,15 @@ void launch_k1(hipStream_t st, DevScene s, SeedsDev sd, uint32_t sv_base, uint32
 void launch_task_fill(hipStream_t st, SeedsDev sd, uint32_t sv_base, uint32_t n_sv, const uint32_t* sv_seed,
                       const uint32_t* start_cnt, const uint32_t* task_off, uint32_t* task_seed, uint32_t* task_entry,
                       uint32_t* task_hit, uint32_t* task_k);
-void launch_k2(hipStream_t st, bool fill, DevScene s, SeedsDev sd, uint32_t sv_base, uint32_t n_tasks,
-               const uint32_t* task_seed, const uint32_t* task_entry, const uint32_t* task_hit,
-               const uint32_t* task_list_off, const uint32_t* raw_off, const uint32_t* cand_pl, const uint32_t* cand_cnt,
-               const Obs* start_hits, uint32_t* list_cnt, const uint32_t* list_ptr, Obs* hits);
+#ifndef EG3D_K2_LDS
+#define EG3D_K2_LDS 0
+#endif
+// EG3D_K2_LDS=0 (default): one wavefront per task. =1: one workgroup per seed of [seed_begin, seed_begin + n_seeds)
+// with the candidate polylines staged in LDS; task_off = first task of each (seed, track entry).
+void launch_k2(hipStream_t st, bool fill, DevScene s, SeedsDev sd, uint32_t seed_begin, uint32_t n_seeds, uint32_t sv_base,
+               uint32_t n_tasks, const uint32_t* task_off, const uint32_t* task_seed, const uint32_t* task_entry,
+               const uint32_t* task_hit, const uint32_t* task_list_off, const uint32_t* raw_off, const uint32_t* cand_pl,
+               const uint32_t* cand_cnt, const Obs* start_hits, uint32_t* list_cnt, const uint32_t* list_ptr, Obs* hits);
 // ---- pipelines 1-2 extractor: sets of potentially compatible polylines -> tasks ----
 // CSR over rows (set * V + view) of view-local polyline ids, ascending per row (device copies).
 struct SetsDev {

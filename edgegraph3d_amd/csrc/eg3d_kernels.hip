@@ -260,6 +260,175 @@ __global__ void __launch_bounds__(256) k2_epipolar_hits(DevScene s, SeedsDev sd,
   }
 }
 
+// EG3D_K2_LDS=1 variant (measured slower on every workload, kept for the record — DESIGN.md "K2 staging"):
+// One workgroup (4 wavefronts) per SEED, one wavefront per task of that seed at a time. All tasks
+// of a seed scan the same candidate polylines (those within 30 px of the seed's observation in each
+// track view, found by K1), once per other track entry — ~19 tasks per seed on the dtu006-shaped
+// workload — so the block first stages the vertices of every candidate of every track entry in LDS
+// with coalesced loads, plus a small directory (entry -> its candidates: polyline id, vertex count,
+// LDS offset), and the per-task scans then read LDS (ds_read_b64) instead of going back to L2/HBM
+// for each (task, entry, candidate). For every other track entry: epipolar line of the start hit,
+// then all 64 lanes test consecutive segments of each candidate polyline; hits inside the detection
+// radius are compacted in segment order with __ballot + popcount. FILL=false counts, FILL=true
+// writes to the offsets produced by the scan of the counts. A seed whose candidates do not fit the
+// staging area (K2_VTX_CAP vertices, K2_DIR_CAP candidates) is scanned from HBM as before.
+#ifndef K2_VTX_CAP
+#define K2_VTX_CAP 3072
+#endif
+#ifndef K2_DIR_CAP
+#define K2_DIR_CAP 192
+#endif
+template <bool FILL>
+__global__ void __launch_bounds__(256) k2_epipolar_hits_staged(DevScene s, SeedsDev sd, uint32_t seed_begin, uint32_t sv_base,
+                                                       const uint32_t* task_off /* per (seed, entry) */,
+                                                       const uint32_t* task_hit, const uint32_t* task_list_off,
+                                                       const uint32_t* raw_off, const uint32_t* cand_pl,
+                                                       const uint32_t* cand_cnt, const Obs* start_hits,
+                                                       uint32_t* list_cnt, const uint32_t* list_ptr, Obs* hits) {
+  __shared__ f2 s_vtx[K2_VTX_CAP];
+  __shared__ uint32_t s_dir_pl[K2_DIR_CAP], s_dir_off[K2_DIR_CAP], s_dir_n[K2_DIR_CAP], s_dir_src[K2_DIR_CAP];
+  __shared__ uint32_t s_entry_first[65];  // directory range of track entry i (k <= 64 staged; else fallback)
+  __shared__ uint32_t s_ok;
+  const uint32_t seed = seed_begin + blockIdx.x;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t t0 = sd.trk_off[seed], k = sd.trk_off[seed + 1] - t0;
+  const uint32_t sv0 = t0 - sv_base;
+  const uint32_t task_first = task_off[sv0], task_last = task_off[sv0 + k];
+  if (task_first == task_last) return;  // block-uniform
+  // ---- directory of the seed's candidate polylines: wave 0 scans the per-entry candidate counts,
+  // one thread per (entry, candidate) then looks its polyline up, wave 0 scans the vertex counts
+  if (threadIdx.x == 0) s_ok = (k <= 64) ? 1u : 0u;
+  if (wave == 0 && k <= 64) {
+    const uint32_t nc = lane < k ? cand_cnt[sv0 + lane] : 0;
+    uint32_t incl = nc;
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+      if ((int)lane >= o) incl += t;
+    }
+    if (lane < k) s_entry_first[lane] = incl - nc;
+    if (lane == 63) {
+      s_entry_first[k] = incl;
+      if (incl > K2_DIR_CAP) s_ok = 0;
+    }
+  }
+  __syncthreads();
+  if (s_ok) {
+    const uint32_t nd = s_entry_first[k];
+    if (threadIdx.x < nd) {
+      uint32_t e = 0;
+      while (s_entry_first[e + 1] <= threadIdx.x) e++;
+      const uint32_t pl_id = cand_pl[raw_off[sv0 + e] + (threadIdx.x - s_entry_first[e])];
+      const uint32_t g = s.view_pl_off[sd.trk_view[t0 + e]] + pl_id;
+      s_dir_pl[threadIdx.x] = pl_id;
+      s_dir_src[threadIdx.x] = s.pl_vtx_off[g];
+      s_dir_n[threadIdx.x] = s.pl_vtx_off[g + 1] - s.pl_vtx_off[g];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      uint32_t run = 0;
+      for (uint32_t base = 0; base < nd; base += 64) {
+        const uint32_t n = base + lane < nd ? s_dir_n[base + lane] : 0;
+        uint32_t incl = n;
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+          if ((int)lane >= o) incl += t;
+        }
+        if (base + lane < nd) s_dir_off[base + lane] = run + incl - n;
+        run += (uint32_t)__shfl((int)incl, 63, 64);
+      }
+      if (lane == 0 && run > K2_VTX_CAP) s_ok = 0;
+    }
+  }
+  __syncthreads();
+  const bool staged = s_ok != 0;
+  if (staged) {  // one wavefront per polyline: coalesced 512-byte rows
+    const uint32_t nd = s_entry_first[k];
+    for (uint32_t d = wave; d < nd; d += 4) {
+      const f2* src = s.vtx + s_dir_src[d];
+      const uint32_t n = s_dir_n[d], o = s_dir_off[d];
+      for (uint32_t x = lane; x < n; x += 64) s_vtx[o + x] = src[x];
+    }
+  }
+  __syncthreads();
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (uint32_t t = task_first + wave; t < task_last; t += 4) {
+    // entry of task t: the (seed, entry) whose task range holds it
+    uint32_t ea = 0;
+    while (ea + 1 < k && task_off[sv0 + ea + 1] <= t) ea++;
+    const uint32_t h = task_hit[t];
+    const Obs hit = start_hits[raw_off[sv0 + ea] + h];
+    const int32_t start_view = sd.trk_view[t0 + ea];
+    float ix, iy;
+    seed_obs_in_view(sd, t0, k, start_view, ix, iy);
+    const float radius = dist(ix, iy, hit.x, hit.y) * 3.0f;
+    const float detsq = radius * radius;
+    const uint32_t lo = task_list_off[t];
+    for (uint32_t i = 0; i < k; i++) {
+      const int32_t cur_view = sd.trk_view[t0 + i];
+      uint32_t cnt = 0;
+      if (cur_view == start_view) {
+        cnt = 1;
+        if (FILL && lane == 0) {
+          Obs o = hit;
+          o.view = cur_view;
+          hits[list_ptr[lo + i]] = o;
+        }
+      } else {
+        float la, lb, lc;
+        if (epiline(s.F, s.F_valid, s.n_views, start_view, cur_view, hit.x, hit.y, la, lb, lc)) {
+          const float sx = sd.trk_xy[2 * (t0 + i)], sy = sd.trk_xy[2 * (t0 + i) + 1];
+          const uint32_t cbase = raw_off[sv0 + i], ncand = cand_cnt[sv0 + i];
+          const uint32_t wbase = FILL ? list_ptr[lo + i] : 0;
+          for (uint32_t c = 0; c < ncand; c++) {
+            uint32_t pl_id, n;
+            uint32_t lo_v = 0;
+            const f2* gv = nullptr;
+            if (staged) {
+              const uint32_t d = s_entry_first[i] + c;
+              pl_id = s_dir_pl[d];
+              n = s_dir_n[d];
+              lo_v = s_dir_off[d];
+            } else {
+              pl_id = cand_pl[cbase + c];
+              const PlRef pl = polyline_of(s, cur_view, pl_id);
+              n = pl.n;
+              gv = pl.v;
+            }
+            for (uint32_t base = 1; base < n; base += 64) {
+              const uint32_t ii = base + lane;
+              bool ok = false;
+              float hx = 0.f, hy = 0.f;
+              if (ii < n) {
+                f2 v1, v0;
+                if (staged) {
+                  v1 = s_vtx[lo_v + ii];
+                  v0 = s_vtx[lo_v + ii - 1];
+                } else {
+                  v1 = gv[ii];
+                  v0 = gv[ii - 1];
+                }
+                if (seg_line_hit(v1.x, v1.y, v0.x, v0.y, la, lb, lc, hx, hy)) ok = dist2(sx, sy, hx, hy) <= detsq;
+              }
+              const unsigned long long mask = __ballot(ok);
+              if (FILL && ok) {
+                Obs o;
+                o.view = cur_view;
+                o.pl = pl_id;
+                o.seg = ii - 1;
+                o.x = hx;
+                o.y = hy;
+                hits[wbase + cnt + __popcll(mask & lt_mask)] = o;
+              }
+              cnt += __popcll(mask);
+            }
+          }
+        }
+      }
+      if (!FILL && lane == 0) list_cnt[lo + i] = cnt;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ N1 ---------
 // Pipelines 1-2 extractor, stage A (polyline_matching.cpp:153-208 with :45-73): every polyline of a
 // set is sampled every 20 px from its start towards its end; each sample is one task whose V lists
@@ -675,8 +844,8 @@ struct TeamWave {
   // are first copied to LDS by all lanes, then walked through address_space(3) pointers (ds_read).
   __device__ __forceinline__ int side_walk(const DevScene& s, Chain& c, int view, const Obs& from, uint32_t direction,
                                            int lo, int ci, int hi, bool towards_start, Pending* out) const {
-    typedef const __attribute__((address_space(3))) f2* lds_f2p;
     typedef const __attribute__((address_space(3))) float* lds_fp;
+    typedef const __attribute__((address_space(3))) f2* lds_f2p;
     const PlRef pl = polyline_of(s, view, from.pl);
     const int first = towards_start ? ci - 1 : ci + 1, step = towards_start ? -1 : 1;
     const int count = towards_start ? ci - lo : hi - ci - 1;
@@ -1245,11 +1414,19 @@ void launch_task_fill(hipStream_t st, SeedsDev sd, uint32_t sv_base, uint32_t n_
   hipLaunchKernelGGL(k_task_fill, blocks_for(n_sv, 256), dim3(256), 0, st, sd, sv_base, n_sv, sv_seed, start_cnt,
                      task_off, task_seed, task_entry, task_hit, task_k);
 }
-void launch_k2(hipStream_t st, bool fill, DevScene s, SeedsDev sd, uint32_t sv_base, uint32_t n_tasks,
-               const uint32_t* task_seed, const uint32_t* task_entry, const uint32_t* task_hit,
-               const uint32_t* task_list_off, const uint32_t* raw_off, const uint32_t* cand_pl, const uint32_t* cand_cnt,
-               const Obs* start_hits, uint32_t* list_cnt, const uint32_t* list_ptr, Obs* hits) {
-  if (!n_tasks) return;
+void launch_k2(hipStream_t st, bool fill, DevScene s, SeedsDev sd, uint32_t seed_begin, uint32_t n_seeds, uint32_t sv_base,
+               uint32_t n_tasks, const uint32_t* task_off, const uint32_t* task_seed, const uint32_t* task_entry,
+               const uint32_t* task_hit, const uint32_t* task_list_off, const uint32_t* raw_off, const uint32_t* cand_pl,
+               const uint32_t* cand_cnt, const Obs* start_hits, uint32_t* list_cnt, const uint32_t* list_ptr, Obs* hits) {
+  if (!n_tasks || !n_seeds) return;
+#if EG3D_K2_LDS
+  if (fill)
+    hipLaunchKernelGGL(k2_epipolar_hits_staged<true>, dim3(n_seeds), dim3(256), 0, st, s, sd, seed_begin, sv_base, task_off,
+                       task_hit, task_list_off, raw_off, cand_pl, cand_cnt, start_hits, list_cnt, list_ptr, hits);
+  else
+    hipLaunchKernelGGL(k2_epipolar_hits_staged<false>, dim3(n_seeds), dim3(256), 0, st, s, sd, seed_begin, sv_base,
+                       task_off, task_hit, task_list_off, raw_off, cand_pl, cand_cnt, start_hits, list_cnt, list_ptr, hits);
+#else
   if (fill)
     hipLaunchKernelGGL(k2_epipolar_hits<true>, blocks_for((uint64_t)n_tasks * 64, 256), dim3(256), 0, st, s, sd, sv_base,
                        n_tasks, task_seed, task_entry, task_hit, task_list_off, raw_off, cand_pl, cand_cnt, start_hits,
@@ -1258,6 +1435,7 @@ void launch_k2(hipStream_t st, bool fill, DevScene s, SeedsDev sd, uint32_t sv_b
     hipLaunchKernelGGL(k2_epipolar_hits<false>, blocks_for((uint64_t)n_tasks * 64, 256), dim3(256), 0, st, s, sd,
                        sv_base, n_tasks, task_seed, task_entry, task_hit, task_list_off, raw_off, cand_pl, cand_cnt,
                        start_hits, list_cnt, list_ptr, hits);
+#endif
 }
 void launch_n1_samples(hipStream_t st, bool fill, DevScene s, SetsDev sets, uint32_t n_rows, uint32_t item_begin,
                        uint32_t n_items, uint32_t* sample_cnt, const uint32_t* sample_off, Obs* samples,
