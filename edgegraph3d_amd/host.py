@@ -102,6 +102,10 @@ class Synth:
         m = int(off[-1])
         return off, D.as_np(s.trk_view, m, np.int32), D.as_np(s.trk_xy, 2 * m, np.float32).reshape(m, 2)
 
+    def seed_truth(self):
+        """[n_seeds, 3] noise-free 3-D positions the seeds were generated from"""
+        return D.as_np(lib().eg3d_synth_seed_truth(self._h), 3 * self.n_seeds, np.float32).reshape(-1, 3).astype(np.float64)
+
     def scene_np(self):
         s = self.scene.contents
         V = int(s.n_views)
@@ -180,6 +184,29 @@ def plg_from_mask(mask):
     d = D.plg_view_to_dict(v)
     lib().eg3d_plg_view_free(C.byref(v))
     return d
+
+
+def estimate_F(n_views, trk_off, trk_view, trk_xy, estimate=True, rng_seed=0):
+    """SURVEY N4 (geometric_utilities.cpp:754-820): fundamental matrices of all ordered view pairs from the
+    point tracks; pairs with fewer than 10 common points are invalid. Returns (F [V,V,9] f64, valid [V,V] u8,
+    n_common [V,V] u32, pairs whose estimate failed). estimate=False: validity rule and counts only."""
+    L = lib()
+    L.eg3d_host_estimate_F.restype = C.c_int
+    L.eg3d_host_estimate_F.argtypes = [C.c_int, C.c_uint64, D.u32p, D.i32p, D.f32p, C.c_int, C.c_uint64, D.f64p,
+                                       D.u8p, D.u32p]
+    off = np.ascontiguousarray(trk_off, np.uint32)
+    view = np.ascontiguousarray(trk_view, np.int32)
+    xy = np.ascontiguousarray(trk_xy, np.float32)
+    V = int(n_views)
+    F = np.zeros((V, V, 9), np.float64)
+    valid = np.zeros((V, V), np.uint8)
+    ncom = np.zeros((V, V), np.uint32)
+    rc = L.eg3d_host_estimate_F(V, len(off) - 1, D.np_ptr(off, C.c_uint32), D.np_ptr(view, C.c_int32),
+                                D.np_ptr(xy, C.c_float), 1 if estimate else 0, rng_seed, D.np_ptr(F, C.c_double),
+                                D.np_ptr(valid, C.c_uint8), D.np_ptr(ncom, C.c_uint32))
+    if rc < 0:
+        raise RuntimeError("eg3d_host_estimate_F failed (%d)" % rc)
+    return F, valid, ncom, rc
 
 
 def png_edge_mask(path):

@@ -353,6 +353,13 @@ extern "C" int eg3d_sfm_analytic_F(const eg3d_sfm* s, double* F, uint8_t* F_vali
   return 0;
 }
 
+extern "C" int eg3d_sfm_estimate_F(const eg3d_sfm* s, int estimate, uint64_t rng_seed, double* F, uint8_t* F_valid,
+                                   uint32_t* n_common) {
+  if (!s) return -1;
+  return eg3d_host_estimate_F((int)s->cams.size(), s->X.size() / 3, s->trk_off.data(), s->trk_view.data(),
+                              s->trk_xy.data(), estimate, rng_seed, F, F_valid, n_common);
+}
+
 static bool load_json(const char* path, JVal& root) {
   std::ifstream f(path, std::ios::binary);
   if (!f) return false;

@@ -2,7 +2,12 @@
 // in C++ over the C ABI (what src/edgegraph3d/edge_matcher.cpp:57-182 + pipelines.cpp:160-176 do):
 //
 //   OpenMVG JSON (cameras + SfM points)  +  polyline graphs of every view
-//     -> fundamental matrices            (edge_matcher.cpp:96; analytic here)
+//     -> fundamental matrices            (edge_matcher.cpp:96 -> geometric_utilities.cpp:754-820): pairs of views
+//                                        with >= 10 common SfM points get a matrix, the others none (exact rule);
+//                                        the matrix is analytic from the cameras by default, or the build's own
+//                                        least-median-of-squares estimate from the tracks with --estimate-F
+//                                        (the reference's cv::findFundamentalMat(FM_LMEDS) is randomised OpenCV
+//                                        code: not reproducible)
 //     -> plg_matching_from_refpoints     (pipelines.cpp:164)            GPU: eg3d_match_refpoints
 //     -> filter_3d_points_close_2d_array (edge_matcher.cpp:150)         host
 //     -> add_3dpoints_to_sfmd            (edge_matcher.cpp:158)         host
@@ -11,7 +16,7 @@
 //
 // Usage:
 //   edge_matcher_refpoints --make-synthetic <config 0..4> <dir>      writes <dir>/input.json, <dir>/plgs.bin
-//   edge_matcher_refpoints <dir>/input.json <dir>/plgs.bin <out.json> [--filter]
+//   edge_matcher_refpoints <dir>/input.json <dir>/plgs.bin <out.json> [--filter] [--estimate-F] [--all-pairs]
 //
 // The polyline graphs come from a container file because building them from edge images (SURVEY
 // N2) is outside this repository's scope. Build (see tests/test_gpu_edge_cases.py):
@@ -62,10 +67,15 @@ static int make_synthetic(int cfg_index, const std::string& dir) {
 int main(int argc, char** argv) {
   if (argc >= 4 && std::strcmp(argv[1], "--make-synthetic") == 0) return make_synthetic(std::atoi(argv[2]), argv[3]);
   if (argc < 4) {
-    std::fprintf(stderr, "usage: %s <input.json> <plgs.bin> <out.json> [--filter]\n", argv[0]);
+    std::fprintf(stderr, "usage: %s <input.json> <plgs.bin> <out.json> [--filter] [--estimate-F] [--all-pairs]\n", argv[0]);
     return 2;
   }
-  const bool do_filter = argc > 4 && std::strcmp(argv[4], "--filter") == 0;
+  bool do_filter = false, estimate_F = false, all_pairs = false;
+  for (int a = 4; a < argc; a++) {
+    do_filter |= std::strcmp(argv[a], "--filter") == 0;
+    estimate_F |= std::strcmp(argv[a], "--estimate-F") == 0;
+    all_pairs |= std::strcmp(argv[a], "--all-pairs") == 0;  // analytic F for every pair, ignoring the 10-point rule
+  }
 
   // ---- inputs (edge_matcher.cpp:64-95)
   eg3d_sfm* sfm = eg3d_sfm_read_json(argv[1]);
@@ -77,7 +87,22 @@ int main(int argc, char** argv) {
   if (sc.n_views != V) return fail("views of the SfM file and of the polyline graphs differ");
   std::vector<double> F((size_t)V * V * 9);
   std::vector<uint8_t> Fv((size_t)V * V);
-  if (eg3d_sfm_analytic_F(sfm, F.data(), Fv.data()) != 0) return fail("fundamental matrices");
+  if (estimate_F) {
+    const int bad = eg3d_sfm_estimate_F(sfm, 1, 0xE63D2018ull, F.data(), Fv.data(), nullptr);
+    if (bad < 0) return fail("fundamental matrices");
+    if (bad > 0) std::printf("%d view pairs: estimate failed, left without a matrix\n", bad);
+  } else {
+    if (eg3d_sfm_analytic_F(sfm, F.data(), Fv.data()) != 0) return fail("fundamental matrices");
+    if (!all_pairs) {  // the reference's rule for which pairs have a matrix at all
+      std::vector<uint8_t> rule((size_t)V * V);
+      if (eg3d_sfm_estimate_F(sfm, 0, 0, nullptr, rule.data(), nullptr) < 0) return fail("fundamental matrices");
+      for (size_t k = 0; k < rule.size(); k++) Fv[k] &= rule[k];
+    }
+  }
+  size_t n_pairs = 0;
+  for (uint8_t v : Fv) n_pairs += v;
+  std::printf("fundamental matrices for %zu of %d ordered view pairs (%s)\n", n_pairs, V * (V - 1),
+              estimate_F ? "least-median-of-squares estimate from the tracks" : "analytic from the cameras");
   sc.cam_P = eg3d_sfm_cam_P(sfm);
   sc.F = F.data();
   sc.F_valid = Fv.data();

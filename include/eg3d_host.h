@@ -160,6 +160,25 @@ int eg3d_sfm_set_point_coords(eg3d_sfm* s, const float* X /* [N][3] */);
  * geometric_utilities.cpp:818-820, whose LMedS estimate is not reproducible without OpenCV) */
 int eg3d_sfm_analytic_F(const eg3d_sfm* s, double* F /* [V][V][9] */, uint8_t* F_valid /* [V][V] */);
 
+/* ------------------------------------ fundamental matrices from the tracks (row N4) -- */
+/* generate_all_fundamental_matrices_from_Points / findFundamentalMatrixFromPoints
+ * (geometric_utilities.cpp:754-820): for every ORDERED pair of views the points seen from both
+ * (ascending id; a point's position on a view = its LAST observation with that view id); pairs with
+ * fewer than 10 common points get no matrix (F_valid = 0: every epipolar line of the pair fails, as
+ * with the reference's 1x1 Mat). n_common (may be NULL) receives the counts.
+ *   estimate = 0: only F_valid / n_common are written — the reference's validity rule, to be combined
+ *                 with eg3d_sfm_analytic_F (F may be NULL);
+ *   estimate = 1: F[i][j] (l_j = F x_i) is estimated from the correspondences by the build's own
+ *                 least-median-of-squares estimator (normalised 8-point samples, deterministic in
+ *                 rng_seed). The reference uses cv::findFundamentalMat(FM_LMEDS), a randomised OpenCV
+ *                 routine: the matrices are NOT comparable bit for bit, only geometrically.
+ * Returns the number of pairs whose estimate failed (>= 0), < 0 on bad arguments. */
+int eg3d_host_estimate_F(int n_views, uint64_t n_points, const uint32_t* trk_off, const int32_t* trk_view,
+                         const float* trk_xy, int estimate, uint64_t rng_seed, double* F /* [V][V][9] */,
+                         uint8_t* F_valid /* [V][V] */, uint32_t* n_common /* [V][V] or NULL */);
+int eg3d_sfm_estimate_F(const eg3d_sfm* s, int estimate, uint64_t rng_seed, double* F, uint8_t* F_valid,
+                        uint32_t* n_common);
+
 #ifdef __cplusplus
 }
 #endif

@@ -709,3 +709,35 @@ extern "C" int orc_next_by_line(const float* vtx, int n, uint32_t start, uint32_
   *flags = (fqp ? 1 : 0) | (reached ? 2 : 0) | (bdv ? 4 : 0);
   return found;
 }
+
+// ---------------------------------------------------------------------------- N4 ----
+// get_point_sets_on_images (edge_graph_3d_utilities.cpp:369-380), find_points_on_both_images (:345-352),
+// get_2d_coordinates_of_point_on_image (:382-393), findFundamentalMatrixFromPoints (geometric_utilities.cpp:754-779)
+#include <set>
+extern "C" int orc_pair_correspondences(int n_views, uint64_t n_points, const uint32_t* trk_off, const int32_t* trk_view,
+                                        const float* trk_xy, int i, int j, uint32_t* ids, float* xy_i, float* xy_j,
+                                        uint32_t* n_common) {
+  // pointsVisibleFromCamN_ as OpenMvgParser fills it: one entry per observation, then copied into a set
+  std::vector<std::set<int>> points_on_images((size_t)n_views);
+  for (uint64_t p = 0; p < n_points; p++)
+    for (uint32_t k = trk_off[p]; k < trk_off[p + 1]; k++)
+      if (trk_view[k] >= 0 && trk_view[k] < n_views) points_on_images[(size_t)trk_view[k]].insert((int)p);
+  std::set<int> both;
+  for (int id : points_on_images[(size_t)i])
+    if (points_on_images[(size_t)j].count(id)) both.insert(id);
+  if (n_common) *n_common = (uint32_t)both.size();
+  if (both.size() < 10) return 0;
+  int n = 0;
+  for (int id : both) {
+    float a[2] = {0, 0}, b[2] = {0, 0};
+    for (uint32_t k = trk_off[id]; k < trk_off[id + 1]; k++) {
+      if (trk_view[k] == i) a[0] = trk_xy[2 * k], a[1] = trk_xy[2 * k + 1];
+      if (trk_view[k] == j) b[0] = trk_xy[2 * k], b[1] = trk_xy[2 * k + 1];
+    }
+    ids[n] = (uint32_t)id;
+    xy_i[2 * n] = a[0], xy_i[2 * n + 1] = a[1];
+    xy_j[2 * n] = b[0], xy_j[2 * n + 1] = b[1];
+    n++;
+  }
+  return n;
+}

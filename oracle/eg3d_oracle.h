@@ -62,6 +62,12 @@ int orc_plg_from_mask(const uint8_t* mask, int width, int height, eg3d_plg_view*
 void orc_free_plg_view(eg3d_plg_view* v);
 
 /* primitive probes for known-answer tests */
+/* N4, the deterministic part of findFundamentalMatrixFromPoints (geometric_utilities.cpp:754-779): the common
+ * points of the ordered view pair (i, j) and their positions, or n = 0 when there are fewer than 10.
+ * ids / xy_i / xy_j must hold n_points entries; returns n. */
+int orc_pair_correspondences(int n_views, uint64_t n_points, const uint32_t* trk_off, const int32_t* trk_view,
+                             const float* trk_xy, int i, int j, uint32_t* ids, float* xy_i, float* xy_j,
+                             uint32_t* n_common);
 float orc_squared_2d_distance(float ax, float ay, float bx, float by);
 float orc_minimum_distancesq(float px, float py, float vx, float vy, float wx, float wy, float* proj);
 int orc_intersect_segment_line(float x1, float y1, float x2, float y2, const float* line, float* inter,

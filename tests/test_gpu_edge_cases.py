@@ -225,8 +225,8 @@ def test_cpp_end_to_end_example(tmp_path):
                            "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-L", "/opt/rocm/lib", "-lamdhip64", "-o", exe])
     d = str(tmp_path)
     subprocess.check_call([exe, "--make-synthetic", "1", d])
-    out = subprocess.run([exe, d + "/input.json", d + "/plgs.bin", d + "/out.json"], capture_output=True, text=True,
-                         timeout=300)
+    out = subprocess.run([exe, d + "/input.json", d + "/plgs.bin", d + "/out.json", "--all-pairs"], capture_output=True,
+                         text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     m = re.search(r"-> (\d+) edge-points \((\d+) observations\)", out.stdout)
     k = re.search(r"kept (\d+) edge-points", out.stdout)
@@ -241,12 +241,33 @@ def test_cpp_end_to_end_example(tmp_path):
     # the appended points carry >= 3 observations with view keys inside the rig
     last = doc["structure"][-1]["value"]["observations"]
     assert len(last) >= 3 and all(0 <= o["key"] < s.n_views for o in last)
-    out2 = subprocess.run([exe, d + "/input.json", d + "/plgs.bin", d + "/out_f.json", "--filter"], capture_output=True,
-                          text=True, timeout=300)
+    out2 = subprocess.run([exe, d + "/input.json", d + "/plgs.bin", d + "/out_f.json", "--filter", "--all-pairs"],
+                          capture_output=True, text=True, timeout=300)
     assert out2.returncode == 0, out2.stdout + out2.stderr
     f = re.search(r"filter: (\d+) of (\d+) points kept", out2.stdout)
     assert int(f.group(2)) == len(doc["structure"]) and 0 < int(f.group(1)) <= int(f.group(2))
     assert len(json.load(open(d + "/out_f.json"))["structure"]) == int(f.group(1))
+    # N4: the reference's rule for which view pairs have a fundamental matrix (>= 10 common SfM points) — the
+    # default — must give what the library gives on the same scene with those pairs switched off; and the
+    # matrices estimated from the tracks (--estimate-F) must reproduce most of the cloud
+    off, view, xy = s.seeds_np()
+    _, rule, _, _ = host.estimate_F(s.n_views, off, view, xy, estimate=False)
+    sc = s.scene_np()
+    sc["F_valid"] = (sc["F_valid"] & rule).astype(np.uint8)
+    sa = host.SceneArrays(sc)
+    ctx = api.Context(C.byref(sa.c))
+    ruled = ctx.match_refpoints(s.seeds)
+    ctx.close()
+    out3 = subprocess.run([exe, d + "/input.json", d + "/plgs.bin", d + "/out_r.json"], capture_output=True, text=True,
+                          timeout=300)
+    assert out3.returncode == 0, out3.stdout + out3.stderr
+    m3 = re.search(r"-> (\d+) edge-points \((\d+) observations\)", out3.stdout)
+    assert int(m3.group(1)) == ruled["n_points"] and int(m3.group(2)) == ruled["n_obs"]
+    out4 = subprocess.run([exe, d + "/input.json", d + "/plgs.bin", d + "/out_e.json", "--estimate-F"], capture_output=True,
+                          text=True, timeout=300)
+    assert out4.returncode == 0, out4.stdout + out4.stderr
+    m4 = re.search(r"-> (\d+) edge-points", out4.stdout)
+    assert 0.5 * ruled["n_points"] <= int(m4.group(1)) <= 1.5 * ruled["n_points"] + 10, out4.stdout
 
 
 def test_invalid_polyline_that_kept_its_vertices_is_ignored():
