@@ -12,7 +12,7 @@
 //   k3a_hypotheses    1 or 4 lanes / hypothesis  orientation + following (4-lane teams when latency-bound)
 //   k3s_select        1 lane / task         uniqueness rule -> chain seeds
 //   k3b_expand        1 WAVE / chain        expand-all-views (wave-cooperative Gauss-Newton)
-//   k4_emit           1 WAVE / chain        ordered SoA output (wave prefix sum of obs counts)
+//   k4_emit           1 WAVE / chain        ordered SoA output (wave prefix sum of obs counts, flat coalesced copy)
 //   k5_gn_filter      1 lane / point        config 5, FP32 Gauss-Newton outlier filter
 // Pipelines 1-2 extractor, stage A' feeding the same task_setup..k4 stages:
 //   k_n1_samples      1 lane / polyline     a sample every 20 px (count pass + fill pass), 1 task each
@@ -1267,15 +1267,16 @@ __global__ void k_chain_cost(StageAView a, const TaskDesc* tasks, const ChainSee
 // One wavefront per chain: lanes take consecutive chain points; the observation offset of each
 // point is the chain's base plus a wave prefix sum of the per-point observation counts, so the
 // writes of X / key / obs_off are coalesced and the per-point list walks run in parallel.
-__global__ void __launch_bounds__(256) k4_emit(const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains,
-                                               ChainLayout L, const unsigned char* scratch, const ChainOut* outs,
-                                               const uint32_t* point_off, const uint32_t* obs_off_in,
-                                               uint64_t point_base, uint64_t obs_base, float* X, uint32_t* obs_off,
-                                               int32_t* obs_view, uint32_t* obs_pl, uint32_t* obs_seg, float* obs_xy,
-                                               uint32_t* key) {
-  const uint32_t j = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t lane = threadIdx.x & 63;
-  if (j >= n_chains) return;
+__global__ void __launch_bounds__(64) k4_emit(const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains,
+                                              ChainLayout L, const unsigned char* scratch, const ChainOut* outs,
+                                              const uint32_t* point_off, const uint32_t* obs_off_in,
+                                              uint64_t point_base, uint64_t obs_base, float* X, uint32_t* obs_off,
+                                              int32_t* obs_view, uint32_t* obs_pl, uint32_t* obs_seg, float* obs_xy,
+                                              uint32_t* key) {
+  __shared__ uint32_t s_excl[65];  // first flat observation index of each of the 64 points in flight (+ total)
+  __shared__ uint32_t s_blk[64];   // where each point's observation block starts in the chain's pool
+  const uint32_t j = blockIdx.x;
+  const uint32_t lane = threadIdx.x;
   const unsigned char* slice = scratch + L.total * (size_t)j;
   const ChainPt* pts = (const ChainPt*)(slice + L.off_pts);
   const Obs* pool = (const Obs*)(slice + L.off_pool);
@@ -1288,6 +1289,7 @@ __global__ void __launch_bounds__(256) k4_emit(const TaskDesc* tasks, const Chai
     const bool act = i < co.n_points;
     ChainPt p;
     p.nobs = 0;
+    p.off = 0;
     if (act) p = pts[co.head + i];
     uint32_t incl = p.nobs;  // inclusive wave scan of the observation counts
 #pragma unroll
@@ -1296,27 +1298,36 @@ __global__ void __launch_bounds__(256) k4_emit(const TaskDesc* tasks, const Chai
       if ((int)lane >= o) incl += t;
     }
     const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+    s_excl[lane] = incl - p.nobs;
+    s_blk[lane] = p.off;
+    if (lane == 63) s_excl[64] = total;
     if (act) {
       const uint64_t pi = pbase + i;
-      uint64_t o = obase + (incl - p.nobs);
       X[3 * pi] = p.X[0];
       X[3 * pi + 1] = p.X[1];
       X[3 * pi + 2] = p.X[2];
-      obs_off[pi] = (uint32_t)o;
+      obs_off[pi] = (uint32_t)(obase + (incl - p.nobs));
       key[4 * pi] = d.seed;
       key[4 * pi + 1] = d.entry;
       key[4 * pi + 2] = d.hit;
       key[4 * pi + 3] = i;
-      for (uint32_t k = 0; k < p.nobs; k++) {
-        const Obs po = pool[p.off + k];
-        obs_view[o] = po.view;
-        obs_pl[o] = po.pl;
-        obs_seg[o] = po.seg;
-        obs_xy[2 * o] = po.x;
-        obs_xy[2 * o + 1] = po.y;
-        o++;
-      }
     }
+    __syncthreads();
+    // the observations of these 64 points, flat: lane f copies observation f, so that consecutive lanes
+    // write consecutive elements of every output array (and read consecutive 16-byte pool entries within a point)
+    for (uint32_t f = lane; f < total; f += 64) {
+      uint32_t lo = 0;  // the point whose range holds f: largest q with s_excl[q] <= f (empty points skipped)
+#pragma unroll
+      for (uint32_t step = 32; step; step >>= 1)
+        if (s_excl[lo + step] <= f) lo += step;
+      const Obs po = pool[s_blk[lo] + (f - s_excl[lo])];
+      const uint64_t o = obase + f;
+      obs_view[o] = po.view;
+      obs_pl[o] = po.pl;
+      obs_seg[o] = po.seg;
+      *(f2*)(obs_xy + 2 * o) = f2{po.x, po.y};
+    }
+    __syncthreads();
     obase += total;
   }
 }
@@ -1524,7 +1535,7 @@ void launch_k4(hipStream_t st, const TaskDesc* tasks, const ChainSeed* chains, u
                uint64_t point_base, uint64_t obs_base, float* X, uint32_t* obs_off, int32_t* obs_view, uint32_t* obs_pl,
                uint32_t* obs_seg, float* obs_xy, uint32_t* key) {
   if (!n_chains) return;
-  hipLaunchKernelGGL(k4_emit, blocks_for((uint64_t)n_chains * 64, 256), dim3(256), 0, st, tasks, chains, n_chains, L, scratch, outs,
+  hipLaunchKernelGGL(k4_emit, dim3(n_chains), dim3(64), 0, st, tasks, chains, n_chains, L, scratch, outs,
                      point_off, obs_off_in, point_base, obs_base, X, obs_off, obs_view, obs_pl, obs_seg, obs_xy, key);
 }
 void launch_k5(hipStream_t st, const float* cam_P, int n_views, const float* X, const uint32_t* obs_off,
