@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -137,6 +138,11 @@ struct eg3d_ctx {
   uint32_t k3a_blocks = 0;
   void* pinned = nullptr;  // pinned host staging area of the D2H copies of a cloud (grow-only)
   size_t pinned_cap = 0;
+  // mailbox for the small read-backs of a step (scan totals, counters): pinned host memory mapped into the
+  // GPU's address space, written by k_publish, polled by the calling thread (no driver round trip)
+  uint32_t* mbox = nullptr;
+  uint32_t* mbox_dev = nullptr;
+  uint32_t mbox_seq = 0;
   uint64_t last_np = 0, last_no = 0;
   int last_chunks = 0;
   uint32_t last_nc = 0;
@@ -158,23 +164,95 @@ static int scan_exclusive_u32(eg3d_ctx* c, const uint32_t* in, uint32_t* out, si
   HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->b_scan_tmp.p, tmp_bytes, in, out, (int)n_plus_one, c->stream));
   return EG3D_OK;
 }
+// ---- small read-backs through the mailbox ----------------------------------------------------------
+// b_scanchk: [0..3] "scan wrapped" flag words (ORed by k_scan_check, cleared by k_publish), [4..5] a saved
+// 64-bit counter.
+static int ensure_mailbox(eg3d_ctx* c) {
+  if (!c->mbox) {
+    void* h = nullptr;
+    HIP_TRY(hipHostMalloc(&h, sizeof(uint32_t) * EG3D_MBOX_WORDS, hipHostMallocMapped | hipHostMallocCoherent));
+    memset(h, 0, sizeof(uint32_t) * EG3D_MBOX_WORDS);
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+      (void)hipHostFree(h);
+      g_err = "eg3d: hipHostGetDevicePointer failed for the read-back mailbox";
+      return EG3D_ERR_HIP;
+    }
+    c->mbox = (uint32_t*)h;
+    c->mbox_dev = (uint32_t*)d;
+  }
+  if (!c->b_scanchk.p) {
+    BUF_TRY(c->b_scanchk.ensure(8 * sizeof(uint32_t)));
+    HIP_TRY(hipMemsetAsync(c->b_scanchk.p, 0, 8 * sizeof(uint32_t), c->stream));
+  }
+  return EG3D_OK;
+}
+struct Readback {
+  eg3d_ctx* c;
+  PubArgs a{};
+  uint32_t off[6] = {0, 0, 0, 0, 0, 0};
+  uint32_t used = 2;
+  explicit Readback(eg3d_ctx* c_) : c(c_) {}
+  int add(const void* dev, uint32_t words) {  // returns the item's index
+    const int i = a.n++;
+    a.src[i] = (const uint32_t*)dev;
+    a.words[i] = words;
+    off[i] = used;
+    used += words;
+    return i;
+  }
+  void clear_after(uint32_t* dev) { a.clear[a.n_clear++] = dev; }
+  const uint32_t* item(int i) const { return c->mbox + off[i]; }
+  // Launch the publish kernel behind everything queued on the stream and wait for its data: a short poll of
+  // the mailbox (the common case: the GPU is a few microseconds behind), then a blocking wait for long kernels.
+  int run() {
+    if (a.n > 6 || a.n_clear > 3 || used > EG3D_MBOX_WORDS) {
+      g_err = "eg3d: internal: read-back too large";
+      return EG3D_ERR_ARG;
+    }
+    const uint32_t seq = ++c->mbox_seq;
+    launch_publish(c->stream, a, c->mbox_dev, seq);
+    HIP_TRY(hipGetLastError());
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spin = 0;; spin++) {
+      if (__atomic_load_n(c->mbox, __ATOMIC_ACQUIRE) == seq) return EG3D_OK;
+      __builtin_ia32_pause();
+      if ((spin & 255u) == 255u &&
+          std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1500))
+        break;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (__atomic_load_n(c->mbox, __ATOMIC_ACQUIRE) != seq) {
+      g_err = "eg3d: the read-back mailbox was not written";
+      return EG3D_ERR_HIP;
+    }
+    return EG3D_OK;
+  }
+};
+// Exclusive scan queued on the stream, its wrap check ORed into flag word `slot`; the total is out[n].
+static int scan_queue_u32(eg3d_ctx* c, const uint32_t* in, uint32_t* out, size_t n_plus_one, int slot) {
+  BUF_TRY(ensure_mailbox(c));
+  BUF_TRY(scan_exclusive_u32(c, in, out, n_plus_one));
+  launch_scan_check(c->stream, out, n_plus_one, c->b_scanchk.as<uint32_t>() + slot);
+  return EG3D_OK;
+}
+static int wrapped_error(const char* what) {
+  g_err = std::string("eg3d: the number of ") + what + " of this batch exceeds 2^32-1; use smaller seed / set ranges";
+  return EG3D_ERR_CAPACITY;
+}
 // Exclusive scan + its total on the host, with overflow detection: phase totals (candidate slots,
 // tasks, lists, hits, hypotheses) are 32-bit; a batch whose total does not fit is refused with
 // EG3D_ERR_CAPACITY instead of sizing buffers from a wrapped number.
 static int scan_total_u32(eg3d_ctx* c, const uint32_t* in, uint32_t* out, size_t n_plus_one, uint32_t& total,
                           const char* what) {
-  BUF_TRY(scan_exclusive_u32(c, in, out, n_plus_one));
-  BUF_TRY(c->b_scanchk.ensure(2 * sizeof(uint32_t)));
-  HIP_TRY(hipMemsetAsync(c->b_scanchk.p, 0, 2 * sizeof(uint32_t), c->stream));
-  launch_scan_check(c->stream, out, n_plus_one, c->b_scanchk.as<uint32_t>());
-  uint32_t h[2] = {0, 0};
-  HIP_TRY(hipMemcpyAsync(h, c->b_scanchk.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  if (h[1]) {
-    g_err = std::string("eg3d: the number of ") + what + " of this batch exceeds 2^32-1; use smaller seed / set ranges";
-    return EG3D_ERR_CAPACITY;
-  }
-  total = h[0];
+  BUF_TRY(scan_queue_u32(c, in, out, n_plus_one, 0));
+  Readback rb(c);
+  const int it = rb.add(out + (n_plus_one - 1), 1);
+  const int iw = rb.add(c->b_scanchk.as<uint32_t>(), 1);
+  rb.clear_after(c->b_scanchk.as<uint32_t>());
+  BUF_TRY(rb.run());
+  if (*rb.item(iw)) return wrapped_error(what);
+  total = *rb.item(it);
   return EG3D_OK;
 }
 
@@ -400,6 +478,7 @@ extern "C" void eg3d_destroy(eg3d_ctx* c) {
                    &c->o_xy, &c->o_key, &c->f_X, &c->f_off, &c->f_view, &c->f_xy, &c->f_Xo, &c->f_inl, &c->b_sets_off, &c->b_sets_ids, &c->b_fscratch, &c->b_queue};
   for (DevBuf* b : all) b->release();
   if (c->pinned) (void)hipHostFree(c->pinned);
+  if (c->mbox) (void)hipHostFree(c->mbox);
   for (int i = 0; i < 8; i++) {
     if (c->ea[i]) (void)hipEventDestroy(c->ea[i]);
     if (c->eb[i]) (void)hipEventDestroy(c->eb[i]);
@@ -641,6 +720,9 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
   uint32_t arena_cap = std::max<uint32_t>(1u << 16, std::min<uint64_t>((uint64_t)B.n_hyp * (k3a_queue ? 32 : 24), 1ull << 26));
   if (c->tune.arena_cap0) arena_cap = c->tune.arena_cap0;  // tests: force the overflow-and-retry path
   Counters hc;
+  BUF_TRY(c->b_cs_task.ensure(sizeof(ChainSeed) * (nt + 1)));
+  BUF_TRY(c->b_valid.ensure(sizeof(uint32_t) * (nt + 1)));
+  BUF_TRY(c->b_chain_off.ensure(sizeof(uint32_t) * (nt + 1)));
   for (int attempt = 0;; attempt++) {
     BUF_TRY(c->b_arena.ensure(sizeof(HPoint) * (size_t)arena_cap));
     HIP_TRY(hipMemsetAsync(c->b_ctr.p, 0, 2 * sizeof(uint32_t), st));  // arena_used, flags (keep bytes)
@@ -657,9 +739,25 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
                  c->b_ctr.as<Counters>());
     }
     HIP_TRY(hipEventRecord(c->eb[3], st));
-    HIP_TRY(hipMemcpyAsync(&hc, c->b_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (!(hc.flags & CTR_ARENA_OVERFLOW)) break;
+    // ---- K3s and the chain scan are queued right behind K3a; K3a's counters (arena overflow?) and the
+    // number of chains come back in ONE read-back. An overflowing attempt is redone from K3a.
+    HIP_TRY(hipMemsetAsync(c->b_valid.as<uint32_t>() + nt, 0, sizeof(uint32_t), st));
+    HIP_TRY(hipEventRecord(c->ea[4], st));
+    launch_k3s(st, nt, c->b_hyp_off.as<uint32_t>(), c->b_res.as<HypResult>(), c->b_cs_task.as<ChainSeed>(),
+               c->b_valid.as<uint32_t>());
+    BUF_TRY(scan_queue_u32(c, c->b_valid.as<uint32_t>(), c->b_chain_off.as<uint32_t>(), nt + 1, 0));
+    Readback rb(c);
+    const int ic = rb.add(c->b_ctr.p, sizeof(Counters) / 4);
+    const int it = rb.add(c->b_chain_off.as<uint32_t>() + nt, 1);
+    const int iw = rb.add(c->b_scanchk.as<uint32_t>(), 1);
+    rb.clear_after(c->b_scanchk.as<uint32_t>());
+    BUF_TRY(rb.run());
+    memcpy(&hc, rb.item(ic), sizeof(Counters));
+    if (!(hc.flags & CTR_ARENA_OVERFLOW)) {
+      if (*rb.item(iw)) return wrapped_error("chains");
+      B.n_chains = *rb.item(it);
+      break;
+    }
     if (attempt >= 6) {
       g_err = "eg3d: hypothesis arena overflow";
       return EG3D_ERR_CAPACITY;
@@ -667,15 +765,6 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
     arena_cap = std::max<uint32_t>(arena_cap * 2, hc.arena_used + (hc.arena_used >> 2));
   }
   H.flags |= (hc.flags & 0xffu);
-  // ---- K3s
-  BUF_TRY(c->b_cs_task.ensure(sizeof(ChainSeed) * (nt + 1)));
-  BUF_TRY(c->b_valid.ensure(sizeof(uint32_t) * (nt + 1)));
-  BUF_TRY(c->b_chain_off.ensure(sizeof(uint32_t) * (nt + 1)));
-  HIP_TRY(hipMemsetAsync(c->b_valid.as<uint32_t>() + nt, 0, sizeof(uint32_t), st));
-  HIP_TRY(hipEventRecord(c->ea[4], st));
-  launch_k3s(st, nt, c->b_hyp_off.as<uint32_t>(), c->b_res.as<HypResult>(), c->b_cs_task.as<ChainSeed>(),
-             c->b_valid.as<uint32_t>());
-  BUF_TRY(scan_total_u32(c, c->b_valid.as<uint32_t>(), c->b_chain_off.as<uint32_t>(), nt + 1, B.n_chains, "chains"));
   BUF_TRY(c->b_chains.ensure(sizeof(ChainSeed) * (B.n_chains + 1)));
   launch_compact_chains(st, nt, c->b_cs_task.as<ChainSeed>(), c->b_valid.as<uint32_t>(), c->b_chain_off.as<uint32_t>(),
                         c->b_chains.as<ChainSeed>());
@@ -684,14 +773,15 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
   const size_t max_scratch = c->tune.max_scratch;  // tests shrink it to force chunking
   float ms_expand = 0, ms_emit = 0;
   uint32_t chunk = 0;
-  unsigned long long bytes_before_chunk = 0;
   for (uint32_t c0 = 0; c0 < B.n_chains; c0 += chunk) {
     // capacities can grow between chunks (overflow -> retry below), so the layout is per chunk
     const ChainLayout L = chain_layout(c->chain_cap, c->pool_cap, (uint32_t)c->V);
     chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(B.n_chains - c0, max_scratch / L.total));
     const uint32_t nc = std::min(chunk, B.n_chains - c0);
-    HIP_TRY(hipMemcpyAsync(&bytes_before_chunk, &c->b_ctr.as<Counters>()->bytes, sizeof(unsigned long long),
-                           hipMemcpyDeviceToHost, st));
+    BUF_TRY(ensure_mailbox(c));
+    uint32_t* const saved_bytes = c->b_scanchk.as<uint32_t>() + 4;  // device copy of the byte counter before this chunk
+    HIP_TRY(hipMemcpyAsync(saved_bytes, &c->b_ctr.as<Counters>()->bytes, sizeof(unsigned long long),
+                           hipMemcpyDeviceToDevice, st));
     BUF_TRY(c->b_cscratch.ensure(L.total * (size_t)nc));
     BUF_TRY(c->b_couts.ensure(sizeof(ChainOut) * (nc + 1)));
     BUF_TRY(c->b_cpts.ensure(sizeof(uint32_t) * (nc + 1)));
@@ -728,8 +818,27 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
                c->b_cscratch.as<unsigned char>(), c->b_couts.as<ChainOut>(), c->b_cpts.as<uint32_t>(),
                c->b_cobs.as<uint32_t>(), c->b_ctr.as<Counters>(), c->b_order.as<uint32_t>());
     HIP_TRY(hipEventRecord(c->eb[5], st));
-    HIP_TRY(hipMemcpyAsync(&hc, c->b_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    // the two output scans are queued right behind K3b; its counters (capacity overflow?) and both totals
+    // come back in ONE read-back
+    BUF_TRY(scan_queue_u32(c, c->b_cpts.as<uint32_t>(), c->b_cpoff.as<uint32_t>(), nc + 1, 0));
+    BUF_TRY(scan_queue_u32(c, c->b_cobs.as<uint32_t>(), c->b_cooff.as<uint32_t>(), nc + 1, 1));
+    uint32_t np = 0, no = 0;
+    {
+      Readback rb(c);
+      const int ic = rb.add(c->b_ctr.p, sizeof(Counters) / 4);
+      const int ip = rb.add(c->b_cpoff.as<uint32_t>() + nc, 1);
+      const int io = rb.add(c->b_cooff.as<uint32_t>() + nc, 1);
+      const int iw = rb.add(c->b_scanchk.as<uint32_t>(), 2);
+      rb.clear_after(c->b_scanchk.as<uint32_t>());
+      rb.clear_after(c->b_scanchk.as<uint32_t>() + 1);
+      BUF_TRY(rb.run());
+      memcpy(&hc, rb.item(ic), sizeof(Counters));
+      np = *rb.item(ip);
+      no = *rb.item(io);
+      const bool overflow = hc.flags & (EG3D_FLAG_CHAIN_OVERFLOW | EG3D_FLAG_OBS_OVERFLOW);
+      if (!overflow && rb.item(iw)[0]) return wrapped_error("edge-points of one chunk");
+      if (!overflow && rb.item(iw)[1]) return wrapped_error("observations of one chunk");
+    }
     if (hc.flags & (EG3D_FLAG_CHAIN_OVERFLOW | EG3D_FLAG_OBS_OVERFLOW)) {
       // a chain outgrew its scratch slice: enlarge the capacities (kept for later calls) and redo
       // this chunk; results of the overflowing attempt are discarded
@@ -738,21 +847,16 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
       if (can_grow) {
         if (hc.flags & EG3D_FLAG_CHAIN_OVERFLOW) c->chain_cap *= 2;
         if (hc.flags & EG3D_FLAG_OBS_OVERFLOW) c->pool_cap *= 2;
-        HIP_TRY(hipMemcpyAsync(&c->b_ctr.as<Counters>()->bytes, &bytes_before_chunk, sizeof(unsigned long long),
-                               hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpyAsync(&c->b_ctr.as<Counters>()->bytes, saved_bytes, sizeof(unsigned long long),
+                               hipMemcpyDeviceToDevice, st));
         chunk = 0;  // do not advance
         continue;
       }
     }
-    uint32_t np = 0, no = 0;
-    BUF_TRY(scan_total_u32(c, c->b_cpts.as<uint32_t>(), c->b_cpoff.as<uint32_t>(), nc + 1, np, "edge-points of one chunk"));
-    BUF_TRY(scan_total_u32(c, c->b_cobs.as<uint32_t>(), c->b_cooff.as<uint32_t>(), nc + 1, no, "observations of one chunk"));
     if (H.n_obs + no > 0xffffffffull) {  // obs_off is 32-bit (include/eg3d.h)
       g_err = "eg3d: more than 2^32-1 observations in one call; use smaller seed / set ranges";
       return EG3D_ERR_CAPACITY;
     }
-    HIP_TRY(hipMemcpyAsync(&hc, c->b_ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, st));
     BUF_TRY(c->o_X.ensure(sizeof(float) * 3 * ((size_t)np + 1)));
     BUF_TRY(c->o_off.ensure(sizeof(uint32_t) * ((size_t)np + 1)));
     BUF_TRY(c->o_key.ensure(sizeof(uint32_t) * 4 * ((size_t)np + 1)));

@@ -14,6 +14,15 @@ struct SeedsDev {
 };
 
 enum : uint32_t { CTR_ARENA_OVERFLOW = 0x100u };
+// arguments of k_publish: up to 6 runs of device words copied to the host mailbox, words cleared afterwards
+struct PubArgs {
+  const uint32_t* src[6];
+  uint32_t words[6];
+  uint32_t* clear[3];
+  int n, n_clear;
+};
+enum { EG3D_MBOX_WORDS = 64 };
+void launch_publish(hipStream_t st, const PubArgs& a, uint32_t* mbox_dev, uint32_t seq);
 struct Counters {
   uint32_t arena_used;
   uint32_t flags;  // EG3D_FLAG_* bits | CTR_ARENA_OVERFLOW
@@ -82,7 +91,7 @@ void launch_k4(hipStream_t st, const TaskDesc* tasks, const ChainSeed* chains, u
                uint64_t point_base, uint64_t obs_base, float* X, uint32_t* obs_off, int32_t* obs_view, uint32_t* obs_pl,
                uint32_t* obs_seg, float* obs_xy, uint32_t* key);
 // {out[n], 1 if the scan wrapped} -> total_and_flag[0..1] (flag word must be zero before the launch)
-void launch_scan_check(hipStream_t st, const uint32_t* out, uint64_t n_plus_one, uint32_t* total_and_flag);
+void launch_scan_check(hipStream_t st, const uint32_t* out, uint64_t n_plus_one, uint32_t* wrapped);
 void launch_k5(hipStream_t st, const float* cam_P, int n_views, const float* X, const uint32_t* obs_off,
                const int32_t* obs_view, const float* obs_xy, uint64_t n, float gn_max_mse, int legacy_abs, float* X_out,
                uint8_t* inlier);

@@ -1386,15 +1386,34 @@ __global__ void __launch_bounds__(K5_BLOCK) k5_gn_filter(const float* cam_P, int
 
 // Exclusive scans of 32-bit counts wrap silently when the total passes 2^32. The counts are
 // non-negative, so a wrapped scan is exactly one whose output decreases somewhere: this check runs
-// after every scan and hands the host {total, wrapped} in one 8-byte read.
-__global__ void k_scan_check(const uint32_t* out, uint64_t n_plus_one, uint32_t* total_and_flag) {
+// after every scan and ORs into a device flag word that k_publish hands to the host (and clears).
+__global__ void k_scan_check(const uint32_t* out, uint64_t n_plus_one, uint32_t* wrapped) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) total_and_flag[0] = out[n_plus_one - 1];
-  if (i + 1 < n_plus_one && out[i + 1] < out[i]) atomicOr(&total_and_flag[1], 1u);
+  if (i + 1 < n_plus_one && out[i + 1] < out[i]) atomicOr(wrapped, 1u);
 }
-void launch_scan_check(hipStream_t st, const uint32_t* out, uint64_t n_plus_one, uint32_t* total_and_flag) {
-  hipLaunchKernelGGL(k_scan_check, dim3((unsigned)((n_plus_one + 255) / 256)), dim3(256), 0, st, out, n_plus_one,
-                     total_and_flag);
+void launch_scan_check(hipStream_t st, const uint32_t* out, uint64_t n_plus_one, uint32_t* wrapped) {
+  hipLaunchKernelGGL(k_scan_check, dim3((unsigned)((n_plus_one + 255) / 256)), dim3(256), 0, st, out, n_plus_one, wrapped);
+}
+
+// Small device -> host read-backs (scan totals, counters) without a driver round trip: one wavefront
+// copies the listed device words into a mailbox in pinned, GPU-mapped host memory and then stores
+// the sequence number the host thread is polling for (system-scope release after system fences).
+__global__ void __launch_bounds__(64) k_publish(PubArgs a, uint32_t* mbox, uint32_t seq) {
+  uint32_t at = 2;  // [0] sequence number, [1] unused, payload from [2]
+  for (int i = 0; i < a.n; i++) {
+    for (uint32_t w = threadIdx.x; w < a.words[i]; w += 64) mbox[at + w] = a.src[i][w];
+    at += a.words[i];
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < a.n_clear; i++) *a.clear[i] = 0;
+    __threadfence_system();
+    __hip_atomic_store(mbox, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+void launch_publish(hipStream_t st, const PubArgs& a, uint32_t* mbox_dev, uint32_t seq) {
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, a, mbox_dev, seq);
 }
 
 // ------------------------------------------------------------ launch wrappers --
