@@ -102,6 +102,12 @@ def main():
                     help="bound the CPU baseline to the first K seeds of the first step's batch (default: all; c4: 128)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON): libraries that print to file descriptor 1 (RCCL's
+    # "Librccl path : ..." banner, for one) are sent to stderr; the line itself goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     # Several steps are kept in flight on separate HIP streams (plus the gather stream and RCCL's):
     # with the runtime's default of 4 hardware queues two of them can share a queue and serialise.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -313,6 +319,18 @@ def main():
                                  "steps in flight the launches of different steps share the GPU, so this duration is "
                                  "longer than the kernel's exclusive time (see roofline.exclusive)"},
         }
+        if world > 1:
+            # the driver derives scaling efficiency itself; this is only where the 1-GPU figure of the SAME workload
+            # lives (the default 1-GPU run measures C3')
+            ref = os.path.join(ROOT, "profiles", "r02_final_%s.json" % wkey)
+            if os.path.exists(ref):
+                try:
+                    r1 = json.load(open(ref))
+                    line["same_workload_on_1_gpu"] = {"value": r1["value"], "ms_per_step": r1["ms_per_step"],
+                                                      "source": "profiles/r02_final_%s.json (python bench.py --workload %s)"
+                                                                % (wkey, wkey)}
+                except Exception:
+                    pass
         if single is not None:
             line["ms_per_step_one_at_a_time"] = single[0] * 1e3
             line["stage_ms_one_at_a_time"] = {n: round(single[2][k], 4) for n, k in STAGES}
@@ -376,7 +394,8 @@ def main():
                               "max_rel_err_X": rep.get("max_rel_X"), "X_bit_exact": rep.get("bitexact_X"),
                               "ids_views_order_exact": bool(rep["ok"]), "obs_xy_bit_exact": rep.get("bitexact_xy"),
                               "tolerance": 1e-4}
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     for w in workers:
         w.todo.put(None)
         w.join(timeout=10)
@@ -388,4 +407,13 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:
+        # worker threads may still be inside the library: report and leave without running destructors under them
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)

@@ -169,6 +169,30 @@ class Context:
         _check(lib().eg3d_last_device_output(self._h, C.byref(d)), "eg3d_last_device_output")
         return d
 
+    def fetch_device_output(self):
+        """Test/bench plumbing: copies the cloud eg3d_last_device_output views (HBM) into numpy arrays shaped like
+        a host result (obs_off gets its final n_obs sentinel). Needs `complete`."""
+        d = self.last_device_output()
+        if not d.complete:
+            raise RuntimeError("the device view does not hold the whole cloud of the last call")
+        try:
+            hip = C.CDLL("libamdhip64.so.7")      # by SONAME: the copy libeg3d.so (or torch) already loaded
+        except OSError:
+            hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+        def fetch(ptr, n, dtype):
+            a = np.empty(n, dtype)
+            if n and hip.hipMemcpy(a.ctypes.data, C.cast(ptr, C.c_void_p), a.nbytes, 2) != 0:
+                raise RuntimeError("hipMemcpy of the device cloud failed")
+            return a
+        n, m = int(d.n_points), int(d.n_obs)
+        return {"n_points": n, "n_obs": m, "X": fetch(d.X, 3 * n, np.float32).reshape(n, 3),
+                "obs_off": np.concatenate([fetch(d.obs_off, n, np.uint32), np.array([m], np.uint32)]),
+                "key": fetch(d.key, 4 * n, np.uint32).reshape(n, 4), "obs_view": fetch(d.obs_view, m, np.int32),
+                "obs_pl": fetch(d.obs_pl, m, np.uint32), "obs_seg": fetch(d.obs_seg, m, np.uint32),
+                "obs_xy": fetch(d.obs_xy, 2 * m, np.float32).reshape(m, 2)}
+
     def candidates(self, seeds_ptr, begin, end):
         c = D.Candidates()
         _check(lib().eg3d_candidates_run(self._h, seeds_ptr, begin, end, C.byref(c)), "eg3d_candidates_run")

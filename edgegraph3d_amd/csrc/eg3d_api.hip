@@ -52,6 +52,29 @@ struct DevBuf {
     cap = want;
     return EG3D_OK;
   }
+  // grow, keeping the first `keep` bytes (device-to-device copy on `st`, old block freed once it is done)
+  int ensure_keep(size_t bytes, size_t keep, hipStream_t st) {
+    if (bytes <= cap && p) return EG3D_OK;
+    if (!p || !keep) return ensure(bytes);
+    void* q = nullptr;
+    const size_t want = bytes + bytes / 2;
+    hipError_t e = hipMalloc(&q, want);
+    if (e != hipSuccess) {
+      g_err = std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e);
+      return EG3D_ERR_HIP;
+    }
+    e = hipMemcpyAsync(q, p, keep, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+      (void)hipFree(q);
+      g_err = std::string("growing a device buffer: ") + hipGetErrorString(e);
+      return EG3D_ERR_HIP;
+    }
+    (void)hipFree(p);
+    p = q;
+    cap = want;
+    return EG3D_OK;
+  }
   void release() {
     if (p) (void)hipFree(p);
     p = nullptr;
@@ -145,6 +168,7 @@ struct eg3d_ctx {
   uint32_t mbox_seq = 0;
   uint64_t last_np = 0, last_no = 0;
   int last_chunks = 0;
+  bool last_accumulated = false;  // the output buffers hold the whole cloud of the last call (device-only calls)
   uint32_t last_nc = 0;
   uint32_t last_nhyp = 0;
 };
@@ -540,6 +564,7 @@ namespace {
 
 struct BatchState {
   uint32_t b, e, n_seeds, sv_base, n_sv, n_tasks, n_lists, n_hits, n_hyp, n_chains, total_raw;
+  uint32_t key0_base;  // added to key[0] of every point (polyline-set path: samples before this batch)
   StageAView a;
   SeedsDev sd;
 };
@@ -857,19 +882,24 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
       g_err = "eg3d: more than 2^32-1 observations in one call; use smaller seed / set ranges";
       return EG3D_ERR_CAPACITY;
     }
-    BUF_TRY(c->o_X.ensure(sizeof(float) * 3 * ((size_t)np + 1)));
-    BUF_TRY(c->o_off.ensure(sizeof(uint32_t) * ((size_t)np + 1)));
-    BUF_TRY(c->o_key.ensure(sizeof(uint32_t) * 4 * ((size_t)np + 1)));
-    BUF_TRY(c->o_view.ensure(sizeof(int32_t) * ((size_t)no + 1)));
-    BUF_TRY(c->o_pl.ensure(sizeof(uint32_t) * ((size_t)no + 1)));
-    BUF_TRY(c->o_seg.ensure(sizeof(uint32_t) * ((size_t)no + 1)));
-    BUF_TRY(c->o_xy.ensure(sizeof(float) * 2 * ((size_t)no + 1)));
-    // chunk-local indices on the device; the global observation base is added on the host
+    // Device-only calls keep the WHOLE cloud of the call in the output buffers (chunk after chunk, batch after
+    // batch, global observation offsets), so that eg3d_last_device_output is complete whatever the chunking —
+    // the RCCL gather reads it. Calls that copy to the host reuse the buffers per chunk (chunk-local offsets,
+    // rebased on the host below).
+    const bool accumulate = device_only != 0;
+    const size_t P0 = accumulate ? (size_t)H.n_points : 0, O0 = accumulate ? (size_t)H.n_obs : 0;
+    BUF_TRY(c->o_X.ensure_keep(sizeof(float) * 3 * (P0 + np + 1), sizeof(float) * 3 * P0, st));
+    BUF_TRY(c->o_off.ensure_keep(sizeof(uint32_t) * (P0 + np + 1), sizeof(uint32_t) * P0, st));
+    BUF_TRY(c->o_key.ensure_keep(sizeof(uint32_t) * 4 * (P0 + np + 1), sizeof(uint32_t) * 4 * P0, st));
+    BUF_TRY(c->o_view.ensure_keep(sizeof(int32_t) * (O0 + no + 1), sizeof(int32_t) * O0, st));
+    BUF_TRY(c->o_pl.ensure_keep(sizeof(uint32_t) * (O0 + no + 1), sizeof(uint32_t) * O0, st));
+    BUF_TRY(c->o_seg.ensure_keep(sizeof(uint32_t) * (O0 + no + 1), sizeof(uint32_t) * O0, st));
+    BUF_TRY(c->o_xy.ensure_keep(sizeof(float) * 2 * (O0 + no + 1), sizeof(float) * 2 * O0, st));
     HIP_TRY(hipEventRecord(c->ea[6], st));
     launch_k4(st, c->b_tasks.as<TaskDesc>(), c->b_chains.as<ChainSeed>() + c0, nc, L, c->b_cscratch.as<unsigned char>(),
-              c->b_couts.as<ChainOut>(), c->b_cpoff.as<uint32_t>(), c->b_cooff.as<uint32_t>(), 0, 0, c->o_X.as<float>(),
-              c->o_off.as<uint32_t>(), c->o_view.as<int32_t>(), c->o_pl.as<uint32_t>(), c->o_seg.as<uint32_t>(),
-              c->o_xy.as<float>(), c->o_key.as<uint32_t>());
+              c->b_couts.as<ChainOut>(), c->b_cpoff.as<uint32_t>(), c->b_cooff.as<uint32_t>(), P0, O0, B.key0_base,
+              c->o_X.as<float>(), c->o_off.as<uint32_t>(), c->o_view.as<int32_t>(), c->o_pl.as<uint32_t>(),
+              c->o_seg.as<uint32_t>(), c->o_xy.as<float>(), c->o_key.as<uint32_t>());
     HIP_TRY(hipEventRecord(c->eb[6], st));
     HIP_TRY(hipStreamSynchronize(st));
     H.flags |= (hc.flags & 0xffu);
@@ -917,8 +947,9 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
     }
     H.n_points += np;
     H.n_obs += no;
-    c->last_np = np;
-    c->last_no = no;
+    c->last_np = accumulate ? H.n_points : np;
+    c->last_no = accumulate ? H.n_obs : no;
+    c->last_accumulated = accumulate;
     c->last_chunks++;
     c->last_nc = nc;
   }
@@ -964,11 +995,12 @@ int run_batch(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, HostOut& H) 
 // collect the epipolar hits of every sample; then the common stage B. `sets` is already on the
 // device; h_row_off is its host copy of the row offsets.
 int run_sets_batch(eg3d_ctx* c, const SetsDev& sets, const uint32_t* h_row_off, uint32_t n_rows_total, uint32_t set_b,
-                   uint32_t set_e, int device_only, HostOut& H) {
+                   uint32_t set_e, int device_only, uint32_t sample_base, HostOut& H) {
   hipStream_t st = c->stream;
   const uint32_t V = (uint32_t)c->V;
   BatchState B;
   memset(&B, 0, sizeof(B));
+  B.key0_base = sample_base;
   const uint32_t item_b = h_row_off[(size_t)set_b * V], item_e = h_row_off[(size_t)set_e * V];
   const uint32_t n_items = item_e - item_b;
   BUF_TRY(c->b_ctr.ensure(sizeof(Counters)));
@@ -1141,7 +1173,7 @@ extern "C" int eg3d_last_device_output(eg3d_ctx* c, eg3d_device_edgepoints* out)
   out->obs_seg = c->o_seg.as<uint32_t>();
   out->obs_xy = c->o_xy.as<float>();
   out->key = c->o_key.as<uint32_t>();
-  out->complete = c->last_chunks <= 1 ? 1 : 0;
+  out->complete = (c->last_accumulated || c->last_chunks <= 1) ? 1 : 0;
   return EG3D_OK;
 }
 
@@ -1195,11 +1227,9 @@ extern "C" int eg3d_match_polyline_sets(eg3d_ctx* c, const eg3d_polyline_sets* p
   for (uint32_t s0 = set_b; s0 < set_e;) {
     uint32_t s1 = s0 + 1;
     while (s1 < set_e && ps->row_off[(size_t)(s1 + 1) * V] - ps->row_off[(size_t)s0 * V] <= max_items) s1++;
-    const size_t p0 = H.key.size() / 4;
     const uint64_t tasks_before = H.n_tasks;
-    int rc = run_sets_batch(c, sd, ps->row_off, n_rows, s0, s1, device_only, H);
+    int rc = run_sets_batch(c, sd, ps->row_off, n_rows, s0, s1, device_only, sample_base, H);  // key[0] = sample index of the call
     if (rc != EG3D_OK) return rc;
-    for (size_t i = p0; i < H.key.size() / 4; i++) H.key[4 * i] += sample_base;  // sample index of the call
     sample_base += (uint32_t)(H.n_tasks - tasks_before);
     s0 = s1;
   }

@@ -88,7 +88,7 @@ void launch_chain_cost(hipStream_t st, StageAView a, const TaskDesc* tasks, cons
                        uint32_t* cost, uint32_t* idx);
 void launch_k4(hipStream_t st, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains, ChainLayout L,
                const unsigned char* scratch, const ChainOut* outs, const uint32_t* point_off, const uint32_t* obs_off_in,
-               uint64_t point_base, uint64_t obs_base, float* X, uint32_t* obs_off, int32_t* obs_view, uint32_t* obs_pl,
+               uint64_t point_base, uint64_t obs_base, uint32_t key0_base, float* X, uint32_t* obs_off, int32_t* obs_view, uint32_t* obs_pl,
                uint32_t* obs_seg, float* obs_xy, uint32_t* key);
 // {out[n], 1 if the scan wrapped} -> total_and_flag[0..1] (flag word must be zero before the launch)
 void launch_scan_check(hipStream_t st, const uint32_t* out, uint64_t n_plus_one, uint32_t* wrapped);

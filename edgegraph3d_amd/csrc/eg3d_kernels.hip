@@ -1270,9 +1270,9 @@ __global__ void k_chain_cost(StageAView a, const TaskDesc* tasks, const ChainSee
 __global__ void __launch_bounds__(64) k4_emit(const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains,
                                               ChainLayout L, const unsigned char* scratch, const ChainOut* outs,
                                               const uint32_t* point_off, const uint32_t* obs_off_in,
-                                              uint64_t point_base, uint64_t obs_base, float* X, uint32_t* obs_off,
-                                              int32_t* obs_view, uint32_t* obs_pl, uint32_t* obs_seg, float* obs_xy,
-                                              uint32_t* key) {
+                                              uint64_t point_base, uint64_t obs_base, uint32_t key0_base, float* X,
+                                              uint32_t* obs_off, int32_t* obs_view, uint32_t* obs_pl, uint32_t* obs_seg,
+                                              float* obs_xy, uint32_t* key) {
   __shared__ uint32_t s_excl[65];  // first flat observation index of each of the 64 points in flight (+ total)
   __shared__ uint32_t s_blk[64];   // where each point's observation block starts in the chain's pool
   const uint32_t j = blockIdx.x;
@@ -1307,7 +1307,7 @@ __global__ void __launch_bounds__(64) k4_emit(const TaskDesc* tasks, const Chain
       X[3 * pi + 1] = p.X[1];
       X[3 * pi + 2] = p.X[2];
       obs_off[pi] = (uint32_t)(obase + (incl - p.nobs));
-      key[4 * pi] = d.seed;
+      key[4 * pi] = d.seed + key0_base;
       key[4 * pi + 1] = d.entry;
       key[4 * pi + 2] = d.hit;
       key[4 * pi + 3] = i;
@@ -1551,11 +1551,11 @@ void launch_chain_cost(hipStream_t st, StageAView a, const TaskDesc* tasks, cons
 }
 void launch_k4(hipStream_t st, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains, ChainLayout L,
                const unsigned char* scratch, const ChainOut* outs, const uint32_t* point_off, const uint32_t* obs_off_in,
-               uint64_t point_base, uint64_t obs_base, float* X, uint32_t* obs_off, int32_t* obs_view, uint32_t* obs_pl,
-               uint32_t* obs_seg, float* obs_xy, uint32_t* key) {
+               uint64_t point_base, uint64_t obs_base, uint32_t key0_base, float* X, uint32_t* obs_off, int32_t* obs_view,
+               uint32_t* obs_pl, uint32_t* obs_seg, float* obs_xy, uint32_t* key) {
   if (!n_chains) return;
   hipLaunchKernelGGL(k4_emit, dim3(n_chains), dim3(64), 0, st, tasks, chains, n_chains, L, scratch, outs,
-                     point_off, obs_off_in, point_base, obs_base, X, obs_off, obs_view, obs_pl, obs_seg, obs_xy, key);
+                     point_off, obs_off_in, point_base, obs_base, key0_base, X, obs_off, obs_view, obs_pl, obs_seg, obs_xy, key);
 }
 void launch_k5(hipStream_t st, const float* cam_P, int n_views, const float* X, const uint32_t* obs_off,
                const int32_t* obs_view, const float* obs_xy, uint64_t n, float gn_max_mse, int legacy_abs, float* X_out,

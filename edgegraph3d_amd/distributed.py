@@ -47,9 +47,8 @@ def shard_ranges_balanced(trk_off, begin, end, world):
 
 class RcclCloudGather:
     """The C-ABI exchange step (include/eg3d_rccl.h: eg3d_allgather_edgepoints in libeg3d_rccl.so) on an
-    RCCL communicator created with ncclCommInitRank; the unique id travels through the caller's
-    existing torch.distributed group (any backend). librccl is resolved by SONAME, so a process that
-    has imported torch shares torch's copy instead of loading a second one."""
+    RCCL communicator created by the same library (eg3d_comm_init: hipSetDevice + ncclCommInitRank); the
+    unique id travels through the caller's existing torch.distributed group (any backend)."""
 
     def __init__(self, dist, world, rank, device_index, stream_ptr=None):
         import ctypes as C
@@ -58,28 +57,26 @@ class RcclCloudGather:
         from . import _cdefs as D
         self.C, self.D = C, D
         self.world, self.rank = world, rank
-        self.nccl = C.CDLL("librccl.so.1")
         pkg = os.path.dirname(os.path.abspath(__file__))
         self.G = C.CDLL(os.path.join(pkg, "libeg3d_rccl.so"))
-
-        class UniqueId(C.Structure):
-            _fields_ = [("internal", C.c_char * 128)]
-
-        uid = UniqueId()
+        self.G.eg3d_comm_unique_id.argtypes = [C.c_void_p]
+        self.G.eg3d_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        self.G.eg3d_comm_destroy.argtypes = [C.c_void_p]
+        uid = (C.c_ubyte * 128)()
         if rank == 0:
-            rc = self.nccl.ncclGetUniqueId(C.byref(uid))
+            rc = self.G.eg3d_comm_unique_id(uid)
             if rc != 0:
-                raise RuntimeError("ncclGetUniqueId failed (%d)" % rc)
+                raise RuntimeError("eg3d_comm_unique_id failed (%d)" % rc)
         if world > 1:
             dev = _t.device("cuda", device_index) if dist.get_backend() == "nccl" else _t.device("cpu")
-            t = _t.frombuffer(bytearray(bytes(uid)), dtype=_t.uint8).clone().to(dev)
+            t = _t.tensor(list(bytes(uid)), dtype=_t.uint8, device=dev)
             dist.broadcast(t, src=0)
-            C.memmove(C.byref(uid), bytes(t.cpu().numpy().tobytes()), 128)
+            raw = bytes(t.cpu().numpy().tobytes())
+            C.memmove(uid, raw, 128)
         self.comm = C.c_void_p()
-        self.nccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
-        rc = self.nccl.ncclCommInitRank(C.byref(self.comm), world, uid, rank)
+        rc = self.G.eg3d_comm_init(uid, world, rank, device_index, C.byref(self.comm))
         if rc != 0:
-            raise RuntimeError("ncclCommInitRank failed (%d)" % rc)
+            raise RuntimeError("eg3d_comm_init (hipSetDevice + ncclCommInitRank) failed (%d) on rank %d" % (rc, rank))
         self.G.eg3d_gather_create.restype = C.c_void_p
         self.G.eg3d_gather_create.argtypes = [C.c_int]
         self.G.eg3d_gather_destroy.argtypes = [C.c_void_p]
@@ -107,8 +104,7 @@ class RcclCloudGather:
             self.G.eg3d_gather_destroy(self.g)
             self.g = None
         if self.comm:
-            self.nccl.ncclCommDestroy.argtypes = [self.C.c_void_p]
-            self.nccl.ncclCommDestroy(self.comm)
+            self.G.eg3d_comm_destroy(self.comm)
             self.comm = self.C.c_void_p()
 
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <algorithm>
 #include <string>
@@ -98,6 +99,27 @@ extern "C" void eg3d_gather_destroy(eg3d_gather* g) {
   (void)hipSetDevice(g->device);
   if (g->pack_done) (void)hipEventDestroy(g->pack_done);
   delete g;
+}
+
+// ---- communicator helpers: created inside this library so that the communicator, the collectives and the
+// device selection all go through the SAME librccl / HIP runtime the gather is linked against
+extern "C" int eg3d_comm_unique_id(void* id128) {
+  static_assert(sizeof(ncclUniqueId) == EG3D_COMM_ID_BYTES, "ncclUniqueId size");
+  if (!id128) return EG3D_GATHER_ERR_ARG;
+  return ncclGetUniqueId((ncclUniqueId*)id128) == ncclSuccess ? 0 : EG3D_GATHER_ERR_NCCL;
+}
+extern "C" int eg3d_comm_init(const void* id128, int n_ranks, int rank, int device, void** comm) {
+  if (!id128 || !comm || n_ranks < 1 || rank < 0 || rank >= n_ranks) return EG3D_GATHER_ERR_ARG;
+  if (hipSetDevice(device) != hipSuccess) return EG3D_GATHER_ERR_HIP;
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  ncclComm_t c = nullptr;
+  if (ncclCommInitRank(&c, n_ranks, id, rank) != ncclSuccess) return EG3D_GATHER_ERR_NCCL;
+  *comm = (void*)c;
+  return 0;
+}
+extern "C" void eg3d_comm_destroy(void* comm) {
+  if (comm) (void)ncclCommDestroy((ncclComm_t)comm);
 }
 
 #define TRY_HIP(e)                   \

@@ -22,6 +22,15 @@ extern "C" {
 
 typedef struct eg3d_gather eg3d_gather; /* staging + result buffers of one rank (grow-only) */
 
+/* Communicator of the gather (thin wrappers, so that a host needs no RCCL headers and the communicator is
+ * created by the same librccl / HIP runtime the collectives run on): rank 0 makes the 128-byte id and
+ * distributes it by any means (bench.py: a torch.distributed broadcast), every rank then calls
+ * eg3d_comm_init, which selects `device` and runs ncclCommInitRank. Any ncclComm_t made elsewhere works too. */
+#define EG3D_COMM_ID_BYTES 128
+int eg3d_comm_unique_id(void* id128);
+int eg3d_comm_init(const void* id128, int n_ranks, int rank, int device, void** comm);
+void eg3d_comm_destroy(void* comm);
+
 eg3d_gather* eg3d_gather_create(int device);
 void eg3d_gather_destroy(eg3d_gather* g);
 

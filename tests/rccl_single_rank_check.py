@@ -21,17 +21,12 @@ def main():
     from edgegraph3d_amd import _cdefs as D
     pkg = os.path.dirname(os.path.abspath(api.__file__))
     G = C.CDLL(os.path.join(pkg, "libeg3d_rccl.so"))
-    nccl = C.CDLL("/opt/rocm/lib/librccl.so")
     hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")
-
-    class UniqueId(C.Structure):
-        _fields_ = [("internal", C.c_char * 128)]
-
-    uid = UniqueId()
-    assert nccl.ncclGetUniqueId(C.byref(uid)) == 0
+    uid = (C.c_ubyte * 128)()
+    assert G.eg3d_comm_unique_id(uid) == 0
     comm = C.c_void_p()
-    nccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
-    assert nccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    G.eg3d_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    assert G.eg3d_comm_init(uid, 1, 0, 0, C.byref(comm)) == 0
     s = host.Synth(1)
     ctx = api.Context(s.scene)
     want = ctx.match_refpoints(s.seeds)
@@ -62,8 +57,8 @@ def main():
     assert np.array_equal(fetch(out.obs_seg, m, np.uint32), want["obs_seg"])
     assert np.array_equal(fetch(out.obs_xy, 2 * m, np.uint32), want["obs_xy"].view(np.uint32).ravel())
     G.eg3d_gather_destroy(g)
-    nccl.ncclCommDestroy.argtypes = [C.c_void_p]
-    nccl.ncclCommDestroy(comm)
+    G.eg3d_comm_destroy.argtypes = [C.c_void_p]
+    G.eg3d_comm_destroy(comm)
     ctx.close()
 
 

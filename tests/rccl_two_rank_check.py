@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Two-rank check of the C-ABI exchange step (include/eg3d_rccl.h: eg3d_allgather_edgepoints) for a
 node with >= 2 GPUs — the single-GPU boxes of the round cannot run it, tests/test_gpu_parity.py
-skips it there. No torch: the communicator comes from ncclGetUniqueId / ncclCommInitRank, the
+skips it there. No torch: the communicator comes from eg3d_comm_unique_id / eg3d_comm_init (ncclCommInitRank), the
 unique id travels through a file.
 
     python tests/rccl_two_rank_check.py            # spawns ranks 0 and 1 (GPUs 0 and 1), prints RCCL-2RANK-OK
@@ -38,11 +38,10 @@ def worker(rank, world, idfile):
     from edgegraph3d_amd.distributed import shard_ranges_balanced
     pkg = os.path.dirname(os.path.abspath(api.__file__))
     G = C.CDLL(os.path.join(pkg, "libeg3d_rccl.so"))
-    nccl = C.CDLL("librccl.so.1")
     hip = C.CDLL("libamdhip64.so")
     uid = UniqueId()
     if rank == 0:
-        assert nccl.ncclGetUniqueId(C.byref(uid)) == 0
+        assert G.eg3d_comm_unique_id(C.byref(uid)) == 0
         with open(idfile + ".tmp", "wb") as f:
             f.write(bytes(uid))
         os.rename(idfile + ".tmp", idfile)
@@ -52,10 +51,9 @@ def worker(rank, world, idfile):
                 break
             time.sleep(0.1)
         C.memmove(C.byref(uid), open(idfile, "rb").read(), 128)
-    assert hip.hipSetDevice(rank) == 0
     comm = C.c_void_p()
-    nccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
-    assert nccl.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0
+    G.eg3d_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    assert G.eg3d_comm_init(C.byref(uid), world, rank, rank, C.byref(comm)) == 0   # hipSetDevice(rank) + ncclCommInitRank
     G.eg3d_gather_create.restype = C.c_void_p
     G.eg3d_gather_create.argtypes = [C.c_int]
     G.eg3d_allgather_edgepoints.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
@@ -122,8 +120,8 @@ def worker(rank, world, idfile):
     assert rc == -4, rc
     print("rank %d: incomplete rank reported to every rank (rc -4)" % rank, flush=True)
     G.eg3d_gather_destroy(g)
-    nccl.ncclCommDestroy.argtypes = [C.c_void_p]
-    nccl.ncclCommDestroy(comm)
+    G.eg3d_comm_destroy.argtypes = [C.c_void_p]
+    G.eg3d_comm_destroy(comm)
     ctx.close()
 
 

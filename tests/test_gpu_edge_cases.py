@@ -203,9 +203,24 @@ def test_chain_expansion_in_many_chunks(monkeypatch):
     ctx = api.Context(s.scene)
     monkeypatch.delenv("EG3D_MAX_SCRATCH_MB")
     parts = ctx.match_refpoints(s.seeds)
-    assert not ctx.last_device_output().complete        # the device view only holds the last chunk
+    assert not ctx.last_device_output().complete        # host-copy calls reuse the device buffers per chunk
     rep = compare_edgepoints(whole, parts)
     assert rep["ok"] and rep["bitexact_X"], rep["msgs"]
+    # a DEVICE-ONLY call keeps the whole cloud in HBM however many chunks it took (what the RCCL gather reads)
+    ctx.match_resident(0, s.n_seeds, device_only=True)
+    dev = ctx.fetch_device_output()
+    for k in ("X", "obs_xy"):
+        assert np.array_equal(dev[k].view(np.uint32), whole[k].view(np.uint32)), k
+    for k in ("obs_off", "key", "obs_view", "obs_pl", "obs_seg"):
+        assert np.array_equal(dev[k], whole[k]), k
+    # the same for the polyline-set path (key[0] = sample index of the whole call, added on the device)
+    n_sets, row_off, ids = s.polyline_sets(3)
+    sets_whole = ctx.match_polyline_sets(n_sets, row_off, ids)
+    ctx.match_polyline_sets(n_sets, row_off, ids, device_only=True)
+    dev = ctx.fetch_device_output()
+    for k in ("obs_off", "key", "obs_view", "obs_pl", "obs_seg"):
+        assert np.array_equal(dev[k], sets_whole[k]), k
+    assert np.array_equal(dev["X"].view(np.uint32), sets_whole["X"].view(np.uint32))
     ctx.close()
 
 
