@@ -16,10 +16,13 @@
 //
 // Usage:
 //   edge_matcher_refpoints --make-synthetic <config 0..4> <dir>      writes <dir>/input.json, <dir>/plgs.bin
+//   edge_matcher_refpoints --make-plgs <plgs.bin> <edge image 0.png> <edge image 1.png> ...
+//        builds the polyline graph of every binary edge image (view i = i-th image; SURVEY N2,
+//        edge_matcher.cpp:84-94 convert_edge_images_to_optimized_polyline_graphs) and writes the container
 //   edge_matcher_refpoints <dir>/input.json <dir>/plgs.bin <out.json> [--filter] [--estimate-F] [--all-pairs]
 //
-// The polyline graphs come from a container file because building them from edge images (SURVEY
-// N2) is outside this repository's scope. Build (see tests/test_gpu_edge_cases.py):
+// The polyline graphs travel in a container file so that the expensive one-off construction from the
+// edge images (--make-plgs) is separate from the matching run. Build (see tests/test_gpu_edge_cases.py):
 //   g++ -std=c++17 -I include examples/edge_matcher_refpoints.cpp -Ledgegraph3d_amd -leg3d -leg3d_host ...
 #include <cstdio>
 #include <cstdlib>
@@ -64,8 +67,37 @@ static int make_synthetic(int cfg_index, const std::string& dir) {
   return rc == 0 ? 0 : fail("writing the synthetic inputs");
 }
 
+static int make_plgs(const char* out_path, int n, char** images) {
+  std::vector<eg3d_plg_view> views((size_t)n);
+  int W = 0, H = 0;
+  for (int i = 0; i < n; i++) {
+    int w = 0, h = 0;
+    if (eg3d_plg_build_from_png(images[i], &w, &h, &views[(size_t)i]) != 0) {
+      std::fprintf(stderr, "edge_matcher_refpoints: cannot build the polyline graph of %s\n", images[i]);
+      return 1;
+    }
+    if (i && (w != W || h != H)) {
+      std::fprintf(stderr, "edge_matcher_refpoints: %s is %dx%d, the first image %dx%d\n", images[i], w, h, W, H);
+      return 1;
+    }
+    W = w;
+    H = h;
+  }
+  eg3d_plg* g = eg3d_plg_from_views(n, W, H, views.data());
+  uint64_t n_pl = 0;
+  for (auto& v : views) {
+    n_pl += v.n_polylines;
+    eg3d_plg_view_free(&v);
+  }
+  if (!g || eg3d_plg_write(out_path, eg3d_plg_scene(g)) != 0) return fail("writing the polyline graphs");
+  std::printf("wrote %s: %d views of %dx%d, %llu polylines\n", out_path, n, W, H, (unsigned long long)n_pl);
+  eg3d_plg_destroy(g);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc >= 4 && std::strcmp(argv[1], "--make-synthetic") == 0) return make_synthetic(std::atoi(argv[2]), argv[3]);
+  if (argc >= 4 && std::strcmp(argv[1], "--make-plgs") == 0) return make_plgs(argv[2], argc - 3, argv + 3);
   if (argc < 4) {
     std::fprintf(stderr, "usage: %s <input.json> <plgs.bin> <out.json> [--filter] [--estimate-F] [--all-pairs]\n", argv[0]);
     return 2;

@@ -175,3 +175,49 @@ def test_png_reader_formats(tmp_path):
         open(p, "wb").write(blob)
         with pytest.raises(RuntimeError):
             host.png_edge_mask(p)
+
+
+def test_example_builds_the_container_from_edge_images(tmp_path):
+    """examples/edge_matcher_refpoints --make-plgs: edge PNGs in, the polyline-graph container the path
+    consumes out (SURVEY N2 end to end from C++). The container read back must hold, view by view, the
+    graphs the library builds from the same images (ids = positions; an invalid polyline has no vertices
+    in the container's CSR)."""
+    import ctypes as C
+    import subprocess
+    from edgegraph3d_amd import _cdefs as D
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "edgegraph3d_amd")
+    exe = str(tmp_path / "edge_matcher_refpoints")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "edge_matcher_refpoints.cpp"), "-L", pkg, "-leg3d", "-leg3d_host",
+                           "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-L", "/opt/rocm/lib", "-lamdhip64", "-o", exe])
+    files = sorted(glob.glob(os.path.join(EDGES, "*.png")))[:3]
+    out = str(tmp_path / "plgs.bin")
+    r = subprocess.run([exe, "--make-plgs", out] + files, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    L = host.lib()
+    L.eg3d_plg_read.restype = C.c_void_p
+    L.eg3d_plg_read.argtypes = [C.c_char_p]
+    L.eg3d_plg_scene.restype = C.POINTER(D.Scene)
+    L.eg3d_plg_scene.argtypes = [C.c_void_p]
+    L.eg3d_plg_destroy.argtypes = [C.c_void_p]
+    g = L.eg3d_plg_read(out.encode())
+    assert g
+    sc = L.eg3d_plg_scene(g).contents
+    assert sc.n_views == 3 and sc.width == 1600 and sc.height == 1200
+    vpo = D.as_np(sc.view_pl_off, 4, np.uint32)
+    pvo = D.as_np(sc.pl_vtx_off, int(vpo[-1]) + 1, np.uint32)
+    vtx = D.as_np(sc.vtx_xy, 2 * int(pvo[-1]), np.float32).reshape(-1, 2)
+    valid = D.as_np(sc.pl_valid, int(vpo[-1]), np.uint8)
+    start = D.as_np(sc.pl_start, int(vpo[-1]), np.uint32)
+    for v, f in enumerate(files):
+        a = host.plg_from_mask(host.png_edge_mask(f))
+        lo, hi = int(vpo[v]), int(vpo[v + 1])
+        assert hi - lo == a["n_polylines"]
+        assert np.array_equal(valid[lo:hi], a["pl_valid"]) and np.array_equal(start[lo:hi], a["pl_start"])
+        for p in np.nonzero(a["pl_valid"])[0][::37]:
+            want = a["vtx_xy"][a["pl_vtx_off"][p]:a["pl_vtx_off"][p + 1]]
+            got = vtx[pvo[lo + p]:pvo[lo + p + 1]]
+            assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+    L.eg3d_plg_destroy(g)
+    assert "3 views of 1600x1200" in r.stdout
