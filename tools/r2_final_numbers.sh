@@ -17,6 +17,8 @@ for f in sorted(glob.glob('gpurun_out/final_*.json')):
     except Exception as e:
         print(f, 'unreadable', e); continue
     cb=d.get('cpu_baseline') or {}
+    if 'value' not in d:
+        print(f.split('final_')[1][:-5], {k: d[k] for k in ('kernel_ms','points_per_s','speedup_vs_cpu_1thread') if k in d}); continue
     print(f.split('final_')[1][:-5], 'value %.4g'%d['value'], 'ms %.3f'%d.get('ms_per_step',0), 'serial', d.get('value_one_step_at_a_time'), d.get('ms_per_step_one_at_a_time'),
           'e2e', (d.get('end_to_end') or {}).get('ms_per_step'), 'cpu', cb.get('value'), cb.get('all_cores'), 'parity', d.get('parity'))
 PY
