@@ -40,7 +40,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
-C4_BATCH = 8192        # seeds per step of the c4 workload (12 whole batches in 100 000 seeds)
+C4_BATCH = 8192        # seeds per step of the c4 workload on one GPU (12 whole batches in 100 000 seeds)
+C4_RANK_SHARE = 4096   # ... and per RANK on several: a step's batch = 4096 x ranks seeds. A chain of this workload runs
+                       # for up to ~0.45 s on its own wavefront, so a rank needs a few thousand seeds per step to keep its
+                       # GPU full behind such tails (measured on one GPU, 4 steps in flight: 1024 / 2048 / 4096 / 8192 seeds
+                       # per step -> 0.98 / 1.70 / 1.94 / 1.98 M edge-points/s). The job (100 000 seeds) is the same at every N.
 STAGES = [("k1_seed_candidates", "ms_candidates"), ("k2_epipolar_hits", "ms_epipolar"),
           ("k3a_hypotheses", "ms_hypotheses"), ("k3s_select", "ms_select"), ("k3b_expand", "ms_expand"),
           ("k4_emit", "ms_emit")]
@@ -84,7 +88,7 @@ def main():
                     help="auto = c3 on one GPU, c4 (strong scaling) on several; c3real = the real dtu006 edge maps")
     ap.add_argument("--config", type=int, default=0, help="deprecated alias: 2/3/4 = --workload c2/c3/c4")
     ap.add_argument("--seeds", type=int, default=0, help="override the workload's seed count (experiments only)")
-    ap.add_argument("--batch-seeds", type=int, default=0, help="seeds per step (default: all; c4: %d)" % C4_BATCH)
+    ap.add_argument("--batch-seeds", type=int, default=0, help="seeds per step (default: all; c4: %d on one GPU, %d per rank on several)" % (C4_BATCH, C4_RANK_SHARE))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed side measurements (one step at a time, end to end): profiling passes want "
@@ -111,6 +115,13 @@ def main():
     # Several steps are kept in flight on separate HIP streams (plus the gather stream and RCCL's):
     # with the runtime's default of 4 hardware queues two of them can share a queue and serialise.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # Several ranks (C4): every context in flight holds its own chain scratch (24 GB by default, read by
+    # eg3d_create); with four contexts that came to 200 GB per rank, and the gathered cloud of a 4096 x ranks step
+    # needs up to ~80 GB more. 12 GB per context is as fast with four 4096-seed steps in flight (measured: 1.87
+    # vs 1.82 M edge-points/s) and leaves the rank at ~115 GB. (One step at a time it would cost a third: more,
+    # shorter K3b launches, each waiting for its own slowest chain — so the single-GPU runs keep 24 GB.)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("EG3D_MAX_SCRATCH_MB", "12288")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
@@ -151,7 +162,7 @@ def main():
         synth = host.Synth(cfg)       # same seeded scene + seeds on every rank
     n_total = synth.n_seeds
     trk_off = synth.seeds_np()[0]
-    batch = args.batch_seeds or (C4_BATCH if wl == "c4" else n_total)
+    batch = args.batch_seeds or ((C4_BATCH if world == 1 else C4_RANK_SHARE * world) if wl == "c4" else n_total)
     batch = min(batch, n_total)
     n_batches = max(1, n_total // batch)
     if args.path == "sets" and wl == "c3real":
@@ -327,8 +338,8 @@ def main():
                 try:
                     r1 = json.load(open(ref))
                     line["same_workload_on_1_gpu"] = {"value": r1["value"], "ms_per_step": r1["ms_per_step"],
-                                                      "source": "profiles/r02_final_%s.json (python bench.py --workload %s)"
-                                                                % (wkey, wkey)}
+                                                      "source": "profiles/r02_final_%s.json (python bench.py --workload %s; one "
+                                                                "GPU takes the same seeds in steps of %d)" % (wkey, wkey, C4_BATCH)}
                 except Exception:
                     pass
         if single is not None:
