@@ -140,6 +140,12 @@ def main():
     if wl == "auto":
         wl = "c3" if world == 1 else "c4"
     dist = None
+    # Dry run of the multi-rank control flow on a box with fewer GPUs than ranks (tests/bench_dryrun_check.sh): the
+    # ranks share the visible GPUs, rendezvous over gloo, and the exchange step is replaced by a count reduction.
+    # Not a measurement: the JSON line says so.
+    dry = os.environ.get("EG3D_BENCH_DRYRUN_GATHER") == "1"
+    if dry:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     if world > 1 or args.force_gather:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -147,7 +153,10 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if api.device_count() < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -213,7 +222,21 @@ def main():
     gather = None
     if dist is not None:
         gstream = torch.cuda.Stream(device=dev, priority=-1)
-        gather = RcclCloudGather(dist, world, rank, local_rank, gstream.cuda_stream)
+        if dry:
+            class _CountOnly:
+                def allgather(self, local):
+                    t = torch.tensor([int(local.n_points)], dtype=torch.int64)
+                    dist.all_reduce(t)
+
+                    class _C:
+                        n_points = int(t.item())
+                    return _C, 0
+
+                def close(self):
+                    pass
+            gather = _CountOnly()
+        else:
+            gather = RcclCloudGather(dist, world, rank, local_rank, gstream.cuda_stream)
 
     def run_steps(first, n, pool, device_only=True):
         """Steps first..first+n-1, at most len(pool) in flight; results (and the collectives, which
@@ -250,7 +273,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dry else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stage_ms = {k: [r["times"][k] for r, _ in results] for _, k in STAGES}
@@ -308,7 +331,8 @@ def main():
             "metric": "triangulated edge-points/sec", "value": value, "unit": "edge-points/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic" if wl != "c3real" else "real dtu006 edge maps + synthetic cameras and seeds", "steps_in_flight": inflight,
+            "data": "DRY RUN of the multi-rank control flow (ranks share a GPU, no collective): not a measurement" if dry else
+                    "synthetic" if wl != "c3real" else "real dtu006 edge maps + synthetic cameras and seeds", "steps_in_flight": inflight,
             "config": {
                 "workload": workload, "workload_key": wkey,
                 "edge_points_per_step": points_done / args.steps, "observations_last_step_rank0": int(last["n_obs"]),
