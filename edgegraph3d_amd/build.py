@@ -71,7 +71,7 @@ def build_hip(force=False, out=None, defines=()):
 # The same library with the OTHER form of cv::triangulatePoints' system (three rows per view, 6x4:
 # OpenCV 2.4-3.1 — the release the reference names; the default build follows the later 4x4 form).
 # The reference pins no OpenCV version, so both are kept bit-exact against the oracle in the
-# matching mode (tests/test_gpu_dlt_forms.py). Selected with EG3D_LIB=<this file>.
+# matching mode (tests/test_dlt_forms.py, tests/dlt6x4_gpu_check.py). Selected with EG3D_LIB=<this file>.
 HIP_LIB_DLT6X4 = os.path.join(PKG, "libeg3d_dlt6x4.so")
 
 
