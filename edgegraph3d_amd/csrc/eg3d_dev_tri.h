@@ -506,8 +506,11 @@ EG3D_HD bool gauss_newton_f32_t(PP cam_P, int pstride, VP views, XYP xy, int n, 
     float diff = mse / (float)(n * 2) - last_mse;
     bool conv;
     if (legacy_abs) {
-      int di = (int)diff;
-      conv = (double)(di < 0 ? -di : di) < 0.0000000005;  // Q9
+      // Q9: ::abs(int) of the truncated difference is 0 exactly when -1 < diff < 1. A NaN or out-of-range
+      // difference (a point without observations gives 0/0) is undefined behaviour in the reference's
+      // float -> int conversion; x86 yields INT_MIN there, i.e. "not converged", which this predicate states
+      // explicitly instead of relying on the conversion (the GPU's cvt returns 0 for NaN).
+      conv = diff > -1.0f && diff < 1.0f;
     } else {
       conv = (double)EG3D_FABSF(diff) < 0.0000000005;
     }

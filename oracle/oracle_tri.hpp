@@ -411,7 +411,11 @@ static inline int GaussNewton_f32(const std::vector<GNObs>& obs, const float ini
     float diff = mse / (n * 2) - last_mse;
     bool conv;
     if (legacy_abs)
-      conv = (double)std::abs((int)diff) < 0.0000000005;  // Q9: ::abs(int) truncation
+      // Q9: ::abs(int) of the truncated difference; 0 exactly when -1 < diff < 1. For NaN / out-of-range
+      // differences (0 observations: 0/0) the reference's float -> int conversion is undefined; x86's cvttss2si
+      // gives INT_MIN, abs() of which is not 0: "not converged". Stated as a predicate so that neither the
+      // compiler's treatment of abs(INT_MIN) nor another target's conversion can change it.
+      conv = diff > -1.0f && diff < 1.0f;
     else
       conv = (double)std::fabs(diff) < 0.0000000005;
     if (conv) break;

@@ -50,3 +50,40 @@ def test_random_mutated_scene_matches_oracle(case):
     rep = compare_edgepoints(rs, gs)
     assert rep["ok"] and rep["bitexact_X"], (case, rep["msgs"][:3])
     ctx.close()
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_gn_filter_degenerate_inputs_match_oracle(case):
+    """Config 5 on inputs a real SfM file can hold: NaN / huge / zero coordinates, points behind the cameras,
+    gross outliers, all observations from one view (singular normal equations), tracks of 0, 1 and 2
+    observations — both abs() behaviours (Q9). X and the inlier flags must equal the oracle's bit for bit."""
+    from oracle import binding as ob
+    s = host.Synth(5)
+    ctx = api.Context(s.scene)
+    orc = ob.Oracle(s.scene)
+    rng = np.random.default_rng(77 + case)
+    X, off, view, xy = s.points(3000 + case)
+    X, xy, view = X.copy(), xy.copy(), view.copy()
+    n = len(X)
+    idx = rng.integers(0, n, 60)
+    X[idx[:10]] = np.nan
+    X[idx[10:20]] *= 1e6
+    X[idx[20:30]] = 0
+    X[idx[30:40]] = -X[idx[30:40]]
+    for p in idx[40:50]:
+        xy[off[p]:off[p + 1]] += rng.normal(0, 200, (off[p + 1] - off[p], 2)).astype(np.float32)
+    for p in idx[50:60]:
+        view[off[p]:off[p + 1]] = view[off[p]]
+    keep = np.ones(len(view), bool)
+    for j, p in enumerate(rng.integers(0, n, 45)):
+        a, b = int(off[p]), int(off[p + 1])
+        keep[a + (j % 3):b] = False
+    noff = np.zeros_like(off)
+    noff[1:] = np.cumsum([keep[off[p]:off[p + 1]].sum() for p in range(n)])
+    view2, xy2 = view[keep], xy[keep]
+    for legacy in (False, True):
+        Xo, inl = orc.gn_filter(X, noff, view2, xy2, 3.0, legacy_abs=legacy)
+        Xg, ing, _ = ctx.gn_filter(X, noff, view2, xy2, 3.0, legacy_abs=legacy)
+        diff = np.nonzero((Xo.view(np.uint32) != Xg.view(np.uint32)).any(1) | (inl != ing))[0]
+        assert len(diff) == 0, (case, legacy, [(int(noff[p + 1] - noff[p]), Xo[p], Xg[p], inl[p], ing[p]) for p in diff[:3]])
+    ctx.close()

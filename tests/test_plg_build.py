@@ -221,3 +221,45 @@ def test_example_builds_the_container_from_edge_images(tmp_path):
             assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
     L.eg3d_plg_destroy(g)
     assert "3 views of 1600x1200" in r.stdout
+
+
+def _random_mask(case):
+    """random strokes, arcs, blobs and salt noise, some touching the border: topologies the real edge maps
+    rarely have (thick strokes, dense junction clusters, isolated pixels, 2x2 blocks)"""
+    rng = np.random.default_rng(4200 + case)
+    h, w = int(rng.integers(24, 140)), int(rng.integers(24, 180))
+    m = np.zeros((h, w), np.uint8)
+    for _ in range(int(rng.integers(2, 14))):
+        kind = rng.integers(0, 4)
+        if kind == 0:      # straight stroke, possibly thick
+            x0, y0, x1, y1 = rng.uniform(-5, w + 5), rng.uniform(-5, h + 5), rng.uniform(-5, w + 5), rng.uniform(-5, h + 5)
+            n = int(max(abs(x1 - x0), abs(y1 - y0)) * 2) + 2
+            t = np.linspace(0, 1, n)
+            xs, ys = np.round(x0 + (x1 - x0) * t).astype(int), np.round(y0 + (y1 - y0) * t).astype(int)
+            for d in range(int(rng.integers(1, 3))):
+                ok = (xs >= 0) & (xs < w) & (ys + d >= 0) & (ys + d < h)
+                m[ys[ok] + d, xs[ok]] = 1
+        elif kind == 1:    # arc
+            cx, cy, r = rng.uniform(0, w), rng.uniform(0, h), rng.uniform(3, 40)
+            a0, a1 = rng.uniform(0, 6.3), rng.uniform(0, 6.3)
+            t = np.linspace(min(a0, a1), max(a0, a1), int(r * 8) + 4)
+            xs, ys = np.round(cx + r * np.cos(t)).astype(int), np.round(cy + r * np.sin(t)).astype(int)
+            ok = (xs >= 0) & (xs < w) & (ys >= 0) & (ys < h)
+            m[ys[ok], xs[ok]] = 1
+        elif kind == 2:    # small filled blob
+            x, y = int(rng.integers(0, w - 3)), int(rng.integers(0, h - 3))
+            m[y:y + int(rng.integers(2, 4)), x:x + int(rng.integers(2, 4))] = 1
+        else:              # salt noise
+            k = int(rng.integers(1, 30))
+            m[rng.integers(0, h, k), rng.integers(0, w, k)] = 1
+    if case % 5 == 0:
+        m[0, :] = 1        # an edge along the image border
+    return m
+
+
+@pytest.mark.parametrize("case", range(40))
+def test_random_masks_product_equals_oracle(case):
+    m = _random_mask(case)
+    a = host.plg_from_mask(m)
+    b = ob.plg_from_mask(m)
+    _same(a, b)

@@ -188,6 +188,26 @@ def test_q9_filter_legacy_integer_abs_accepts_points_below_one_pixel_unchanged()
     assert not np.array_equal(Xn, Xl)
 
 
+def test_q9_legacy_abs_on_a_point_without_observations_is_not_converged():
+    """A point with no observations makes the filter's mean-square error 0/0. With the legacy ::abs(int) the
+    reference then converts NaN to int — undefined; x86 gives INT_MIN, whose abs() is not 0, so the loop goes on to
+    the singular normal equations and the point is rejected. Oracle and device state that outcome as a predicate
+    (-1 < diff < 1) instead of performing the conversion (a GPU's conversion gives 0 and would ACCEPT the point:
+    found by tests/test_gpu_fuzz.py). Both abs() behaviours reject; the coordinates come back unchanged."""
+    s = host.Synth(0)
+    X, off, view, xy = s.points(50)
+    off = off.copy()
+    off[3:] -= off[3] - off[2]          # point 2 loses all its observations
+    n_cut = int(s.points(50)[1][3] - s.points(50)[1][2])
+    view2 = np.concatenate([view[:off[2]], view[off[2] + n_cut:]])
+    xy2 = np.concatenate([xy[:off[2]], xy[off[2] + n_cut:]])
+    o = ob.Oracle(s.scene)
+    for legacy in (False, True):
+        Xo, inl = o.gn_filter(X, off, view2, xy2, 3.0, legacy_abs=legacy)
+        assert inl[2] == 0 and np.array_equal(Xo[2].view(np.uint32), X[2].view(np.uint32))
+        assert inl.sum() > 10
+
+
 def test_q15_direction_mismatch_is_counted_not_crashing():
     s = host.Synth(1)
     r = ob.Oracle(s.scene).match(s.seeds, 0, s.n_seeds, 1)
