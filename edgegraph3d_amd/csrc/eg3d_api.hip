@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -316,6 +317,21 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
       g_err = "eg3d_create: a view has more than " + std::to_string(EG3D_MAX_POLYLINES_PER_VIEW) + " polylines";
       return EG3D_ERR_CAPACITY;
     }
+  // Vertex coordinates of valid polylines must be finite and within +-1e7 px. The grid construction samples
+  // every segment each ~2.6 px (polyline_graph_2d.cpp:819-835) whether or not it lies inside the image: a stray
+  // 1e20 coordinate would keep the reference (and this library's host grid builder) sampling for years, and a
+  // NaN makes its cell conversions undefined. Such a scene is refused instead.
+  {
+    const uint32_t np_all = sc->view_pl_off[sc->n_views];
+    for (uint32_t p = 0; p < np_all; p++) {
+      if (!sc->pl_valid[p]) continue;
+      for (size_t k = 2 * (size_t)sc->pl_vtx_off[p]; k < 2 * (size_t)sc->pl_vtx_off[p + 1]; k++)
+        if (!(std::fabs(sc->vtx_xy[k]) <= 1e7f)) {
+          g_err = "eg3d_create: polyline " + std::to_string(p) + " has a vertex coordinate that is not finite or beyond +-1e7 px";
+          return EG3D_ERR_ARG;
+        }
+    }
+  }
   HIP_TRY(hipSetDevice(device));
   eg3d_ctx* c = new eg3d_ctx();
   c->device = device;

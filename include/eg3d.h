@@ -61,7 +61,8 @@ typedef struct eg3d_scene {
   const uint8_t* F_valid;     /* [V][V] 0 => "1x1 Mat" => epiline fails (geometric_utilities.cpp:826,840) */
   const uint32_t* view_pl_off;/* [V+1] polyline index range of each view in the arrays below */
   const uint32_t* pl_vtx_off; /* [NP+1] vertex range of each polyline (global indices into vtx_xy) */
-  const float* vtx_xy;        /* [NV][2] polyline_coords */
+  const float* vtx_xy;        /* [NV][2] polyline_coords; on valid polylines finite and within +-1e7 px (eg3d_create refuses
+                                 the scene otherwise: the reference's grid sampling does not terminate on such input) */
   const uint32_t* pl_start;   /* [NP] node id `start` */
   const uint32_t* pl_end;     /* [NP] node id `end`   */
   const uint8_t* pl_valid;    /* [NP] PolyLineGraph2D::is_valid_polyline (polyline_graph_2d.cpp:1141-1147); the vertices of an

@@ -58,3 +58,46 @@ def draw(case):
     new_off[1:] = np.cumsum([keep[off[p]:off[p + 1]].sum() for p in range(len(off) - 1)])
     seeds = host.SeedsArrays(new_off, view[keep], xy[keep])
     return s, host.SceneArrays(sc), seeds
+
+
+HOSTILE_KINDS = ["seed_nan", "seed_inf", "seed_huge", "vtx_dup", "cam_zero", "F_nan", "vtx_nan", "vtx_huge"]
+
+
+def hostile(case, kinds):
+    """Hostile numeric inputs: NaN / inf / huge coordinates in seed observations and polyline vertices, zero-length
+    segments, a camera of zeros, a NaN fundamental matrix."""
+    rng = np.random.default_rng(9000 + case)
+    cfg = host.default_config(1)
+    cfg.n_views = int(rng.integers(4, 12))
+    cfg.n_seeds = int(rng.integers(60, 140))
+    cfg.rng_seed = int(rng.integers(1, 2**62))
+    s = host.Synth(cfg)
+    sc = s.scene_np()
+    off, view, xy = s.seeds_np()
+    xy = xy.copy()
+    vt = sc["vtx_xy"].copy()
+    m = len(xy)
+    if "seed_nan" in kinds:
+        xy[rng.integers(0, m, 6)] = np.nan
+    if "seed_inf" in kinds:
+        xy[rng.integers(0, m, 4), 0] = np.inf
+        xy[rng.integers(0, m, 4), 1] = -np.inf
+    if "seed_huge" in kinds:
+        xy[rng.integers(0, m, 6)] = [3e9, -7e12]
+    if "vtx_dup" in kinds:
+        k = rng.integers(1, len(vt) - 1, 200)
+        vt[k] = vt[k - 1]
+    if "vtx_nan" in kinds:
+        vt[rng.integers(0, len(vt), 20)] = np.nan
+    if "vtx_huge" in kinds:
+        vt[rng.integers(0, len(vt), 20)] = [1e20, -1e20]
+    sc["vtx_xy"] = vt
+    if "cam_zero" in kinds:
+        P = sc["cam_P"].copy()
+        P[int(rng.integers(0, sc["n_views"]))] = 0
+        sc["cam_P"] = P
+    if "F_nan" in kinds:
+        F = sc["F"].copy()
+        F[int(rng.integers(0, sc["n_views"])), int(rng.integers(0, sc["n_views"]))] = np.nan
+        sc["F"] = F
+    return s, host.SceneArrays(sc), host.SeedsArrays(off, view, xy)

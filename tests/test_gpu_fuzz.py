@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from edgegraph3d_amd import api, host
-from fuzz_scenes import draw
+from fuzz_scenes import HOSTILE_KINDS, draw, hostile
 from parity_util import compare_edgepoints
 
 pytestmark = pytest.mark.gpu
@@ -87,3 +87,29 @@ def test_gn_filter_degenerate_inputs_match_oracle(case):
         diff = np.nonzero((Xo.view(np.uint32) != Xg.view(np.uint32)).any(1) | (inl != ing))[0]
         assert len(diff) == 0, (case, legacy, [(int(noff[p + 1] - noff[p]), Xo[p], Xg[p], inl[p], ing[p]) for p in diff[:3]])
     ctx.close()
+
+
+@pytest.mark.parametrize("case", range(12))
+def test_hostile_numeric_inputs_match_oracle(case):
+    """NaN / inf / 1e12 seed observations, zero-length segments, a camera matrix of zeros, a NaN fundamental
+    matrix — alone (cases 0-5) and three at a time: inputs on which conversions and comparisons could differ between
+    x86 and the GPU. The result must still equal the oracle's bit for bit."""
+    ok_kinds = HOSTILE_KINDS[:6]
+    kinds = [ok_kinds[case]] if case < 6 else list(np.random.default_rng(case).choice(ok_kinds, 3, replace=False))
+    s, sa, seeds = hostile(case, kinds)
+    n = len(seeds.trk_off) - 1
+    ctx = api.Context(C.byref(sa.c))
+    got = ctx.match_refpoints(C.byref(seeds.c), 0, n)
+    ref = _oracle(C.byref(sa.c)).match(C.byref(seeds.c), 0, n, nthreads=8)
+    rep = compare_edgepoints(ref, got)
+    assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], (case, kinds, rep["msgs"][:3])
+    ctx.close()
+
+
+@pytest.mark.parametrize("kind", ["vtx_nan", "vtx_huge"])
+def test_scene_with_non_finite_or_absurd_vertices_is_refused(kind):
+    """include/eg3d.h: vertices of valid polylines must be finite and within +-1e7 px — the reference's grid
+    sampling walks every segment in ~2.6 px steps wherever it lies, so a 1e20 coordinate never finishes."""
+    s, sa, seeds = hostile(4, [kind])
+    with pytest.raises(RuntimeError, match="not finite or beyond"):
+        api.Context(C.byref(sa.c))
