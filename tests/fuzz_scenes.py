@@ -17,6 +17,10 @@ def draw(case):
     cfg.vtx_noise_px = float(rng.choice([0.0, 0.15, 0.5]))
     cfg.invalid_frac = float(rng.choice([0.0, 0.01, 0.15]))
     cfg.seed_offset_px = float(rng.choice([0.0, 3.0, 6.0, 12.0]))
+    if case >= 100:        # many views: lazy pre-solves (>= 64 views), long observation lists (chunked lane groups)
+        cfg.n_views = [70, 110, 200][case - 100]
+        cfg.n_seeds = 24
+        cfg.max_track = 40
     if case % 4 == 1:      # a small image: more seeds near the border, coarser grids
         cfg.width, cfg.height = 640, 480
         cfg.focal, cfg.ppx, cfg.ppy = 1150.0, 330.0, 245.0

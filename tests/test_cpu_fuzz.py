@@ -36,3 +36,54 @@ def test_hostile_numeric_inputs_hostsim_vs_oracle(case):
     got = hs.match(C.byref(sa.c), C.byref(seeds.c), 0, n, cand)
     rep = compare_edgepoints(ref, got)
     assert rep["ok"] and rep["bitexact_X"], (case, rep["msgs"][:3])
+
+
+def _mutated_cloud(case):
+    """An oracle cloud of a mutated scene, then made irregular the way a caller could hand it back: repeated 3-D
+    coordinates inside and across chains, NaN coordinates, observations on / outside the image border, NaN
+    observation coordinates."""
+    import numpy as np
+    s, sa, seeds = draw(case)
+    n = len(seeds.trk_off) - 1
+    o = ob.Oracle(C.byref(sa.c))
+    cloud = o.match(C.byref(seeds.c), 0, n, 1)
+    rng = np.random.default_rng(500 + case)
+    X, xy = cloud["X"].copy(), cloud["obs_xy"].copy()
+    m = len(X)
+    if m > 20:
+        i = rng.integers(1, m, 12)
+        X[i] = X[i - 1]                                   # consecutive duplicates: no edge, same node
+        j = rng.integers(0, m, 8)
+        X[j] = X[rng.integers(0, m, 8)]                   # far duplicates: node shared between chains
+        X[rng.integers(0, m, 3)] = np.nan
+        k = rng.integers(0, len(xy), 10)
+        xy[k[:3]] = [0.0, 5.0]
+        xy[k[3:6]] = [float(sa.c.width), float(sa.c.height)]
+        xy[k[6:8]] = [-4.0, 1e9]
+        xy[k[8:]] = np.nan
+    cloud["X"], cloud["obs_xy"] = X, xy
+    return sa, o, cloud
+
+
+@pytest.mark.parametrize("case", [0, 2, 4, 7, 8, 14])
+def test_replay_and_dedup_on_irregular_clouds_match_oracle(case):
+    """Row a17 replay and the 3 px dedup (N3) on irregular clouds: product (flat tables) == oracle (the reference's
+    containers), including NaN coordinates and observations off the image (the dedup's bounds rule)."""
+    import numpy as np
+    from edgegraph3d_amd import _cdefs as D
+    from edgegraph3d_amd import host
+    sa, o, cloud = _mutated_cloud(case)
+    got, ref = host.replay_matches(C.byref(sa.c), cloud), o.replay_matches(cloud)
+    assert set(got) == set(ref)
+    for f in ref:
+        x, y = got[f], ref[f]
+        if isinstance(y, np.ndarray):
+            assert np.array_equal(x.view(np.uint32) if x.dtype.kind == "f" else x, y.view(np.uint32) if y.dtype.kind == "f" else y), (case, f)
+        else:
+            assert x == y, (case, f)
+    ep = D.EdgePointsArrays(cloud)
+    npts = int(cloud["n_points"])
+    keep_o, keep_h = np.zeros(max(npts, 1), np.uint8), np.zeros(max(npts, 1), np.uint8)
+    assert ob.lib().orc_filter_close_2d(o._h, C.byref(ep.c), D.np_ptr(keep_o, C.c_uint8)) == 0
+    assert host.lib().eg3d_host_filter_close_2d(sa.c.n_views, sa.c.width, sa.c.height, C.byref(ep.c), D.np_ptr(keep_h, C.c_uint8)) == 0
+    assert np.array_equal(keep_o, keep_h), case

@@ -15,7 +15,7 @@ from parity_util import compare_edgepoints
 
 pytestmark = pytest.mark.gpu
 
-CASES = list(range(40))
+CASES = list(range(40)) + [100, 101, 102]
 
 
 def _oracle(scene_ptr):
@@ -43,6 +43,9 @@ def test_random_mutated_scene_matches_oracle(case):
             assert np.array_equal(bits(x), bits(y)), (case, k)
         else:
             assert x == y, (case, k, x, y)
+    if case >= 100:   # many views: the polyline-set oracle alone takes minutes there
+        ctx.close()
+        return
     # the polyline-set path on the same mutated scene
     n_sets, row_off, ids = s.polyline_sets(2)
     gs = ctx.match_polyline_sets(n_sets, row_off, ids)
