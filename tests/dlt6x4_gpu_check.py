@@ -36,6 +36,21 @@ def main():
         assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], rep
         print("config %d: %d edge-points bit-exact in 6x4 mode" % (cfg, got["n_points"]))
         ctx.close()
+    # the randomised / hostile scenes of tests/fuzz_scenes.py, in this mode
+    from fuzz_scenes import HOSTILE_KINDS, draw, hostile
+    n_ok = 0
+    for make, cases in ((draw, list(range(0, 40, 3)) + [101]), (lambda c: hostile(c, [HOSTILE_KINDS[c]]), range(6))):
+        for case in cases:
+            s, sa, seeds = make(case)
+            n = len(seeds.trk_off) - 1
+            ctx = api.Context(C.byref(sa.c))
+            got = ctx.match_refpoints(C.byref(seeds.c), 0, n)
+            ref = ob.Oracle(C.byref(sa.c)).match(C.byref(seeds.c), 0, n, os.cpu_count())
+            rep = compare_edgepoints(ref, got)
+            assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], (case, rep["msgs"][:3])
+            ctx.close()
+            n_ok += 1
+    print("%d randomised / hostile scenes bit-exact in 6x4 mode" % n_ok)
 
 
 if __name__ == "__main__":
