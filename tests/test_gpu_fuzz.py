@@ -116,3 +116,41 @@ def test_scene_with_non_finite_or_absurd_vertices_is_refused(kind):
     s, sa, seeds = hostile(4, [kind])
     with pytest.raises(RuntimeError, match="not finite or beyond"):
         api.Context(C.byref(sa.c))
+
+
+def test_one_context_many_calls_of_different_shapes(monkeypatch):
+    """A context's buffers only grow and are reused by every call; device-only calls accumulate their cloud over
+    chunks. A random sequence of calls on ONE context — seed ranges of very different sizes, host-copy and
+    device-only calls alternating, forced chunking — must give, call by call, what a fresh computation gives."""
+    monkeypatch.setenv("EG3D_MAX_SCRATCH_MB", "64")      # several chunks on the larger ranges
+    s = host.Synth(2)
+    ctx = api.Context(s.scene)
+    monkeypatch.delenv("EG3D_MAX_SCRATCH_MB")
+    ctx.upload_seeds(s.seeds)
+    whole = ctx.match_resident(0, s.n_seeds)
+    key0 = whole["key"][:, 0]
+    rng = np.random.default_rng(31)
+
+    def expect(b, e):
+        sel = (key0 >= b) & (key0 < e)
+        first = int(np.argmax(sel)) if sel.any() else 0
+        n = int(sel.sum())
+        o0, o1 = int(whole["obs_off"][first]), int(whole["obs_off"][first + n])
+        return {"X": whole["X"][first:first + n], "key": whole["key"][first:first + n],
+                "obs_off": whole["obs_off"][first:first + n + 1] - o0, "obs_view": whole["obs_view"][o0:o1],
+                "obs_pl": whole["obs_pl"][o0:o1], "obs_seg": whole["obs_seg"][o0:o1], "obs_xy": whole["obs_xy"][o0:o1]}
+
+    for it in range(14):
+        b = int(rng.integers(0, s.n_seeds))
+        e = int(min(s.n_seeds, b + rng.choice([0, 1, 7, 60, 400, 2000])))
+        want = expect(b, e)
+        if it % 2:
+            ctx.match_resident(b, e, device_only=True)
+            got = ctx.fetch_device_output()
+        else:
+            got = ctx.match_resident(b, e)
+        for k in ("X", "obs_xy"):
+            assert np.array_equal(got[k].view(np.uint32).ravel(), want[k].view(np.uint32).ravel()), (it, b, e, k)
+        for k in ("key", "obs_off", "obs_view", "obs_pl", "obs_seg"):
+            assert np.array_equal(got[k], want[k]), (it, b, e, k)
+    ctx.close()
