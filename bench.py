@@ -291,13 +291,12 @@ def main():
         torch.cuda.synchronize()
         single = ((time.perf_counter() - ts) / ns, sum(tot for _, tot in rs) / ns,
                   {k: sum(r["times"][k] for r, _ in rs) / ns for _, k in STAGES})
-        if sets is None:   # timed at the C ABI (the Python wrapper's numpy conversion is not part of the product)
+        # timed at the C ABI (the Python wrapper's numpy conversion is not part of the product)
+        if sets is None:
             tt = [workers[0].ctx.time_match_to_host(*step_range(i)) for i in range(ns)]
-            e2e = (sum(t for t, _ in tt) / ns, sum(n for _, n in tt) / ns)
         else:
-            ts = time.perf_counter()
-            rs = run_steps(0, ns, workers[:1], device_only=False)
-            e2e = ((time.perf_counter() - ts) / ns, sum(tot for _, tot in rs) / ns)
+            tt = [workers[0].ctx.time_match_sets_to_host(sets[0], sets[1], sets[2]) for _ in range(ns)]
+        e2e = (sum(t for t, _ in tt) / ns, sum(n for _, n in tt) / ns)
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -377,7 +376,7 @@ def main():
             line["value_one_step_at_a_time"] = single[1] / single[0]
             line["end_to_end"] = {"ms_per_step": e2e[0] * 1e3, "value": e2e[1] / e2e[0],
                                   "what": "one step at a time incl. the D2H copy of the edge-point cloud into "
-                                          "caller-owned host arrays (eg3d_match_resident, device_only=0), timed at the C ABI"}
+                                          "caller-owned host arrays (eg3d_match_resident / eg3d_match_polyline_sets, device_only=0), timed at the C ABI"}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import binding as ob   # cpu_baseline leg: the checker timed as the CPU port
             sys.path.insert(0, os.path.join(ROOT, "tests"))

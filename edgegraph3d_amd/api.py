@@ -138,6 +138,21 @@ class Context:
         lib().eg3d_free_edgepoints(C.byref(e))
         return dt, n
 
+    def time_match_sets_to_host(self, n_sets, row_off, pl_ids):
+        """The same for eg3d_match_polyline_sets: (seconds, n_points) of one call with device_only=0 at the C ABI."""
+        import time
+        row_off = np.ascontiguousarray(row_off, np.uint32)
+        pl_ids = np.ascontiguousarray(pl_ids if len(pl_ids) else [0], np.uint32)
+        ps = D.PolylineSets(n_sets, D.np_ptr(row_off, C.c_uint32), D.np_ptr(pl_ids, C.c_uint32))
+        e, tm = D.EdgePoints(), D.StageTimes()
+        t0 = time.perf_counter()
+        rc = lib().eg3d_match_polyline_sets(self._h, C.byref(ps), 0, n_sets, 0, C.byref(e), C.byref(tm))
+        dt = time.perf_counter() - t0
+        _check(rc, "eg3d_match_polyline_sets")
+        n = int(e.n_points)
+        lib().eg3d_free_edgepoints(C.byref(e))
+        return dt, n
+
     def match_refpoints(self, seeds_ptr, begin=0, end=None, device_only=False):
         if end is None:
             end = int(seeds_ptr.contents.n_seeds) if hasattr(seeds_ptr, "contents") else int(seeds_ptr.n_seeds)
