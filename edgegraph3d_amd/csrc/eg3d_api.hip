@@ -22,6 +22,7 @@
 
 #include "../../include/eg3d.h"
 #include "../../include/eg3d_host.h"
+#include "eg3d_host_copy.h"
 #include "eg3d_kernels.h"
 
 using namespace eg3d;
@@ -713,27 +714,7 @@ struct RawVec {
   }
 };
 
-// host memcpy of a large block on a few threads (the D2H of a cloud lands in pinned staging at PCIe
-// speed; one core copying it on to the caller's pageable arrays would be the slow part)
-static void copy_mt(void* dst, const void* src, size_t bytes) {
-#ifndef EG3D_COPY_THREADS
-#define EG3D_COPY_THREADS 16
-#endif
-  const size_t kMin = 4u << 20;
-  if (bytes < 2 * kMin) {
-    memcpy(dst, src, bytes);
-    return;
-  }
-  const int nt = (int)std::min<size_t>(EG3D_COPY_THREADS, bytes / kMin);
-  std::vector<std::thread> th;
-  const size_t per = (bytes / nt + 63) & ~(size_t)63;
-  for (int t = 0; t < nt; t++) {
-    const size_t a = (size_t)t * per, b = std::min(bytes, a + per);
-    if (a >= b) break;
-    th.emplace_back([=] { memcpy((char*)dst + a, (const char*)src + a, b - a); });
-  }
-  for (auto& t : th) t.join();
-}
+static void copy_mt(void* dst, const void* src, size_t bytes) { eg3d::copy_mt(dst, src, bytes); }
 
 struct HostOut {
   RawVec<float> X, xy;
@@ -995,6 +976,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
       for (int k = 0; k < 7; k++) copy_mt(dst[k], (char*)c->pinned + at[k], sz[k]);
 #ifdef EG3D_COPY_TIMING
       const auto tc2 = std::chrono::steady_clock::now();
+      fprintf(stderr, "chunk: p0 %zu o0 %zu np %u no %u nc %u  ", p0, o0, np, no, nc);
       fprintf(stderr, "copy timing: %.1f MB  D2H %.2f ms  host copy %.2f ms\n", total / 1e6,
               std::chrono::duration<double, std::milli>(tc1 - tc0).count(),
               std::chrono::duration<double, std::milli>(tc2 - tc1).count());

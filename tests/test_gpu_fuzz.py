@@ -154,3 +154,21 @@ def test_one_context_many_calls_of_different_shapes(monkeypatch):
         for k in ("key", "obs_off", "obs_view", "obs_pl", "obs_seg"):
             assert np.array_equal(got[k], want[k]), (it, b, e, k)
     ctx.close()
+
+
+def test_host_copy_of_a_large_cloud_equals_the_device_arrays():
+    """Independent of the oracle: the cloud a host-copy call returns must be, byte for byte, what a device-only call
+    leaves in HBM (fetched with plain hipMemcpy) — on a cloud large enough for the staged, multi-threaded copy
+    (0.45 GB) and on odd sub-ranges whose array sizes vary."""
+    s = host.Synth(3)
+    ctx = api.Context(s.scene)
+    ctx.upload_seeds(s.seeds)
+    for b, e in ((0, s.n_seeds), (17, 4001), (1234, 5555), (3000, 6268)):
+        hostc = ctx.match_resident(b, e)
+        ctx.match_resident(b, e, device_only=True)
+        dev = ctx.fetch_device_output()
+        for k in ("X", "obs_xy"):
+            assert np.array_equal(hostc[k].view(np.uint32).ravel(), dev[k].view(np.uint32).ravel()), (b, e, k)
+        for k in ("key", "obs_off", "obs_view", "obs_pl", "obs_seg"):
+            assert np.array_equal(hostc[k], dev[k]), (b, e, k)
+    ctx.close()
