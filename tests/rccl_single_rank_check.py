@@ -27,10 +27,15 @@ def main():
     comm = C.c_void_p()
     G.eg3d_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     assert G.eg3d_comm_init(uid, 1, 0, 0, C.byref(comm)) == 0
-    s = host.Synth(1)
+    # default: the small scene; EG3D_GATHER_CHECK="<config> <seed_begin> <seed_end>" for a large one (ad hoc, e.g.
+    # "4 0 8192": a whole multi-chunk C4 step, a 7 GB cloud through pack / all-gather / unpack)
+    spec = os.environ.get("EG3D_GATHER_CHECK", "1").split()
+    s = host.Synth(int(spec[0]))
+    b, e = (int(spec[1]), int(spec[2])) if len(spec) == 3 else (0, s.n_seeds)
     ctx = api.Context(s.scene)
-    want = ctx.match_refpoints(s.seeds)
-    ctx.match_resident(0, s.n_seeds, device_only=True)
+    ctx.upload_seeds(s.seeds)
+    want = ctx.match_resident(b, e)
+    ctx.match_resident(b, e, device_only=True)
     local = ctx.last_device_output()
     G.eg3d_gather_create.restype = C.c_void_p
     G.eg3d_allgather_edgepoints.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
