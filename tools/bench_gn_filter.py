@@ -43,5 +43,8 @@ if "--no-cpu" not in sys.argv:
     line["cpu_baseline"] = {"value": m / dt, "unit": "points/s", "cores": 1, "kind": "port", "sample": "first %d points" % m}
     line["parity_bitexact_on_sample"] = bool(np.array_equal(inl[:m], ir) and np.array_equal(Xo[:m].view(np.uint32), Xr.view(np.uint32)))
     line["speedup_vs_cpu_1thread"] = line["points_per_s"] / (m / dt)
+    # parity on ALL points (oracle on every host thread: not a timing)
+    Xa, ia = o.gn_filter(X, off, view, xy, 2.25, nthreads=os.cpu_count() or 1)
+    line["parity_bitexact_all_points"] = bool(np.array_equal(inl, ia) and np.array_equal(Xo.view(np.uint32), Xa.view(np.uint32)))
 print(json.dumps(line))
 ctx.close()
