@@ -27,7 +27,7 @@ def main():
     rep = compare_edgepoints(want, got)
     assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], rep
     ctx.close()
-    for cfg in (1, 2):
+    for cfg in (1, 2, 3):
         s = host.Synth(cfg)
         ctx = api.Context(s.scene)
         got = ctx.match_refpoints(s.seeds)
