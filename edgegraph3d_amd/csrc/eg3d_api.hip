@@ -297,11 +297,67 @@ static std::vector<DevBuf*> scene_bufs(eg3d_ctx* c) {
           &c->b_pls,  &c->b_ple, &c->b_g30o, &c->b_g30i, &c->b_g4o, &c->b_g4i};
 }
 
+// Everything about a scene that can be checked on the host, before a device is touched: the library indexes
+// device arrays with these offsets and ids, so an inconsistent scene is refused here instead of faulting there.
+static int validate_scene(const eg3d_scene* sc) {
+  if (sc->n_views < 1 || sc->width < 1 || sc->height < 1 || !sc->cam_P || !sc->F || !sc->F_valid || !sc->view_pl_off ||
+      !sc->pl_vtx_off || !sc->pl_start || !sc->pl_end || !sc->pl_valid) {
+    g_err = "eg3d_create: bad arguments (null array, no views or empty image)";
+    return EG3D_ERR_ARG;
+  }
+  if (sc->n_views > EG3D_MAX_VIEWS) {
+    g_err = "eg3d_create: more than " + std::to_string(EG3D_MAX_VIEWS) + " views";
+    return EG3D_ERR_CAPACITY;
+  }
+  if (sc->view_pl_off[0] != 0) {
+    g_err = "eg3d_create: view_pl_off[0] must be 0";
+    return EG3D_ERR_ARG;
+  }
+  for (int v = 0; v < sc->n_views; v++) {
+    if (sc->view_pl_off[v + 1] < sc->view_pl_off[v]) {
+      g_err = "eg3d_create: view_pl_off is not ascending";
+      return EG3D_ERR_ARG;
+    }
+    if (sc->view_pl_off[v + 1] - sc->view_pl_off[v] > (uint32_t)EG3D_MAX_POLYLINES_PER_VIEW) {
+      g_err = "eg3d_create: a view has more than " + std::to_string(EG3D_MAX_POLYLINES_PER_VIEW) + " polylines";
+      return EG3D_ERR_CAPACITY;
+    }
+  }
+  const uint32_t np_all = sc->view_pl_off[sc->n_views];
+  if (sc->pl_vtx_off[0] != 0) {
+    g_err = "eg3d_create: pl_vtx_off[0] must be 0";
+    return EG3D_ERR_ARG;
+  }
+  for (uint32_t p = 0; p < np_all; p++)
+    if (sc->pl_vtx_off[p + 1] < sc->pl_vtx_off[p]) {
+      g_err = "eg3d_create: pl_vtx_off is not ascending";
+      return EG3D_ERR_ARG;
+    }
+  if (sc->pl_vtx_off[np_all] && !sc->vtx_xy) {
+    g_err = "eg3d_create: vtx_xy is null";
+    return EG3D_ERR_ARG;
+  }
+  // Vertex coordinates of valid polylines must be finite and within +-1e7 px. The grid construction samples
+  // every segment each ~2.6 px (polyline_graph_2d.cpp:819-835) whether or not it lies inside the image: a stray
+  // 1e20 coordinate would keep the reference (and this library's host grid builder) sampling for years, and a
+  // NaN makes its cell conversions undefined. Such a scene is refused instead.
+  for (uint32_t p = 0; p < np_all; p++) {
+    if (!sc->pl_valid[p]) continue;
+    for (size_t k = 2 * (size_t)sc->pl_vtx_off[p]; k < 2 * (size_t)sc->pl_vtx_off[p + 1]; k++)
+      if (!(std::fabs(sc->vtx_xy[k]) <= 1e7f)) {
+        g_err = "eg3d_create: polyline " + std::to_string(p) + " has a vertex coordinate that is not finite or beyond +-1e7 px";
+        return EG3D_ERR_ARG;
+      }
+  }
+  return EG3D_OK;
+}
+
 extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
-  if (!sc || !out || sc->n_views < 1) {
+  if (!sc || !out) {
     g_err = "eg3d_create: bad arguments";
     return EG3D_ERR_ARG;
   }
+  BUF_TRY(validate_scene(sc));
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     g_err = "eg3d_create: no HIP device available (this library has no CPU fallback)";
@@ -310,30 +366,6 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
   if (device < 0 || device >= ndev) {
     g_err = "eg3d_create: device index out of range";
     return EG3D_ERR_ARG;
-  }
-  if (sc->n_views > EG3D_MAX_VIEWS) {
-    g_err = "eg3d_create: more than " + std::to_string(EG3D_MAX_VIEWS) + " views";
-    return EG3D_ERR_CAPACITY;
-  }
-  for (int v = 0; v < sc->n_views; v++)
-    if (sc->view_pl_off[v + 1] - sc->view_pl_off[v] > (uint32_t)EG3D_MAX_POLYLINES_PER_VIEW) {
-      g_err = "eg3d_create: a view has more than " + std::to_string(EG3D_MAX_POLYLINES_PER_VIEW) + " polylines";
-      return EG3D_ERR_CAPACITY;
-    }
-  // Vertex coordinates of valid polylines must be finite and within +-1e7 px. The grid construction samples
-  // every segment each ~2.6 px (polyline_graph_2d.cpp:819-835) whether or not it lies inside the image: a stray
-  // 1e20 coordinate would keep the reference (and this library's host grid builder) sampling for years, and a
-  // NaN makes its cell conversions undefined. Such a scene is refused instead.
-  {
-    const uint32_t np_all = sc->view_pl_off[sc->n_views];
-    for (uint32_t p = 0; p < np_all; p++) {
-      if (!sc->pl_valid[p]) continue;
-      for (size_t k = 2 * (size_t)sc->pl_vtx_off[p]; k < 2 * (size_t)sc->pl_vtx_off[p + 1]; k++)
-        if (!(std::fabs(sc->vtx_xy[k]) <= 1e7f)) {
-          g_err = "eg3d_create: polyline " + std::to_string(p) + " has a vertex coordinate that is not finite or beyond +-1e7 px";
-          return EG3D_ERR_ARG;
-        }
-    }
   }
   HIP_TRY(hipSetDevice(device));
   eg3d_ctx* c = new eg3d_ctx();
@@ -549,7 +581,20 @@ extern "C" int eg3d_upload_seeds(eg3d_ctx* c, const eg3d_seeds* s) {
     return EG3D_ERR_ARG;
   }
   HIP_TRY(hipSetDevice(c->device));
+  if (!s->trk_off || (s->n_seeds && s->trk_off[s->n_seeds] && (!s->trk_view || !s->trk_xy))) {
+    g_err = "eg3d_upload_seeds: null array";
+    return EG3D_ERR_ARG;
+  }
   const uint32_t n = s->n_seeds;
+  if (s->trk_off[0] != 0) {
+    g_err = "eg3d_upload_seeds: trk_off[0] must be 0";
+    return EG3D_ERR_ARG;
+  }
+  for (uint32_t i = 0; i < n; i++)
+    if (s->trk_off[i + 1] < s->trk_off[i]) {
+      g_err = "eg3d_upload_seeds: trk_off is not ascending";
+      return EG3D_ERR_ARG;
+    }
   const uint32_t m = s->trk_off[n];
   for (uint32_t i = 0; i < m; i++)
     if (s->trk_view[i] < 0 || s->trk_view[i] >= c->V) {

@@ -98,3 +98,53 @@ def test_no_gpu_means_loud_failure():
     s = host.Synth(0)
     with pytest.raises(api.Eg3dError):
         api.Context(s.scene)
+
+
+def test_inconsistent_scenes_are_refused_before_any_device_is_touched():
+    """eg3d_create validates the scene on the host first (the kernels index device arrays with its offsets): a
+    descending offset array, a non-zero first offset, a null array, an empty image, a NaN / 1e20 vertex all give
+    EG3D_ERR_ARG — here, without a GPU, where a consistent scene gives EG3D_ERR_NODEVICE."""
+    import ctypes as C
+    from edgegraph3d_amd import api
+    L = api.lib()
+    L.eg3d_last_error.restype = C.c_char_p
+    s = host.Synth(0)
+    base = s.scene_np()
+
+    def create(mut):
+        sc = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in base.items()}
+        mut(sc)
+        sa = host.SceneArrays(sc)
+        h = C.c_void_p()
+        rc = L.eg3d_create(C.byref(sa.c), 0, C.byref(h))
+        if rc == 0:
+            L.eg3d_destroy(h)
+        return rc, (L.eg3d_last_error() or b"").decode()
+
+    rc, msg = create(lambda sc: None)
+    assert rc in (0, -4), (rc, msg)          # fine scene: created on a GPU box, "no device" here
+
+    def desc_vpo(sc):
+        sc["view_pl_off"][1] = sc["view_pl_off"][2] + 1
+
+    def desc_pvo(sc):
+        sc["pl_vtx_off"][3] = sc["pl_vtx_off"][5] + 7
+
+    def first_vpo(sc):
+        sc["view_pl_off"][0] = 1
+
+    def nan_vtx(sc):
+        p = int(np.nonzero(sc["pl_valid"])[0][0])
+        sc["vtx_xy"][sc["pl_vtx_off"][p]] = np.nan
+
+    def huge_vtx(sc):
+        p = int(np.nonzero(sc["pl_valid"])[0][0])
+        sc["vtx_xy"][sc["pl_vtx_off"][p]] = 1e20
+
+    def no_image(sc):
+        sc["width"] = 0
+
+    for mut in (desc_vpo, desc_pvo, first_vpo, nan_vtx, huge_vtx, no_image):
+        rc, msg = create(mut)
+        assert rc == -1, (mut.__name__, rc, msg)
+        assert "eg3d_create" in msg

@@ -310,3 +310,20 @@ def test_invalid_polyline_that_kept_its_vertices_is_ignored():
     seeds_ref = _oracle(C.byref(sa.c)).match(s.seeds, 0, s.n_seeds, nthreads=8)
     assert compare_edgepoints(seeds_ref, seeds_got)["ok"]
     ctx.close()
+
+
+def test_inconsistent_seed_arrays_are_refused():
+    """eg3d_upload_seeds: a descending or non-zero-based offset array and an out-of-range view id are refused (the
+    kernels would index the camera and fundamental matrices with them)."""
+    s = host.Synth(0)
+    off, view, xy = s.seeds_np()
+    ctx = api.Context(s.scene)
+    bad_off = off.copy()
+    bad_off[2] = bad_off[4] + 3
+    for o, v in ((bad_off, view), (off + 1, view), (off, np.where(np.arange(len(view)) == 5, 99, view))):
+        sd = host.SeedsArrays(o, v, xy)
+        with pytest.raises(RuntimeError):
+            ctx.upload_seeds(C.byref(sd.c))
+    ctx.upload_seeds(s.seeds)                      # the context is still usable
+    assert ctx.match_resident(0, s.n_seeds)["n_points"] > 0
+    ctx.close()
