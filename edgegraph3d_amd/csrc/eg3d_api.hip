@@ -1439,8 +1439,25 @@ extern "C" int eg3d_gn_filter(eg3d_ctx* c, const float* X, const uint32_t* obs_o
     g_err = "eg3d_gn_filter: bad arguments";
     return EG3D_ERR_ARG;
   }
-  HIP_TRY(hipSetDevice(c->device));
+  if (n >= 0xffffffffull) {
+    g_err = "eg3d_gn_filter: more than 2^32-2 points in one call";
+    return EG3D_ERR_CAPACITY;
+  }
+  if (n && obs_off[0] != 0) {
+    g_err = "eg3d_gn_filter: obs_off[0] must be 0";
+    return EG3D_ERR_ARG;
+  }
+  for (uint64_t i = 0; i < n; i++)
+    if (obs_off[i + 1] < obs_off[i]) {
+      g_err = "eg3d_gn_filter: obs_off is not ascending";
+      return EG3D_ERR_ARG;
+    }
   const uint64_t m = n ? obs_off[n] : 0;
+  if (m && (!obs_view || !obs_xy)) {
+    g_err = "eg3d_gn_filter: null observation arrays";
+    return EG3D_ERR_ARG;
+  }
+  HIP_TRY(hipSetDevice(c->device));
   for (uint64_t i = 0; i < m; i++)
     if (obs_view[i] < 0 || obs_view[i] >= c->V) {
       g_err = "eg3d_gn_filter: view id out of range";

@@ -327,3 +327,17 @@ def test_inconsistent_seed_arrays_are_refused():
     ctx.upload_seeds(s.seeds)                      # the context is still usable
     assert ctx.match_resident(0, s.n_seeds)["n_points"] > 0
     ctx.close()
+
+
+def test_gn_filter_refuses_inconsistent_observation_arrays():
+    s = host.Synth(0)
+    X, off, view, xy = s.points(100)
+    ctx = api.Context(s.scene)
+    bad = off.copy()
+    bad[10] = bad[20] + 5
+    for o, v in ((bad, view), (off + 2, view), (off, np.where(np.arange(len(view)) == 3, -1, view))):
+        with pytest.raises(RuntimeError):
+            ctx.gn_filter(X, o, v, xy, 2.25)
+    Xo, inl, _ = ctx.gn_filter(X, off, view, xy, 2.25)
+    assert inl.sum() > 0
+    ctx.close()
