@@ -93,6 +93,20 @@ extern "C" int eg3d_host_replay_matches(const eg3d_scene* sc, const eg3d_edgepoi
   const uint64_t N = pts->n_points;
   const uint32_t NP = sc->view_pl_off[V];
   if (N >= 0xfffffff0ull) return -3;  // node / polyline ids are 32-bit here (documented narrowing)
+  // the cloud normally comes from eg3d_match_*; one built by the caller is checked before its ids index the scene
+  if (N && (!pts->X || !pts->obs_off || !pts->key)) return -1;
+  for (uint64_t p = 0; p < N; p++)
+    if (pts->obs_off[p + 1] < pts->obs_off[p] || pts->obs_off[p + 1] > pts->n_obs) return -1;
+  if (N && pts->obs_off[N] && (!pts->obs_view || !pts->obs_pl || !pts->obs_seg || !pts->obs_xy)) return -1;
+  for (uint64_t o = 0, no = N ? pts->obs_off[N] : 0; o < no; o++) {
+    const int32_t v = pts->obs_view[o];
+    if (v < 0 || v >= V) return -1;
+    const uint32_t npl = sc->view_pl_off[v + 1] - sc->view_pl_off[v];
+    if (pts->obs_pl[o] >= npl) return -1;
+    const uint32_t g = sc->view_pl_off[v] + pts->obs_pl[o];
+    const uint32_t nv = sc->pl_vtx_off[g + 1] - sc->pl_vtx_off[g];
+    if (pts->obs_seg[o] >= (nv ? nv : 1u)) return -1;
+  }
   NodeTable table(N);
   std::vector<float> node_X;
   std::vector<uint64_t> node_point;

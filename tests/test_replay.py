@@ -4,6 +4,7 @@ the quirks of the structure: exact-coordinate node identity, duplicate suppressi
 orientation, the one-interval-per-start-segment std::set, the cross-polyline extreme rule and the
 -1 "invalid coordinate" node."""
 import numpy as np
+import pytest
 
 from edgegraph3d_amd import host
 from oracle import binding as ob
@@ -98,3 +99,19 @@ def test_replay_quirks_hand_built():
     a, b = int(got["iv_off"][pl0]), int(got["iv_off"][pl0 + 1])
     assert list(got["iv_start_seg"][a:b]) == [0, 1]
     assert got["iv_end_seg"][a] == 0  # A..B on the same segment, not the later 0..1 interval
+
+
+def test_replay_refuses_a_cloud_whose_ids_do_not_fit_the_scene():
+    s = host.Synth(0)
+    cloud = ob.Oracle(s.scene).match(s.seeds, 0, s.n_seeds, 1)
+    V = s.scene_np()["n_views"]
+    for field, value in (("obs_view", V), ("obs_view", -1), ("obs_pl", 10**6), ("obs_seg", 10**6)):
+        bad = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in cloud.items()}
+        bad[field][5] = value
+        with pytest.raises(Exception):
+            host.replay_matches(s.scene, bad)
+    bad = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in cloud.items()}
+    bad["obs_off"][3] = bad["obs_off"][6] + 1
+    with pytest.raises(Exception):
+        host.replay_matches(s.scene, bad)
+    assert host.replay_matches(s.scene, cloud)["n_nodes"] > 0
