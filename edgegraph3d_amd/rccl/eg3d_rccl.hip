@@ -215,6 +215,63 @@ extern "C" int eg3d_allgather_edgepoints(eg3d_gather* g, void* nccl_comm, int n_
   return 0;
 }
 
+// The gather's pack layout and compaction kernel WITHOUT the collective: several clouds resident on this GPU (the
+// results of several contexts, or of several steps) become one ordered cloud, part order = seed order. Every
+// part is packed into its padded slot exactly as a rank packs its block, then k_unpack rebases and compacts —
+// so the r > 0 path of the N-rank exchange runs on a single GPU.
+extern "C" int eg3d_concat_edgepoints(eg3d_gather* g, int n_parts, const eg3d_device_edgepoints* parts, void* hip_stream,
+                                      eg3d_device_edgepoints* out) {
+  if (!g || !parts || !out || n_parts < 1) return EG3D_GATHER_ERR_ARG;
+  hipStream_t st = (hipStream_t)hip_stream;
+  TRY_HIP(hipSetDevice(g->device));
+  const size_t R = (size_t)n_parts;
+  std::vector<uint64_t> h(3 * R);
+  uint64_t mp = 0, mo = 0, tp = 0, to = 0;
+  for (size_t r = 0; r < R; r++) {
+    if (!parts[r].complete) return EG3D_GATHER_ERR_INCOMPLETE;
+    h[3 * r] = parts[r].n_points;
+    h[3 * r + 1] = parts[r].n_obs;
+    h[3 * r + 2] = 0;
+    mp = std::max(mp, h[3 * r]);
+    mo = std::max(mo, h[3 * r + 1]);
+    tp += h[3 * r];
+    to += h[3 * r + 1];
+  }
+  if (to > 0xffffffffull) return EG3D_GATHER_ERR_RANGE;
+  const Layout L = make_layout(mp, mo);
+  if (g->cnt_dev.ensure(sizeof(uint64_t) * (4 * R + 4)) || g->recv.ensure(L.bytes * R) || g->X.ensure(tp * 12 + 16) ||
+      g->off.ensure((tp + 1) * 4) || g->key.ensure(tp * 16 + 16) || g->view.ensure(to * 4 + 16) ||
+      g->pl.ensure(to * 4 + 16) || g->seg.ensure(to * 4 + 16) || g->xy.ensure(to * 8 + 16))
+    return EG3D_GATHER_ERR_HIP;
+  TRY_HIP(hipMemcpyAsync(g->cnt_dev.p, h.data(), sizeof(uint64_t) * h.size(), hipMemcpyHostToDevice, st));
+  for (size_t r = 0; r < R; r++) {
+    unsigned char* slot = (unsigned char*)g->recv.p + r * L.bytes;
+    const uint64_t np = parts[r].n_points, no = parts[r].n_obs;
+    const void* src[7] = {parts[r].X, parts[r].obs_off, parts[r].key, parts[r].obs_view, parts[r].obs_pl, parts[r].obs_seg,
+                          parts[r].obs_xy};
+    const uint64_t nbytes[7] = {np * 12, np * 4, np * 16, no * 4, no * 4, no * 4, no * 8};
+    for (int f = 0; f < 7; f++)
+      if (nbytes[f]) TRY_HIP(hipMemcpyAsync(slot + L.off[f], src[f], nbytes[f], hipMemcpyDeviceToDevice, st));
+  }
+  hipLaunchKernelGGL(k_unpack, dim3(64, n_parts, 7), dim3(256), 0, st, (const unsigned char*)g->recv.p, L,
+                     (const uint64_t*)g->cnt_dev.p, n_parts, (float*)g->X.p, (uint32_t*)g->off.p, (uint32_t*)g->key.p,
+                     (int32_t*)g->view.p, (uint32_t*)g->pl.p, (uint32_t*)g->seg.p, (float*)g->xy.p);
+  const uint32_t last = (uint32_t)to;
+  TRY_HIP(hipMemcpyAsync((uint32_t*)g->off.p + tp, &last, 4, hipMemcpyHostToDevice, st));
+  TRY_HIP(hipStreamSynchronize(st));
+  out->n_points = tp;
+  out->n_obs = to;
+  out->X = (const float*)g->X.p;
+  out->obs_off = (const uint32_t*)g->off.p;
+  out->obs_view = (const int32_t*)g->view.p;
+  out->obs_pl = (const uint32_t*)g->pl.p;
+  out->obs_seg = (const uint32_t*)g->seg.p;
+  out->obs_xy = (const float*)g->xy.p;
+  out->key = (const uint32_t*)g->key.p;
+  out->complete = 1;
+  return 0;
+}
+
 extern "C" int eg3d_gather_wait_pack(eg3d_gather* g) {
   if (!g || !g->pack_done) return EG3D_GATHER_ERR_ARG;
   return hipEventSynchronize(g->pack_done) == hipSuccess ? 0 : EG3D_GATHER_ERR_HIP;

@@ -52,6 +52,13 @@ int eg3d_allgather_edgepoints(eg3d_gather* g, void* nccl_comm, int n_ranks, int 
                               const eg3d_device_edgepoints* local, eg3d_device_edgepoints* out,
                               uint64_t* rank_points, uint64_t* rank_obs);
 
+/* The same packing and compaction without the collective: `n_parts` complete clouds resident on this GPU (of several
+ * contexts or steps; parts[i] = what eg3d_last_device_output returned, still valid) become one ordered cloud, part
+ * order = seed order, observation offsets rebased — every part takes the place a rank's block has in the exchange.
+ * `out` views buffers of `g` (valid until the next call on `g`). */
+int eg3d_concat_edgepoints(eg3d_gather* g, int n_parts, const eg3d_device_edgepoints* parts, void* hip_stream,
+                           eg3d_device_edgepoints* out);
+
 /* Blocks the host until the last eg3d_allgather_edgepoints on `g` has copied `local` into its send
  * buffer: from then on the producing context may overwrite its output buffers (next step) while
  * the collective itself is still in flight on the gather stream. */

@@ -61,6 +61,36 @@ def main():
     assert np.array_equal(fetch(out.obs_pl, m, np.uint32), want["obs_pl"])
     assert np.array_equal(fetch(out.obs_seg, m, np.uint32), want["obs_seg"])
     assert np.array_equal(fetch(out.obs_xy, 2 * m, np.uint32), want["obs_xy"].view(np.uint32).ravel())
+    # ---- the N-rank shape of the exchange on ONE GPU: eg3d_concat_edgepoints packs several resident clouds into
+    # padded per-part slots and runs the same compaction kernel (rebased offsets, r > 0 blocks). Parts = unequal
+    # seed ranges computed on cloned contexts, one of them EMPTY; the result must be the single-call cloud.
+    def check_equal(o, w, label):
+        nn, mm = int(o.n_points), int(o.n_obs)
+        assert nn == w["n_points"] and mm == w["n_obs"], (label, nn, w["n_points"])
+        assert np.array_equal(fetch(o.X, 3 * nn, np.uint32), w["X"].view(np.uint32).ravel()), label
+        assert np.array_equal(fetch(o.obs_off, nn + 1, np.uint32), w["obs_off"]), label
+        assert np.array_equal(fetch(o.key, 4 * nn, np.uint32), w["key"].ravel()), label
+        assert np.array_equal(fetch(o.obs_view, mm, np.int32), w["obs_view"]), label
+        assert np.array_equal(fetch(o.obs_pl, mm, np.uint32), w["obs_pl"]), label
+        assert np.array_equal(fetch(o.obs_seg, mm, np.uint32), w["obs_seg"]), label
+        assert np.array_equal(fetch(o.obs_xy, 2 * mm, np.uint32), w["obs_xy"].view(np.uint32).ravel()), label
+
+    G.eg3d_concat_edgepoints.argtypes = [C.c_void_p, C.c_int, C.POINTER(D.DeviceEdgePoints), C.c_void_p,
+                                         C.POINTER(D.DeviceEdgePoints)]
+    span = e - b
+    for cuts in ((0.1, 0.1, 0.55), (0.5,), (0.0, 0.33, 0.34, 0.9)):
+        edges = [b] + [b + int(span * c) for c in cuts] + [e]
+        ctxs = [ctx] + [ctx.clone() for _ in range(len(edges) - 2)]
+        parts = (D.DeviceEdgePoints * (len(edges) - 1))()
+        for i, cx in enumerate(ctxs):
+            cx.match_resident(edges[i], edges[i + 1], device_only=True)
+            parts[i] = cx.last_device_output()
+        cat = D.DeviceEdgePoints()
+        rc = G.eg3d_concat_edgepoints(g, len(ctxs), parts, None, C.byref(cat))
+        assert rc == 0, rc
+        check_equal(cat, want, "concat %s" % (cuts,))
+        for cx in ctxs[1:]:
+            cx.close()
     G.eg3d_gather_destroy(g)
     G.eg3d_comm_destroy.argtypes = [C.c_void_p]
     G.eg3d_comm_destroy(comm)
