@@ -160,6 +160,11 @@ struct eg3d_ctx {
   DevBuf f_X, f_off, f_view, f_xy, f_Xo, f_inl;
   DevBuf b_sets_off, b_sets_ids;  // polyline sets of the current eg3d_match_polyline_sets call
   DevBuf b_fscratch, b_queue;     // K3a following: per-lane staging lists, work-queue head
+  // K3b: working slices of the resident chains (b_cscratch: 8 XCDs x slots_per_xcd slices), the slot pools,
+  // and the staging area finished chains are packed into (sized from the previous launches; grow-only)
+  DevBuf b_pools, b_stage_pts, b_stage_obs, b_stage_used;
+  uint32_t slots_per_xcd = 0;
+  uint64_t stage_cap_pts = 0, stage_cap_obs = 0;
   hipEvent_t ea[8], eb[8];  // begin/end events per stage: 1 K1, 2 K2, 3 K3a, 4 K3s, 5 K3b, 6 K4, 0 misc, 7 whole call
   uint32_t chain_cap = 384, pool_cap = 0, hyp_cap = 160;
   uint32_t k3a_blocks = 0;
@@ -480,6 +485,18 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   c->k3a_blocks = (uint32_t)prop.multiProcessorCount * 2;  // 2 blocks x 4 waves per CU
+  {
+    // working-slice slots per XCD: what can be resident (occupancy query x CUs of an XCD) plus a margin —
+    // the occupancy API may be one block per CU off, and a pool must never be smaller than the residency
+    const int per_cu = k3b_blocks_per_cu();
+    if (per_cu < 1) {
+      g_err = "eg3d_create: occupancy query of the expand kernel failed";
+      eg3d_destroy(c);
+      return EG3D_ERR_HIP;
+    }
+    const uint32_t cus_per_xcd = ((uint32_t)prop.multiProcessorCount + 7u) / 8u;
+    c->slots_per_xcd = ((uint32_t)per_cu + 1u) * cus_per_xcd + 16u;
+  }
   HIP_TRY(hipStreamSynchronize(c->stream));
   // from here on the scene buffers belong to the (shareable) owner, not to this context
   c->scene_owner = std::make_shared<DevOwner>();
@@ -531,6 +548,9 @@ extern "C" int eg3d_clone(eg3d_ctx* parent, eg3d_ctx** out) {
   c->pool_cap = parent->pool_cap;
   c->hyp_cap = parent->hyp_cap;
   c->k3a_blocks = parent->k3a_blocks;
+  c->slots_per_xcd = parent->slots_per_xcd;
+  c->stage_cap_pts = parent->stage_cap_pts;  // sizing hints only: the clone allocates its own staging area
+  c->stage_cap_obs = parent->stage_cap_obs;
   *out = c;
   return EG3D_OK;
 }
@@ -550,7 +570,8 @@ extern "C" void eg3d_destroy(eg3d_ctx* c) {
                    &c->b_nhyp, &c->b_hyp_off, &c->b_res, &c->b_hscratch, &c->b_arena, &c->b_ctr, &c->b_cs_task,
                    &c->b_valid, &c->b_chain_off, &c->b_chains, &c->b_cscratch, &c->b_couts, &c->b_cpts, &c->b_cobs,
                    &c->b_cpoff, &c->b_cooff, &c->b_scan_tmp, &c->b_scanchk, &c->b_cost, &c->b_cidx, &c->b_cost2, &c->b_order, &c->o_X, &c->o_off, &c->o_view, &c->o_pl, &c->o_seg,
-                   &c->o_xy, &c->o_key, &c->f_X, &c->f_off, &c->f_view, &c->f_xy, &c->f_Xo, &c->f_inl, &c->b_sets_off, &c->b_sets_ids, &c->b_fscratch, &c->b_queue};
+                   &c->o_xy, &c->o_key, &c->f_X, &c->f_off, &c->f_view, &c->f_xy, &c->f_Xo, &c->f_inl, &c->b_sets_off, &c->b_sets_ids, &c->b_fscratch, &c->b_queue,
+                   &c->b_pools, &c->b_stage_pts, &c->b_stage_obs, &c->b_stage_used};
   for (DevBuf* b : all) b->release();
   if (c->pinned) (void)hipHostFree(c->pinned);
   if (c->mbox) (void)hipHostFree(c->mbox);
@@ -856,8 +877,10 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
   launch_compact_chains(st, nt, c->b_cs_task.as<ChainSeed>(), c->b_valid.as<uint32_t>(), c->b_chain_off.as<uint32_t>(),
                         c->b_chains.as<ChainSeed>());
   HIP_TRY(hipEventRecord(c->eb[4], st));
-  // ---- K3b + K4 in chunks bounded by scratch size
-  const size_t max_scratch = c->tune.max_scratch;  // tests shrink it to force chunking
+  // ---- K3b + K4. One launch takes all the chains of the batch: their working slices are slots of a fixed arena
+  // (8 XCDs x slots_per_xcd), so nothing grows with the number of chains but the staging area the finished chains
+  // are packed into. (EG3D_MAX_SCRATCH_MB, a test knob, still cuts the chains into several launches.)
+  const size_t max_scratch = c->tune.max_scratch;
   float ms_expand = 0, ms_emit = 0;
   uint32_t chunk = 0;
   for (uint32_t c0 = 0; c0 < B.n_chains; c0 += chunk) {
@@ -869,7 +892,33 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
     uint32_t* const saved_bytes = c->b_scanchk.as<uint32_t>() + 4;  // device copy of the byte counter before this chunk
     HIP_TRY(hipMemcpyAsync(saved_bytes, &c->b_ctr.as<Counters>()->bytes, sizeof(unsigned long long),
                            hipMemcpyDeviceToDevice, st));
-    BUF_TRY(c->b_cscratch.ensure(L.total * (size_t)nc));
+    BUF_TRY(c->b_cscratch.ensure(L.total * 8 * (size_t)c->slots_per_xcd));
+    SlotPools pools;
+    pools.slots_per_xcd = c->slots_per_xcd;
+    pools.ring_n = 1;
+    while (pools.ring_n <= c->slots_per_xcd) pools.ring_n <<= 1;
+    pools.stride = 32 + pools.ring_n;
+    BUF_TRY(c->b_pools.ensure(sizeof(uint32_t) * 8 * (size_t)pools.stride));
+    pools.base = c->b_pools.as<uint32_t>();
+    launch_pool_init(st, pools);
+    // staging area: what the previous launches needed, or a first guess (an overflowing launch is repeated once
+    // with the exact need, which the output scans report)
+    {
+      const uint64_t guess_pts = 96ull * nc;
+      const uint64_t per_pt = (uint64_t)std::min(100, std::max(8, c->V / 2));
+      const uint64_t want_pts = std::max<uint64_t>(c->stage_cap_pts, guess_pts);
+      const uint64_t want_obs = std::max<uint64_t>(c->stage_cap_obs, guess_pts * per_pt);
+      BUF_TRY(c->b_stage_pts.ensure(sizeof(StagePt) * (size_t)want_pts));
+      BUF_TRY(c->b_stage_obs.ensure(sizeof(Obs) * (size_t)want_obs));
+      BUF_TRY(c->b_stage_used.ensure(2 * sizeof(unsigned long long)));
+      HIP_TRY(hipMemsetAsync(c->b_stage_used.p, 0, 2 * sizeof(unsigned long long), st));
+    }
+    StageBuf stage;
+    stage.pts = c->b_stage_pts.as<StagePt>();
+    stage.obs = c->b_stage_obs.as<Obs>();
+    stage.cap_pts = c->b_stage_pts.cap / sizeof(StagePt);
+    stage.cap_obs = c->b_stage_obs.cap / sizeof(Obs);
+    stage.used = c->b_stage_used.as<unsigned long long>();
     BUF_TRY(c->b_couts.ensure(sizeof(ChainOut) * (nc + 1)));
     BUF_TRY(c->b_cpts.ensure(sizeof(uint32_t) * (nc + 1)));
     BUF_TRY(c->b_cobs.ensure(sizeof(uint32_t) * (nc + 1)));
@@ -902,7 +951,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
     launch_k3b(st, c->ds, B.a, c->b_tasks.as<TaskDesc>(), c->b_chains.as<ChainSeed>() + c0, nc,
                c->b_hyp_off.as<uint32_t>(), c->b_res.as<HypResult>(), c->b_arena.as<HPoint>(),
                c->b_map_view.as<int32_t>(), c->b_map_entry.as<uint32_t>(), c->b_map_n.as<uint32_t>(), L,
-               c->b_cscratch.as<unsigned char>(), c->b_couts.as<ChainOut>(), c->b_cpts.as<uint32_t>(),
+               c->b_cscratch.as<unsigned char>(), pools, stage, c->b_couts.as<ChainOut>(), c->b_cpts.as<uint32_t>(),
                c->b_cobs.as<uint32_t>(), c->b_ctr.as<Counters>(), c->b_order.as<uint32_t>());
     HIP_TRY(hipEventRecord(c->eb[5], st));
     // the two output scans are queued right behind K3b; its counters (capacity overflow?) and both totals
@@ -926,8 +975,23 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
       if (!overflow && rb.item(iw)[0]) return wrapped_error("edge-points of one chunk");
       if (!overflow && rb.item(iw)[1]) return wrapped_error("observations of one chunk");
     }
+    if (hc.flags & CTR_SLOT_STARVED) {
+      g_err = "eg3d: internal: the expand kernel found no free working slice (slot pool smaller than the residency)";
+      return EG3D_ERR_HIP;
+    }
+    if (!(hc.flags & (EG3D_FLAG_CHAIN_OVERFLOW | EG3D_FLAG_OBS_OVERFLOW)) && (np > stage.cap_pts || no > stage.cap_obs)) {
+      // the staging area was too small for this launch: its chains were counted but not all packed. Size it
+      // for what they need (kept for later calls) and repeat the launch.
+      c->stage_cap_pts = std::max<uint64_t>(c->stage_cap_pts, (uint64_t)np + np / 16 + 64);
+      c->stage_cap_obs = std::max<uint64_t>(c->stage_cap_obs, (uint64_t)no + no / 16 + 64);
+      HIP_TRY(hipMemcpyAsync(&c->b_ctr.as<Counters>()->bytes, saved_bytes, sizeof(unsigned long long),
+                             hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      chunk = 0;  // do not advance
+      continue;
+    }
     if (hc.flags & (EG3D_FLAG_CHAIN_OVERFLOW | EG3D_FLAG_OBS_OVERFLOW)) {
-      // a chain outgrew its scratch slice: enlarge the capacities (kept for later calls) and redo
+      // a chain outgrew its working slice: enlarge the capacities (kept for later calls) and redo
       // this chunk; results of the overflowing attempt are discarded
       const bool can_grow = ((hc.flags & EG3D_FLAG_CHAIN_OVERFLOW) && c->chain_cap < 8192) ||
                             ((hc.flags & EG3D_FLAG_OBS_OVERFLOW) && c->pool_cap < (1u << 20));
@@ -958,9 +1022,11 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
     BUF_TRY(c->o_seg.ensure_keep(sizeof(uint32_t) * (O0 + no + 1), sizeof(uint32_t) * O0, st));
     BUF_TRY(c->o_xy.ensure_keep(sizeof(float) * 2 * (O0 + no + 1), sizeof(float) * 2 * O0, st));
     HIP_TRY(hipEventRecord(c->ea[6], st));
-    launch_k4(st, c->b_tasks.as<TaskDesc>(), c->b_chains.as<ChainSeed>() + c0, nc, L, c->b_cscratch.as<unsigned char>(),
+    c->stage_cap_pts = std::max<uint64_t>(c->stage_cap_pts, (uint64_t)np + np / 16);  // sizing hint of the next launch
+    c->stage_cap_obs = std::max<uint64_t>(c->stage_cap_obs, (uint64_t)no + no / 16);
+    launch_k4(st, c->b_tasks.as<TaskDesc>(), c->b_chains.as<ChainSeed>() + c0, nc, stage,
               c->b_couts.as<ChainOut>(), c->b_cpoff.as<uint32_t>(), c->b_cooff.as<uint32_t>(), P0, O0, B.key0_base,
-              c->o_X.as<float>(), c->o_off.as<uint32_t>(), c->o_view.as<int32_t>(), c->o_pl.as<uint32_t>(),
+              c->o_X.as<float>(), c->o_off.as<eg3d_off_t>(), c->o_view.as<int32_t>(), c->o_pl.as<uint32_t>(),
               c->o_seg.as<uint32_t>(), c->o_xy.as<float>(), c->o_key.as<uint32_t>());
     HIP_TRY(hipEventRecord(c->eb[6], st));
     HIP_TRY(hipStreamSynchronize(st));

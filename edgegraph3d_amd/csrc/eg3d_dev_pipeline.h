@@ -239,6 +239,7 @@ EG3D_HD void chain_bind(Chain& c, const ChainLayout& L, unsigned char* slice) {
 struct ChainOut {
   uint32_t n_points, n_obs, flags, head;
   uint64_t bytes;
+  uint64_t spt, sobs;  // where the finished chain was packed in the launch's staging area (k3b_expand)
   uint64_t tsec[12];  // diagnostic section ticks (zero unless built with EG3D_SECTION_TIMING)
 };
 
@@ -347,6 +348,23 @@ EG3D_HD_FLAT void expand_chain(const Team& tm, const DevScene& s, const StageAVi
   c.tsec[7] = EG3D_TICK() - t_begin;
   for (int k = 0; k < 12; k++) out.tsec[k] = c.tsec[k];
 }
+
+// A finished chain leaves its working slice as a packed record in the launch's STAGING area: n_points
+// point headers (16 B) followed, in a second array, by the observations of those points back to back
+// in chain order (16 B each). K4 turns the records into the ordered SoA output.
+struct StagePt {
+  float X[3];
+  uint32_t nobs;
+};
+// Staging area of one K3b launch: bump-allocated by the chains as they finish (order of completion).
+// The counters keep counting past the capacity, so the host learns the exact need of an overflowing
+// launch and repeats it once with room for everything.
+struct StageBuf {
+  StagePt* pts;
+  Obs* obs;
+  unsigned long long cap_pts, cap_obs;
+  unsigned long long* used;  // [0] points, [1] observations
+};
 
 // K4 body: copy one finished chain into the ordered SoA output.
 EG3D_HD void emit_chain(const ChainLayout& L, const unsigned char* slice, const ChainOut& co, const TaskDesc& d,

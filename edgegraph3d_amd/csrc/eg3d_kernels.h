@@ -13,7 +13,8 @@ struct SeedsDev {
   const float* trk_xy;
 };
 
-enum : uint32_t { CTR_ARENA_OVERFLOW = 0x100u };
+enum : uint32_t { CTR_ARENA_OVERFLOW = 0x100u, CTR_SLOT_STARVED = 0x200u /* k3b_expand found no free working slice (internal) */ };
+typedef uint32_t eg3d_off_t;  // element type of obs_off in the output cloud
 // arguments of k_publish: up to 6 runs of device words copied to the host mailbox, words cleared afterwards
 struct PubArgs {
   const uint32_t* src[6];
@@ -79,16 +80,24 @@ void launch_k3s(hipStream_t st, uint32_t n_tasks, const uint32_t* hyp_off, const
                 uint32_t* valid);
 void launch_compact_chains(hipStream_t st, uint32_t n_tasks, const ChainSeed* per_task, const uint32_t* valid,
                            const uint32_t* chain_off, ChainSeed* chains);
+// Pools of working-slice slots of k3b_expand, one per XCD (see the kernel): 8 x `stride` words,
+// [0] pop tickets, [16] push tickets, [32 ..] a ring of ring_n (power of two >= slots_per_xcd) cells.
+struct SlotPools {
+  uint32_t* base;
+  uint32_t stride, ring_n, slots_per_xcd;
+};
+int k3b_blocks_per_cu();  // resident k3b_expand workgroups per CU (occupancy query; 0 on failure)
+void launch_pool_init(hipStream_t st, SlotPools pools);
 void launch_k3b(hipStream_t st, DevScene s, StageAView a, const TaskDesc* tasks, const ChainSeed* chains,
                 uint32_t n_chains, const uint32_t* hyp_off, const HypResult* res, const HPoint* arena,
                 const int32_t* map_view, const uint32_t* map_entry, const uint32_t* map_n, ChainLayout L,
-                unsigned char* scratch, ChainOut* outs, uint32_t* out_points, uint32_t* out_obs, Counters* ctr,
-                const uint32_t* order);
+                unsigned char* slices, SlotPools pools, StageBuf stage, ChainOut* outs, uint32_t* out_points,
+                uint32_t* out_obs, Counters* ctr, const uint32_t* order);
 void launch_chain_cost(hipStream_t st, StageAView a, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains,
                        uint32_t* cost, uint32_t* idx);
-void launch_k4(hipStream_t st, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains, ChainLayout L,
-               const unsigned char* scratch, const ChainOut* outs, const uint32_t* point_off, const uint32_t* obs_off_in,
-               uint64_t point_base, uint64_t obs_base, uint32_t key0_base, float* X, uint32_t* obs_off, int32_t* obs_view, uint32_t* obs_pl,
+void launch_k4(hipStream_t st, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains, StageBuf stage,
+               const ChainOut* outs, const uint32_t* point_off, const uint32_t* obs_off_in, uint64_t point_base,
+               uint64_t obs_base, uint32_t key0_base, float* X, eg3d_off_t* obs_off, int32_t* obs_view, uint32_t* obs_pl,
                uint32_t* obs_seg, float* obs_xy, uint32_t* key);
 // {out[n], 1 if the scan wrapped} -> total_and_flag[0..1] (flag word must be zero before the launch)
 void launch_scan_check(hipStream_t st, const uint32_t* out, uint64_t n_plus_one, uint32_t* wrapped);

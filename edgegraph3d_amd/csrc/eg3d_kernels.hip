@@ -260,174 +260,6 @@ __global__ void __launch_bounds__(256) k2_epipolar_hits(DevScene s, SeedsDev sd,
   }
 }
 
-// EG3D_K2_LDS=1 variant (measured slower on every workload, kept for the record — DESIGN.md "K2 staging"):
-// One workgroup (4 wavefronts) per SEED, one wavefront per task of that seed at a time. All tasks
-// of a seed scan the same candidate polylines (those within 30 px of the seed's observation in each
-// track view, found by K1), once per other track entry — ~19 tasks per seed on the dtu006-shaped
-// workload — so the block first stages the vertices of every candidate of every track entry in LDS
-// with coalesced loads, plus a small directory (entry -> its candidates: polyline id, vertex count,
-// LDS offset), and the per-task scans then read LDS (ds_read_b64) instead of going back to L2/HBM
-// for each (task, entry, candidate). For every other track entry: epipolar line of the start hit,
-// then all 64 lanes test consecutive segments of each candidate polyline; hits inside the detection
-// radius are compacted in segment order with __ballot + popcount. FILL=false counts, FILL=true
-// writes to the offsets produced by the scan of the counts. A seed whose candidates do not fit the
-// staging area (K2_VTX_CAP vertices, K2_DIR_CAP candidates) is scanned from HBM as before.
-#ifndef K2_VTX_CAP
-#define K2_VTX_CAP 3072
-#endif
-#ifndef K2_DIR_CAP
-#define K2_DIR_CAP 192
-#endif
-template <bool FILL>
-__global__ void __launch_bounds__(256) k2_epipolar_hits_staged(DevScene s, SeedsDev sd, uint32_t seed_begin, uint32_t sv_base,
-                                                       const uint32_t* task_off /* per (seed, entry) */,
-                                                       const uint32_t* task_hit, const uint32_t* task_list_off,
-                                                       const uint32_t* raw_off, const uint32_t* cand_pl,
-                                                       const uint32_t* cand_cnt, const Obs* start_hits,
-                                                       uint32_t* list_cnt, const uint32_t* list_ptr, Obs* hits) {
-  __shared__ f2 s_vtx[K2_VTX_CAP];
-  __shared__ uint32_t s_dir_pl[K2_DIR_CAP], s_dir_off[K2_DIR_CAP], s_dir_n[K2_DIR_CAP], s_dir_src[K2_DIR_CAP];
-  __shared__ uint32_t s_entry_first[65];  // directory range of track entry i (k <= 64 staged; else fallback)
-  __shared__ uint32_t s_ok;
-  const uint32_t seed = seed_begin + blockIdx.x;
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t t0 = sd.trk_off[seed], k = sd.trk_off[seed + 1] - t0;
-  const uint32_t sv0 = t0 - sv_base;
-  const uint32_t task_first = task_off[sv0], task_last = task_off[sv0 + k];
-  if (task_first == task_last) return;  // block-uniform
-  // ---- directory of the seed's candidate polylines: wave 0 scans the per-entry candidate counts,
-  // one thread per (entry, candidate) then looks its polyline up, wave 0 scans the vertex counts
-  if (threadIdx.x == 0) s_ok = (k <= 64) ? 1u : 0u;
-  if (wave == 0 && k <= 64) {
-    const uint32_t nc = lane < k ? cand_cnt[sv0 + lane] : 0;
-    uint32_t incl = nc;
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
-      if ((int)lane >= o) incl += t;
-    }
-    if (lane < k) s_entry_first[lane] = incl - nc;
-    if (lane == 63) {
-      s_entry_first[k] = incl;
-      if (incl > K2_DIR_CAP) s_ok = 0;
-    }
-  }
-  __syncthreads();
-  if (s_ok) {
-    const uint32_t nd = s_entry_first[k];
-    if (threadIdx.x < nd) {
-      uint32_t e = 0;
-      while (s_entry_first[e + 1] <= threadIdx.x) e++;
-      const uint32_t pl_id = cand_pl[raw_off[sv0 + e] + (threadIdx.x - s_entry_first[e])];
-      const uint32_t g = s.view_pl_off[sd.trk_view[t0 + e]] + pl_id;
-      s_dir_pl[threadIdx.x] = pl_id;
-      s_dir_src[threadIdx.x] = s.pl_vtx_off[g];
-      s_dir_n[threadIdx.x] = s.pl_vtx_off[g + 1] - s.pl_vtx_off[g];
-    }
-    __syncthreads();
-    if (wave == 0) {
-      uint32_t run = 0;
-      for (uint32_t base = 0; base < nd; base += 64) {
-        const uint32_t n = base + lane < nd ? s_dir_n[base + lane] : 0;
-        uint32_t incl = n;
-        for (int o = 1; o < 64; o <<= 1) {
-          const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
-          if ((int)lane >= o) incl += t;
-        }
-        if (base + lane < nd) s_dir_off[base + lane] = run + incl - n;
-        run += (uint32_t)__shfl((int)incl, 63, 64);
-      }
-      if (lane == 0 && run > K2_VTX_CAP) s_ok = 0;
-    }
-  }
-  __syncthreads();
-  const bool staged = s_ok != 0;
-  if (staged) {  // one wavefront per polyline: coalesced 512-byte rows
-    const uint32_t nd = s_entry_first[k];
-    for (uint32_t d = wave; d < nd; d += 4) {
-      const f2* src = s.vtx + s_dir_src[d];
-      const uint32_t n = s_dir_n[d], o = s_dir_off[d];
-      for (uint32_t x = lane; x < n; x += 64) s_vtx[o + x] = src[x];
-    }
-  }
-  __syncthreads();
-  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  for (uint32_t t = task_first + wave; t < task_last; t += 4) {
-    // entry of task t: the (seed, entry) whose task range holds it
-    uint32_t ea = 0;
-    while (ea + 1 < k && task_off[sv0 + ea + 1] <= t) ea++;
-    const uint32_t h = task_hit[t];
-    const Obs hit = start_hits[raw_off[sv0 + ea] + h];
-    const int32_t start_view = sd.trk_view[t0 + ea];
-    float ix, iy;
-    seed_obs_in_view(sd, t0, k, start_view, ix, iy);
-    const float radius = dist(ix, iy, hit.x, hit.y) * 3.0f;
-    const float detsq = radius * radius;
-    const uint32_t lo = task_list_off[t];
-    for (uint32_t i = 0; i < k; i++) {
-      const int32_t cur_view = sd.trk_view[t0 + i];
-      uint32_t cnt = 0;
-      if (cur_view == start_view) {
-        cnt = 1;
-        if (FILL && lane == 0) {
-          Obs o = hit;
-          o.view = cur_view;
-          hits[list_ptr[lo + i]] = o;
-        }
-      } else {
-        float la, lb, lc;
-        if (epiline(s.F, s.F_valid, s.n_views, start_view, cur_view, hit.x, hit.y, la, lb, lc)) {
-          const float sx = sd.trk_xy[2 * (t0 + i)], sy = sd.trk_xy[2 * (t0 + i) + 1];
-          const uint32_t cbase = raw_off[sv0 + i], ncand = cand_cnt[sv0 + i];
-          const uint32_t wbase = FILL ? list_ptr[lo + i] : 0;
-          for (uint32_t c = 0; c < ncand; c++) {
-            uint32_t pl_id, n;
-            uint32_t lo_v = 0;
-            const f2* gv = nullptr;
-            if (staged) {
-              const uint32_t d = s_entry_first[i] + c;
-              pl_id = s_dir_pl[d];
-              n = s_dir_n[d];
-              lo_v = s_dir_off[d];
-            } else {
-              pl_id = cand_pl[cbase + c];
-              const PlRef pl = polyline_of(s, cur_view, pl_id);
-              n = pl.n;
-              gv = pl.v;
-            }
-            for (uint32_t base = 1; base < n; base += 64) {
-              const uint32_t ii = base + lane;
-              bool ok = false;
-              float hx = 0.f, hy = 0.f;
-              if (ii < n) {
-                f2 v1, v0;
-                if (staged) {
-                  v1 = s_vtx[lo_v + ii];
-                  v0 = s_vtx[lo_v + ii - 1];
-                } else {
-                  v1 = gv[ii];
-                  v0 = gv[ii - 1];
-                }
-                if (seg_line_hit(v1.x, v1.y, v0.x, v0.y, la, lb, lc, hx, hy)) ok = dist2(sx, sy, hx, hy) <= detsq;
-              }
-              const unsigned long long mask = __ballot(ok);
-              if (FILL && ok) {
-                Obs o;
-                o.view = cur_view;
-                o.pl = pl_id;
-                o.seg = ii - 1;
-                o.x = hx;
-                o.y = hy;
-                hits[wbase + cnt + __popcll(mask & lt_mask)] = o;
-              }
-              cnt += __popcll(mask);
-            }
-          }
-        }
-      }
-      if (!FILL && lane == 0) list_cnt[lo + i] = cnt;
-    }
-  }
-}
 
 // ------------------------------------------------------------------ N1 ---------
 // Pipelines 1-2 extractor, stage A (polyline_matching.cpp:153-208 with :45-73): every polyline of a
@@ -763,13 +595,6 @@ __global__ void k_compact_chains(uint32_t n_tasks, const ChainSeed* per_task, co
 #ifndef EG3D_WAVE_SLOT_STEP
 #define EG3D_WAVE_SLOT_STEP 0 /* measured slower: failed speculative candidates run all 30 GN iterations */
 #endif
-#ifndef EG3D_COOP_NUM
-#define EG3D_COOP_NUM 3 /* cooperative when passes*NUM < longest_solve*DEN */
-#define EG3D_COOP_DEN 2
-#endif
-#ifndef EG3D_COOP_GN
-#define EG3D_COOP_GN 1 /* wave-cooperative Gauss-Newton (eg3d_dev_coopgn.h); 0 = one lane per solve */
-#endif
 #ifndef EG3D_LOOKAHEAD
 #define EG3D_LOOKAHEAD 8 /* steps walked ahead per round (<= 8, and <= 64 / observations of the end point) */
 #endif
@@ -1022,7 +847,6 @@ struct TeamWave {
       // ---- stage 3: the Deff Gauss-Newton solves as one batch (request j on lane j)
       const uint64_t tq2 = EG3D_TICK();
       c.tsec[5] += tq2 - tq1;
-#if EG3D_GN_GROUPS
       {
         const bool want = lane() < Deff;
         const float X0f[3] = {(float)X0[0], (float)X0[1], (float)X0[2]};  // DLT results are float-valued
@@ -1033,34 +857,6 @@ struct TeamWave {
         (void)ok;
         (void)Xr;
       }
-#else
-      {
-        const int g = lane() / n_end, k = lane() - g * n_end;
-        const int n = g < Deff ? L->la_m[g] : 0;
-        const bool act = g < Deff && k < n;
-        const int gs = g < Deff ? g : 0;
-        double X[3];
-        X[0] = __shfl(X0[0], gs);
-        X[1] = __shfl(X0[1], gs);
-        X[2] = __shfl(X0[2], gs);
-        int32_t view = 0;
-        float ox = 0.f, oy = 0.f;
-        if (act) {
-          const Obs& o = L->tmp_a[g * n_end + k];
-          view = o.view;
-          ox = o.x;
-          oy = o.y;
-        }
-        const bool ok = coop_gn_rows(s.cam_P, *L, act, gs, k, n > 0 ? n : 1, g * n_end, view, ox, oy, X);
-        if (act && k == 0) {
-          L->res_ok[g] = ok ? 1 : 0;
-          L->x0[g][0] = (float)X[0];
-          L->x0[g][1] = (float)X[1];
-          L->x0[g][2] = (float)X[2];
-        }
-        __syncthreads();
-      }
-#endif
       // ---- stage 4: accept in order
       c.tsec[6] += EG3D_TICK() - tq2;
       bool redo = false, stop = false;
@@ -1115,7 +911,6 @@ struct TeamWave {
   // uniform section: all lanes hold the same (a, n, X0) and receive the same answer
   __device__ __forceinline__ bool gn_array(const DevScene& s, const Obs* a, int n, const double X0[3],
                                            float Xout[3]) const {
-#if EG3D_GN_GROUPS
     // one request (lane 0), the whole wave on its rows
     const float X0f[3] = {(float)X0[0], (float)X0[1], (float)X0[2]};  // callers pass float-valued starts
     float Xr[3];
@@ -1124,14 +919,9 @@ struct TeamWave {
     Xout[1] = __shfl(Xr[1], 0);
     Xout[2] = __shfl(Xr[2], 0);
     return __shfl(ok ? 1 : 0, 0) != 0;
-#else
-    if (EG3D_COOP_GN && n <= EG3D_COOP_ROWS) return coop_gn_single(s.cam_P, *L, a, n, X0, Xout);
-    return coop_gn_big(s.cam_P, *L, a, n, false, 0, 0.f, 0.f, X0, Xout);
-#endif
   }
   __device__ __forceinline__ bool add_one(const DevScene& s, const Chain& c, const ChainPt& p, const Obs& extra,
                                           float Xout[3]) const {
-#if EG3D_GN_GROUPS
     const float X0f[3] = {p.X[0], p.X[1], p.X[2]};
     float Xr[3];
     const bool ok = coop_gn_groups(s.cam_P, *L, lane() == 0, c.pool + p.off, (int)p.nobs, true, extra.view, extra.x,
@@ -1140,9 +930,6 @@ struct TeamWave {
     Xout[1] = __shfl(Xr[1], 0);
     Xout[2] = __shfl(Xr[2], 0);
     return __shfl(ok ? 1 : 0, 0) != 0;
-#else
-    return add_observation_solve(s, c, p, extra, Xout);
-#endif
   }
   // B independent ADD solves, 64 per window, request j on lane j. A window goes cooperative
   // (rows = observations) when that needs fewer row-passes than the longest single solve;
@@ -1157,7 +944,6 @@ struct TeamWave {
       o.pl = o.seg = 0;
       o.x = o.y = 0.f;
       const bool want = j < B && get(j, pt, o);
-#if EG3D_GN_GROUPS
       float X[3] = {0.f, 0.f, 0.f};
       float X0[3] = {0.f, 0.f, 0.f};
       if (want) {
@@ -1167,56 +953,6 @@ struct TeamWave {
       }
       const bool ok = coop_gn_groups(s.cam_P, *L, want, want ? c.pool + pt->off : nullptr, want ? (int)pt->nobs : 0, true,
                                      o.view, o.x, o.y, X0, X);
-#else
-      const int n = want ? (int)pt->nobs + 1 : 0;
-      int tot = n, mx = n, chunks_total = (n + 63) >> 6;
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) {
-        tot += __shfl_xor(tot, d);
-        chunks_total += __shfl_xor(chunks_total, d);
-        const int t = __shfl_xor(mx, d);
-        mx = t > mx ? t : mx;
-      }
-      if (mx == 0) continue;
-      const int passes = (tot + EG3D_COOP_ROWS - 1) / EG3D_COOP_ROWS;
-      const bool coop = EG3D_COOP_GN && mx <= EG3D_COOP_ROWS && passes * EG3D_COOP_NUM < mx * EG3D_COOP_DEN;
-      float X[3] = {0.f, 0.f, 0.f};
-      bool ok = false;
-      if (coop) {
-        float X0[3] = {0.f, 0.f, 0.f};
-        uint32_t off = 0;
-        if (want) {
-          X0[0] = pt->X[0];
-          X0[1] = pt->X[1];
-          X0[2] = pt->X[2];
-          off = pt->off;
-        }
-        ok = coop_gn_window(s.cam_P, c.pool, *L, want, off, n - 1, o, X0, X);
-      } else if (EG3D_COOP_GN && mx > EG3D_COOP_ROWS && chunks_total * 2 < mx) {
-        // long solves (V > 64 scenes), few of them: the whole wave takes the requests one at a time
-        const unsigned long long wanted = __ballot(want);
-        for (int q = 0; q < 64; q++) {
-          if (!((wanted >> q) & 1ull)) continue;
-          const uint32_t off_q = (uint32_t)__shfl((int)(want ? pt->off : 0u), q);
-          const int nb_q = __shfl(n - 1, q);
-          const int32_t ev = __shfl(o.view, q);
-          const float ex = __shfl(o.x, q), ey = __shfl(o.y, q);
-          const float x0 = __shfl(want ? pt->X[0] : 0.f, q), x1 = __shfl(want ? pt->X[1] : 0.f, q),
-                      x2 = __shfl(want ? pt->X[2] : 0.f, q);
-          const double X0d[3] = {(double)x0, (double)x1, (double)x2};
-          float Xq[3];
-          const bool okq = coop_gn_big(s.cam_P, *L, c.pool + off_q, nb_q, true, ev, ex, ey, X0d, Xq);
-          if (lane() == q) {
-            ok = okq;
-            X[0] = Xq[0];
-            X[1] = Xq[1];
-            X[2] = Xq[2];
-          }
-        }
-      } else if (want) {
-        ok = add_observation_solve(s, c, *pt, o, X);
-      }
-#endif
       if (want) put(j, ok, X);
     }
   }
@@ -1225,23 +961,153 @@ struct TeamWave {
 #ifndef EG3D_K3B_WAVES
 #define EG3D_K3B_WAVES 3 /* measured: 3 waves/SIMD (168 VGPRs) beats 2 and 4 on C2 and C3 */
 #endif
+// ---- working slices: a slot-indexed arena ---------------------------------------------------------
+// A chain's working state (point headers, observation pool, candidate / pending arrays) lives in a
+// SLICE of ChainLayout::total bytes. Slices belong to SLOTS, not to chains: the arena holds as many
+// slices as wavefronts can be resident (a few thousand), a chain borrows one for its lifetime and the
+// next chain on that slot reuses the same addresses — the arena is a few hundred MB that stays in
+// L2 / Infinity Cache and in the TLB, where a slice per chain was 4 GB (C3') to tens of GB (C4) of
+// first-touch traffic per launch. Slots are XCD-AFFINE: the per-XCD L2s are not coherent with each
+// other, so a slice is only ever touched through ONE XCD's L2 — a wave reads its XCC id and takes a
+// slot from that XCD's pool. Hand-over needs no cache maintenance then: the releasing wave waits for
+// its stores to be acknowledged by that L2 (s_waitcnt vmcnt(0)) before it returns the slot, and a chain
+// never reads a byte of its slice that it has not written itself (so a stale line in a CU's L1 from
+// an earlier tenant is never observed). The pool of an XCD is a ring of slot ids with ticket counters:
+// pop = take a ticket, then swap the cell at that position to 0 until a slot id comes out; push = take a
+// ticket, then CAS the cell from 0 to the id. A pool holds at least as many slots as blocks can be
+// resident on its XCD, so a pop only ever waits for a push that is already under way.
+__global__ void k_pool_init(SlotPools P) {
+  uint32_t* b = P.base + (size_t)blockIdx.x * P.stride;
+  for (uint32_t i = threadIdx.x; i < P.ring_n; i += blockDim.x) b[32 + i] = i < P.slots_per_xcd ? i + 1u : 0u;
+  if (threadIdx.x == 0) {
+    b[0] = 0;
+    b[16] = P.slots_per_xcd;
+  }
+}
+__device__ __forceinline__ uint32_t xcc_id() {
+  uint32_t v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 7u;
+}
+#define EG3D_SLOT_NONE 0xffffffffu
+__device__ __forceinline__ uint32_t pool_pop(const SlotPools& P, uint32_t xcc) {
+  uint32_t* b = P.base + (size_t)xcc * P.stride;
+  const uint32_t h = atomicAdd(&b[0], 1u);
+  uint32_t* cell = &b[32 + (h & (P.ring_n - 1u))];
+  for (uint32_t spin = 0; spin < (1u << 22); spin++) {  // bounded: a pool smaller than the residency is a host bug
+    const uint32_t v = atomicExch(cell, 0u);
+    if (v) return v - 1u;
+    __builtin_amdgcn_s_sleep(16);
+  }
+  return EG3D_SLOT_NONE;
+}
+__device__ __forceinline__ void pool_push(const SlotPools& P, uint32_t xcc, uint32_t slot) {
+  uint32_t* b = P.base + (size_t)xcc * P.stride;
+  const uint32_t t = atomicAdd(&b[16], 1u);
+  uint32_t* cell = &b[32 + (t & (P.ring_n - 1u))];
+  for (uint32_t spin = 0; spin < (1u << 22); spin++) {
+    if (atomicCAS(cell, 0u, slot + 1u) == 0u) return;
+    __builtin_amdgcn_s_sleep(4);
+  }
+}
+
+// One wavefront per chain, launched longest-first. The finished chain is PACKED into the launch's
+// staging area (point headers + its observations back to back, bump-allocated in order of completion)
+// before the slot is returned: what leaves the kernel is the chain's result, 16 B per point and per
+// observation written once with coalesced stores — not the working slice.
 __global__ void __launch_bounds__(64, EG3D_K3B_WAVES) k3b_expand(DevScene s, StageAView a, const TaskDesc* tasks,
                                                  const ChainSeed* chains, uint32_t n_chains, const uint32_t* hyp_off,
                                                  const HypResult* res, const HPoint* arena, const int32_t* map_view,
                                                  const uint32_t* map_entry, const uint32_t* map_n, ChainLayout L,
-                                                 unsigned char* scratch, ChainOut* outs, uint32_t* out_points,
-                                                 uint32_t* out_obs, Counters* ctr, const uint32_t* order) {
+                                                 unsigned char* slices, SlotPools pools, StageBuf stage, ChainOut* outs,
+                                                 uint32_t* out_points, uint32_t* out_obs, Counters* ctr,
+                                                 const uint32_t* order) {
   if (blockIdx.x >= n_chains) return;
+  __shared__ CoopLds lds;
+  const uint32_t lane = threadIdx.x;
   const uint32_t j = order[blockIdx.x];  // longest-first schedule; results stay indexed by chain
+  const uint32_t xcc = xcc_id();
+  uint32_t slot = 0;
+  if (lane == 0) slot = pool_pop(pools, xcc);
+  slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+  ChainOut co;
+  if (slot == EG3D_SLOT_NONE) {
+    if (lane == 0) {
+      memset(&co, 0, sizeof(co));
+      outs[j] = co;
+      out_points[j] = 0;
+      out_obs[j] = 0;
+      atomicOr(&ctr->flags, CTR_SLOT_STARVED);
+    }
+    return;
+  }
   const ChainSeed cs = chains[j];
   const TaskDesc d = tasks[cs.task];
-  ChainOut co;
-  __shared__ CoopLds lds;
+  unsigned char* slice = slices + L.total * ((size_t)xcc * pools.slots_per_xcd + slot);
   TeamWave tm;
   tm.L = &lds;
-  expand_chain(tm, s, a, d, cs, hyp_off[cs.task], res, arena, map_view, map_entry, map_n, L,
-               scratch + L.total * (size_t)j, co);
-  if (threadIdx.x == 0) {
+  expand_chain(tm, s, a, d, cs, hyp_off[cs.task], res, arena, map_view, map_entry, map_n, L, slice, co);
+  // ---- pack the result: 64 points at a time, their observations as one flat range
+  unsigned long long pb = 0, ob = 0;
+  if (lane == 0) {
+    pb = atomicAdd(&stage.used[0], (unsigned long long)co.n_points);
+    ob = atomicAdd(&stage.used[1], (unsigned long long)co.n_obs);
+  }
+  pb = (unsigned long long)__shfl((long long)pb, 0);
+  ob = (unsigned long long)__shfl((long long)ob, 0);
+  co.spt = pb;
+  co.sobs = ob;
+  if (pb + co.n_points <= stage.cap_pts && ob + co.n_obs <= stage.cap_obs) {
+    __syncthreads();
+    uint32_t* s_excl = (uint32_t*)&lds.prod[0][0];  // [65] first flat observation of each of the 64 points in flight
+    uint32_t* s_blk = s_excl + 65;                  // [64] where each point's block starts in the pool
+    const ChainPt* pts = (const ChainPt*)(slice + L.off_pts) + co.head;
+    const Obs* pool = (const Obs*)(slice + L.off_pool);
+    StagePt* spt = stage.pts + pb;
+    Obs* sob = stage.obs + ob;
+    for (uint32_t i0 = 0; i0 < co.n_points; i0 += 64) {
+      const uint32_t i = i0 + lane;
+      const bool act = i < co.n_points;
+      ChainPt p;
+      p.nobs = 0;
+      p.off = 0;
+      p.X[0] = p.X[1] = p.X[2] = 0.f;
+      if (act) p = pts[i];
+      uint32_t incl = p.nobs;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+        if ((int)lane >= o) incl += t;
+      }
+      const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+      s_excl[lane] = incl - p.nobs;
+      s_blk[lane] = p.off;
+      if (lane == 63) s_excl[64] = total;
+      if (act) {
+        StagePt sp;
+        sp.X[0] = p.X[0];
+        sp.X[1] = p.X[1];
+        sp.X[2] = p.X[2];
+        sp.nobs = p.nobs;
+        spt[i] = sp;
+      }
+      __syncthreads();
+      for (uint32_t f = lane; f < total; f += 64) {
+        uint32_t lo = 0;  // the point whose range holds f: largest q with s_excl[q] <= f (empty points skipped)
+#pragma unroll
+        for (uint32_t step = 32; step; step >>= 1)
+          if (s_excl[lo + step] <= f) lo += step;
+        sob[f] = pool[s_blk[lo] + (f - s_excl[lo])];
+      }
+      __syncthreads();
+      sob += total;
+    }
+  }
+  // every store to the slice has been acknowledged by this XCD's L2 before the slot changes hands
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (lane == 0) {
+    pool_push(pools, xcc, slot);
     outs[j] = co;
     out_points[j] = co.n_points;
     out_obs[j] = co.n_obs;
@@ -1264,33 +1130,32 @@ __global__ void k_chain_cost(StageAView a, const TaskDesc* tasks, const ChainSee
 }
 
 // ------------------------------------------------------------------ K4 ---------
-// One wavefront per chain: lanes take consecutive chain points; the observation offset of each
-// point is the chain's base plus a wave prefix sum of the per-point observation counts, so the
-// writes of X / key / obs_off are coalesced and the per-point list walks run in parallel.
+// One wavefront per chain, in OUTPUT order: the chain's packed record (k3b_expand) becomes its slice
+// of the ordered SoA cloud. Lanes take consecutive points; the observation offset of each point is
+// the chain's base plus a wave prefix sum of the per-point counts; the observations of the record are
+// already one flat range, so lane f copies observation f: coalesced 16-byte reads, coalesced rows in
+// every output array.
 __global__ void __launch_bounds__(64) k4_emit(const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains,
-                                              ChainLayout L, const unsigned char* scratch, const ChainOut* outs,
-                                              const uint32_t* point_off, const uint32_t* obs_off_in,
-                                              uint64_t point_base, uint64_t obs_base, uint32_t key0_base, float* X,
-                                              uint32_t* obs_off, int32_t* obs_view, uint32_t* obs_pl, uint32_t* obs_seg,
-                                              float* obs_xy, uint32_t* key) {
-  __shared__ uint32_t s_excl[65];  // first flat observation index of each of the 64 points in flight (+ total)
-  __shared__ uint32_t s_blk[64];   // where each point's observation block starts in the chain's pool
+                                              StageBuf stage, const ChainOut* outs, const uint32_t* point_off,
+                                              const uint32_t* obs_off_in, uint64_t point_base, uint64_t obs_base,
+                                              uint32_t key0_base, float* X, eg3d_off_t* obs_off, int32_t* obs_view,
+                                              uint32_t* obs_pl, uint32_t* obs_seg, float* obs_xy, uint32_t* key) {
   const uint32_t j = blockIdx.x;
   const uint32_t lane = threadIdx.x;
-  const unsigned char* slice = scratch + L.total * (size_t)j;
-  const ChainPt* pts = (const ChainPt*)(slice + L.off_pts);
-  const Obs* pool = (const Obs*)(slice + L.off_pool);
   const ChainOut co = outs[j];
+  const StagePt* spt = stage.pts + co.spt;
+  const Obs* sob = stage.obs + co.sobs;
   const TaskDesc d = tasks[chains[j].task];
   const uint64_t pbase = point_base + point_off[j];
-  uint64_t obase = obs_base + obs_off_in[j];
+  const uint64_t obase = obs_base + obs_off_in[j];
+  uint32_t run = 0;  // observations of the points before this group of 64
   for (uint32_t i0 = 0; i0 < co.n_points; i0 += 64) {
     const uint32_t i = i0 + lane;
     const bool act = i < co.n_points;
-    ChainPt p;
+    StagePt p;
     p.nobs = 0;
-    p.off = 0;
-    if (act) p = pts[co.head + i];
+    p.X[0] = p.X[1] = p.X[2] = 0.f;
+    if (act) p = spt[i];
     uint32_t incl = p.nobs;  // inclusive wave scan of the observation counts
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -1298,37 +1163,26 @@ __global__ void __launch_bounds__(64) k4_emit(const TaskDesc* tasks, const Chain
       if ((int)lane >= o) incl += t;
     }
     const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
-    s_excl[lane] = incl - p.nobs;
-    s_blk[lane] = p.off;
-    if (lane == 63) s_excl[64] = total;
     if (act) {
       const uint64_t pi = pbase + i;
       X[3 * pi] = p.X[0];
       X[3 * pi + 1] = p.X[1];
       X[3 * pi + 2] = p.X[2];
-      obs_off[pi] = (uint32_t)(obase + (incl - p.nobs));
+      obs_off[pi] = (eg3d_off_t)(obase + run + (incl - p.nobs));
       key[4 * pi] = d.seed + key0_base;
       key[4 * pi + 1] = d.entry;
       key[4 * pi + 2] = d.hit;
       key[4 * pi + 3] = i;
     }
-    __syncthreads();
-    // the observations of these 64 points, flat: lane f copies observation f, so that consecutive lanes
-    // write consecutive elements of every output array (and read consecutive 16-byte pool entries within a point)
-    for (uint32_t f = lane; f < total; f += 64) {
-      uint32_t lo = 0;  // the point whose range holds f: largest q with s_excl[q] <= f (empty points skipped)
-#pragma unroll
-      for (uint32_t step = 32; step; step >>= 1)
-        if (s_excl[lo + step] <= f) lo += step;
-      const Obs po = pool[s_blk[lo] + (f - s_excl[lo])];
-      const uint64_t o = obase + f;
-      obs_view[o] = po.view;
-      obs_pl[o] = po.pl;
-      obs_seg[o] = po.seg;
-      *(f2*)(obs_xy + 2 * o) = f2{po.x, po.y};
-    }
-    __syncthreads();
-    obase += total;
+    run += total;
+  }
+  for (uint32_t f = lane; f < co.n_obs; f += 64) {
+    const Obs po = sob[f];
+    const uint64_t o = obase + f;
+    obs_view[o] = po.view;
+    obs_pl[o] = po.pl;
+    obs_seg[o] = po.seg;
+    *(f2*)(obs_xy + 2 * o) = f2{po.x, po.y};
   }
 }
 
@@ -1449,14 +1303,6 @@ void launch_k2(hipStream_t st, bool fill, DevScene s, SeedsDev sd, uint32_t seed
                const uint32_t* task_hit, const uint32_t* task_list_off, const uint32_t* raw_off, const uint32_t* cand_pl,
                const uint32_t* cand_cnt, const Obs* start_hits, uint32_t* list_cnt, const uint32_t* list_ptr, Obs* hits) {
   if (!n_tasks || !n_seeds) return;
-#if EG3D_K2_LDS
-  if (fill)
-    hipLaunchKernelGGL(k2_epipolar_hits_staged<true>, dim3(n_seeds), dim3(256), 0, st, s, sd, seed_begin, sv_base, task_off,
-                       task_hit, task_list_off, raw_off, cand_pl, cand_cnt, start_hits, list_cnt, list_ptr, hits);
-  else
-    hipLaunchKernelGGL(k2_epipolar_hits_staged<false>, dim3(n_seeds), dim3(256), 0, st, s, sd, seed_begin, sv_base,
-                       task_off, task_hit, task_list_off, raw_off, cand_pl, cand_cnt, start_hits, list_cnt, list_ptr, hits);
-#else
   if (fill)
     hipLaunchKernelGGL(k2_epipolar_hits<true>, blocks_for((uint64_t)n_tasks * 64, 256), dim3(256), 0, st, s, sd, sv_base,
                        n_tasks, task_seed, task_entry, task_hit, task_list_off, raw_off, cand_pl, cand_cnt, start_hits,
@@ -1465,7 +1311,6 @@ void launch_k2(hipStream_t st, bool fill, DevScene s, SeedsDev sd, uint32_t seed
     hipLaunchKernelGGL(k2_epipolar_hits<false>, blocks_for((uint64_t)n_tasks * 64, 256), dim3(256), 0, st, s, sd,
                        sv_base, n_tasks, task_seed, task_entry, task_hit, task_list_off, raw_off, cand_pl, cand_cnt,
                        start_hits, list_cnt, list_ptr, hits);
-#endif
 }
 void launch_n1_samples(hipStream_t st, bool fill, DevScene s, SetsDev sets, uint32_t n_rows, uint32_t item_begin,
                        uint32_t n_items, uint32_t* sample_cnt, const uint32_t* sample_off, Obs* samples,
@@ -1535,27 +1380,35 @@ void launch_compact_chains(hipStream_t st, uint32_t n_tasks, const ChainSeed* pe
   hipLaunchKernelGGL(k_compact_chains, blocks_for(n_tasks, 256), dim3(256), 0, st, n_tasks, per_task, valid, chain_off,
                      chains);
 }
+int k3b_blocks_per_cu() {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k3b_expand, 64, 0) != hipSuccess || n < 1) return 0;
+  return n;
+}
+void launch_pool_init(hipStream_t st, SlotPools pools) {
+  hipLaunchKernelGGL(k_pool_init, dim3(8), dim3(256), 0, st, pools);
+}
 void launch_k3b(hipStream_t st, DevScene s, StageAView a, const TaskDesc* tasks, const ChainSeed* chains,
                 uint32_t n_chains, const uint32_t* hyp_off, const HypResult* res, const HPoint* arena,
                 const int32_t* map_view, const uint32_t* map_entry, const uint32_t* map_n, ChainLayout L,
-                unsigned char* scratch, ChainOut* outs, uint32_t* out_points, uint32_t* out_obs, Counters* ctr,
-                const uint32_t* order) {
+                unsigned char* slices, SlotPools pools, StageBuf stage, ChainOut* outs, uint32_t* out_points,
+                uint32_t* out_obs, Counters* ctr, const uint32_t* order) {
   if (!n_chains) return;
   hipLaunchKernelGGL(k3b_expand, dim3(n_chains), dim3(64), 0, st, s, a, tasks, chains, n_chains, hyp_off, res,
-                     arena, map_view, map_entry, map_n, L, scratch, outs, out_points, out_obs, ctr, order);
+                     arena, map_view, map_entry, map_n, L, slices, pools, stage, outs, out_points, out_obs, ctr, order);
 }
 void launch_chain_cost(hipStream_t st, StageAView a, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains,
                        uint32_t* cost, uint32_t* idx) {
   if (!n_chains) return;
   hipLaunchKernelGGL(k_chain_cost, blocks_for(n_chains, 256), dim3(256), 0, st, a, tasks, chains, n_chains, cost, idx);
 }
-void launch_k4(hipStream_t st, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains, ChainLayout L,
-               const unsigned char* scratch, const ChainOut* outs, const uint32_t* point_off, const uint32_t* obs_off_in,
-               uint64_t point_base, uint64_t obs_base, uint32_t key0_base, float* X, uint32_t* obs_off, int32_t* obs_view,
-               uint32_t* obs_pl, uint32_t* obs_seg, float* obs_xy, uint32_t* key) {
+void launch_k4(hipStream_t st, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains, StageBuf stage,
+               const ChainOut* outs, const uint32_t* point_off, const uint32_t* obs_off_in, uint64_t point_base,
+               uint64_t obs_base, uint32_t key0_base, float* X, eg3d_off_t* obs_off, int32_t* obs_view, uint32_t* obs_pl,
+               uint32_t* obs_seg, float* obs_xy, uint32_t* key) {
   if (!n_chains) return;
-  hipLaunchKernelGGL(k4_emit, dim3(n_chains), dim3(64), 0, st, tasks, chains, n_chains, L, scratch, outs,
-                     point_off, obs_off_in, point_base, obs_base, key0_base, X, obs_off, obs_view, obs_pl, obs_seg, obs_xy, key);
+  hipLaunchKernelGGL(k4_emit, dim3(n_chains), dim3(64), 0, st, tasks, chains, n_chains, stage, outs, point_off,
+                     obs_off_in, point_base, obs_base, key0_base, X, obs_off, obs_view, obs_pl, obs_seg, obs_xy, key);
 }
 void launch_k5(hipStream_t st, const float* cam_P, int n_views, const float* X, const uint32_t* obs_off,
                const int32_t* obs_view, const float* obs_xy, uint64_t n, float gn_max_mse, int legacy_abs, float* X_out,
