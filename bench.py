@@ -225,12 +225,13 @@ def main():
         if dry:
             class _CountOnly:
                 def allgather(self, local):
-                    t = torch.tensor([int(local.n_points)], dtype=torch.int64)
+                    t = torch.tensor([int(local.n_points) if local is not None else 0, 0 if local is not None else 1],
+                                     dtype=torch.int64)
                     dist.all_reduce(t)
 
                     class _C:
-                        n_points = int(t.item())
-                    return _C, 0
+                        n_points = int(t[0].item())
+                    return _C, (-4 if int(t[1].item()) else 0)
 
                 def close(self):
                     pass
@@ -248,14 +249,20 @@ def main():
         for i in range(n):
             w = pool[i % len(pool)]
             r = w.done.get()
-            if isinstance(r, Exception):
-                raise r
-            total = r["n_points"]
+            failed = r if isinstance(r, Exception) else None
             if gather is not None:
-                cloud, rc = gather.allgather(w.ctx.last_device_output())  # synchronous on the gather stream
+                # a rank whose step failed still takes part in the collective (local = None): the status word makes
+                # EVERY rank return EG3D_GATHER_ERR_INCOMPLETE, so no rank is left blocked in the exchange
+                cloud, rc = gather.allgather(None if failed else w.ctx.last_device_output())  # synchronous on the gather stream
+                if failed is not None:
+                    raise failed
                 if rc != 0:
                     raise RuntimeError("eg3d_allgather_edgepoints failed on every rank with rc=%d" % rc)
                 total = int(cloud.n_points)
+            else:
+                if failed is not None:
+                    raise failed
+                total = r["n_points"]
             if submitted < n:
                 w.todo.put((first + submitted, device_only))
                 submitted += 1

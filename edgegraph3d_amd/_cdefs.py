@@ -5,6 +5,7 @@ import numpy as np
 
 u8p = C.POINTER(C.c_uint8)
 u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
 i32p = C.POINTER(C.c_int32)
 f32p = C.POINTER(C.c_float)
 f64p = C.POINTER(C.c_double)
@@ -26,7 +27,7 @@ class PolylineSets(C.Structure):
 
 
 class EdgePoints(C.Structure):
-    _fields_ = [("n_points", C.c_uint64), ("n_obs", C.c_uint64), ("X", f32p), ("obs_off", u32p),
+    _fields_ = [("n_points", C.c_uint64), ("n_obs", C.c_uint64), ("X", f32p), ("obs_off", u64p),
                 ("obs_view", i32p), ("obs_pl", u32p), ("obs_seg", u32p), ("obs_xy", f32p), ("key", u32p),
                 ("n_tasks", C.c_uint64), ("n_hypotheses", C.c_uint64), ("n_chains", C.c_uint64),
                 ("flags", C.c_uint32), ("_owner", C.c_void_p)]
@@ -119,7 +120,7 @@ class EdgePointsArrays:
     exposes an EdgePoints struct over them, for the host steps that consume a cloud."""
 
     def __init__(self, d):
-        self.a = {"X": np.ascontiguousarray(d["X"], np.float32), "obs_off": np.ascontiguousarray(d["obs_off"], np.uint32),
+        self.a = {"X": np.ascontiguousarray(d["X"], np.float32), "obs_off": np.ascontiguousarray(d["obs_off"], np.uint64),
                   "obs_view": np.ascontiguousarray(d["obs_view"], np.int32),
                   "obs_pl": np.ascontiguousarray(d["obs_pl"], np.uint32),
                   "obs_seg": np.ascontiguousarray(d["obs_seg"], np.uint32),
@@ -128,7 +129,7 @@ class EdgePointsArrays:
         a = self.a
         n = len(a["obs_off"]) - 1
         self.c = EdgePoints(n, int(a["obs_off"][-1]) if n >= 0 else 0, np_ptr(a["X"], C.c_float),
-                            np_ptr(a["obs_off"], C.c_uint32), np_ptr(a["obs_view"], C.c_int32),
+                            np_ptr(a["obs_off"], C.c_uint64), np_ptr(a["obs_view"], C.c_int32),
                             np_ptr(a["obs_pl"], C.c_uint32), np_ptr(a["obs_seg"], C.c_uint32),
                             np_ptr(a["obs_xy"], C.c_float), np_ptr(a["key"], C.c_uint32), 0, 0, 0, 0, None)
 
@@ -138,7 +139,7 @@ def edgepoints_to_dict(e):
     return {
         "n_points": n, "n_obs": m,
         "X": as_np(e.X, 3 * n, np.float32).reshape(n, 3),
-        "obs_off": as_np(e.obs_off, n + 1, np.uint32),
+        "obs_off": as_np(e.obs_off, n + 1, np.uint64),
         "obs_view": as_np(e.obs_view, m, np.int32),
         "obs_pl": as_np(e.obs_pl, m, np.uint32),
         "obs_seg": as_np(e.obs_seg, m, np.uint32),

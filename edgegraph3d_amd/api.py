@@ -203,7 +203,7 @@ class Context:
             return a
         n, m = int(d.n_points), int(d.n_obs)
         return {"n_points": n, "n_obs": m, "X": fetch(d.X, 3 * n, np.float32).reshape(n, 3),
-                "obs_off": np.concatenate([fetch(d.obs_off, n, np.uint32), np.array([m], np.uint32)]),
+                "obs_off": np.concatenate([fetch(d.obs_off, n, np.uint64), np.array([m], np.uint64)]),
                 "key": fetch(d.key, 4 * n, np.uint32).reshape(n, 4), "obs_view": fetch(d.obs_view, m, np.int32),
                 "obs_pl": fetch(d.obs_pl, m, np.uint32), "obs_seg": fetch(d.obs_seg, m, np.uint32),
                 "obs_xy": fetch(d.obs_xy, 2 * m, np.float32).reshape(m, 2)}

@@ -49,7 +49,8 @@ def _run(cmd):
 
 def build_host(force=False):
     srcs = _all_sources(HOST_DIR, (".cpp",))
-    deps = srcs + _all_sources(HOST_DIR, (".hpp", ".h")) + _all_sources(INC_DIR, (".h",)) + _all_sources(CSRC_DIR, (".h", ".hpp"))
+    deps = (srcs + _all_sources(HOST_DIR, (".hpp", ".h")) + _all_sources(INC_DIR, (".h",)) + _all_sources(CSRC_DIR, (".h", ".hpp"))
+            + _all_sources(os.path.join(PKG, "rccl"), (".h",)))
     if force or _newer(HOST_LIB, deps):
         _run(["g++"] + HOST_FLAGS + ["-I", INC_DIR, "-I", CSRC_DIR, "-o", HOST_LIB] + srcs + ["-lz"])  # libz: PNG inflate
     return HOST_LIB
@@ -100,7 +101,7 @@ def build_rccl(force=False):
     """The RCCL all-gather of the edge-point cloud for C/C++ hosts (include/eg3d_rccl.h): its own
     library so that libeg3d.so carries no communication dependency."""
     src = os.path.join(PKG, "rccl", "eg3d_rccl.hip")
-    deps = [src] + _all_sources(INC_DIR, (".h",))
+    deps = [src] + _all_sources(INC_DIR, (".h",)) + _all_sources(os.path.join(PKG, "rccl"), (".h",))
     if force or _newer(RCCL_LIB, deps):
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         _run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", INC_DIR, src,

@@ -784,7 +784,8 @@ static void copy_mt(void* dst, const void* src, size_t bytes) { eg3d::copy_mt(ds
 
 struct HostOut {
   RawVec<float> X, xy;
-  RawVec<uint32_t> off, pl, seg, key;
+  RawVec<uint32_t> pl, seg, key;
+  RawVec<uint64_t> off;
   RawVec<int32_t> view;
   uint64_t n_points = 0, n_obs = 0, n_tasks = 0, n_hyp = 0, n_chains = 0;
   uint32_t flags = 0;
@@ -1004,10 +1005,6 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
         continue;
       }
     }
-    if (H.n_obs + no > 0xffffffffull) {  // obs_off is 32-bit (include/eg3d.h)
-      g_err = "eg3d: more than 2^32-1 observations in one call; use smaller seed / set ranges";
-      return EG3D_ERR_CAPACITY;
-    }
     // Device-only calls keep the WHOLE cloud of the call in the output buffers (chunk after chunk, batch after
     // batch, global observation offsets), so that eg3d_last_device_output is complete whatever the chunking —
     // the RCCL gather reads it. Calls that copy to the host reuse the buffers per chunk (chunk-local offsets,
@@ -1015,7 +1012,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
     const bool accumulate = device_only != 0;
     const size_t P0 = accumulate ? (size_t)H.n_points : 0, O0 = accumulate ? (size_t)H.n_obs : 0;
     BUF_TRY(c->o_X.ensure_keep(sizeof(float) * 3 * (P0 + np + 1), sizeof(float) * 3 * P0, st));
-    BUF_TRY(c->o_off.ensure_keep(sizeof(uint32_t) * (P0 + np + 1), sizeof(uint32_t) * P0, st));
+    BUF_TRY(c->o_off.ensure_keep(sizeof(eg3d_off_t) * (P0 + np + 1), sizeof(eg3d_off_t) * P0, st));
     BUF_TRY(c->o_key.ensure_keep(sizeof(uint32_t) * 4 * (P0 + np + 1), sizeof(uint32_t) * 4 * P0, st));
     BUF_TRY(c->o_view.ensure_keep(sizeof(int32_t) * (O0 + no + 1), sizeof(int32_t) * O0, st));
     BUF_TRY(c->o_pl.ensure_keep(sizeof(uint32_t) * (O0 + no + 1), sizeof(uint32_t) * O0, st));
@@ -1057,7 +1054,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
       // D2H through the context's pinned staging area (grow-only): seven async copies at PCIe speed, one
       // synchronisation, then multi-threaded copies into the caller's pageable arrays. (A pageable
       // hipMemcpy runs at ~2 GB/s and made the copy 3x the compute time on the dtu006-shaped workload.)
-      const size_t sz[7] = {sizeof(float) * 3 * np, sizeof(uint32_t) * np,      sizeof(uint32_t) * 4 * np, sizeof(int32_t) * no,
+      const size_t sz[7] = {sizeof(float) * 3 * np, sizeof(eg3d_off_t) * np,   sizeof(uint32_t) * 4 * np, sizeof(int32_t) * no,
                             sizeof(uint32_t) * no,  sizeof(uint32_t) * no,      sizeof(float) * 2 * no};
       const void* src[7] = {c->o_X.p, c->o_off.p, c->o_key.p, c->o_view.p, c->o_pl.p, c->o_seg.p, c->o_xy.p};
       void* dst[7] = {H.X.data() + p0 * 3, H.off.data() + p0,  H.key.data() + p0 * 4, H.view.data() + o0,
@@ -1093,7 +1090,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
               std::chrono::duration<double, std::milli>(tc2 - tc1).count());
 #endif
       if (o0)
-        for (size_t i = p0; i < p0 + np; i++) H.off[i] += (uint32_t)o0;
+        for (size_t i = p0; i < p0 + np; i++) H.off[i] += (uint64_t)o0;
     }
     H.n_points += np;
     H.n_obs += no;
@@ -1254,7 +1251,7 @@ static int finish_match(HostOut& H, int device_only, float total, eg3d_edgepoint
       g_err = "eg3d: out of host memory for the edge-point cloud";
       return EG3D_ERR_ARG;
     }
-    H.off[npts] = (uint32_t)H.n_obs;
+    H.off[npts] = H.n_obs;
     out->X = H.X.release();
     out->obs_off = H.off.release();
     out->obs_view = H.view.release();
@@ -1317,7 +1314,7 @@ extern "C" int eg3d_last_device_output(eg3d_ctx* c, eg3d_device_edgepoints* out)
   out->n_points = c->last_np;
   out->n_obs = c->last_no;
   out->X = c->o_X.as<float>();
-  out->obs_off = c->o_off.as<uint32_t>();
+  out->obs_off = c->o_off.as<eg3d_off_t>();
   out->obs_view = c->o_view.as<int32_t>();
   out->obs_pl = c->o_pl.as<uint32_t>();
   out->obs_seg = c->o_seg.as<uint32_t>();
@@ -1578,6 +1575,10 @@ extern "C" int eg3d_probe_sections(eg3d_ctx* c, double* sum, double* slowest, ui
   if (n_chains) *n_chains = c->last_nc;
   return EG3D_OK;
 }
+
+// Gauss-Newton diagnostics of the expand kernel since the last reset (eg3d_dev_coopgn.h g_gn_dbg)
+namespace eg3d { int gn_dbg_read(unsigned long long* out, int reset); }
+extern "C" int eg3d_probe_gn(unsigned long long* out128, int reset) { return eg3d::gn_dbg_read(out128, reset); }
 
 extern "C" int eg3d_probe_hyp_sections(eg3d_ctx* c, double* sum, double* slowest, uint32_t* counts) {
   if (!c || !sum || !slowest || !counts) return EG3D_ERR_ARG;

@@ -74,6 +74,16 @@ static_assert(sizeof(CoopLds) <= 12800, "CoopLds must fit 10 LDS allocation unit
 struct GnRow {
   double j00, j01, j02, j10, j11, j12, r0, r1;
 };
+#if defined(EG3D_SECTION_TIMING)
+// diagnostic (timing builds): [0..31] requests by iterations run, [32..63] rounds by iterations run,
+// [64] requests, [65] accepted, [66] rows of all requests, [67] row-iterations a round's lanes were held
+// (64 x iterations x chunks), [68] row-iterations of live groups (rows x iterations), [69] rounds,
+// [70..101] LONG requests by iterations, [102] long requests, [103] long rounds
+__device__ unsigned long long g_gn_dbg[128];
+#define EG3D_GN_DBG(i, v) atomicAdd(&g_gn_dbg[i], (unsigned long long)(v))
+#else
+#define EG3D_GN_DBG(i, v) ((void)0)
+#endif
 __device__ __forceinline__ void gn_row(const float* __restrict__ P, float ox, float oy, const double X[3], GnRow& w) {
   const double p00 = P[0], p01 = P[1], p02 = P[2], p03 = P[3];
   const double p10 = P[4], p11 = P[5], p12 = P[6], p13 = P[7];
@@ -103,8 +113,11 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
   bool done = !act, ok = false;
   double last_mse = 0;
   const double two_n = (double)(n * 2);
+  int dbg_it = 0, dbg_round = 0;
   for (int it = 0; it < 30; it++) {
     if (!__any(!done)) break;
+    dbg_round++;
+    if (!done) dbg_it++;
     // ---- pass 1: H (6) and mse; accumulator e lives in group lane e % G, slot e / G
     double acc[4] = {0, 0, 0, 0};
     GnRow w;
@@ -264,6 +277,25 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
     __syncthreads();
   }
   if (act && !done) ok = last_mse < 9;
+#if defined(__HIP_DEVICE_COMPILE__) && defined(EG3D_SECTION_TIMING)
+  if (act && l == 0) {
+    EG3D_GN_DBG(dbg_it < 31 ? dbg_it : 31, 1);
+    EG3D_GN_DBG(64, 1);
+    EG3D_GN_DBG(65, ok ? 1 : 0);
+    EG3D_GN_DBG(66, n);
+    EG3D_GN_DBG(68, n * dbg_it);
+    if (cmax > 1) {
+      EG3D_GN_DBG(70 + (dbg_it < 31 ? dbg_it : 31), 1);
+      EG3D_GN_DBG(102, 1);
+    }
+  }
+  if (lane == 0) {
+    EG3D_GN_DBG(32 + (dbg_round < 31 ? dbg_round : 31), 1);
+    EG3D_GN_DBG(67, 64 * dbg_round * cmax);
+    EG3D_GN_DBG(69, 1);
+    if (cmax > 1) EG3D_GN_DBG(103, 1);
+  }
+#endif
   return ok;
 }
 

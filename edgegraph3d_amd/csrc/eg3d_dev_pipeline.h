@@ -368,7 +368,7 @@ struct StageBuf {
 
 // K4 body: copy one finished chain into the ordered SoA output.
 EG3D_HD void emit_chain(const ChainLayout& L, const unsigned char* slice, const ChainOut& co, const TaskDesc& d,
-                        uint64_t point_base, uint64_t obs_base, float* X, uint32_t* obs_off, int32_t* obs_view,
+                        uint64_t point_base, uint64_t obs_base, float* X, uint64_t* obs_off, int32_t* obs_view,
                         uint32_t* obs_pl, uint32_t* obs_seg, float* obs_xy, uint32_t* key) {
   const ChainPt* pts = (const ChainPt*)(slice + L.off_pts);
   const Obs* pool = (const Obs*)(slice + L.off_pool);
@@ -379,7 +379,7 @@ EG3D_HD void emit_chain(const ChainLayout& L, const unsigned char* slice, const 
     X[3 * pi] = p.X[0];
     X[3 * pi + 1] = p.X[1];
     X[3 * pi + 2] = p.X[2];
-    obs_off[pi] = (uint32_t)o;
+    obs_off[pi] = o;
     key[4 * pi] = d.seed;
     key[4 * pi + 1] = d.entry;
     key[4 * pi + 2] = d.hit;

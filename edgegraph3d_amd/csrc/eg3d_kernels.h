@@ -14,7 +14,7 @@ struct SeedsDev {
 };
 
 enum : uint32_t { CTR_ARENA_OVERFLOW = 0x100u, CTR_SLOT_STARVED = 0x200u /* k3b_expand found no free working slice (internal) */ };
-typedef uint32_t eg3d_off_t;  // element type of obs_off in the output cloud
+typedef uint64_t eg3d_off_t;  // element type of obs_off in the output cloud (include/eg3d.h)
 // arguments of k_publish: up to 6 runs of device words copied to the host mailbox, words cleared afterwards
 struct PubArgs {
   const uint32_t* src[6];

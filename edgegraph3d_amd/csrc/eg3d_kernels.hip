@@ -1380,6 +1380,16 @@ void launch_compact_chains(hipStream_t st, uint32_t n_tasks, const ChainSeed* pe
   hipLaunchKernelGGL(k_compact_chains, blocks_for(n_tasks, 256), dim3(256), 0, st, n_tasks, per_task, valid, chain_off,
                      chains);
 }
+#ifdef EG3D_SECTION_TIMING
+int gn_dbg_read(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gn_dbg), sizeof(unsigned long long) * 128) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[128] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_gn_dbg), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 int k3b_blocks_per_cu() {
   int n = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k3b_expand, 64, 0) != hipSuccess || n < 1) return 0;

@@ -1,20 +1,20 @@
 """Multi-GPU plumbing of the path: seed sharding and the all-gather of the edge-point cloud.
 
-One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI; "gloo" on CPU for
-tests). Seeds are independent units, so rank r owns the contiguous range
+One process per GPU (torch.distributed for rendezvous; RCCL over xGMI for the exchange; "gloo" on CPU
+for tests). Seeds are independent units, so rank r owns the contiguous range
 shard_ranges_balanced(...)[r] (balanced by the sum of track lengths; shard_range = by count)
 and the concatenation of the per-rank outputs in rank order IS the single-process output. The
-only exchange step is the variable-length all-gather of the cloud: counts first (16 B/rank),
-then ONE padded all_gather_into_tensor of the packed SoA
-    [X(12 B/pt) | obs_off(4) | key(16) | obs_view(4/obs) | obs_pl(4) | obs_seg(4) | obs_xy(8)]
-— a single large message per rank so every xGMI link carries traffic at once.
+only exchange step is the variable-length all-gather of the cloud (include/eg3d_rccl.h): counts first
+(24 B/rank), then the seven arrays of every rank's cloud
+    X(12 B/pt) | obs_off(8) | key(16) | obs_view(4/obs) | obs_pl(4) | obs_seg(4) | obs_xy(8)
+travel straight to their final position in every receiver's result arrays (no packing or padding), and
+the observation offsets of ranks > 0 are rebased. RcclCloudGather = the C-ABI entry point on GPUs;
+HostCloudGather = the same plan on host arrays around any torch.distributed backend.
 """
 import torch
 
-POINT_FIELDS = (("X", 12), ("obs_off", 4), ("key", 16))
-OBS_FIELDS = (("obs_view", 4), ("obs_pl", 4), ("obs_seg", 4), ("obs_xy", 8))
-_DTYPES = {"X": torch.float32, "obs_off": torch.int32, "key": torch.int32, "obs_view": torch.int32,
-           "obs_pl": torch.int32, "obs_seg": torch.int32, "obs_xy": torch.float32}
+FIELDS = (("X", 12, True), ("obs_off", 8, True), ("key", 16, True), ("obs_view", 4, False), ("obs_pl", 4, False),
+          ("obs_seg", 4, False), ("obs_xy", 8, False))  # name, bytes per element, per point (else per observation)
 
 
 def shard_range(n_seeds, world):
@@ -57,6 +57,7 @@ class RcclCloudGather:
         from . import _cdefs as D
         self.C, self.D = C, D
         self.world, self.rank = world, rank
+        self.g, self.comm = None, None
         pkg = os.path.dirname(os.path.abspath(__file__))
         self.G = C.CDLL(os.path.join(pkg, "libeg3d_rccl.so"))
         self.G.eg3d_comm_unique_id.argtypes = [C.c_void_p]
@@ -85,104 +86,115 @@ class RcclCloudGather:
                                                      C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         self.g = self.G.eg3d_gather_create(device_index)
         if not self.g:
+            self.close()  # do not leak the communicator
             raise RuntimeError("eg3d_gather_create failed")
         self.stream = C.c_void_p(stream_ptr) if stream_ptr else None
         self.rank_points = (C.c_uint64 * world)()
         self.rank_obs = (C.c_uint64 * world)()
 
     def allgather(self, local_dev):
-        """local_dev = Context.last_device_output(). Returns (DeviceEdgePoints of the whole cloud, rc);
+        """local_dev = Context.last_device_output(), or None when this rank has no usable result (its match
+        failed): it still takes part, and the status word makes EVERY rank return EG3D_GATHER_ERR_INCOMPLETE (-4)
+        instead of leaving the others inside the collective. Returns (DeviceEdgePoints of the whole cloud, rc);
         every rank gets the same rc (see include/eg3d_rccl.h)."""
         C = self.C
         out = self.D.DeviceEdgePoints()
         rc = self.G.eg3d_allgather_edgepoints(self.g, self.comm, self.world, self.rank, self.stream,
-                                              C.byref(local_dev), C.byref(out), self.rank_points, self.rank_obs)
+                                              C.byref(local_dev) if local_dev is not None else None, C.byref(out),
+                                              self.rank_points, self.rank_obs)
+        if rc == -6:
+            self.abandon_comm()
         return out, rc
 
     def close(self):
-        if self.g:
+        if getattr(self, "g", None):
             self.G.eg3d_gather_destroy(self.g)
             self.g = None
-        if self.comm:
+        if getattr(self, "comm", None):
             self.G.eg3d_comm_destroy(self.comm)
             self.comm = self.C.c_void_p()
 
+    def abandon_comm(self):
+        """After EG3D_GATHER_ERR_FATAL (-6) the library has aborted the communicator: forget it."""
+        self.comm = self.C.c_void_p()
 
-class CloudGather:
-    """Reusable staging buffers + the two collectives. `local` maps field name -> 1-D uint8
-    tensor (raw bytes, on `device`) holding this rank's n_points / n_obs elements."""
+    def __enter__(self):
+        return self
 
-    def __init__(self, dist, world, device):
-        self.dist, self.world, self.device = dist, world, device
-        self.cap = 0
-        self.send = self.recv = None
-        self.pack_done = None  # event recorded once `local` has been copied into the send buffer
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
-    def allgather(self, local, n_points, n_obs):
-        dist, world, dev = self.dist, self.world, self.device
-        cnt = torch.tensor([n_points, n_obs], dtype=torch.int64, device=dev)
-        allc = torch.empty(2 * world, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(allc, cnt)
-        counts = allc.view(world, 2).cpu()
-        mp, mo = int(counts[:, 0].max()), int(counts[:, 1].max())
-        nbytes = mp * sum(s for _, s in POINT_FIELDS) + mo * sum(s for _, s in OBS_FIELDS)
-        nbytes = max(nbytes, 16)
-        if self.cap < nbytes:
-            self.cap = int(nbytes * 1.25) + 256
-            self.send = torch.empty(self.cap, dtype=torch.uint8, device=dev)
-            self.recv = torch.empty(self.cap * world, dtype=torch.uint8, device=dev)
-        send = self.send[:nbytes]
-        o = 0
-        for name, per in POINT_FIELDS:
-            if n_points:
-                send[o:o + n_points * per].copy_(local[name][:n_points * per])
-            o += mp * per
-        for name, per in OBS_FIELDS:
-            if n_obs:
-                send[o:o + n_obs * per].copy_(local[name][:n_obs * per])
-            o += mo * per
-        if dev.type == "cuda":
-            # the producer may overwrite `local` (the context's output buffers) once this has fired;
-            # the collective itself then overlaps with the producer's next step
-            self.pack_done = torch.cuda.Event()
-            self.pack_done.record()
-        recv = self.recv[:nbytes * world]
-        dist.all_gather_into_tensor(recv, send)
-        return recv, counts, (mp, mo, nbytes)
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
-    def wait_pack(self):
-        """Block the host until the last allgather() no longer reads its `local` buffers."""
-        if self.pack_done is not None:
-            self.pack_done.synchronize()
-            self.pack_done = None
 
-    def unpack(self, recv, counts, layout):
-        """Compact the padded per-rank blocks into one cloud (rank order = seed order); obs_off is
-        rebased so it indexes the concatenated observation arrays."""
-        mp, mo, nbytes = layout
-        parts = {n: [] for n, _ in POINT_FIELDS + OBS_FIELDS}
-        obs_base = 0
-        for r in range(self.world):
-            np_, no_ = int(counts[r, 0]), int(counts[r, 1])
-            blk = recv[r * nbytes:(r + 1) * nbytes]
-            o = 0
-            for name, per in POINT_FIELDS:
-                t = blk[o:o + np_ * per].view(_DTYPES[name])
-                if name == "obs_off":
-                    t = t + obs_base
-                parts[name].append(t)
-                o += mp * per
-            for name, per in OBS_FIELDS:
-                parts[name].append(blk[o:o + no_ * per].view(_DTYPES[name]))
-                o += mo * per
-            obs_base += no_
-        out = {n: torch.cat(v) for n, v in parts.items()}
-        # n_obs sentinel, as the C ABI (eg3d_edgepoints.obs_off[n_points]) and the RCCL path return it
-        out["obs_off"] = torch.cat([out["obs_off"], torch.tensor([obs_base], dtype=out["obs_off"].dtype,
-                                                                  device=out["obs_off"].device)])
-        out["X"] = out["X"].view(-1, 3)
-        out["key"] = out["key"].view(-1, 4)
-        out["obs_xy"] = out["obs_xy"].view(-1, 2)
-        out["n_points"] = int(counts[:, 0].sum())
-        out["n_obs"] = int(counts[:, 1].sum())
-        return out
+class HostCloudGather:
+    """The exchange on HOST arrays over any torch.distributed backend (gloo on CPU): the transport is one
+    broadcast per (rank, array) of the raw bytes; the plan (bases, totals, status) and the placement + rebasing
+    of every rank's cloud are the C functions eg3d_host_gather_plan / eg3d_host_gather_place of libeg3d_host.so —
+    the same arithmetic eg3d_allgather_edgepoints applies to device buffers."""
+
+    def __init__(self, dist, world, rank):
+        from . import host as _host
+        self.dist, self.world, self.rank = dist, world, rank
+        self.H = _host.lib()
+
+    def allgather(self, local):
+        """local = a cloud dict as the C ABI returns it (obs_off with its sentinel), or None for "this rank has
+        no usable result". Returns (whole cloud dict or None, rc), the same rc on every rank."""
+        import ctypes as C
+        import numpy as np
+        from . import _cdefs as D
+        dist, world, rank = self.dist, self.world, self.rank
+        mine = [int(local["n_points"]), int(local["n_obs"]), 0] if local is not None else [0, 0, 1]
+        allc = torch.empty(3 * world, dtype=torch.int64)
+        dist.all_gather_into_tensor(allc, torch.tensor(mine, dtype=torch.int64))
+        counts = np.ascontiguousarray(allc.numpy().astype(np.uint64))
+        pbase = np.zeros(world, np.uint64)
+        obase = np.zeros(world, np.uint64)
+        tp, to = C.c_uint64(), C.c_uint64()
+        self.H.eg3d_host_gather_plan.argtypes = [C.c_int, D.u64p, D.u64p, D.u64p, D.u64p, D.u64p]
+        rc = self.H.eg3d_host_gather_plan(world, D.np_ptr(counts, C.c_uint64), D.np_ptr(pbase, C.c_uint64),
+                                          D.np_ptr(obase, C.c_uint64), C.byref(tp), C.byref(to))
+        if rc != 0:
+            return None, rc
+        tp, to = int(tp.value), int(to.value)
+        whole = {"X": np.zeros((tp, 3), np.float32), "obs_off": np.zeros(tp + 1, np.uint64),
+                 "key": np.zeros((tp, 4), np.uint32), "obs_view": np.zeros(to, np.int32), "obs_pl": np.zeros(to, np.uint32),
+                 "obs_seg": np.zeros(to, np.uint32), "obs_xy": np.zeros((to, 2), np.float32)}
+        whole_c = D.EdgePointsArrays(whole)
+        whole_c.c.n_points, whole_c.c.n_obs = tp, to
+        self.H.eg3d_host_gather_place.argtypes = [C.POINTER(D.EdgePoints), C.c_uint64, C.c_uint64, C.POINTER(D.EdgePoints)]
+        dtypes = {"X": np.float32, "obs_off": np.uint64, "key": np.uint32, "obs_view": np.int32, "obs_pl": np.uint32,
+                  "obs_seg": np.uint32, "obs_xy": np.float32}
+        for r in range(world):
+            np_r, no_r = int(counts[3 * r]), int(counts[3 * r + 1])
+            part = {}
+            for name, per, per_point in FIELDS:
+                n_el = np_r if per_point else no_r
+                nbytes = n_el * per
+                if r == rank:
+                    a = np.ascontiguousarray(local[name] if name != "obs_off" else local[name][:np_r], dtypes[name])
+                    buf = torch.from_numpy(a.view(np.uint8).reshape(-1).copy()) if nbytes else torch.zeros(0, dtype=torch.uint8)
+                else:
+                    buf = torch.empty(nbytes, dtype=torch.uint8)
+                if nbytes:
+                    dist.broadcast(buf, src=r)
+                part[name] = buf.numpy().view(dtypes[name]) if nbytes else np.zeros(0, dtypes[name])
+            part["obs_off"] = np.concatenate([part["obs_off"], np.array([no_r], np.uint64)])  # EdgePointsArrays wants the sentinel
+            part_c = D.EdgePointsArrays(part)
+            part_c.c.n_points, part_c.c.n_obs = np_r, no_r
+            rc = self.H.eg3d_host_gather_place(C.byref(part_c.c), int(pbase[r]), int(obase[r]), C.byref(whole_c.c))
+            if rc != 0:
+                return None, rc
+        out = dict(whole_c.a)
+        out["obs_off"][tp] = to
+        out["X"] = out["X"].reshape(-1, 3)
+        out["key"] = out["key"].reshape(-1, 4)
+        out["obs_xy"] = out["obs_xy"].reshape(-1, 2)
+        out["n_points"], out["n_obs"] = tp, to
+        return out, 0

@@ -21,7 +21,7 @@ extern "C" int eg3d_host_filter_close_2d(int n_views, int width, int height, con
   // the image border, negative, NaN, or a view id out of range). The reference indexes its arrays
   // unchecked there (undefined behaviour); here such an observation never makes a point "fresh"
   // and marks nothing — the CPU oracle adopts the same rule.
-  auto cell_of = [&](uint32_t j) -> int64_t {
+  auto cell_of = [&](uint64_t j) -> int64_t {
     const int32_t v = pts->obs_view[j];
     const float fx = pts->obs_xy[2 * j] / CELL, fy = pts->obs_xy[2 * j + 1] / CELL;
     if (v < 0 || v >= n_views || !(fx > -1.0f) || !(fy > -1.0f) || !(fx < (float)w) || !(fy < (float)h)) return -1;
@@ -30,15 +30,15 @@ extern "C" int eg3d_host_filter_close_2d(int n_views, int width, int height, con
     return (int64_t)(plane * (size_t)v + (size_t)cy * w + cx);
   };
   for (uint64_t i = 0; i < pts->n_points; i++) {
-    const uint32_t a = pts->obs_off[i], b = pts->obs_off[i + 1];
+    const uint64_t a = pts->obs_off[i], b = pts->obs_off[i + 1];
     bool fresh = false;
-    for (uint32_t j = a; j < b && !fresh; j++) {
+    for (uint64_t j = a; j < b && !fresh; j++) {
       const int64_t c = cell_of(j);
       fresh = c >= 0 && occ[(size_t)c] == 0;
     }
     keep[i] = fresh;
     if (fresh)
-      for (uint32_t j = a; j < b; j++) {
+      for (uint64_t j = a; j < b; j++) {
         const int64_t c = cell_of(j);
         if (c >= 0) occ[(size_t)c] = 1;
       }

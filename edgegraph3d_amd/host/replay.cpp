@@ -89,6 +89,7 @@ bool ordered(float ax, float ay, float bx, float by, float cx, float cy) {
 extern "C" int eg3d_host_replay_matches(const eg3d_scene* sc, const eg3d_edgepoints* pts, eg3d_graph3d* out) {
   if (!sc || !pts || !out) return -1;
   memset(out, 0, sizeof(*out));
+  if (sc->n_views < 1 || !sc->view_pl_off || !sc->pl_vtx_off || !sc->vtx_xy) return -1;
   const int V = sc->n_views;
   const uint64_t N = pts->n_points;
   const uint32_t NP = sc->view_pl_off[V];
@@ -105,7 +106,7 @@ extern "C" int eg3d_host_replay_matches(const eg3d_scene* sc, const eg3d_edgepoi
     if (pts->obs_pl[o] >= npl) return -1;
     const uint32_t g = sc->view_pl_off[v] + pts->obs_pl[o];
     const uint32_t nv = sc->pl_vtx_off[g + 1] - sc->pl_vtx_off[g];
-    if (pts->obs_seg[o] >= (nv ? nv : 1u)) return -1;
+    if (nv < 2 || pts->obs_seg[o] >= nv - 1) return -1;  // a segment index of a polyline that has segments
   }
   NodeTable table(N);
   std::vector<float> node_X;
@@ -221,8 +222,8 @@ extern "C" int eg3d_host_replay_matches(const eg3d_scene* sc, const eg3d_edgepoi
     node_point[nb] = i;
     std::fill(slot1.begin(), slot1.end(), -1);
     std::fill(slot2.begin(), slot2.end(), -1);
-    for (uint32_t o = pts->obs_off[i - 1]; o < pts->obs_off[i]; o++) slot1[pts->obs_view[o]] = o;
-    for (uint32_t o = pts->obs_off[i]; o < pts->obs_off[i + 1]; o++) slot2[pts->obs_view[o]] = o;
+    for (uint64_t o = pts->obs_off[i - 1]; o < pts->obs_off[i]; o++) slot1[pts->obs_view[o]] = (int64_t)o;
+    for (uint64_t o = pts->obs_off[i]; o < pts->obs_off[i + 1]; o++) slot2[pts->obs_view[o]] = (int64_t)o;
     for (int v = 0; v < V; v++) {
       if (slot1[v] < 0 || slot2[v] < 0) continue;
       const uint64_t o1 = (uint64_t)slot1[v], o2 = (uint64_t)slot2[v];

@@ -299,7 +299,7 @@ extern "C" int eg3d_sfm_add_edgepoints(eg3d_sfm* s, const eg3d_edgepoints* p, co
   if (!s || !p) return -1;
   for (uint64_t i = 0; i < p->n_points; i++) {
     if (keep && !keep[i]) continue;
-    const uint32_t a = p->obs_off[i], b = p->obs_off[i + 1];
+    const uint64_t a = p->obs_off[i], b = p->obs_off[i + 1];
     eg3d_sfm_add_point(s, p->X + 3 * i, (int)(b - a), p->obs_view + a, p->obs_xy + 2 * (size_t)a);
   }
   return 0;

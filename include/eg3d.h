@@ -87,7 +87,8 @@ typedef struct eg3d_edgepoints {
   uint64_t n_points;
   uint64_t n_obs;
   float* X;            /* [n_points][3] */
-  uint32_t* obs_off;   /* [n_points+1] */
+  uint64_t* obs_off;   /* [n_points+1]; 64-bit: the cloud of one call may hold more than 2^32 observations
+                          (BASELINE config 4 as one call: 56 M points, 4.1 G observations) */
   int32_t* obs_view;   /* [n_obs] */
   uint32_t* obs_pl;    /* [n_obs] polyline id inside its view */
   uint32_t* obs_seg;   /* [n_obs] segment index */
@@ -216,7 +217,7 @@ int eg3d_match_resident(eg3d_ctx* ctx, uint32_t seed_begin, uint32_t seed_end, i
 typedef struct eg3d_device_edgepoints {
   uint64_t n_points, n_obs;
   const float* X;
-  const uint32_t* obs_off;
+  const uint64_t* obs_off;
   const int32_t* obs_view;
   const uint32_t* obs_pl;
   const uint32_t* obs_seg;

@@ -106,6 +106,19 @@ int eg3d_host_filter_close_2d(int n_views, int width, int height, const eg3d_edg
 int eg3d_host_observation_filter(int n_cameras, const uint32_t* obs_off, uint64_t n_points, uint64_t first_edgepoint,
                                  int forced_min_filter, uint8_t* inlier_inout);
 
+/* ------------------------------------------ the cloud exchange on host arrays -- */
+/* The arithmetic of eg3d_allgather_edgepoints (include/eg3d_rccl.h) for clouds held in HOST memory — what a
+ * CPU / non-RCCL transport (MPI, gloo) needs around its own all-gather of the raw arrays, and what the
+ * world_size-2 gloo test of the multi-GPU path drives. counts3[r] = {n_points, n_obs, status} of rank r.
+ * eg3d_host_gather_plan fills the per-rank bases (where rank r's points / observations start in the gathered
+ * cloud) and the totals; returns 0, or -4 (EG3D_GATHER_ERR_INCOMPLETE) when any status is non-zero.
+ * eg3d_host_gather_place copies rank r's cloud `part` to its place in `whole` (arrays allocated by the caller for
+ * the totals; obs_off has total_points + 1 entries) and rebases its observation offsets by obs_base;
+ * the caller writes the sentinel whole->obs_off[total_points] = total_obs. */
+int eg3d_host_gather_plan(int n_ranks, const uint64_t* counts3, uint64_t* point_base, uint64_t* obs_base,
+                          uint64_t* total_points, uint64_t* total_obs);
+int eg3d_host_gather_place(const eg3d_edgepoints* part, uint64_t point_base, uint64_t obs_base, eg3d_edgepoints* whole);
+
 /* ------------------------------------------- PLGMatchesManager replay (row a17) -- */
 /* What plgmm.add_matched_3dpolyline(chain) leaves behind when the reference runs the path
  * (plg_matching_from_refpoints.cpp:74-77 -> plg_matches_manager.cpp:99-180): the 3-D polyline graph

@@ -100,10 +100,11 @@ class PLGMatchesManager {
   int replay(const eg3d_scene& sc, const std::vector<eg3d_edgepoints>& parts) {
     eg3d_host_free_graph3d(&g_);
     std::vector<float> X, xy;
-    std::vector<uint32_t> off(1, 0), pl, seg, key;
+    std::vector<uint32_t> pl, seg, key;
+    std::vector<uint64_t> off(1, 0);
     std::vector<int32_t> view;
     for (const eg3d_edgepoints& e : parts) {
-      const uint32_t base = (uint32_t)view.size();
+      const uint64_t base = (uint64_t)view.size();
       X.insert(X.end(), e.X, e.X + 3 * e.n_points);
       key.insert(key.end(), e.key, e.key + 4 * e.n_points);
       for (uint64_t i = 0; i < e.n_points; i++) off.push_back(base + e.obs_off[i + 1]);
@@ -270,7 +271,7 @@ class PLGEdgeManager {
         for (uint64_t i = 0; i < e.n_points; i++) {
           std::vector<PolyLineGraph2D::plg_point> obs;
           std::vector<int> views;
-          for (uint32_t j = e.obs_off[i]; j < e.obs_off[i + 1]; j++) {
+          for (uint64_t j = e.obs_off[i]; j < e.obs_off[i + 1]; j++) {
             obs.push_back({e.obs_pl[j], {e.obs_seg[j], {e.obs_xy[2 * j], e.obs_xy[2 * j + 1]}}});
             views.push_back(e.obs_view[j]);
           }
@@ -309,7 +310,7 @@ class PLGEdgeManager {
       for (uint64_t i = 0; i < e.n_points; i++) {
         std::vector<PolyLineGraph2D::plg_point> obs;
         std::vector<int> views;
-        for (uint32_t j = e.obs_off[i]; j < e.obs_off[i + 1]; j++) {
+        for (uint64_t j = e.obs_off[i]; j < e.obs_off[i + 1]; j++) {
           obs.push_back({e.obs_pl[j], {e.obs_seg[j], {e.obs_xy[2 * j], e.obs_xy[2 * j + 1]}}});
           views.push_back(e.obs_view[j]);
         }

@@ -133,7 +133,7 @@ static int pack_edgepoints(orc_ctx* c, std::vector<std::vector<EdgePoint>>& per_
   out->n_points = np;
   out->n_obs = no;
   out->X = (float*)malloc(sizeof(float) * 3 * (np ? np : 1));
-  out->obs_off = (uint32_t*)malloc(sizeof(uint32_t) * (np + 1));
+  out->obs_off = (uint64_t*)malloc(sizeof(uint64_t) * (np + 1));
   out->obs_view = (int32_t*)malloc(sizeof(int32_t) * (no ? no : 1));
   out->obs_pl = (uint32_t*)malloc(sizeof(uint32_t) * (no ? no : 1));
   out->obs_seg = (uint32_t*)malloc(sizeof(uint32_t) * (no ? no : 1));
@@ -145,7 +145,7 @@ static int pack_edgepoints(orc_ctx* c, std::vector<std::vector<EdgePoint>>& per_
       out->X[3 * pi] = ep.p.X.x;
       out->X[3 * pi + 1] = ep.p.X.y;
       out->X[3 * pi + 2] = ep.p.X.z;
-      out->obs_off[pi] = (uint32_t)oi;
+      out->obs_off[pi] = (uint64_t)oi;
       for (int k = 0; k < 4; k++) out->key[4 * pi + k] = ep.key[k];
       for (size_t j = 0; j < ep.p.obs.size(); j++) {
         out->obs_view[oi] = ep.p.views[j];
@@ -157,7 +157,7 @@ static int pack_edgepoints(orc_ctx* c, std::vector<std::vector<EdgePoint>>& per_
       }
       pi++;
     }
-  out->obs_off[np] = (uint32_t)oi;
+  out->obs_off[np] = (uint64_t)oi;
   Stats tot;
   for (auto& s : tstats) {
     tot.n_tasks += s.n_tasks;

@@ -181,7 +181,7 @@ extern "C" int hostsim_match(const eg3d_scene* sc, const eg3d_seeds* seeds, uint
   out->n_points = np;
   out->n_obs = no;
   out->X = (float*)malloc(sizeof(float) * 3 * (np ? np : 1));
-  out->obs_off = (uint32_t*)malloc(sizeof(uint32_t) * (np + 1));
+  out->obs_off = (uint64_t*)malloc(sizeof(uint64_t) * (np + 1));
   out->obs_view = (int32_t*)malloc(sizeof(int32_t) * (no ? no : 1));
   out->obs_pl = (uint32_t*)malloc(sizeof(uint32_t) * (no ? no : 1));
   out->obs_seg = (uint32_t*)malloc(sizeof(uint32_t) * (no ? no : 1));
@@ -194,7 +194,7 @@ extern "C" int hostsim_match(const eg3d_scene* sc, const eg3d_seeds* seeds, uint
     pb += couts[j].n_points;
     ob += couts[j].n_obs;
   }
-  out->obs_off[np] = (uint32_t)no;
+  out->obs_off[np] = (uint64_t)no;
   out->n_tasks = nt;
   out->n_hypotheses = n_hyp;
   out->n_chains = chains.size();

@@ -55,7 +55,7 @@ def main():
         return a
     n, m = int(out.n_points), int(out.n_obs)
     assert np.array_equal(fetch(out.X, 3 * n, np.uint32), want["X"].view(np.uint32).ravel())
-    assert np.array_equal(fetch(out.obs_off, n + 1, np.uint32), want["obs_off"])
+    assert np.array_equal(fetch(out.obs_off, n + 1, np.uint64), want["obs_off"])
     assert np.array_equal(fetch(out.key, 4 * n, np.uint32), want["key"].ravel())
     assert np.array_equal(fetch(out.obs_view, m, np.int32), want["obs_view"])
     assert np.array_equal(fetch(out.obs_pl, m, np.uint32), want["obs_pl"])
@@ -68,7 +68,7 @@ def main():
         nn, mm = int(o.n_points), int(o.n_obs)
         assert nn == w["n_points"] and mm == w["n_obs"], (label, nn, w["n_points"])
         assert np.array_equal(fetch(o.X, 3 * nn, np.uint32), w["X"].view(np.uint32).ravel()), label
-        assert np.array_equal(fetch(o.obs_off, nn + 1, np.uint32), w["obs_off"]), label
+        assert np.array_equal(fetch(o.obs_off, nn + 1, np.uint64), w["obs_off"]), label
         assert np.array_equal(fetch(o.key, 4 * nn, np.uint32), w["key"].ravel()), label
         assert np.array_equal(fetch(o.obs_view, mm, np.int32), w["obs_view"]), label
         assert np.array_equal(fetch(o.obs_pl, mm, np.uint32), w["obs_pl"]), label
@@ -91,6 +91,13 @@ def main():
         check_equal(cat, want, "concat %s" % (cuts,))
         for cx in ctxs[1:]:
             cx.close()
+    # a part that views the gather's OWN result buffers (the `out` of an earlier call on g) is refused, not read
+    # after it has been freed or overwritten (include/eg3d_rccl.h)
+    ctx.match_resident(b, e, device_only=True)
+    alias = (D.DeviceEdgePoints * 2)()
+    alias[0] = cat
+    alias[1] = ctx.last_device_output()
+    assert G.eg3d_concat_edgepoints(g, 2, alias, None, C.byref(D.DeviceEdgePoints())) == -1
     G.eg3d_gather_destroy(g)
     G.eg3d_comm_destroy.argtypes = [C.c_void_p]
     G.eg3d_comm_destroy(comm)

@@ -93,7 +93,7 @@ def worker(rank, world, idfile):
         assert m == int(whole["obs_off"][first + n]) - o0
         assert np.array_equal(fetch(out.X, 3 * n, np.uint32), whole["X"][first:first + n].view(np.uint32).ravel())
         assert np.array_equal(fetch(out.key, 4 * n, np.uint32), whole["key"][first:first + n].ravel())
-        assert np.array_equal(fetch(out.obs_off, n + 1, np.uint32), whole["obs_off"][first:first + n + 1] - o0)
+        assert np.array_equal(fetch(out.obs_off, n + 1, np.uint64), whole["obs_off"][first:first + n + 1] - o0)
         assert np.array_equal(fetch(out.obs_view, m, np.int32), whole["obs_view"][o0:o0 + m])
         assert np.array_equal(fetch(out.obs_pl, m, np.uint32), whole["obs_pl"][o0:o0 + m])
         assert np.array_equal(fetch(out.obs_seg, m, np.uint32), whole["obs_seg"][o0:o0 + m])

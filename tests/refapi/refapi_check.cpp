@@ -96,7 +96,7 @@ int main(int argc, char** argv) {
         continue;
       }
       for (size_t j = 0; j < obs.size(); j++) {
-        const uint32_t o = e.obs_off[i] + (uint32_t)j;
+        const uint64_t o = e.obs_off[i] + (uint64_t)j;
         if (views[j] != e.obs_view[o] || obs[j].polyline_id != e.obs_pl[o] || obs[j].plp.segment_index != e.obs_seg[o] ||
             std::memcmp(&obs[j].plp.coords, e.obs_xy + 2 * o, 8) != 0)
           bad++;

@@ -1,9 +1,11 @@
 """N>1 path on CPU: world_size-2 gloo. Each rank computes its contiguous, sum-of-track-length
 balanced seed shard with the HOST SIMULATION of the device code (tests/hostsim: the kernels'
 per-lane bodies of stage B compiled for the host; stage A from the oracle, as the hostsim takes
-it), all-gathers the edge-point cloud with the packing / ordering logic of
-edgegraph3d_amd/distributed.py and must reproduce the single-process oracle output exactly, on
-every rank. (The RCCL exchange itself — include/eg3d_rccl.h — needs GPUs: tests/rccl_two_rank_check.py.)"""
+it), then the cloud is exchanged by HostCloudGather: gloo moves the raw arrays, the C functions of the
+product (eg3d_host_gather_plan / eg3d_host_gather_place — the plan eg3d_allgather_edgepoints applies to
+device buffers) place and rebase them. Every rank must reproduce the single-process oracle output
+exactly; a rank without a result must make every rank return the same error.
+(The RCCL exchange itself — include/eg3d_rccl.h — needs GPUs: tests/rccl_two_rank_check.py.)"""
 import os
 import socket
 
@@ -14,7 +16,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from edgegraph3d_amd import host
-from edgegraph3d_amd.distributed import CloudGather, shard_range, shard_ranges_balanced
+from edgegraph3d_amd.distributed import HostCloudGather, shard_range, shard_ranges_balanced
 
 
 def _free_port():
@@ -41,17 +43,13 @@ def _worker(rank, world, port, cfg, q):
     b, e = shard_ranges_balanced(s.seeds_np()[0], 0, s.n_seeds, world)[rank]
     # stage B = the device code run on the host; its keys carry the global seed index, as the GPU's do
     r = hs.match(s.scene, s.seeds, b, e, o.candidates_raw(s.seeds, b, e))
-    dev = torch.device("cpu")
-
-    def raw(a):
-        return torch.from_numpy(np.ascontiguousarray(a)).view(torch.uint8).reshape(-1) if a.size else torch.zeros(16, dtype=torch.uint8)
-
-    local = {"X": raw(r["X"]), "obs_off": raw(r["obs_off"][:-1]), "key": raw(r["key"]), "obs_view": raw(r["obs_view"]),
-             "obs_pl": raw(r["obs_pl"]), "obs_seg": raw(r["obs_seg"]), "obs_xy": raw(r["obs_xy"])}
-    g = CloudGather(dist, world, dev)
-    recv, counts, layout = g.allgather(local, r["n_points"], r["n_obs"])
-    cloud = g.unpack(recv, counts, layout)
-    q.put((rank, {k: (v.numpy().copy() if torch.is_tensor(v) else v) for k, v in cloud.items()}))
+    g = HostCloudGather(dist, world, rank)
+    cloud, rc = g.allgather(r)
+    assert rc == 0
+    # a rank whose match failed still takes part (local = None): EVERY rank gets EG3D_GATHER_ERR_INCOMPLETE
+    none, rc_bad = g.allgather(None if rank == world - 1 else r)
+    assert none is None and rc_bad == -4
+    q.put((rank, {k: (np.array(v) if isinstance(v, np.ndarray) else v) for k, v in cloud.items()}))
     dist.barrier()
     dist.destroy_process_group()
 
