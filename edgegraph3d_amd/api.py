@@ -208,6 +208,35 @@ class Context:
                 "obs_pl": fetch(d.obs_pl, m, np.uint32), "obs_seg": fetch(d.obs_seg, m, np.uint32),
                 "obs_xy": fetch(d.obs_xy, 2 * m, np.float32).reshape(m, 2)}
 
+    def fetch_device_points(self, dev, p0, p1):
+        """Test plumbing: points [p0, p1) of a device-resident cloud `dev` (a DeviceEdgePoints: this context's last
+        output, or the result of a gather / concat) as numpy arrays, observation offsets rebased to the slice.
+        For clouds too large to copy whole (BASELINE config 4 in one call: 82 GB)."""
+        try:
+            hip = C.CDLL("libamdhip64.so.7")
+        except OSError:
+            hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+        def fetch(ptr, first, n, dtype):
+            a = np.empty(n, dtype)
+            src = C.cast(ptr, C.c_void_p).value + first * a.itemsize if n else 0
+            if n and hip.hipMemcpy(a.ctypes.data, C.c_void_p(src), a.nbytes, 2) != 0:
+                raise RuntimeError("hipMemcpy of the device cloud failed")
+            return a
+        n_all, m_all = int(dev.n_points), int(dev.n_obs)
+        n = p1 - p0
+        off = fetch(dev.obs_off, p0, n + (1 if p1 < n_all else 0), np.uint64)
+        if p1 >= n_all:
+            off = np.concatenate([off, np.array([m_all], np.uint64)])
+        o0, o1 = (int(off[0]), int(off[-1])) if n else (0, 0)
+        m = o1 - o0
+        return {"n_points": n, "n_obs": m, "X": fetch(dev.X, 3 * p0, 3 * n, np.float32).reshape(n, 3),
+                "obs_off": off - np.uint64(o0), "key": fetch(dev.key, 4 * p0, 4 * n, np.uint32).reshape(n, 4),
+                "obs_view": fetch(dev.obs_view, o0, m, np.int32), "obs_pl": fetch(dev.obs_pl, o0, m, np.uint32),
+                "obs_seg": fetch(dev.obs_seg, o0, m, np.uint32),
+                "obs_xy": fetch(dev.obs_xy, 2 * o0, 2 * m, np.float32).reshape(m, 2)}
+
     def candidates(self, seeds_ptr, begin, end):
         c = D.Candidates()
         _check(lib().eg3d_candidates_run(self._h, seeds_ptr, begin, end, C.byref(c)), "eg3d_candidates_run")

@@ -69,15 +69,15 @@ def build_hip(force=False, out=None, defines=()):
     return out
 
 
-# The same library with the OTHER form of cv::triangulatePoints' system (three rows per view, 6x4:
-# OpenCV 2.4-3.1 — the release the reference names; the default build follows the later 4x4 form).
-# The reference pins no OpenCV version, so both are kept bit-exact against the oracle in the
-# matching mode (tests/test_dlt_forms.py, tests/dlt6x4_gpu_check.py). Selected with EG3D_LIB=<this file>.
-HIP_LIB_DLT6X4 = os.path.join(PKG, "libeg3d_dlt6x4.so")
+# The same library with the OTHER form of cv::triangulatePoints' system (two rows per view, 4x4: OpenCV >= 3.2 /
+# 4.x; the default build follows the 6x4 form of the OpenCV 3.1 the reference names). Both are kept bit-exact
+# against the oracle in the matching mode: the whole `-m gpu` suite runs once per library (tests/conftest.py).
+# Selected with EG3D_LIB=<this file>.
+HIP_LIB_DLT4X4 = os.path.join(PKG, "libeg3d_dlt4x4.so")
 
 
-def build_hip_dlt6x4(force=False):
-    return build_hip(force, HIP_LIB_DLT6X4, ("-DEG3D_DLT_ROWS=3",))
+def build_hip_dlt4x4(force=False):
+    return build_hip(force, HIP_LIB_DLT4X4, ("-DEG3D_DLT_ROWS=2",))
 
 
 PROBE_LIB = os.path.join(ROOT, "tests", "probe", "libeg3d_probe.so")
@@ -121,7 +121,7 @@ def build_oracle(force=False):
 def build_all(force=False):
     build_host(force)
     build_hip(force)
-    build_hip_dlt6x4(force)
+    build_hip_dlt4x4(force)
     build_probe(force)
     build_rccl(force)
     build_oracle(force)

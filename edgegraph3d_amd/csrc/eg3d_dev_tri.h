@@ -63,12 +63,14 @@ EG3D_HD void project_f32(const float* P, float X, float Y, float Z, float& u, fl
 
 EG3D_HD double absd(double v) { return v < 0.0 ? -v : v; }
 
-// Which system cv::triangulatePoints builds depends on the OpenCV release (the reference pins
-// none: "OpenCV >= 3.1, tested 3.1"): EG3D_DLT_ROWS = 3 is the legacy cvTriangulatePoints of OpenCV
-// 2.4-3.1 (6x4: rows x*P2-P0, y*P2-P1, x*P1-y*P0 per view), 2 the later 4x4 rewrite. Compile-time
-// here (register budget), run-time in the oracle (orc_set_dlt_rows); eg3d_dlt_rows() reports it.
+// Which system cv::triangulatePoints builds depends on the OpenCV release: EG3D_DLT_ROWS = 3 is the
+// cvTriangulatePoints of OpenCV 2.4-3.1 (6x4: rows x*P2-P0, y*P2-P1, x*P1-y*P0 per view), 2 the later 4x4
+// rewrite. The reference names OpenCV 3.1 ("OpenCV >= 3.1, tested 3.1": README.md:23,32; the calls are
+// triangulation.cpp:216,290), so the DEFAULT build is the 6x4 form; libeg3d_dlt4x4.so is the same library for
+// a reference linked against a later OpenCV. Compile-time here (register budget), run-time in the oracle
+// (orc_set_dlt_rows); eg3d_dlt_rows() reports it.
 #ifndef EG3D_DLT_ROWS
-#define EG3D_DLT_ROWS 2
+#define EG3D_DLT_ROWS 3
 #endif
 #define EG3D_DLT_M (2 * EG3D_DLT_ROWS)
 

@@ -71,7 +71,7 @@ def lib():
                 from edgegraph3d_amd import api
                 rows = api.lib().eg3d_dlt_rows()
             except Exception:
-                rows = 2
+                rows = 3
         assert L.orc_set_dlt_rows(int(rows)) == 0
         _LIB = L
     return _LIB

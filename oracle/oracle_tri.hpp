@@ -62,7 +62,7 @@ static inline vec2 compute_projection(const float* P, const vec3& X) {
 //   rows per view = 2 : the later rewrite (Matx<double,4,4>): a 4x4 system without the third row.
 // Both are restated (from knowledge of the sources — none are in this container); the switch is
 // orc_set_dlt_rows(), the product's compile-time EG3D_DLT_ROWS. Only the Gauss-Newton START changes.
-static int g_dlt_rows = 2;
+static int g_dlt_rows = 3;  // the form of the OpenCV release the reference names (3.1); see eg3d_dev_tri.h
 
 // One-sided (Hestenes) Jacobi SVD of an m x 4 double matrix (m = 4 or 6), restating OpenCV's
 // JacobiSVDImpl_<double> as reached from cvSVD / SVD::compute inside cvTriangulatePoints: for

@@ -66,8 +66,32 @@ def make_dlt6x4(cfg_index, name):
     print(name, "points", r["n_points"], "obs", r["n_obs"])
 
 
+def make_sets_dlt6x4(cfg_index, name, max_sets):
+    """Outputs of the sets of synthetic_tiny_sets_v1.npz with the 6x4 DLT system (outputs only)."""
+    assert ob.lib().orc_set_dlt_rows(3) == 0
+    s = host.Synth(cfg_index)
+    n, row_off, ids = s.polyline_sets(max_sets)
+    r = ob.Oracle(s.scene).match_polyline_sets(n, row_off, ids, 0, n, 1)
+    assert ob.lib().orc_set_dlt_rows(2) == 0
+    out = {"out_" + k: r[k] for k in ("X", "obs_off", "obs_view", "obs_pl", "obs_seg", "obs_xy", "key")}
+    out["out_counts"] = np.array([r["stats"]["n_tasks"], r["stats"]["n_chains"], r["flags"]], np.int64)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(name, "sets", n, "points", r["n_points"], "obs", r["n_obs"])
+
+
 if __name__ == "__main__":
-    os.environ["EG3D_ORACLE_DLT_ROWS"] = "2"  # the v1 fixtures are the default (4x4) form
-    make(0, "synthetic_tiny_v1.npz")
-    make_sets(0, "synthetic_tiny_sets_v1.npz", 3)
-    make_dlt6x4(0, "synthetic_tiny_v1_dlt6x4.npz")
+    # the v1 base files hold the inputs and the outputs of the 4x4 form; the *_dlt6x4 files the outputs of the 6x4
+    # form (OpenCV <= 3.1, the product's default since round 3). `--only-new` leaves committed files untouched.
+    os.environ["EG3D_ORACLE_DLT_ROWS"] = "2"
+    only_new = "--only-new" in sys.argv
+
+    def want(name):
+        return not (only_new and os.path.exists(os.path.join(HERE, name)))
+    if want("synthetic_tiny_v1.npz"):
+        make(0, "synthetic_tiny_v1.npz")
+    if want("synthetic_tiny_sets_v1.npz"):
+        make_sets(0, "synthetic_tiny_sets_v1.npz", 3)
+    if want("synthetic_tiny_v1_dlt6x4.npz"):
+        make_dlt6x4(0, "synthetic_tiny_v1_dlt6x4.npz")
+    if want("synthetic_tiny_sets_v1_dlt6x4.npz"):
+        make_sets_dlt6x4(0, "synthetic_tiny_sets_v1_dlt6x4.npz", 3)

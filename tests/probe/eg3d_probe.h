@@ -13,6 +13,7 @@ extern "C" {
 int eg3d_probe_arith(uint64_t n, const double* a, const double* b, const double* c, double* out_d, const float* fa,
                      const float* fb, const float* fc, float* out_f);
 /* n_cases triangulations of k observations each; cam_P = [n_views][16] host array */
+int eg3d_probe_dlt_rows(void); /* the DLT form the probe was compiled with (EG3D_DLT_ROWS) */
 int eg3d_probe_triangulate(const float* cam_P, int n_views, uint64_t n_cases, int k, const int32_t* views, const float* xy,
                            float* X, uint8_t* valid, double* dlt_X0);
 #ifdef __cplusplus

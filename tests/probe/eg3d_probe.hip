@@ -63,6 +63,8 @@ __global__ void k_probe_tri(const float* cam_P, uint64_t n, int k, const int32_t
     if ((expr) != hipSuccess) return -2; \
   } while (0)
 
+extern "C" int eg3d_probe_dlt_rows(void) { return EG3D_DLT_ROWS; }
+
 extern "C" int eg3d_probe_arith(uint64_t n, const double* a, const double* b, const double* c, double* od,
                                 const float* fa, const float* fb, const float* fc, float* of) {
   double *da, *db, *dc, *dod;

@@ -7,6 +7,7 @@ import os
 import numpy as np
 import pytest
 
+import forms
 from edgegraph3d_amd import api, host
 from parity_util import compare_edgepoints
 
@@ -21,8 +22,10 @@ def load():
     return z, scene
 
 
-def expected(z):
-    d = {k: z["out_" + k] for k in ("X", "obs_off", "obs_view", "obs_pl", "obs_seg", "obs_xy", "key")}
+def expected(z, rows):
+    """The fixture's outputs for one DLT form (the inputs, stage A and the filter part do not depend on it)."""
+    zo = z if rows == 2 else np.load(forms.golden_path("synthetic_tiny_v1", rows))
+    d = {k: zo["out_" + k] for k in ("X", "obs_off", "obs_view", "obs_pl", "obs_seg", "obs_xy", "key")}
     d["n_points"], d["n_obs"] = len(d["X"]), len(d["obs_view"])
     return d
 
@@ -38,27 +41,29 @@ def test_generator_reproduces_fixture_inputs():
     assert np.array_equal(xy.view(np.uint32), z["seeds_trk_xy"].view(np.uint32))
 
 
-def test_oracle_reproduces_fixture_outputs():
+@pytest.mark.parametrize("rows", forms.FORMS, ids=[forms.IDS[r] for r in forms.FORMS])
+def test_oracle_reproduces_fixture_outputs(rows):
     from oracle import binding as ob
     z, scene = load()
     sa = host.SceneArrays(scene)
     se = host.SeedsArrays(z["seeds_trk_off"], z["seeds_trk_view"], z["seeds_trk_xy"])
     o = ob.Oracle(C.byref(sa.c))
-    r = o.match(C.byref(se.c), 0, len(z["seeds_trk_off"]) - 1, 1)
-    rep = compare_edgepoints(expected(z), r)
+    with forms.oracle_rows(rows):
+        r = o.match(C.byref(se.c), 0, len(z["seeds_trk_off"]) - 1, 1)
+    rep = compare_edgepoints(expected(z, rows), r)
     assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], rep
     Xo, inl = o.gn_filter(z["gn_X"], z["gn_off"], z["gn_view"], z["gn_xy"], 3.0)
     assert np.array_equal(inl, z["gn_inlier"]) and np.array_equal(Xo.view(np.uint32), z["gn_Xout"].view(np.uint32))
 
 
 @pytest.mark.gpu
-def test_hip_path_reproduces_fixture():
+def test_hip_path_reproduces_fixture(eg3d_form):
     z, scene = load()
     sa = host.SceneArrays(scene)
     se = host.SeedsArrays(z["seeds_trk_off"], z["seeds_trk_view"], z["seeds_trk_xy"])
     ctx = api.Context(C.byref(sa.c))
     got = ctx.match_refpoints(C.byref(se.c), 0, len(z["seeds_trk_off"]) - 1)
-    rep = compare_edgepoints(expected(z), got, rel_tol=1e-4)
+    rep = compare_edgepoints(expected(z, eg3d_form), got, rel_tol=1e-4)
     assert rep["ok"], rep["msgs"]
     c = ctx.candidates(C.byref(se.c), 0, len(z["seeds_trk_off"]) - 1)
     for k in ("cand_off", "cand_pl", "start_off", "start_pl", "start_seg", "task_sv", "task_hit", "task_list_off",
@@ -70,19 +75,25 @@ def test_hip_path_reproduces_fixture():
 
 
 # ---- pipelines 1-2 extractor ----
-def load_sets():
+def load_sets(rows=2):
+    """The sets and, for one DLT form, the expected output (the sets themselves are in the base file)."""
     z = np.load(os.path.join(HERE, "golden", "synthetic_tiny_sets_v1.npz"))
+    if rows != 2:
+        zo = np.load(forms.golden_path("synthetic_tiny_sets_v1", rows))
+        z = {**{k: z[k] for k in z.files}, **{k: zo[k] for k in zo.files}}
     d = {k: z["out_" + k] for k in ("X", "obs_off", "obs_view", "obs_pl", "obs_seg", "obs_xy", "key")}
     d["n_points"], d["n_obs"] = len(d["X"]), len(d["obs_view"])
     return z, d
 
 
-def test_oracle_reproduces_sets_fixture():
+@pytest.mark.parametrize("rows", forms.FORMS, ids=[forms.IDS[r] for r in forms.FORMS])
+def test_oracle_reproduces_sets_fixture(rows):
     from oracle import binding as ob
-    z, want = load_sets()
+    z, want = load_sets(rows)
     _, scene = load()
     sa = host.SceneArrays(scene)
-    r = ob.Oracle(C.byref(sa.c)).match_polyline_sets(int(z["n_sets"]), z["row_off"], z["pl_ids"], nthreads=2)
+    with forms.oracle_rows(rows):
+        r = ob.Oracle(C.byref(sa.c)).match_polyline_sets(int(z["n_sets"]), z["row_off"], z["pl_ids"], nthreads=2)
     rep = compare_edgepoints(want, r)
     assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], rep
     assert [r["stats"]["n_tasks"], r["stats"]["n_chains"], r["flags"]] == list(z["out_counts"])
@@ -108,8 +119,8 @@ def test_sets_fixture_invariants():
 
 
 @pytest.mark.gpu
-def test_hip_path_reproduces_sets_fixture():
-    z, want = load_sets()
+def test_hip_path_reproduces_sets_fixture(eg3d_form):
+    z, want = load_sets(eg3d_form)
     _, scene = load()
     sa = host.SceneArrays(scene)
     ctx = api.Context(C.byref(sa.c))

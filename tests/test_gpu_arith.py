@@ -49,8 +49,17 @@ def test_ieee_primitives_match_x86_bit_for_bit(ctx):
 
 
 def test_triangulation_matches_oracle_including_degenerate_dlt(ctx):
+    """(The probe library has ONE DLT form, its compile-time EG3D_DLT_ROWS: the oracle is put in that mode here
+    whatever form the suite's product library of this run has.)"""
+    import forms
     from oracle import binding as ob
     c, s = ctx
+    c.eg3d_probe_dlt_rows.restype = C.c_int
+    with forms.oracle_rows(c.eg3d_probe_dlt_rows()):
+        _triangulation_check(c, s, ob)
+
+
+def _triangulation_check(c, s, ob):
     off, view, xy = s.seeds_np()
     cv, cxy = [], []
     for i in range(s.n_seeds):

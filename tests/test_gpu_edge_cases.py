@@ -1,10 +1,12 @@
 """-m gpu: edge cases of the C ABI against the oracle — empty and ragged inputs, tracks that are too
 short or repeat a view (Q2), seeds far from every edge, invalid F pairs, invalid arguments."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
+from edgegraph3d_amd import _cdefs as D
 from edgegraph3d_amd import api, host
 from parity_util import compare_edgepoints
 
@@ -224,6 +226,85 @@ def test_chain_expansion_in_many_chunks(monkeypatch):
     ctx.close()
 
 
+def _check_example_outputs_against_oracle(d, doc, doc_f):
+    from oracle import binding as ob
+    H = host.lib()
+    H.eg3d_sfm_read_json.restype = C.c_void_p
+    H.eg3d_sfm_read_json.argtypes = [C.c_char_p]
+    H.eg3d_sfm_destroy.argtypes = [C.c_void_p]
+    H.eg3d_sfm_n_views.argtypes = [C.c_void_p]
+    H.eg3d_sfm_cam_P.argtypes = [C.c_void_p]
+    H.eg3d_sfm_cam_P.restype = D.f32p
+    H.eg3d_sfm_seeds.argtypes = [C.c_void_p, C.POINTER(D.Seeds)]
+    H.eg3d_sfm_points.argtypes = [C.c_void_p]
+    H.eg3d_sfm_points.restype = D.f32p
+    H.eg3d_sfm_analytic_F.argtypes = [C.c_void_p, D.f64p, D.u8p]
+    H.eg3d_plg_read.restype = C.c_void_p
+    H.eg3d_plg_read.argtypes = [C.c_char_p]
+    H.eg3d_plg_scene.restype = C.POINTER(D.Scene)
+    H.eg3d_plg_scene.argtypes = [C.c_void_p]
+    H.eg3d_plg_destroy.argtypes = [C.c_void_p]
+    sfm = H.eg3d_sfm_read_json((d + "/input.json").encode())
+    plg = H.eg3d_plg_read((d + "/plgs.bin").encode())
+    assert sfm and plg
+    V = H.eg3d_sfm_n_views(sfm)
+    F = np.zeros((V, V, 9), np.float64)
+    Fv = np.zeros((V, V), np.uint8)
+    assert H.eg3d_sfm_analytic_F(sfm, D.np_ptr(F, C.c_double), D.np_ptr(Fv, C.c_uint8)) == 0   # --all-pairs
+    sc = D.Scene()
+    C.memmove(C.byref(sc), H.eg3d_plg_scene(plg), C.sizeof(D.Scene))
+    sc.cam_P = H.eg3d_sfm_cam_P(sfm)
+    sc.F = D.np_ptr(F, C.c_double)
+    sc.F_valid = D.np_ptr(Fv, C.c_uint8)
+    seeds = D.Seeds()
+    H.eg3d_sfm_seeds(sfm, C.byref(seeds))
+    n0 = int(seeds.n_seeds)
+    o = ob.Oracle(C.byref(sc))
+    ref = o.match(C.byref(seeds), 0, n0, os.cpu_count())
+    ep = D.EdgePointsArrays(ref)
+    keep = np.zeros(max(1, ref["n_points"]), np.uint8)
+    assert ob.lib().orc_filter_close_2d(o._h, C.byref(ep.c), D.np_ptr(keep, C.c_uint8)) == 0
+    # the expected SfM structure: the input's points, then the kept edge-points in emission order
+    trk_off = D.as_np(seeds.trk_off, n0 + 1, np.uint32).astype(np.int64)
+    n_trk = int(trk_off[-1])
+    X = [D.as_np(H.eg3d_sfm_points(sfm), 3 * n0, np.float32).reshape(n0, 3).copy()]
+    views = [D.as_np(seeds.trk_view, n_trk, np.int32).copy()]
+    xy = [D.as_np(seeds.trk_xy, 2 * n_trk, np.float32).reshape(n_trk, 2).copy()]
+    off = list(trk_off)
+    eo = ref["obs_off"].astype(np.int64)
+    for i in np.nonzero(keep[:ref["n_points"]])[0]:
+        X.append(ref["X"][i:i + 1])
+        views.append(ref["obs_view"][eo[i]:eo[i + 1]])
+        xy.append(ref["obs_xy"][eo[i]:eo[i + 1]])
+        off.append(off[-1] + int(eo[i + 1] - eo[i]))
+    X, views, xy, off = np.concatenate(X), np.concatenate(views), np.concatenate(xy), np.array(off, np.int64)
+
+    def same_structure(doc_structure, X, off, views, xy):
+        assert len(doc_structure) == len(off) - 1
+        for i, p in enumerate(doc_structure):
+            v = p["value"]
+            assert np.array_equal(np.array(v["X"], np.float64).astype(np.float32).view(np.uint32), X[i].view(np.uint32)), i
+            ob_ = v["observations"]
+            assert [q["key"] for q in ob_] == list(views[off[i]:off[i + 1]]), i
+            got_xy = np.array([q["value"]["x"] for q in ob_], np.float64).astype(np.float32).reshape(-1, 2)
+            assert np.array_equal(got_xy.view(np.uint32), xy[off[i]:off[i + 1]].view(np.uint32)), i
+    same_structure(doc["structure"], X, off, views, xy)
+    # ---- `--filter`: Gauss-Newton refinement of EVERY point (inliers moved), then the observation-count filter
+    # on the edge-points, then removal
+    off32 = off.astype(np.uint32)
+    Xo, inl = o.gn_filter(X, off32, views, xy, 2.25, nthreads=os.cpu_count())
+    Xf = np.where(inl[:, None] != 0, Xo, X)
+    inl = np.ascontiguousarray(inl, np.uint8)
+    ob.lib().orc_observation_filter(V, D.np_ptr(off32, C.c_uint32), len(off) - 1, n0, -1, D.np_ptr(inl, C.c_uint8))
+    sel = np.nonzero(inl)[0]
+    foff = np.concatenate([[0], np.cumsum((off[1:] - off[:-1])[sel])])
+    fviews = np.concatenate([views[off[i]:off[i + 1]] for i in sel])
+    fxy = np.concatenate([xy[off[i]:off[i + 1]] for i in sel])
+    same_structure(doc_f["structure"], Xf[sel], foff, fviews, fxy)
+    H.eg3d_plg_destroy(plg)
+    H.eg3d_sfm_destroy(sfm)
+
+
 def test_cpp_end_to_end_example(tmp_path):
     """examples/edge_matcher_refpoints.cpp: OpenMVG JSON + polyline-graph file in, pipeline 3 on the GPU
     through the C ABI, dedup, add points, (optional) ./filter -e, OpenMVG JSON out — all from C++.
@@ -262,6 +343,12 @@ def test_cpp_end_to_end_example(tmp_path):
     f = re.search(r"filter: (\d+) of (\d+) points kept", out2.stdout)
     assert int(f.group(2)) == len(doc["structure"]) and 0 < int(f.group(1)) <= int(f.group(2))
     assert len(json.load(open(d + "/out_f.json"))["structure"]) == int(f.group(1))
+    # ---- N3 END TO END AGAINST THE ORACLE: the structure the example wrote (SfM points + de-duplicated edge-points,
+    # and after `--filter` the Gauss-Newton-refined, observation-filtered set) must be what the ORACLE derives from
+    # the same input files: oracle match -> orc_filter_close_2d -> append -> [orc_gn_filter -> orc_observation_filter
+    # -> remove] (filtering_close_plgps.cpp:99-124, output_utilities.cpp:96-111, gauss_newton.cpp:136-178,
+    # outliers_filtering.cpp:14-114). Only the file readers are the product's here.
+    _check_example_outputs_against_oracle(d, doc, json.load(open(d + "/out_f.json")))
     # N4: the reference's rule for which view pairs have a fundamental matrix (>= 10 common SfM points) — the
     # default — must give what the library gives on the same scene with those pairs switched off; and the
     # matrices estimated from the tracks (--estimate-F) must reproduce most of the cloud

@@ -116,6 +116,41 @@ def test_gn_filter_parity(have_gpu):
     ctx.close()
 
 
+def test_gn_filter_full_config5_one_million_points(have_gpu):
+    """BASELINE configs[4] at its FULL size: 1 000 000 edge-points of the 16-view rig (k in 3..10, 5.76 M
+    observations), both abs() behaviours of Q9 — X and the inlier flags of every point bit-exact."""
+    s = host.Synth(5)
+    X, off, view, xy = s.points(1000000)
+    assert len(off) - 1 == 1000000
+    ctx = api.Context(s.scene)
+    o = _oracle(s.scene)
+    for legacy in (False, True):
+        Xo, inl, ms = ctx.gn_filter(X, off, view, xy, 2.25, legacy_abs=legacy)
+        Xr, ir = o.gn_filter(X, off, view, xy, 2.25, legacy_abs=legacy, nthreads=os.cpu_count())
+        assert np.array_equal(inl, ir) and np.array_equal(Xo.view(np.uint32), Xr.view(np.uint32))
+        assert 0.3 < inl.mean() < 1.0
+    ctx.close()
+
+
+@pytest.mark.timeout(1200)
+def test_c4_far_end_window_parity(have_gpu):
+    """BASELINE configs[3], the LAST 1200 of its 100 000 seeds (98 800 .. 100 000) on the full scene and the
+    full resident seed set: global seed indices near the end of the range, a window the first-seeds test never
+    touches. Bit-exact, ids and order included."""
+    s = host.Synth(4)
+    assert s.n_seeds == 100000
+    lo, hi = s.n_seeds - 1200, s.n_seeds
+    ctx = api.Context(s.scene)
+    ctx.upload_seeds(s.seeds)
+    got = ctx.match_resident(lo, hi)
+    ref = _oracle(s.scene).match(s.seeds, lo, hi, nthreads=os.cpu_count())
+    rep = compare_edgepoints(ref, got, rel_tol=1e-4)
+    assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], rep["msgs"]
+    assert (got["flags"] & 7) == 0 and got["n_points"] > 300000
+    assert got["key"][:, 0].min() >= lo and got["key"][:, 0].max() < hi
+    ctx.close()
+
+
 def test_c4_shaped_subset_parity_and_capacity_growth(have_gpu):
     """200 views / ~20k segments per view (BASELINE configs[3] shape), first 40 seeds: points carry
     dozens of observations, which outgrows the default per-chain pool -> the library must enlarge

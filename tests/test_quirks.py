@@ -5,6 +5,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import forms
 from edgegraph3d_amd import _cdefs as D
 from edgegraph3d_amd import host
 from oracle import binding as ob
@@ -254,34 +255,47 @@ def _same_cloud(a, b):
             np.array_equal(a["X"].view(np.uint32), b["X"].view(np.uint32)) and np.array_equal(a["obs_view"], b["obs_view"]))
 
 
-def test_q4_abandoning_the_view_is_pinned_by_the_fixture():
+@pytest.mark.parametrize("rows", forms.FORMS, ids=[forms.IDS[r] for r in forms.FORMS])
+def test_q4_abandoning_the_view_is_pinned_by_the_fixture(rows):
     """Q4 (triangulation.cpp:807-808): a chain point whose projection is > 4 px from its unique
     polyline ABANDONS the whole view (`return false` in a void function), it does not just skip the
-    point. Config 0 = the scene of tests/golden/synthetic_tiny_v1.npz."""
-    import os
-    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "synthetic_tiny_v1.npz"))
-    ref = _run_with_fix(0, 0, None, 0)
+    point. Config 0 = the scene of tests/golden/synthetic_tiny_v1.npz (outputs per DLT form)."""
+    z = np.load(forms.golden_path("synthetic_tiny_v1", rows))
+    with forms.oracle_rows(rows):
+        ref = _run_with_fix(0, 0, None, 0)
+        fixed = _run_with_fix(0, 0, None, 1 << 4)
     assert np.array_equal(ref["X"].view(np.uint32), z["out_X"].view(np.uint32)) and np.array_equal(ref["obs_view"], z["out_obs_view"])
-    fixed = _run_with_fix(0, 0, None, 1 << 4)
     assert not _same_cloud(ref, fixed)
     assert fixed["n_obs"] > ref["n_obs"]  # a corrected version keeps attaching the view to later chain points
 
 
-def test_q13_lower_bound_attachment_is_pinned_by_the_fixture():
+@pytest.mark.parametrize("rows", forms.FORMS, ids=[forms.IDS[r] for r in forms.FORMS])
+def test_q13_lower_bound_attachment_is_pinned_by_the_fixture(rows):
     """Q13 (plg_matching.cpp:1017, :1364-1368): attaching a view at the lower bound of its interval
     runs no direction search at all, so it fails unless the chain has a single point."""
-    ref = _run_with_fix(0, 0, None, 0)
-    fixed = _run_with_fix(0, 0, None, 1 << 13)
+    with forms.oracle_rows(rows):
+        ref = _run_with_fix(0, 0, None, 0)
+        fixed = _run_with_fix(0, 0, None, 1 << 13)
     assert not _same_cloud(ref, fixed)
 
 
-def test_q12_stale_direction2_points_are_exercised():
+@pytest.mark.parametrize("rows", forms.FORMS, ids=[forms.IDS[r] for r in forms.FORMS])
+def test_q12_stale_direction2_points_are_exercised(rows):
     """Q12 (triangulation.cpp:559-561, plg_matching.cpp:355-368): a compatible triple whose direction
     2 is invalid inherits the direction-2 points an earlier, rejected triple of the same start hit
-    left in the shared buffer. C2 seeds 80..90 contain such a start hit (seed 85)."""
-    ref = _run_with_fix(2, 80, 90, 0)
-    fixed = _run_with_fix(2, 80, 90, 1 << 12)
+    left in the shared buffer. C2 seeds 80..90 contain such a start hit (seed 85): with either DLT form a
+    corrected implementation gives a different cloud, and only that seed's chains change."""
+    with forms.oracle_rows(rows):
+        ref = _run_with_fix(2, 80, 90, 0)
+        fixed = _run_with_fix(2, 80, 90, 1 << 12)
     assert not _same_cloud(ref, fixed)
-    per_seed_ref = np.bincount(ref["key"][:, 0], minlength=90)
-    per_seed_fix = np.bincount(fixed["key"][:, 0], minlength=90)
-    assert list(np.nonzero(per_seed_ref != per_seed_fix)[0]) == [85]
+
+    def per_seed(r):  # (points, observations, X bits) of every seed's chains
+        out = {}
+        off = r["obs_off"].astype(np.int64)
+        for sd in range(80, 90):
+            m = r["key"][:, 0] == sd
+            out[sd] = (int(m.sum()), int((off[1:][m] - off[:-1][m]).sum()), r["X"][m].view(np.uint32).tobytes())
+        return out
+    a, b = per_seed(ref), per_seed(fixed)
+    assert [sd for sd in range(80, 90) if a[sd] != b[sd]] == [85]
