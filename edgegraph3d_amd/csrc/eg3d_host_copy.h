@@ -25,12 +25,21 @@ inline void copy_mt(void* dst, const void* src, size_t bytes, int max_threads = 
   }
   const int nt = (int)std::min<size_t>((size_t)max_threads, bytes / min_per_thread);
   const size_t per = ((bytes + (size_t)nt - 1) / (size_t)nt + 63) & ~(size_t)63;  // ceil: nt * per covers every byte
+  // a thread that cannot be created (std::system_error: resource limits) leaves its share, and everything after
+  // it, to the calling thread — the copy completes either way and no exception leaves the C ABI above
   std::vector<std::thread> th;
-  for (int t = 0; t < nt; t++) {
-    const size_t a = (size_t)t * per, b = std::min(bytes, a + per);
-    if (a >= b) break;
-    th.emplace_back([=] { memcpy((char*)dst + a, (const char*)src + a, b - a); });
+  size_t done = 0;
+  try {
+    th.reserve((size_t)nt);
+    for (int t = 0; t < nt; t++) {
+      const size_t a = (size_t)t * per, b = std::min(bytes, a + per);
+      if (a >= b) break;
+      th.emplace_back([=] { memcpy((char*)dst + a, (const char*)src + a, b - a); });
+      done = b;
+    }
+  } catch (...) {
   }
+  if (done < bytes) memcpy((char*)dst + done, (const char*)src + done, bytes - done);
   for (auto& t : th) t.join();
 }
 

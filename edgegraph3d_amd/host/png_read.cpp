@@ -8,6 +8,7 @@
 // 1 where an 8-bit BGR load of the image would be pure white.
 #include <zlib.h>
 
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -23,7 +24,12 @@ int paeth(int a, int b, int c) {
 }
 }  // namespace
 
-extern "C" int eg3d_png_read_edge_mask(const char* path, int* width, int* height, uint8_t** mask_out) {
+// Limits of what is decoded (a hostile file must not be able to take the process down): the file itself and the
+// decoded image are bounded before anything is allocated, and no C++ exception leaves the extern "C" functions.
+static const size_t kMaxFileBytes = (size_t)1 << 30;     // 1 GiB of PNG
+static const size_t kMaxDecodedBytes = (size_t)1 << 30;  // 1 GiB of decoded scanlines (e.g. 16384 x 16384 RGBA 8-bit)
+
+static int png_read_edge_mask_impl(const char* path, int* width, int* height, uint8_t** mask_out) {
   if (!path || !width || !height || !mask_out) return -1;
   *mask_out = nullptr;
   FILE* f = fopen(path, "rb");
@@ -32,8 +38,21 @@ extern "C" int eg3d_png_read_edge_mask(const char* path, int* width, int* height
   {
     unsigned char buf[1 << 16];
     size_t n;
-    while ((n = fread(buf, 1, sizeof(buf), f)) > 0) file.insert(file.end(), buf, buf + n);
+    bool too_big = false;
+    while ((n = fread(buf, 1, sizeof(buf), f)) > 0) {
+      if (file.size() + n > kMaxFileBytes) {
+        too_big = true;
+        break;
+      }
+      try {
+        file.insert(file.end(), buf, buf + n);
+      } catch (...) {
+        fclose(f);
+        return -6;
+      }
+    }
     fclose(f);
+    if (too_big) return -4;
   }
   static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
   if (file.size() < 8 + 25 || memcmp(file.data(), sig, 8) != 0) return -3;
@@ -78,8 +97,11 @@ extern "C" int eg3d_png_read_edge_mask(const char* path, int* width, int* height
   const size_t bits_pp = (size_t)channels * depth;
   const size_t stride = ((size_t)w * bits_pp + 7) / 8;
   const size_t bpp = bits_pp >= 8 ? bits_pp / 8 : 1;
+  if ((stride + 1) > kMaxDecodedBytes / (size_t)h) return -4;  // a ~100-byte header must not buy gigabytes
   std::vector<unsigned char> raw((stride + 1) * (size_t)h);
   {
+    // zlib counts avail_in / avail_out in 32 bits: both sizes are bounded far below that (limits above)
+    static_assert(kMaxFileBytes <= UINT_MAX && kMaxDecodedBytes <= UINT_MAX, "one inflate call must cover the stream");
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
     if (inflateInit(&zs) != Z_OK) return -5;
@@ -146,6 +168,18 @@ extern "C" int eg3d_png_read_edge_mask(const char* path, int* width, int* height
   *height = (int)h;
   *mask_out = mask;
   return 0;
+}
+
+extern "C" int eg3d_png_read_edge_mask(const char* path, int* width, int* height, uint8_t** mask_out) {
+  try {
+    return png_read_edge_mask_impl(path, width, height, mask_out);
+  } catch (...) {  // std::bad_alloc and friends: an error code, never std::terminate through the C ABI
+    if (mask_out && *mask_out) {
+      free(*mask_out);
+      *mask_out = nullptr;
+    }
+    return -6;
+  }
 }
 
 extern "C" int eg3d_plg_build_from_png(const char* path, int* width, int* height, eg3d_plg_view* out) {

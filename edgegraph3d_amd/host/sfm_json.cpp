@@ -398,7 +398,7 @@ static const JVal* data_of(const JVal& item) {  // item.value.ptr_wrapper.data, 
   return (d && d->t == JVal::OBJ) ? d : nullptr;
 }
 
-extern "C" eg3d_sfm* eg3d_sfm_read_json(const char* path) {
+static eg3d_sfm* sfm_read_json_impl(const char* path, eg3d_sfm*& s) {
   JVal root;
   if (!path || !load_json(path, root)) return nullptr;
   const JVal *views = root.get("views"), *intr = root.get("intrinsics"), *extr = root.get("extrinsics"),
@@ -406,7 +406,7 @@ extern "C" eg3d_sfm* eg3d_sfm_read_json(const char* path) {
   if (!views || !intr || !extr || !structure || views->t != JVal::ARR || intr->t != JVal::ARR || extr->t != JVal::ARR ||
       structure->t != JVal::ARR)
     return nullptr;
-  eg3d_sfm* s = nullptr;
+  s = nullptr;
   try {
     std::string base = (rp && rp->t == JVal::STR) ? rp->s : "";
     struct K {
@@ -485,7 +485,28 @@ extern "C" eg3d_sfm* eg3d_sfm_read_json(const char* path) {
   return s;
 }
 
+// No C++ exception crosses the C ABI: a file too large for memory (std::bad_alloc from the DOM or the point arrays)
+// is a failed read, not std::terminate.
+extern "C" eg3d_sfm* eg3d_sfm_read_json(const char* path) {
+  eg3d_sfm* s = nullptr;
+  try {
+    return sfm_read_json_impl(path, s);
+  } catch (...) {
+    delete s;
+    return nullptr;
+  }
+}
+
+static int sfm_write_json_impl(const eg3d_sfm* s, const char* in_path, const char* out_path);
 extern "C" int eg3d_sfm_write_json(const eg3d_sfm* s, const char* in_path, const char* out_path) {
+  try {
+    return sfm_write_json_impl(s, in_path, out_path);
+  } catch (...) {
+    return -1;
+  }
+}
+
+static int sfm_write_json_impl(const eg3d_sfm* s, const char* in_path, const char* out_path) {
   if (!s || !out_path) return -1;
   g_nonfinite_written = false;
   JVal in;

@@ -175,6 +175,23 @@ def test_png_reader_formats(tmp_path):
         open(p, "wb").write(blob)
         with pytest.raises(RuntimeError):
             host.png_edge_mask(p)
+    # a ~100-byte file whose header CLAIMS a 32768 x 32768 RGBA 16-bit image (8.6 GB of scanlines) is refused
+    # before anything of that size is allocated — it must neither take gigabytes nor abort the process
+    import struct
+    import zlib
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xffffffff)
+    bomb = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 32768, 32768, 16, 6, 0, 0, 0)) +
+            chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b""))
+    open(p, "wb").write(bomb)
+    with pytest.raises(RuntimeError):
+        host.png_edge_mask(p)
+    # the largest image the reader accepts by its documented limit still decodes (1-bit grey, 32768 wide)
+    wide = np.zeros((2, 32768), bool)
+    wide[1, ::7] = True
+    _write_png(p, 32768, 2, 1, 0, [bytes(np.packbits(r.astype(np.uint8))) for r in wide], None, [0])
+    assert np.array_equal(host.png_edge_mask(p).astype(bool), wide)
 
 
 def test_example_builds_the_container_from_edge_images(tmp_path):
