@@ -6,8 +6,10 @@
 // output_sfm_data (src/edgegraph3d/io/output/output_sfm_data.cpp:186-229: sfm_data_version,
 // root_path, views, intrinsics, control_points copied from the input file; extrinsics rewritten
 // with keys 0..V-1; structure rewritten with keys 0..N-1 and id_feat 0). Own design: a small
-// recursive-descent JSON DOM instead of rapidjson; numbers keep their source text when copied
-// through, floats are written with the shortest round-trip representation.
+// recursive-descent JSON DOM instead of rapidjson. The TEXT of the written file is what rapidjson's
+// PrettyWriter produces for the same document (json_text.hpp): floats through Grisu2 + its notation rule,
+// numbers copied from the input re-printed from the reader's verdict on them, strings decoded and re-escaped —
+// checked byte for byte against the reference tree's vendored rapidjson (tests/test_json_rapidjson.py).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -21,6 +23,7 @@
 
 #include "../../include/eg3d_host.h"
 #include "camera_model.hpp"
+#include "json_text.hpp"
 
 namespace {
 
@@ -136,13 +139,68 @@ struct Parser {
       return v;
     }
     p++;
-    while (p < e && *p != '"') {
-      if (*p == '\\' && p + 1 < e) {
-        v.s.push_back(*p++);
+    auto hex4 = [&](uint32_t& out) {
+      out = 0;
+      for (int k = 0; k < 4; k++) {
+        if (p >= e) return false;
+        const char c = *p++;
+        out <<= 4;
+        if (c >= '0' && c <= '9')
+          out |= (uint32_t)(c - '0');
+        else if (c >= 'a' && c <= 'f')
+          out |= (uint32_t)(c - 'a' + 10);
+        else if (c >= 'A' && c <= 'F')
+          out |= (uint32_t)(c - 'A' + 10);
+        else
+          return false;
       }
-      v.s.push_back(*p++);
+      return true;
+    };
+    while (p < e && *p != '"') {  // the value is kept DECODED (the writer re-escapes it its own way)
+      if (*p == '\\') {
+        p++;
+        if (p >= e) break;
+        const char c = *p++;
+        switch (c) {
+          case '"': v.s += '"'; break;
+          case '\\': v.s += '\\'; break;
+          case '/': v.s += '/'; break;
+          case 'b': v.s += '\b'; break;
+          case 'f': v.s += '\f'; break;
+          case 'n': v.s += '\n'; break;
+          case 'r': v.s += '\r'; break;
+          case 't': v.s += '\t'; break;
+          case 'u': {
+            uint32_t cp = 0, lo = 0;
+            if (!hex4(cp)) {
+              ok = false;
+              return v;
+            }
+            if (cp >= 0xD800 && cp <= 0xDBFF) {  // surrogate pair
+              if (p + 1 < e && p[0] == '\\' && p[1] == 'u') {
+                p += 2;
+                if (!hex4(lo) || lo < 0xDC00 || lo > 0xDFFF) {
+                  ok = false;
+                  return v;
+                }
+                cp = 0x10000 + (((cp - 0xD800) << 10) | (lo - 0xDC00));
+              } else {
+                ok = false;
+                return v;
+              }
+            }
+            eg3d_json::append_utf8(v.s, cp);
+            break;
+          }
+          default: ok = false; return v;
+        }
+      } else
+        v.s.push_back(*p++);
     }
-    if (p < e) p++;
+    if (p < e)
+      p++;
+    else
+      ok = false;
     return v;
   }
 };
@@ -155,8 +213,14 @@ void write_val(std::ostream& os, const JVal& v, int ind) {
   switch (v.t) {
     case JVal::NUL: os << "null"; break;
     case JVal::BOOL: os << (v.b ? "true" : "false"); break;
-    case JVal::NUM: os << v.s; break;
-    case JVal::STR: os << '"' << v.s << '"'; break;
+    case JVal::NUM: {
+      // a number copied through from the input: what the reference's reader + writer make of the literal
+      bool good = true;
+      const std::string n = eg3d_json::normalize_number(v.s, &good);
+      os << (good ? n : v.s);
+      break;
+    }
+    case JVal::STR: os << '"' << eg3d_json::escape_string(v.s) << '"'; break;
     case JVal::ARR:
       if (v.a.empty()) {
         os << "[]";
@@ -179,7 +243,7 @@ void write_val(std::ostream& os, const JVal& v, int ind) {
       os << "{\n";
       for (size_t i = 0; i < v.o.size(); i++) {
         indent(os, ind + 1);
-        os << '"' << v.o[i].first << "\": ";
+        os << '"' << eg3d_json::escape_string(v.o[i].first) << "\": ";
         write_val(os, v.o[i].second, ind + 1);
         os << (i + 1 < v.o.size() ? ",\n" : "\n");
       }
@@ -199,14 +263,7 @@ std::string num_text(float f) {
     g_nonfinite_written = true;
     return "null";
   }
-  char buf[40];
-  for (int prec = 1; prec <= 17; prec++) {
-    snprintf(buf, sizeof(buf), "%.*g", prec, d);
-    if (strtod(buf, nullptr) == d) break;
-  }
-  std::string s(buf);
-  if (s.find_first_of(".eEn") == std::string::npos) s += ".0";
-  return s;
+  return eg3d_json::double_text(d);
 }
 JVal jnum(float f) {
   JVal v;
@@ -483,6 +540,30 @@ static eg3d_sfm* sfm_read_json_impl(const char* path, eg3d_sfm*& s) {
     return nullptr;
   }
   return s;
+}
+
+// Diagnostics of the writer's text rules (include/eg3d_host.h), used by tests/test_json_rapidjson.py
+extern "C" int eg3d_host_json_double_text(double d, char* buf, int cap) {
+  if (!buf || cap < 2 || !(d == d) || d > 1.7976931348623157e308 || d < -1.7976931348623157e308) return -1;
+  const std::string s = eg3d_json::double_text(d);
+  if ((int)s.size() + 1 > cap) return -1;
+  memcpy(buf, s.c_str(), s.size() + 1);
+  return (int)s.size();
+}
+extern "C" int eg3d_host_json_number_text(const char* literal, char* buf, int cap) {
+  if (!literal || !buf || cap < 2) return -1;
+  bool ok = true;
+  const std::string s = eg3d_json::normalize_number(literal, &ok);
+  if (!ok || (int)s.size() + 1 > cap) return -1;
+  memcpy(buf, s.c_str(), s.size() + 1);
+  return (int)s.size();
+}
+extern "C" int eg3d_host_json_cached_power(int index, uint64_t* f, int* e) {
+  if (index < 0 || index > 86 || !f || !e) return -1;
+  const eg3d_json::Fp p = eg3d_json::cached_powers()[index];
+  *f = p.f;
+  *e = p.e;
+  return 0;
 }
 
 // No C++ exception crosses the C ABI: a file too large for memory (std::bad_alloc from the DOM or the point arrays)

@@ -153,6 +153,13 @@ void eg3d_host_free_graph3d(eg3d_graph3d* g);
 typedef struct eg3d_sfm eg3d_sfm; /* host mirror of SfMData (SfMData.h:16-30) */
 eg3d_sfm* eg3d_sfm_read_json(const char* path);          /* OpenMvgParser::parse, OpenMvgParser.cpp:39-301 */
 int eg3d_sfm_write_json(const eg3d_sfm* s, const char* in_path_for_passthrough, const char* out_path); /* output_sfm_data.cpp:186-229 */
+/* The writer's text rules on their own (json_text.hpp): a finite double as rapidjson's Writer prints it (Grisu2 +
+ * notation); a JSON number literal as the reference's reader (default flags) + writer re-print it; the computed
+ * Grisu cached power 10^(-348 + 8*index), index 0..86. Return the text length, or -1. Checked against the reference
+ * tree's vendored rapidjson by tests/test_json_rapidjson.py. */
+int eg3d_host_json_double_text(double d, char* buf, int cap);
+int eg3d_host_json_number_text(const char* literal, char* buf, int cap);
+int eg3d_host_json_cached_power(int index, uint64_t* f, int* e);
 eg3d_sfm* eg3d_sfm_create(int n_views, int width, int height);
 void eg3d_sfm_destroy(eg3d_sfm* s);
 int eg3d_sfm_n_views(const eg3d_sfm* s);
