@@ -35,6 +35,8 @@ struct CoopLds {
       f2 vtx[EG3D_STAGE_VTX];
       float epi[EG3D_STAGE_EPI][4];
     } walk;
+    // the matrices of up to 8 concurrent 2-view DLTs (look-ahead following: one per lane; a uniform section: slot 0)
+    double dlt_work[8][EG3D_DLT_WORK_DOUBLES];
   };
   int32_t la_m[8];               // look-ahead following: observations kept by step j
   uint32_t la_fl[8];             //   and the diagnostic flags its walks raised

@@ -180,6 +180,15 @@ struct TeamSeq {
     return 0;
   }
   EG3D_HD uint32_t or_reduce(uint32_t v) const { return v; }
+  // the 2-view DLT of a uniform section (a wavefront team keeps the decomposition's matrices in LDS)
+  EG3D_HD void dlt(const float* P1, float x1, float y1, const float* P2, float x2, float y2, double X0[3]) const {
+    dlt2(P1, x1, y1, P2, x2, y2, X0);
+  }
+  // a value every member holds identically (a wavefront team keeps it in scalar registers)
+  template <class T>
+  EG3D_HD T uni(const T& v) const {
+    return v;
+  }
   // members that share one item of an n_items-wide parallel section (a power of two), and the
   // merge of their partial closest-point results (smaller distance, then smaller segment index)
   // number of leading j in [0, m) for which pred(j) holds
@@ -313,7 +322,7 @@ EG3D_HD bool triangulate_array_team(const Team& tm, const DevScene& s, const Obs
   const int la = n - 1;
   if (a[mi].view == a[la].view) flags |= 16u;
   double X0[3];
-  dlt2(s.cam_P + (size_t)a[mi].view * 16, a[mi].x, a[mi].y, s.cam_P + (size_t)a[la].view * 16, a[la].x, a[la].y, X0);
+  tm.dlt(s.cam_P + (size_t)a[mi].view * 16, a[mi].x, a[mi].y, s.cam_P + (size_t)a[la].view * 16, a[la].x, a[la].y, X0);
   const uint64_t t1 = EG3D_TICK();
   const bool ok = tm.gn_array(s, a, n, X0, Xout);
   if (tsec) {
@@ -325,9 +334,17 @@ EG3D_HD bool triangulate_array_team(const Team& tm, const DevScene& s, const Obs
 
 // Triangulation fallback of a candidate whose all-observation solve failed: first valid 3-subset
 // + greedy ADD (triangulation.cpp:1105-1158); compacts sel to the kept observations.
-EG3D_HD int stepn_fallback(const DevScene& s, Obs* sel, int m, Obs* tmp, uint8_t* mask, float Xout[3], uint32_t& flags) {
+template <class Team>
+EG3D_HD int stepn_fallback(const Team& tm, const DevScene& s, Obs* sel, int m, Obs* tmp, uint8_t* mask, float Xout[3],
+                           uint32_t& flags) {
   if (m <= 3) return 0;
-  if (!triangulate_combinations<0>(s.cam_P, sel, m, tmp, mask, Xout, flags)) return 0;
+  struct TeamDlt {
+    const Team& tm;
+    EG3D_HD void operator()(const float* P1, float x1, float y1, const float* P2, float x2, float y2, double X0[3]) const {
+      tm.dlt(P1, x1, y1, P2, x2, y2, X0);
+    }
+  };
+  if (!triangulate_combinations<0>(s.cam_P, sel, m, tmp, mask, Xout, flags, TeamDlt{tm})) return 0;
   int k = 0;
   for (int i = 0; i < m; i++)
     if (mask[i]) sel[k++] = sel[i];
@@ -352,7 +369,7 @@ EG3D_HD_FLAT int stepn_chain(const Team& tm, const DevScene& s, Chain& c, const 
       c.tsec[1] += EG3D_TICK() - tw0;
       if (!m) continue;
       if (triangulate_array_team(tm, s, c.tmp_a, m, Xout, c.flags, c.tsec)) return m;
-      m = stepn_fallback(s, c.tmp_a, m, c.tmp_b, c.tmp_mask, Xout, c.flags);
+      m = stepn_fallback(tm, s, c.tmp_a, m, c.tmp_b, c.tmp_mask, Xout, c.flags);
       if (m) return m;
     }
     return 0;
@@ -390,7 +407,7 @@ EG3D_HD_FLAT int stepn_chain(const Team& tm, const DevScene& s, Chain& c, const 
       Xout[2] = sl.X[2];
     } else {
       for (int i = 0; i < m; i++) c.tmp_a[i] = sl.sel[i];
-      m = stepn_fallback(s, c.tmp_a, m, c.tmp_b, c.tmp_mask, Xout, c.flags);
+      m = stepn_fallback(tm, s, c.tmp_a, m, c.tmp_b, c.tmp_mask, Xout, c.flags);
       if (!m) continue;
       return m;
     }
@@ -570,10 +587,10 @@ EG3D_HD_FLAT bool attach_view(const Team& tm, const DevScene& s, Chain& c, const
   float Xc[3];
   if (pre_ok) {
     // the central solve was done speculatively (chain state unchanged since): reuse it
-    if (!*pre_ok) return false;
-    Xc[0] = pre_X[0];
-    Xc[1] = pre_X[1];
-    Xc[2] = pre_X[2];
+    if (!tm.uni(*pre_ok)) return false;
+    Xc[0] = tm.uni(pre_X[0]);
+    Xc[1] = tm.uni(pre_X[1]);
+    Xc[2] = tm.uni(pre_X[2]);
   } else {
     uint64_t t0 = EG3D_TICK();
     bool okc = tm.add_one(s, c, chain_at(c, ci), o, Xc);
@@ -808,8 +825,12 @@ EG3D_HD_FLAT void view_candidates(const Team& tm, const DevScene& s, Chain& c, i
     }
   }
   tm.sync();
-  if (!lazy_presolve(s)) central_presolves(tm, s, c, v, from, c.len);
   c.tsec[0] += EG3D_TICK() - tc0;
+  if (!lazy_presolve(s)) {
+    const uint64_t tp0 = EG3D_TICK();
+    central_presolves(tm, s, c, v, from, c.len);
+    c.tsec[10] += EG3D_TICK() - tp0;  // (diagnostic: all speculative central solves are booked with the epc pre-solves)
+  }
 }
 
 // Offer the chain to view v. epc = the task's epipolar hits in v (may be empty).
@@ -873,14 +894,16 @@ EG3D_HD_FLAT void expand_to_view(const Team& tm, const DevScene& s, Chain& c, in
       last_matched = idx_second;
       continue;
     }
-    const ViewCand vc = c.cand[c.head + cur];
+    const ViewCand vc = tm.uni(c.cand[c.head + cur]);
     if (!vc.valid) continue;
     c.bytes += 8ull * (s.pl_vtx_off[s.view_pl_off[v] + vc.pl + 1] - s.pl_vtx_off[s.view_pl_off[v] + vc.pl]);
     if (vc.d2 > 16.0f) return;  // abandons this view (Q4)
     if (lazy_presolve(s) && c.head + cur >= spec_slot_hi) {
       int to = cur + EG3D_SPEC_WINDOW;
       if (to > c.len) to = c.len;
+      const uint64_t tp0 = EG3D_TICK();
       central_presolves(tm, s, c, v, cur, to);
+      c.tsec[10] += EG3D_TICK() - tp0;
       spec_slot_hi = c.head + to;
     }
     Obs o;

@@ -321,11 +321,11 @@ EG3D_HD_FLAT void expand_chain(const Team& tm, const DevScene& s, const StageAVi
   tm.sync();
   c.tsec[9] = EG3D_TICK() - t_begin;
   // every view except the three selected, ascending; epc = the task's hits in that view
-  const uint32_t base = track_base(a, d.seed);
-  const uint32_t n = track_n_views(a, map_n, d.seed);
+  const uint32_t base = tm.uni(track_base(a, d.seed));
+  const uint32_t n = tm.uni(track_n_views(a, map_n, d.seed));
   const int32_t* mv = map_view + base;
   const uint32_t* me = map_entry + base;
-  const uint32_t lo = a.task_list_off[cs.task];
+  const uint32_t lo = tm.uni(a.task_list_off[cs.task]);
   uint32_t j = 0;
   for (int v = 0; v < s.n_views; v++) {
     if (v == d.sel_view[0] || v == d.sel_view[1] || v == d.sel_view[2]) continue;
@@ -333,8 +333,8 @@ EG3D_HD_FLAT void expand_chain(const Team& tm, const DevScene& s, const StageAVi
     const Obs* epc = nullptr;
     int n_epc = 0;
     if (j < n && mv[j] == v) {
-      epc = a.hits + a.list_ptr[lo + me[j]];
-      n_epc = (int)a.list_cnt[lo + me[j]];
+      epc = a.hits + tm.uni(a.list_ptr[lo + me[j]]);
+      n_epc = (int)tm.uni(a.list_cnt[lo + me[j]]);
     }
     expand_to_view(tm, s, c, v, epc, n_epc, centre);
   }

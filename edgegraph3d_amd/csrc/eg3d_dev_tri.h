@@ -166,6 +166,132 @@ EG3D_HD void svd4_smallest_v(double At[4][EG3D_DLT_M], double out[4]) {
   for (int k = 0; k < 4; k++) out[k] = Vt[last][k];
 }
 
+// The same decomposition with the matrices in caller-provided MEMORY (work[0 .. 4M) = At, then Vt[16], then W[4]):
+// same operations in the same order => same bits. The expand kernel passes LDS: there the 80 vector registers of the
+// 6x4 form's At / Vt would sit on top of a chain's whole live state and push it out to scratch memory.
+template <class DP>
+EG3D_HD void svd4_smallest_v_mem(DP work, double out[4]) {
+  constexpr int M = EG3D_DLT_M;
+  DP At = work, Vt = work + 4 * M, W = work + 4 * M + 16;
+  for (int i = 0; i < 4; i++)
+    for (int k = 0; k < 4; k++) Vt[i * 4 + k] = (i == k) ? 1.0 : 0.0;
+  const double eps = 2.2204460492503131e-16 * 10;
+  for (int i = 0; i < 4; i++) {
+    double sd = 0;
+    for (int k = 0; k < M; k++) sd += At[i * M + k] * At[i * M + k];
+    W[i] = sd;
+  }
+#pragma unroll 1
+  for (int iter = 0; iter < 30; iter++) {
+    bool changed = false;
+#pragma unroll 1
+    for (int i = 0; i < 3; i++)
+#pragma unroll 1
+      for (int j = i + 1; j < 4; j++) {
+        double a = W[i], p = 0, b = W[j];
+        for (int k = 0; k < M; k++) p += At[i * M + k] * At[j * M + k];
+        {
+          const double ab = a * b, p2 = p * p, t = (eps * eps) * ab;
+          bool skip;
+          if (t > 1e-250 && p2 > t * 1.0000001)
+            skip = false;
+          else if (t > 1e-250 && p2 < t * 0.9999999)
+            skip = true;
+          else
+            skip = absd(p) <= eps * EG3D_SQRT(ab);
+          if (skip) continue;
+        }
+        p *= 2;
+        double beta = a - b, gamma = EG3D_SQRT(p * p + beta * beta);
+        double c, s;
+        if (beta < 0) {
+          double delta = (gamma - beta) * 0.5;
+          s = EG3D_SQRT(delta / gamma);
+          c = p / (gamma * s * 2);
+        } else {
+          c = EG3D_SQRT((gamma + beta) / (gamma * 2));
+          s = p / (gamma * c * 2);
+        }
+        a = 0;
+        b = 0;
+        for (int k = 0; k < M; k++) {
+          const double ai = At[i * M + k], aj = At[j * M + k];
+          double t0 = c * ai + s * aj;
+          double t1 = c * aj - s * ai;
+          At[i * M + k] = t0;
+          At[j * M + k] = t1;
+          a += t0 * t0;
+          b += t1 * t1;
+        }
+        W[i] = a;
+        W[j] = b;
+        changed = true;
+        for (int k = 0; k < 4; k++) {
+          const double vi = Vt[i * 4 + k], vj = Vt[j * 4 + k];
+          double t0 = c * vi + s * vj;
+          double t1 = c * vj - s * vi;
+          Vt[i * 4 + k] = t0;
+          Vt[j * 4 + k] = t1;
+        }
+      }
+    if (!changed) break;
+  }
+  double Ws[4];
+  for (int i = 0; i < 4; i++) {
+    double sd = 0;
+    for (int k = 0; k < M; k++) sd += At[i * M + k] * At[i * M + k];
+    Ws[i] = EG3D_SQRT(sd);
+  }
+  // descending selection sort; track which row ends up last
+  int order[4] = {0, 1, 2, 3};
+  for (int i = 0; i < 3; i++) {
+    int j = i;
+    for (int k = i + 1; k < 4; k++)
+      if (Ws[j] < Ws[k]) j = k;
+    if (i != j) {
+      double tw = Ws[i];
+      Ws[i] = Ws[j];
+      Ws[j] = tw;
+      int to = order[i];
+      order[i] = order[j];
+      order[j] = to;
+    }
+  }
+  const int last = order[3];
+  for (int k = 0; k < 4; k++) out[k] = Vt[last * 4 + k];
+}
+#define EG3D_DLT_WORK_DOUBLES (4 * EG3D_DLT_M + 16 + 4)
+template <class DP>
+EG3D_HD void dlt2_mem(const float* P1, float x1, float y1, const float* P2, float x2, float y2, DP work, double X0[3]) {
+  constexpr int M = EG3D_DLT_M;
+  {
+    double x = x1, y = y1;
+    for (int k = 0; k < 4; k++) {
+      work[k * M + 0] = x * (double)P1[8 + k] - (double)P1[k];
+      work[k * M + 1] = y * (double)P1[8 + k] - (double)P1[4 + k];
+#if EG3D_DLT_ROWS == 3
+      work[k * M + 2] = x * (double)P1[4 + k] - y * (double)P1[k];
+#endif
+    }
+  }
+  {
+    double x = x2, y = y2;
+    for (int k = 0; k < 4; k++) {
+      work[k * M + EG3D_DLT_ROWS + 0] = x * (double)P2[8 + k] - (double)P2[k];
+      work[k * M + EG3D_DLT_ROWS + 1] = y * (double)P2[8 + k] - (double)P2[4 + k];
+#if EG3D_DLT_ROWS == 3
+      work[k * M + EG3D_DLT_ROWS + 2] = x * (double)P2[4 + k] - y * (double)P2[k];
+#endif
+    }
+  }
+  double v[4];
+  svd4_smallest_v_mem(work, v);
+  float h0 = (float)v[0], h1 = (float)v[1], h2 = (float)v[2], h3 = (float)v[3];
+  X0[0] = (double)(h0 / h3);
+  X0[1] = (double)(h1 / h3);
+  X0[2] = (double)(h2 / h3);
+}
+
 // 2-view DLT: per view the rows x*P(2,:)-P(0,:), y*P(2,:)-P(1,:) [, x*P(1,:)-y*P(0,:)] in double;
 // the homogeneous solution is rounded to float before the float division by w
 // (triangulation.cpp:216-224).
@@ -390,8 +516,16 @@ EG3D_HD bool gauss_newton_f64(const float* cam_P, Cursor& cur, const double X0[3
 
 // TRI on an observation array: DLT on (first minimal view id, LAST entry) — Q1/Q11 — then GN.
 // flags gets EG3D_FLAG_DEGENERATE_DLT (16) when both DLT views coincide.
-template <int KEEP = EG3D_KEEP_OBS>
-EG3D_HD bool triangulate_array(const float* cam_P, const Obs* a, int n, float Xout[3], uint32_t& flags) {
+// `dlt` = the 2-view DLT to use (default: dlt2 with its matrices in registers; the expand kernel passes one that
+// keeps them in LDS).
+struct DltInRegisters {
+  EG3D_HD void operator()(const float* P1, float x1, float y1, const float* P2, float x2, float y2, double X0[3]) const {
+    dlt2(P1, x1, y1, P2, x2, y2, X0);
+  }
+};
+template <int KEEP = EG3D_KEEP_OBS, class Dlt = DltInRegisters>
+EG3D_HD bool triangulate_array(const float* cam_P, const Obs* a, int n, float Xout[3], uint32_t& flags,
+                               const Dlt& dlt = Dlt()) {
   int mi = 0;
   int32_t mv = a[0].view;
   for (int i = 0; i < n; i++)
@@ -402,7 +536,7 @@ EG3D_HD bool triangulate_array(const float* cam_P, const Obs* a, int n, float Xo
   const int la = n - 1;
   if (a[mi].view == a[la].view) flags |= 16u;
   double X0[3];
-  dlt2(cam_P + (size_t)a[mi].view * 16, a[mi].x, a[mi].y, cam_P + (size_t)a[la].view * 16, a[la].x, a[la].y, X0);
+  dlt(cam_P + (size_t)a[mi].view * 16, a[mi].x, a[mi].y, cam_P + (size_t)a[la].view * 16, a[la].x, a[la].y, X0);
   ArrayCursor c;
   c.a = a;
   c.n = n;
@@ -414,9 +548,9 @@ EG3D_HD bool triangulate_array(const float* cam_P, const Obs* a, int n, float Xo
 // First 3-subset (std::prev_permutation order of the selection mask) that triangulates, then
 // greedy ADD of the remaining observations in list order (triangulation.cpp:1105-1158).
 // `sel` receives the final mask; `tmp` must hold n observations.
-template <int KEEP = EG3D_KEEP_OBS>
+template <int KEEP = EG3D_KEEP_OBS, class Dlt = DltInRegisters>
 EG3D_HD bool triangulate_combinations(const float* cam_P, const Obs* a, int n, Obs* tmp, uint8_t* sel,
-                                      float Xout[3], uint32_t& flags) {
+                                      float Xout[3], uint32_t& flags, const Dlt& dlt = Dlt()) {
   // enumerate 3-subsets i<j<k in the order prev_permutation visits {1,1,1,0,...}:
   // lexicographically descending masks == ascending (i,j,k) with k fastest
   bool valid = false;
@@ -427,7 +561,7 @@ EG3D_HD bool triangulate_combinations(const float* cam_P, const Obs* a, int n, O
         tmp[0] = a[i];
         tmp[1] = a[j];
         tmp[2] = a[k];
-        if (triangulate_array<KEEP>(cam_P, tmp, 3, Xout, flags)) {
+        if (triangulate_array<KEEP>(cam_P, tmp, 3, Xout, flags, dlt)) {
           valid = true;
           bi = i;
           bj = j;

@@ -619,6 +619,26 @@ struct TeamWave {
     total = __popcll(m);
     return __popcll(m & ((1ull << lane()) - 1ull));
   }
+  template <class T>
+  __device__ __forceinline__ T uni(const T& v) const {
+    static_assert(sizeof(T) % 4 == 0, "uni(): whole dwords");
+    union {
+      T t;
+      int w[sizeof(T) / 4];
+    } u;
+    u.t = v;
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 4; i++) u.w[i] = __builtin_amdgcn_readfirstlane(u.w[i]);
+    return u.t;
+  }
+  // uniform section: every lane runs the same decomposition on the same LDS words (slot 0)
+  __device__ __forceinline__ void dlt(const float* P1, float x1, float y1, const float* P2, float x2, float y2,
+                                      double X0[3]) const {
+    typedef __attribute__((address_space(3))) double* lds_dp;
+    __syncthreads();
+    dlt2_mem(P1, x1, y1, P2, x2, y2, (lds_dp)&L->dlt_work[0][0], X0);
+    __syncthreads();
+  }
   __device__ __forceinline__ uint32_t or_reduce(uint32_t v) const {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v |= (uint32_t)__shfl_xor((int)v, d);
@@ -842,7 +862,9 @@ struct TeamWave {
           }
         const int la = n - 1;
         if (a[mi].view == a[la].view) dfl = 16u;
-        dlt2(s.cam_P + (size_t)a[mi].view * 16, a[mi].x, a[mi].y, s.cam_P + (size_t)a[la].view * 16, a[la].x, a[la].y, X0);
+        typedef __attribute__((address_space(3))) double* lds_dp;
+        dlt2_mem(s.cam_P + (size_t)a[mi].view * 16, a[mi].x, a[mi].y, s.cam_P + (size_t)a[la].view * 16, a[la].x, a[la].y,
+                 (lds_dp)&L->dlt_work[lane() & 7][0], X0);
       }
       // ---- stage 3: the Deff Gauss-Newton solves as one batch (request j on lane j)
       const uint64_t tq2 = EG3D_TICK();
@@ -1025,7 +1047,7 @@ __global__ void __launch_bounds__(64, EG3D_K3B_WAVES) k3b_expand(DevScene s, Sta
   if (blockIdx.x >= n_chains) return;
   __shared__ CoopLds lds;
   const uint32_t lane = threadIdx.x;
-  const uint32_t j = order[blockIdx.x];  // longest-first schedule; results stay indexed by chain
+  const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)order[blockIdx.x]);  // longest-first schedule; results stay indexed by chain
   const uint32_t xcc = xcc_id();
   uint32_t slot = 0;
   if (lane == 0) slot = pool_pop(pools, xcc);
@@ -1041,12 +1063,14 @@ __global__ void __launch_bounds__(64, EG3D_K3B_WAVES) k3b_expand(DevScene s, Sta
     }
     return;
   }
-  const ChainSeed cs = chains[j];
-  const TaskDesc d = tasks[cs.task];
-  unsigned char* slice = slices + L.total * ((size_t)xcc * pools.slots_per_xcd + slot);
   TeamWave tm;
   tm.L = &lds;
-  expand_chain(tm, s, a, d, cs, hyp_off[cs.task], res, arena, map_view, map_entry, map_n, L, slice, co);
+  // wave-uniform descriptors: kept in scalar registers for the chain's whole life (as vector registers they would be
+  // 17 of the 168 the kernel may use, and spilled)
+  const ChainSeed cs = tm.uni(chains[j]);
+  const TaskDesc d = tm.uni(tasks[cs.task]);
+  unsigned char* slice = slices + L.total * ((size_t)xcc * pools.slots_per_xcd + slot);
+  expand_chain(tm, s, a, d, cs, tm.uni(hyp_off[cs.task]), res, arena, map_view, map_entry, map_n, L, slice, co);
   // ---- pack the result: 64 points at a time, their observations as one flat range
   unsigned long long pb = 0, ob = 0;
   if (lane == 0) {
