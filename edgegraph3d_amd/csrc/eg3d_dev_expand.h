@@ -184,6 +184,10 @@ struct TeamSeq {
   EG3D_HD void dlt(const float* P1, float x1, float y1, const float* P2, float x2, float y2, double X0[3]) const {
     dlt2(P1, x1, y1, P2, x2, y2, X0);
   }
+  // ... and the one of the rarely taken 3-subset fallback
+  EG3D_HD void dlt_rare(const float* P1, float x1, float y1, const float* P2, float x2, float y2, double X0[3]) const {
+    dlt2(P1, x1, y1, P2, x2, y2, X0);
+  }
   // a value every member holds identically (a wavefront team keeps it in scalar registers)
   template <class T>
   EG3D_HD T uni(const T& v) const {
@@ -341,7 +345,7 @@ EG3D_HD int stepn_fallback(const Team& tm, const DevScene& s, Obs* sel, int m, O
   struct TeamDlt {
     const Team& tm;
     EG3D_HD void operator()(const float* P1, float x1, float y1, const float* P2, float x2, float y2, double X0[3]) const {
-      tm.dlt(P1, x1, y1, P2, x2, y2, X0);
+      tm.dlt_rare(P1, x1, y1, P2, x2, y2, X0);
     }
   };
   if (!triangulate_combinations<0>(s.cam_P, sel, m, tmp, mask, Xout, flags, TeamDlt{tm})) return 0;

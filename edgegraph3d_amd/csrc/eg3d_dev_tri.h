@@ -188,8 +188,14 @@ EG3D_HD void svd4_smallest_v_mem(DP work, double out[4]) {
     for (int i = 0; i < 3; i++)
 #pragma unroll 1
       for (int j = i + 1; j < 4; j++) {
+        // the two rows travel to registers ONCE per rotation (one memory round trip, then register arithmetic)
+        double ai[M], aj[M];
+        for (int k = 0; k < M; k++) {
+          ai[k] = At[i * M + k];
+          aj[k] = At[j * M + k];
+        }
         double a = W[i], p = 0, b = W[j];
-        for (int k = 0; k < M; k++) p += At[i * M + k] * At[j * M + k];
+        for (int k = 0; k < M; k++) p += ai[k] * aj[k];
         {
           const double ab = a * b, p2 = p * p, t = (eps * eps) * ab;
           bool skip;
@@ -215,9 +221,8 @@ EG3D_HD void svd4_smallest_v_mem(DP work, double out[4]) {
         a = 0;
         b = 0;
         for (int k = 0; k < M; k++) {
-          const double ai = At[i * M + k], aj = At[j * M + k];
-          double t0 = c * ai + s * aj;
-          double t1 = c * aj - s * ai;
+          double t0 = c * ai[k] + s * aj[k];
+          double t1 = c * aj[k] - s * ai[k];
           At[i * M + k] = t0;
           At[j * M + k] = t1;
           a += t0 * t0;
@@ -543,6 +548,116 @@ EG3D_HD bool triangulate_array(const float* cam_P, const Obs* a, int n, float Xo
   c.extra = nullptr;
   c.i = 0;
   return gauss_newton_f64<ArrayCursor, KEEP>(cam_P, c, X0, Xout);
+}
+
+// The same solve for EXACTLY THREE observations (every point of the 3-view hypothesis stage): the three rows live in
+// registers between the two passes of an iteration — the general solver keeps them in a lane-private array sized for
+// 16 observations (1 KB of scratch memory per lane, the bulk of the hypothesis kernels' HBM traffic). Same
+// operations in the same order as gauss_newton_f64 with n = 3 => same bits.
+struct GnRow3 {
+  double j00, j01, j02, j10, j11, j12, r0, r1;
+};
+EG3D_HD void gn_row3(const float* P, float ox, float oy, const double X[3], GnRow3& w) {
+  double p00 = P[0], p01 = P[1], p02 = P[2], p03 = P[3];
+  double p10 = P[4], p11 = P[5], p12 = P[6], p13 = P[7];
+  double p20 = P[8], p21 = P[9], p22 = P[10], p23 = P[11];
+  double xH = ((p00 * X[0] + p01 * X[1]) + p02 * X[2]) + p03 * 1.0;
+  double yH = ((p10 * X[0] + p11 * X[1]) + p12 * X[2]) + p13 * 1.0;
+  double zH = ((p20 * X[0] + p21 * X[1]) + p22 * X[2]) + p23 * 1.0;
+  w.r0 = (double)ox - xH / zH;
+  w.r1 = (double)oy - yH / zH;
+  double zz = zH * zH;
+  w.j00 = (p00 * zH - p20 * xH) / zz;
+  w.j10 = (p10 * zH - p20 * yH) / zz;
+  w.j01 = (p01 * zH - p21 * xH) / zz;
+  w.j11 = (p11 * zH - p21 * yH) / zz;
+  w.j02 = (p02 * zH - p22 * xH) / zz;
+  w.j12 = (p12 * zH - p22 * yH) / zz;
+}
+EG3D_HD bool gauss_newton3_f64(const float* cam_P, const Obs* a, const double X0[3], float Xout[3]) {
+  double X[3] = {X0[0], X0[1], X0[2]};
+  double last_mse = 0;
+  const double two_n = 6.0;
+  const float* P0 = cam_P + (size_t)a[0].view * 16;
+  const float* P1 = cam_P + (size_t)a[1].view * 16;
+  const float* P2 = cam_P + (size_t)a[2].view * 16;
+  const float x0 = a[0].x, y0 = a[0].y, x1 = a[1].x, y1 = a[1].y, x2 = a[2].x, y2 = a[2].y;
+  for (int it = 0; it < 30; it++) {
+    GnRow3 w0, w1, w2;
+    gn_row3(P0, x0, y0, X, w0);
+    gn_row3(P1, x1, y1, X, w1);
+    gn_row3(P2, x2, y2, X, w2);
+    double mse = 0;
+    double H00 = 0, H01 = 0, H02 = 0, H11 = 0, H12 = 0, H22 = 0;
+#define EG3D_GN3_ACC(w)   \
+  mse += w.r0 * w.r0;     \
+  mse += w.r1 * w.r1;     \
+  H00 += w.j00 * w.j00;   \
+  H00 += w.j10 * w.j10;   \
+  H01 += w.j00 * w.j01;   \
+  H01 += w.j10 * w.j11;   \
+  H02 += w.j00 * w.j02;   \
+  H02 += w.j10 * w.j12;   \
+  H11 += w.j01 * w.j01;   \
+  H11 += w.j11 * w.j11;   \
+  H12 += w.j01 * w.j02;   \
+  H12 += w.j11 * w.j12;   \
+  H22 += w.j02 * w.j02;   \
+  H22 += w.j12 * w.j12;
+    EG3D_GN3_ACC(w0)
+    EG3D_GN3_ACC(w1)
+    EG3D_GN3_ACC(w2)
+#undef EG3D_GN3_ACC
+    if (absd(mse / two_n - last_mse) < 0.0000005) break;
+    last_mse = mse / two_n;
+    const double H10 = H01, H20 = H02, H21 = H12;
+    double d = H00 * (H11 * H22 - H12 * H21) - H01 * (H10 * H22 - H12 * H20) + H02 * (H10 * H21 - H11 * H20);
+    if (d < 0.00001) return false;
+    double id = 1. / d;
+    double I00 = (H11 * H22 - H12 * H21) * id;
+    double I01 = (H02 * H21 - H01 * H22) * id;
+    double I02 = (H01 * H12 - H02 * H11) * id;
+    double I10 = (H12 * H20 - H10 * H22) * id;
+    double I11 = (H00 * H22 - H02 * H20) * id;
+    double I12 = (H02 * H10 - H00 * H12) * id;
+    double I20 = (H10 * H21 - H11 * H20) * id;
+    double I21 = (H01 * H20 - H00 * H21) * id;
+    double I22 = (H00 * H11 - H01 * H10) * id;
+    double d0 = 0, d1 = 0, d2 = 0;
+#define EG3D_GN3_UPD(w)                                                  \
+  d0 += ((I00 * w.j00 + I01 * w.j01) + I02 * w.j02) * w.r0;              \
+  d0 += ((I00 * w.j10 + I01 * w.j11) + I02 * w.j12) * w.r1;              \
+  d1 += ((I10 * w.j00 + I11 * w.j01) + I12 * w.j02) * w.r0;              \
+  d1 += ((I10 * w.j10 + I11 * w.j11) + I12 * w.j12) * w.r1;              \
+  d2 += ((I20 * w.j00 + I21 * w.j01) + I22 * w.j02) * w.r0;              \
+  d2 += ((I20 * w.j10 + I21 * w.j11) + I22 * w.j12) * w.r1;
+    EG3D_GN3_UPD(w0)
+    EG3D_GN3_UPD(w1)
+    EG3D_GN3_UPD(w2)
+#undef EG3D_GN3_UPD
+    X[0] += d0;
+    X[1] += d1;
+    X[2] += d2;
+  }
+  if (!(last_mse < 9)) return false;
+  Xout[0] = (float)X[0];
+  Xout[1] = (float)X[1];
+  Xout[2] = (float)X[2];
+  return true;
+}
+// TRI on exactly three observations (triangulate_array with n = 3).
+EG3D_HD bool triangulate3(const float* cam_P, const Obs* a, float Xout[3], uint32_t& flags) {
+  int mi = 0;
+  int32_t mv = a[0].view;
+  for (int i = 0; i < 3; i++)
+    if (a[i].view < mv) {
+      mv = a[i].view;
+      mi = i;
+    }
+  if (a[mi].view == a[2].view) flags |= 16u;
+  double X0[3];
+  dlt2(cam_P + (size_t)a[mi].view * 16, a[mi].x, a[mi].y, cam_P + (size_t)a[2].view * 16, a[2].x, a[2].y, X0);
+  return gauss_newton3_f64(cam_P, a, X0, Xout);
 }
 
 // First 3-subset (std::prev_permutation order of the selection mask) that triangulates, then

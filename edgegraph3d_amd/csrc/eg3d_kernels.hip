@@ -595,6 +595,9 @@ __global__ void k_compact_chains(uint32_t n_tasks, const ChainSeed* per_task, co
 #ifndef EG3D_WAVE_SLOT_STEP
 #define EG3D_WAVE_SLOT_STEP 0 /* measured slower: failed speculative candidates run all 30 GN iterations */
 #endif
+#ifndef EG3D_DLT_HOT_IN_LDS
+#define EG3D_DLT_HOT_IN_LDS 1 /* the DLTs of chain following keep their matrices in LDS (1) or in registers (0); the rare 3-subset fallback's always in LDS */
+#endif
 #ifndef EG3D_LOOKAHEAD
 #define EG3D_LOOKAHEAD 8 /* steps walked ahead per round (<= 8, and <= 64 / observations of the end point) */
 #endif
@@ -634,9 +637,23 @@ struct TeamWave {
   // uniform section: every lane runs the same decomposition on the same LDS words (slot 0)
   __device__ __forceinline__ void dlt(const float* P1, float x1, float y1, const float* P2, float x2, float y2,
                                       double X0[3]) const {
+#if EG3D_DLT_HOT_IN_LDS
+    dlt_rare(P1, x1, y1, P2, x2, y2, X0);
+#else
+    dlt2(P1, x1, y1, P2, x2, y2, X0);
+#endif
+  }
+  __device__ __forceinline__ void dlt_rare(const float* P1, float x1, float y1, const float* P2, float x2, float y2,
+                                           double X0[3]) const {
+    // ONE lane runs the decomposition on slot 0 (64 lanes writing the same LDS words would serialise); the start
+    // point is then broadcast
     typedef __attribute__((address_space(3))) double* lds_dp;
     __syncthreads();
-    dlt2_mem(P1, x1, y1, P2, x2, y2, (lds_dp)&L->dlt_work[0][0], X0);
+    double r[3] = {0, 0, 0};
+    if (lane() == 0) dlt2_mem(P1, x1, y1, P2, x2, y2, (lds_dp)&L->dlt_work[0][0], r);
+    X0[0] = __shfl(r[0], 0);
+    X0[1] = __shfl(r[1], 0);
+    X0[2] = __shfl(r[2], 0);
     __syncthreads();
   }
   __device__ __forceinline__ uint32_t or_reduce(uint32_t v) const {
@@ -862,9 +879,13 @@ struct TeamWave {
           }
         const int la = n - 1;
         if (a[mi].view == a[la].view) dfl = 16u;
+#if EG3D_DLT_HOT_IN_LDS
         typedef __attribute__((address_space(3))) double* lds_dp;
         dlt2_mem(s.cam_P + (size_t)a[mi].view * 16, a[mi].x, a[mi].y, s.cam_P + (size_t)a[la].view * 16, a[la].x, a[la].y,
                  (lds_dp)&L->dlt_work[lane() & 7][0], X0);
+#else
+        dlt2(s.cam_P + (size_t)a[mi].view * 16, a[mi].x, a[mi].y, s.cam_P + (size_t)a[la].view * 16, a[la].x, a[la].y, X0);
+#endif
       }
       // ---- stage 3: the Deff Gauss-Newton solves as one batch (request j on lane j)
       const uint64_t tq2 = EG3D_TICK();
