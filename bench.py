@@ -115,13 +115,9 @@ def main():
     # Several steps are kept in flight on separate HIP streams (plus the gather stream and RCCL's):
     # with the runtime's default of 4 hardware queues two of them can share a queue and serialise.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    # Several ranks (C4): every context in flight holds its own chain scratch (24 GB by default, read by
-    # eg3d_create); with four contexts that came to 200 GB per rank, and the gathered cloud of a 4096 x ranks step
-    # needs up to ~80 GB more. 12 GB per context is as fast with four 4096-seed steps in flight (measured: 1.87
-    # vs 1.82 M edge-points/s) and leaves the rank at ~115 GB. (One step at a time it would cost a third: more,
-    # shorter K3b launches, each waiting for its own slowest chain — so the single-GPU runs keep 24 GB.)
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        os.environ.setdefault("EG3D_MAX_SCRATCH_MB", "12288")
+    # (Round 3: a context's chain working set is a fixed arena of ~0.5 GB — slots, not a slice per chain — plus the
+    # staging area of one step's cloud, so nothing has to be capped per rank any more; the gathered cloud of a
+    # 4096 x ranks step is held once, ~28 GB at 8 ranks.)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
@@ -349,6 +345,9 @@ def main():
                                 "by the sum of track lengths, RCCL all-gather of the cloud (eg3d_allgather_edgepoints)"
                                 % world),
                 "arithmetic": "2-D geometry f32, DLT+Gauss-Newton f64 (as the reference)",
+                "dlt_form": ("6x4 system of cv::triangulatePoints in OpenCV <= 3.1 (the release the reference names)"
+                             if api.lib().eg3d_dlt_rows() == 3 else "4x4 system of cv::triangulatePoints in OpenCV >= 3.2 "
+                             "(EG3D_LIB = libeg3d_dlt4x4.so)"),
             },
             "stage_ms": {n: round(avg[k], 4) for n, k in STAGES},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -363,12 +362,12 @@ def main():
         if world > 1:
             # the driver derives scaling efficiency itself; this is only where the 1-GPU figure of the SAME workload
             # lives (the default 1-GPU run measures C3')
-            ref = os.path.join(ROOT, "profiles", "r02_final_%s.json" % wkey)
+            ref = os.path.join(ROOT, "profiles", "r03_final_%s.json" % wkey)
             if os.path.exists(ref):
                 try:
                     r1 = json.load(open(ref))
                     line["same_workload_on_1_gpu"] = {"value": r1["value"], "ms_per_step": r1["ms_per_step"],
-                                                      "source": "profiles/r02_final_%s.json (python bench.py --workload %s; one "
+                                                      "source": "profiles/r03_final_%s.json (python bench.py --workload %s; one "
                                                                 "GPU takes the same seeds in steps of %d)" % (wkey, wkey, C4_BATCH)}
                 except Exception:
                     pass
@@ -431,7 +430,7 @@ def main():
             else:
                 gfull = workers[0].ctx.match_resident(b, ce)
             rep = compare_edgepoints(r, gfull, rel_tol=1e-4)
-            line["parity"] = {"vs": "oracle (CPU restatement; parity unpinned, see DESIGN.md 3)", "points_compared": int(pts),
+            line["parity"] = {"vs": "oracle (CPU restatement, same DLT form; parity unpinned, see DESIGN.md 3)", "points_compared": int(pts),
                               "max_rel_err_X": rep.get("max_rel_X"), "X_bit_exact": rep.get("bitexact_X"),
                               "ids_views_order_exact": bool(rep["ok"]), "obs_xy_bit_exact": rep.get("bitexact_xy"),
                               "tolerance": 1e-4}

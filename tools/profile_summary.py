@@ -132,6 +132,21 @@ def main():
             if not k.startswith("k"):
                 continue
             lines.append("%-28s %s" % (k, "  ".join("%s=%.3g" % (c, v[0]) for c, v in sorted(d.items()))))
+    # derived: fraction of the 64 lanes active in the VALU instructions of the dominant kernels
+    merged = defaultdict(dict)
+    for sq in (a.sq or []):
+        if os.path.exists(sq):
+            for k, d in counter_stats(sq).items():
+                merged[k].update({c: v[0] for c, v in d.items()})
+    der = []
+    for k, d in merged.items():
+        if d.get("SQ_ACTIVE_INST_VALU") and d.get("SQ_THREAD_CYCLES_VALU") and k.startswith("k3"):
+            der.append("%-28s active-lane fraction of VALU instructions = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) = %.3f"
+                       % (k, d["SQ_THREAD_CYCLES_VALU"] / (64.0 * d["SQ_ACTIVE_INST_VALU"])))
+    if der:
+        lines.append("")
+        lines.append("# derived")
+        lines.extend(der)
     open(os.path.join(a.out, "%s_rocprof_summary.txt" % a.tag), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
