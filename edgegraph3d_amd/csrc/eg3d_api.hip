@@ -116,12 +116,13 @@ struct HostGrids {
 //   EG3D_K3A_TEAM=0|1      force 1-lane / 4-lane hypothesis teams (default: by batch size)
 //   EG3D_K3A_QUEUE=0|1     force the lane-level following queue off / on
 //   EG3D_ARENA_CAP0=n      initial hypothesis arena capacity (tests: forces the overflow-and-retry path)
-//   EG3D_MAX_SCRATCH_MB=n  chain scratch budget per K3b launch (tests: forces chunking)
+//   EG3D_MAX_SCRATCH_MB=n  tests: cut the chains of a batch into several K3b launches of at most n MB / slice size
+//                          chains each (default: one launch takes all chains — their working slices are slots)
 //   EG3D_NO_LPT=1          launch chains in identity order instead of longest-first (diagnostic)
 struct Tunables {
   int k3a_team = -1, k3a_queue = -1;
   uint32_t arena_cap0 = 0;
-  size_t max_scratch = (size_t)24 << 30;
+  size_t max_scratch = 0;  // 0 = no limit
   bool use_lpt = true;
   static Tunables from_env() {
     Tunables t;
@@ -887,7 +888,8 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
   for (uint32_t c0 = 0; c0 < B.n_chains; c0 += chunk) {
     // capacities can grow between chunks (overflow -> retry below), so the layout is per chunk
     const ChainLayout L = chain_layout(c->chain_cap, c->pool_cap, (uint32_t)c->V);
-    chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(B.n_chains - c0, max_scratch / L.total));
+    chunk = (uint32_t)std::max<size_t>(1, max_scratch ? std::min<size_t>(B.n_chains - c0, max_scratch / L.total)
+                                                      : (size_t)(B.n_chains - c0));
     const uint32_t nc = std::min(chunk, B.n_chains - c0);
     BUF_TRY(ensure_mailbox(c));
     uint32_t* const saved_bytes = c->b_scanchk.as<uint32_t>() + 4;  // device copy of the byte counter before this chunk
