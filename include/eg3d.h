@@ -208,12 +208,12 @@ int eg3d_match_resident(eg3d_ctx* ctx, uint32_t seed_begin, uint32_t seed_end, i
 
 /* Device-resident view of the edge-points produced by the most recent eg3d_match_* call
  * (pointers into the context's HBM buffers, valid until the next call on this context).
- * A call made with device_only != 0 keeps its WHOLE result in these buffers however many seed
- * batches and scratch chunks it took (global observation offsets; obs_off has n_points entries, no
- * sentinel) and `complete` is 1 — this is what the multi-GPU all-gather of the edge-point cloud
- * consumes without a host trip; the buffers grow to the size of the call's cloud (12 B + 20 B per
- * observation per point). A call that copies to the host (device_only == 0) reuses the buffers per
- * chunk: `complete` is then 1 only if it ran as a single chunk. */
+ * A call made with device_only != 0 keeps its WHOLE result in these buffers however many internal
+ * seed batches (16 384 seeds, one expand launch each) it took (global 64-bit observation offsets;
+ * obs_off has n_points entries, no sentinel) and `complete` is 1 — this is what the multi-GPU exchange
+ * of the edge-point cloud consumes without a host trip; the buffers grow to the size of the call's
+ * cloud (12 + 8 + 16 B per point, 20 B per observation). A call that copies to the host
+ * (device_only == 0) reuses the buffers per batch: `complete` is then 1 only if it ran as a single one. */
 typedef struct eg3d_device_edgepoints {
   uint64_t n_points, n_obs;
   const float* X;
