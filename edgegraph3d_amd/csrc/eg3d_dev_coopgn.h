@@ -104,6 +104,55 @@ __device__ __forceinline__ void gn_row(const float* __restrict__ P, float ox, fl
   w.j12 = (p12 * zH - p22 * yH) / zz;
 }
 
+// s + A[0] + B[0] + A[1] + B[1] + ... in exactly that order (the order contract of the normal equations), with the
+// LDS reads of up to 8 rows in flight before the first addition needs one: the plain loop waited out the full LDS
+// latency once per row (ds_read2_b64 -> s_waitcnt lgkmcnt(0) -> two dependent adds: ~130 cycles per row, a third of
+// a Gauss-Newton iteration); same additions, same order => same bits.
+__device__ __forceinline__ double ordered_sum2(double s, const double* __restrict__ A, const double* __restrict__ B, int rows) {
+  int m = 0;
+  for (; m + 8 <= rows; m += 8) {
+    double a[8], b[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      a[k] = A[m + k];
+      b[k] = B[m + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      s += a[k];
+      s += b[k];
+    }
+  }
+  if (m + 4 <= rows) {
+    double a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      a[k] = A[m + k];
+      b[k] = B[m + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      s += a[k];
+      s += b[k];
+    }
+    m += 4;
+  }
+  if (m + 2 <= rows) {
+    const double a0 = A[m], b0 = B[m], a1 = A[m + 1], b1 = B[m + 1];
+    s += a0;
+    s += b0;
+    s += a1;
+    s += b1;
+    m += 2;
+  }
+  if (m < rows) {
+    const double a0 = A[m], b0 = B[m];
+    s += a0;
+    s += b0;
+  }
+  return s;
+}
+
 // One round. Lane state: act (member of a group), l = index in its group of G >= 2 lanes starting
 // at lane gb, the request's n rows (the first nb from a[], the last one the extra observation),
 // start point X (identical on the lanes of a group). cmax = chunks per pass (wave-uniform maximum).
@@ -163,14 +212,7 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
         for (int t = 0; t < 4; t++) {  // G >= 2 => at most 4 of the 7 accumulators per lane
           const int e = l + t * G;
           if (e < 7 && rows > 0) {
-            const double* A = &L.prod[2 * e][gb];
-            const double* Bp = &L.prod[2 * e + 1][gb];
-            double s = acc[t];
-            for (int m = 0; m < rows; m++) {
-              s += A[m];
-              s += Bp[m];
-            }
-            acc[t] = s;
+            acc[t] = ordered_sum2(acc[t], &L.prod[2 * e][gb], &L.prod[2 * e + 1][gb], rows);
           }
         }
       }
@@ -250,14 +292,7 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
         for (int t = 0; t < 2; t++) {  // G >= 2 => at most 2 of the 3 accumulators per lane
           const int e = l + t * G;
           if (e < 3 && rows > 0) {
-            const double* A = &L.prod[2 * e][gb];
-            const double* Bp = &L.prod[2 * e + 1][gb];
-            double s = dac[t];
-            for (int m = 0; m < rows; m++) {
-              s += A[m];
-              s += Bp[m];
-            }
-            dac[t] = s;
+            dac[t] = ordered_sum2(dac[t], &L.prod[2 * e][gb], &L.prod[2 * e + 1][gb], rows);
           }
         }
       }
