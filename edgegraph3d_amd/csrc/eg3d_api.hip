@@ -141,7 +141,7 @@ struct eg3d_ctx {
   hipStream_t stream = nullptr;
   int V = 0, W = 0, H = 0;
   DevScene ds;
-  DevBuf b_camP, b_F, b_Fv, b_vpo, b_pvo, b_vtx, b_pls, b_ple, b_g30o, b_g30i, b_g4o, b_g4i;
+  DevBuf b_camP, b_F, b_Fv, b_vpo, b_pvo, b_vtx, b_pls, b_ple, b_g30o, b_g30i, b_g4o, b_g4i, b_bbo, b_bb;
   std::shared_ptr<DevOwner> scene_owner;  // owns b_camP .. b_g4i
   // host copies of the grids for eg3d_get_grid (per view CSR with view-local offsets)
   std::shared_ptr<HostGrids> hg;
@@ -299,7 +299,7 @@ extern "C" int eg3d_device_count(void) {
 }
 
 static std::vector<DevBuf*> scene_bufs(eg3d_ctx* c) {
-  return {&c->b_camP, &c->b_F,   &c->b_Fv,   &c->b_vpo,  &c->b_pvo, &c->b_vtx,
+  return {&c->b_bbo,  &c->b_bb,  &c->b_camP, &c->b_F,   &c->b_Fv,   &c->b_vpo,  &c->b_pvo, &c->b_vtx,
           &c->b_pls,  &c->b_ple, &c->b_g30o, &c->b_g30i, &c->b_g4o, &c->b_g4i};
 }
 
@@ -426,6 +426,32 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
   UP(b_vtx, vtx_up, (size_t)NV * 2);
   UP(b_pls, sc->pl_start, NP);
   UP(b_ple, sc->pl_end, NP);
+  {
+    // bounding boxes of blocks of EG3D_BB_SEGS segments (the pre-test of the expand stage's closest-point scans)
+    std::vector<uint32_t> bbo(NP + 1, 0);
+    std::vector<float> bb;
+    for (uint32_t p = 0; p < NP; p++) {
+      const uint32_t a = pvo_up[p], b = pvo_up[p + 1];
+      const uint32_t nseg = b > a + 1 ? b - a - 1 : 0;
+      for (uint32_t s0 = 0; s0 < nseg; s0 += EG3D_BB_SEGS) {
+        const uint32_t s1 = std::min(nseg, s0 + (uint32_t)EG3D_BB_SEGS);
+        float x0 = vtx_up[2 * (size_t)(a + s0)], y0 = vtx_up[2 * (size_t)(a + s0) + 1], x1 = x0, y1 = y0;
+        for (uint32_t i = s0 + 1; i <= s1; i++) {
+          const float x = vtx_up[2 * (size_t)(a + i)], y = vtx_up[2 * (size_t)(a + i) + 1];
+          x0 = std::min(x0, x);
+          y0 = std::min(y0, y);
+          x1 = std::max(x1, x);
+          y1 = std::max(y1, y);
+        }
+        bb.insert(bb.end(), {x0, y0, x1, y1});
+      }
+      bbo[p + 1] = (uint32_t)(bb.size() / 4);
+    }
+    if (bb.empty()) bb.assign(4, 0.f);
+    UP(b_bbo, bbo.data(), bbo.size());
+    UP(b_bb, bb.data(), bb.size());
+    HIP_TRY(hipStreamSynchronize(c->stream));  // `bbo` / `bb` go out of scope
+  }
   // grids: built on the host (row a3), one CSR over (view, cell) per cell size
   for (int which = 0; which < 2; which++) {
     std::vector<uint32_t> off(1, 0), ids;
@@ -479,6 +505,8 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
   d.g30_ids = c->b_g30i.as<uint32_t>();
   d.g4_off = c->b_g4o.as<uint32_t>();
   d.g4_ids = c->b_g4i.as<uint32_t>();
+  d.pl_bb_off = c->b_bbo.as<uint32_t>();
+  d.pl_bb = c->b_bb.as<float>();
   // observation slots per chain (blocks double when they fill, so budget ~3x the live count);
   // grown automatically when a chain overflows
   c->pool_cap = std::min<uint32_t>(32768, 768u * (uint32_t)std::min(V, 32));

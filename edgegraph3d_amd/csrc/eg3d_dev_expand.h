@@ -806,12 +806,12 @@ EG3D_HD_FLAT void view_candidates(const Team& tm, const DevScene& s, Chain& c, i
       project_f32(P, pt.X[0], pt.X[1], pt.X[2], u, w);
       uint32_t pl_id;
       if (unique_polyline_4px(s, v, u, w, pl_id)) {
-        PlRef pl = polyline_of(s, v, pl_id);
+        PlRef pl = polyline_of_bb(s, v, pl_id);
         const uint32_t nseg = pl.n - 1u;
         const uint32_t chunk = (nseg + (uint32_t)G - 1u) / (uint32_t)G;
         const uint32_t s0 = (uint32_t)part * chunk;
         const uint32_t s1 = s0 + chunk < nseg ? s0 + chunk : nseg;
-        if (s0 < s1 || part == 0) d2 = polyline_closest_range(pl, u, w, s0 < nseg ? s0 : nseg, s1, cp);
+        if (s0 < s1 || part == 0) d2 = polyline_closest_pruned(pl, u, w, s0 < nseg ? s0 : nseg, s1, cp);
         have = true;
         vc.pl = pl_id;
       }

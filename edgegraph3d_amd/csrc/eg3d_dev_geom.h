@@ -54,7 +54,9 @@ struct PlRefT {
   uint32_t n;      // vertex count
   uint32_t start;  // node ids (reference polyline::start / ::end)
   uint32_t end;
+  const float* bb = nullptr;  // optional: bounding boxes (min x, min y, max x, max y) of blocks of EG3D_BB_SEGS segments
 };
+#define EG3D_BB_SEGS 8
 typedef PlRefT<const f2*> PlRef;
 
 // A point on a polyline: segment index + coordinates (reference pl_point).
@@ -398,6 +400,91 @@ EG3D_HD float polyline_closest_range(const PlRef& pl, float px, float py, uint32
       bx = cx;
       by = cy;
       bseg = i;
+    }
+  }
+  out.seg = bseg;
+  out.x = bx;
+  out.y = by;
+  return best;
+}
+
+// polyline_closest_range with a PRE-TEST per block of EG3D_BB_SEGS segments: a block whose bounding box is farther
+// from p than the best distance found so far cannot hold the closest segment and is not scanned. The result is the
+// one of the plain scan, bit for bit: (1) segment 0 is the initial best exactly as there (NaN included: a NaN best
+// is never replaced, and `bound > NaN` never prunes); (2) the block nearest to p is scanned next, which makes the
+// bound tight at once; (3) then every block in ascending order — a segment replaces the best when it is strictly
+// closer, or EQUALLY close with a smaller index (the plain scan keeps the first of equal distances). The bound is
+// conservative in floating point: the computed distance of a segment is at least (gap - E)^2 (1 - 1e-6) per axis,
+// E = 8 ulp of the largest coordinate involved (the closest point is v + t (w - v), t in [0,1], rounded; the
+// difference p - q is rounded once; the squares are formed in double), and a NaN / infinite p never prunes.
+EG3D_HD float polyline_closest_pruned(const PlRef& pl, float px, float py, uint32_t s0, uint32_t s1, PlPt& out) {
+  if (!pl.bb || s1 <= s0) return polyline_closest_range(pl, px, py, s0, s1, out);
+  float bx = 0.0f, by = 0.0f;
+  float best = __builtin_inff();
+  uint32_t bseg = 0xffffffffu;
+  uint32_t first = s0;
+  if (s0 == 0) {
+    best = seg_closest(px, py, pl.v[0].x, pl.v[0].y, pl.v[1].x, pl.v[1].y, bx, by);
+    bseg = 0;
+    first = 1;
+  }
+  auto bound = [&](uint32_t b) -> float {
+    const float* q = pl.bb + 4 * (size_t)b;
+    const float x0 = q[0], y0 = q[1], x1 = q[2], y1 = q[3];
+    float gx = x0 - px, gy = y0 - py;
+    const float hx = px - x1, hy = py - y1;
+    gx = gx > hx ? gx : hx;
+    gy = gy > hy ? gy : hy;
+    float m = __builtin_fabsf(px);
+    const float apy = __builtin_fabsf(py), ax0 = __builtin_fabsf(x0), ay0 = __builtin_fabsf(y0), ax1 = __builtin_fabsf(x1), ay1 = __builtin_fabsf(y1);
+    m = m > apy ? m : apy;
+    m = m > ax0 ? m : ax0;
+    m = m > ay0 ? m : ay0;
+    m = m > ax1 ? m : ax1;
+    m = m > ay1 ? m : ay1;
+    const float E = m * 9.6e-7f;
+    gx -= E;
+    gy -= E;
+    gx = gx > 0.0f ? gx : 0.0f;  // (NaN -> 0: never prunes)
+    gy = gy > 0.0f ? gy : 0.0f;
+    return (gx * gx + gy * gy) * 0.999999f;
+  };
+  auto scan = [&](uint32_t i0, uint32_t i1) {
+    for (uint32_t i = i0; i < i1; i++) {
+      float cx, cy;
+      const float d = seg_closest(px, py, pl.v[i].x, pl.v[i].y, pl.v[i + 1].x, pl.v[i + 1].y, cx, cy);
+      if (d < best || (d == best && i < bseg && bseg != 0xffffffffu)) {  // (an infinite distance never becomes the best)
+        best = d;
+        bx = cx;
+        by = cy;
+        bseg = i;
+      }
+    }
+  };
+  if (first < s1) {
+    const uint32_t b0 = first / EG3D_BB_SEGS, b1 = (s1 - 1) / EG3D_BB_SEGS;
+    // (2) the nearest block first
+    uint32_t nb = b0;
+    float nbound = bound(b0);
+    for (uint32_t b = b0 + 1; b <= b1; b++) {
+      const float t = bound(b);
+      if (t < nbound) {
+        nbound = t;
+        nb = b;
+      }
+    }
+    {
+      const uint32_t i0 = nb * EG3D_BB_SEGS > first ? nb * EG3D_BB_SEGS : first;
+      const uint32_t i1 = (nb + 1) * EG3D_BB_SEGS < s1 ? (nb + 1) * EG3D_BB_SEGS : s1;
+      scan(i0, i1);
+    }
+    // (3) the others, ascending
+    for (uint32_t b = b0; b <= b1; b++) {
+      if (b == nb) continue;
+      if (bound(b) > best) continue;
+      const uint32_t i0 = b * EG3D_BB_SEGS > first ? b * EG3D_BB_SEGS : first;
+      const uint32_t i1 = (b + 1) * EG3D_BB_SEGS < s1 ? (b + 1) * EG3D_BB_SEGS : s1;
+      scan(i0, i1);
     }
   }
   out.seg = bseg;

@@ -214,6 +214,39 @@ extern "C" void hostsim_free_edgepoints(eg3d_edgepoints* e) {
 }
 
 // ---- primitive probes so the device bodies can be KAT-tested on CPU too ----
+// polyline_closest_pruned (block bounding-box pre-test) against the plain scan polyline_closest_range on one
+// polyline and many query points: returns the number of queries whose (distance bits, segment, x, y) differ.
+extern "C" int hostsim_closest_pruned_mismatches(const float* vtx, int n, const float* pts, int n_pts, uint32_t s0,
+                                                 uint32_t s1) {
+  std::vector<float> bb;
+  const uint32_t nseg = n > 1 ? (uint32_t)n - 1u : 0u;
+  for (uint32_t b0 = 0; b0 < nseg; b0 += EG3D_BB_SEGS) {
+    const uint32_t b1 = b0 + EG3D_BB_SEGS < nseg ? b0 + EG3D_BB_SEGS : nseg;
+    float x0 = vtx[2 * b0], y0 = vtx[2 * b0 + 1], x1 = x0, y1 = y0;
+    for (uint32_t i = b0 + 1; i <= b1; i++) {
+      x0 = vtx[2 * i] < x0 ? vtx[2 * i] : x0;
+      y0 = vtx[2 * i + 1] < y0 ? vtx[2 * i + 1] : y0;
+      x1 = vtx[2 * i] > x1 ? vtx[2 * i] : x1;
+      y1 = vtx[2 * i + 1] > y1 ? vtx[2 * i + 1] : y1;
+    }
+    bb.insert(bb.end(), {x0, y0, x1, y1});
+  }
+  PlRef plain, boxed;
+  plain.v = boxed.v = (const f2*)vtx;
+  plain.n = boxed.n = (uint32_t)n;
+  plain.start = boxed.start = 0;
+  plain.end = boxed.end = 1;
+  boxed.bb = bb.empty() ? nullptr : bb.data();
+  int bad = 0;
+  for (int k = 0; k < n_pts; k++) {
+    PlPt a, b;
+    const float da = polyline_closest_range(plain, pts[2 * k], pts[2 * k + 1], s0, s1, a);
+    const float db = polyline_closest_pruned(boxed, pts[2 * k], pts[2 * k + 1], s0, s1, b);
+    if (memcmp(&da, &db, 4) != 0 || a.seg != b.seg || memcmp(&a.x, &b.x, 4) != 0 || memcmp(&a.y, &b.y, 4) != 0) bad++;
+  }
+  return bad;
+}
+
 extern "C" float hostsim_dist2(float ax, float ay, float bx, float by) { return dist2(ax, ay, bx, by); }
 extern "C" float hostsim_seg_closest(float px, float py, float vx, float vy, float wx, float wy, float* q) {
   return seg_closest(px, py, vx, vy, wx, wy, q[0], q[1]);

@@ -5,6 +5,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from edgegraph3d_amd import _cdefs as D
 from edgegraph3d_amd import api, host
 from oracle import binding as ob
 from parity_util import compare_edgepoints
@@ -148,3 +149,48 @@ def test_inconsistent_scenes_are_refused_before_any_device_is_touched():
         rc, msg = create(mut)
         assert rc == -1, (mut.__name__, rc, msg)
         assert "eg3d_create" in msg
+
+
+def test_closest_point_scan_with_box_pretest_equals_the_plain_scan():
+    """eg3d_dev_geom.h polyline_closest_pruned (the expand stage's per-view closest-point scan skips blocks of 8 segments
+    whose bounding box is farther than the best distance so far) must return the plain scan's result bit for bit: first
+    of equal distances, NaN / infinite queries, zero-length and repeated segments, sub-ranges that cut blocks, huge
+    coordinates (where the rounding slack of the bound matters)."""
+    import ctypes as C
+    import hostsim_binding as hs
+    L = hs.lib()
+    rng = np.random.default_rng(11)
+    total = 0
+    for case in range(60):
+        n = int(rng.integers(2, 400))
+        scale = float(10.0 ** rng.integers(0, 8))          # up to the +-1e7 px the library accepts
+        kind = case % 6
+        if kind == 0:      # smooth curve
+            tt = np.linspace(0, rng.uniform(1, 12), n)
+            v = np.stack([np.cos(tt) * tt * 20, np.sin(tt) * tt * 20], 1)
+        elif kind == 1:    # random walk with repeated vertices (zero-length segments)
+            v = np.cumsum(rng.normal(0, 3, (n, 2)), 0)
+            v[rng.integers(0, n, n // 5)] = v[0]
+        elif kind == 2:    # two identical passes over the same stroke: exact ties between far-apart segments
+            h = np.cumsum(rng.normal(0, 2, ((n + 1) // 2, 2)), 0)
+            v = np.concatenate([h, h[::-1]])[:n]
+        elif kind == 3:    # integer grid coordinates: many exactly equal distances
+            v = rng.integers(-30, 30, (n, 2)).astype(np.float64)
+        elif kind == 4:    # axis-aligned staircase
+            v = np.cumsum(np.stack([rng.integers(0, 3, n), rng.integers(0, 3, n)], 1), 0).astype(np.float64)
+        else:
+            v = rng.uniform(-500, 500, (n, 2))
+        v = np.ascontiguousarray(v * (scale if kind in (0, 5) else 1.0), np.float32)
+        n = len(v)
+        q = np.concatenate([v[rng.integers(0, n, 150)] + rng.normal(0, 4, (150, 2)).astype(np.float32),
+                            (rng.uniform(-2, 2, (60, 2)) * np.abs(v).max()).astype(np.float32),
+                            v[rng.integers(0, n, 40)],                                    # exactly on vertices
+                            np.array([[np.nan, 0], [0, np.nan], [np.inf, 1], [-np.inf, -np.inf], [1e30, -1e30], [0, 0]], np.float32)])
+        q = np.ascontiguousarray(q, np.float32)
+        nseg = n - 1
+        ranges = [(0, nseg)] + [tuple(sorted(rng.integers(0, nseg + 1, 2))) for _ in range(4)]
+        for s0, s1 in ranges:
+            bad = L.hostsim_closest_pruned_mismatches(D.np_ptr(v, C.c_float), n, D.np_ptr(q, C.c_float), len(q), int(s0), int(s1))
+            assert bad == 0, (case, kind, n, s0, s1, bad)
+            total += len(q)
+    assert total > 50000
