@@ -507,6 +507,18 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
   d.g4_ids = c->b_g4i.as<uint32_t>();
   d.pl_bb_off = c->b_bbo.as<uint32_t>();
   d.pl_bb = c->b_bb.as<float>();
+  {
+    bool mid = true;
+    for (size_t v = 0; v < (size_t)V && mid; v++)
+      for (int k = 0; k < 12 && mid; k++) {
+        const float p = sc->cam_P[v * 16 + k];
+        if (p != 0.0f) {
+          const float a = p < 0 ? -p : p;
+          mid = a >= 7.888609052210118e-31f && a <= 1.2676506002282294e+30f;  // 2^-100 .. 2^100 (NaN fails)
+        }
+      }
+    d.cams_mid_range = mid ? 1 : 0;
+  }
   // observation slots per chain (blocks double when they fill, so budget ~3x the live count);
   // grown automatically when a chain overflows
   c->pool_cap = std::min<uint32_t>(32768, 768u * (uint32_t)std::min(V, 32));

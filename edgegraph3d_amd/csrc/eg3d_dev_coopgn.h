@@ -50,6 +50,7 @@ struct CoopLds {
   uint8_t row_req[EG3D_COOP_ROWS];   // row (short rounds) / group slot (long rounds) -> request lane
   uint8_t row_k[EG3D_COOP_ROWS];     // row -> its index in the request
   uint8_t res_ok[EG3D_COOP_ROWS];
+  uint8_t cams_mid_range;  // DevScene::cams_mid_range (set once per workgroup): enables the shared-reciprocal rows
 };
 static_assert(sizeof(CoopLds) <= 12800, "CoopLds must fit 10 LDS allocation units (3 waves per SIMD)");
 
@@ -86,16 +87,65 @@ __device__ unsigned long long g_gn_dbg[128];
 #else
 #define EG3D_GN_DBG(i, v) ((void)0)
 #endif
-__device__ __forceinline__ void gn_row(const float* __restrict__ P, float ox, float oy, const double X[3], GnRow& w) {
+// ---- the eight divisions of a row with TWO shared reciprocals -------------------------------------------------
+// A correctly rounded FP64 division is, on gfx950, the sequence  sd = div_scale(den), sn = div_scale(num),
+// r = rcp(sd), two Newton steps on r (4 fma), q = sn * r, t = fma(-sd, q, sn), q' = div_fmas(t, r, q),
+// div_fixup(q', den, num)  — 11 VALU instructions of which SIX depend on the divisor only. A row divides two numbers
+// by zH and six by zH^2. Whenever div_scale leaves its operands alone (no operand or quotient near the ends of the
+// exponent range) and no operand is NaN / infinite / zero-divisor, the sequence reduces to rcp + 4 fma per DIVISOR and
+// mul + 2 fma + div_fixup per NUMERATOR, with exactly the values the full sequence produces => the same bits. That regime is
+// guaranteed by a range test per row: xH, yH, zH in [2^-100, 2^100] and — checked once per scene on the host — every
+// non-zero camera entry in that range too; a non-zero numerator p_a zH - p_b xH is then a difference of two
+// rounded products of magnitude >= 2^-200, hence >= 2^-253, and a zero numerator gives the signed zero the full
+// sequence gives. Rows outside the regime take the plain divisions. (tests/test_gpu_arith.py compares the two on
+// random and edge operands; every parity test runs through it.)
+struct GnRecip {
+  double d, r;
+};
+__device__ __forceinline__ bool gn_mid_range(double v) {  // 2^-100 <= |v| < 2^101, finite
+  const uint32_t e = ((uint32_t)__double2hiint(v) >> 20) & 0x7ffu;
+  return (e - 923u) <= 200u;
+}
+__device__ __forceinline__ GnRecip gn_recip(double den) {
+  double r = __builtin_amdgcn_rcp(den);
+  double e = __builtin_fma(-den, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-den, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  GnRecip R;
+  R.d = den;
+  R.r = r;
+  return R;
+}
+__device__ __forceinline__ double gn_div(double num, const GnRecip& R) {
+  const double q = num * R.r;
+  const double t = __builtin_fma(-R.d, q, num);
+  // the full sequence's last step: leaves a finite quotient alone and gives a zero numerator its sign (-0 / d)
+  return __builtin_amdgcn_div_fixup(__builtin_fma(t, R.r, q), R.d, num);
+}
+__device__ __forceinline__ void gn_row(const float* __restrict__ P, float ox, float oy, const double X[3], GnRow& w,
+                                       bool cams_mid_range = false) {
   const double p00 = P[0], p01 = P[1], p02 = P[2], p03 = P[3];
   const double p10 = P[4], p11 = P[5], p12 = P[6], p13 = P[7];
   const double p20 = P[8], p21 = P[9], p22 = P[10], p23 = P[11];
   const double xH = ((p00 * X[0] + p01 * X[1]) + p02 * X[2]) + p03 * 1.0;
   const double yH = ((p10 * X[0] + p11 * X[1]) + p12 * X[2]) + p13 * 1.0;
   const double zH = ((p20 * X[0] + p21 * X[1]) + p22 * X[2]) + p23 * 1.0;
+  const double zz = zH * zH;
+  if (cams_mid_range && gn_mid_range(xH) && gn_mid_range(yH) && gn_mid_range(zH)) {
+    const GnRecip rz = gn_recip(zH), rzz = gn_recip(zz);
+    w.r0 = (double)ox - gn_div(xH, rz);
+    w.r1 = (double)oy - gn_div(yH, rz);
+    w.j00 = gn_div(p00 * zH - p20 * xH, rzz);
+    w.j10 = gn_div(p10 * zH - p20 * yH, rzz);
+    w.j01 = gn_div(p01 * zH - p21 * xH, rzz);
+    w.j11 = gn_div(p11 * zH - p21 * yH, rzz);
+    w.j02 = gn_div(p02 * zH - p22 * xH, rzz);
+    w.j12 = gn_div(p12 * zH - p22 * yH, rzz);
+    return;
+  }
   w.r0 = (double)ox - xH / zH;
   w.r1 = (double)oy - yH / zH;
-  const double zz = zH * zH;
   w.j00 = (p00 * zH - p20 * xH) / zz;
   w.j10 = (p10 * zH - p20 * yH) / zz;
   w.j01 = (p01 * zH - p21 * xH) / zz;
@@ -188,7 +238,7 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
           ox = xx;
           oy = xy;
         }
-        gn_row(cam_P + (size_t)view * 16, ox, oy, X, w);
+        gn_row(cam_P + (size_t)view * 16, ox, oy, X, w, L.cams_mid_range != 0);
         L.prod[0][lane] = w.j00 * w.j00;
         L.prod[1][lane] = w.j10 * w.j10;
         L.prod[2][lane] = w.j00 * w.j01;
@@ -275,7 +325,7 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
             ox = xx;
             oy = xy;
           }
-          gn_row(cam_P + (size_t)view * 16, ox, oy, X, w);
+          gn_row(cam_P + (size_t)view * 16, ox, oy, X, w, L.cams_mid_range != 0);
         }
         L.prod[0][lane] = ((I00 * w.j00 + I01 * w.j01) + I02 * w.j02) * w.r0;
         L.prod[1][lane] = ((I00 * w.j10 + I01 * w.j11) + I02 * w.j12) * w.r1;

@@ -1086,6 +1086,8 @@ __global__ void __launch_bounds__(64, EG3D_K3B_WAVES) k3b_expand(DevScene s, Sta
   }
   TeamWave tm;
   tm.L = &lds;
+  if (lane == 0) lds.cams_mid_range = s.cams_mid_range ? 1 : 0;
+  __syncthreads();
   // wave-uniform descriptors: kept in scalar registers for the chain's whole life (as vector registers they would be
   // 17 of the 168 the kernel may use, and spilled)
   const ChainSeed cs = tm.uni(chains[j]);

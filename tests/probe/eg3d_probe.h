@@ -16,6 +16,12 @@ int eg3d_probe_arith(uint64_t n, const double* a, const double* b, const double*
 int eg3d_probe_dlt_rows(void); /* the DLT form the probe was compiled with (EG3D_DLT_ROWS) */
 int eg3d_probe_triangulate(const float* cam_P, int n_views, uint64_t n_cases, int k, const int32_t* views, const float* xy,
                            float* X, uint8_t* valid, double* dlt_X0);
+/* the shared-reciprocal division of the Gauss-Newton rows: out[0..n) = num/den, out[n..2n) = gn_div(num, gn_recip(den)),
+ * out[2n..3n) = 1.0 where den is in the admitted range */
+int eg3d_probe_gn_div(uint64_t n, const double* num, const double* den, double* out3n);
+/* GnRow (j00 j01 j02 j10 j11 j12 r0 r1) of n rows with the plain divisions (out[0..8n)) and through the guarded fast
+ * path (out[8n..16n)); P16 = one 4x4 camera matrix per row */
+int eg3d_probe_gn_rows(uint64_t n, const float* P16, const float* oxy, const double* X, double* out16n);
 #ifdef __cplusplus
 }
 #endif

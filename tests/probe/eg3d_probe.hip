@@ -8,6 +8,7 @@
 
 #include "eg3d_probe.h"
 #include "eg3d_dev_pipeline.h"
+#include "eg3d_dev_coopgn.h"
 
 using namespace eg3d;
 
@@ -126,5 +127,65 @@ extern "C" int eg3d_probe_triangulate(const float* cam_P, int n_views, uint64_t 
   (void)hipFree(dX);
   (void)hipFree(dval);
   (void)hipFree(ddlt);
+  return 0;
+}
+
+// ---- the shared-reciprocal divisions of the Gauss-Newton rows (eg3d_dev_coopgn.h) against plain divisions ----
+// pairs: out[0][i] = num / den (the compiler's full sequence), out[1][i] = gn_div(num, gn_recip(den)),
+// out[2][i] = 1 when den is in the range the row test admits. rows: GnRow of the plain and of the guarded fast path.
+__global__ void k_probe_gn_div(uint64_t n, const double* num, const double* den, double* out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = num[i] / den[i];
+  const GnRecip R = gn_recip(den[i]);
+  out[n + i] = gn_div(num[i], R);
+  out[2 * n + i] = gn_mid_range(den[i]) ? 1.0 : 0.0;
+}
+__global__ void k_probe_gn_rows(uint64_t n, const float* P, const float* oxy, const double* X, double* out) {
+  uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double Xi[3] = {X[3 * i], X[3 * i + 1], X[3 * i + 2]};
+  GnRow a, b;
+  gn_row(P + 16 * i, oxy[2 * i], oxy[2 * i + 1], Xi, a, false);
+  gn_row(P + 16 * i, oxy[2 * i], oxy[2 * i + 1], Xi, b, true);
+  const double va[8] = {a.j00, a.j01, a.j02, a.j10, a.j11, a.j12, a.r0, a.r1};
+  const double vb[8] = {b.j00, b.j01, b.j02, b.j10, b.j11, b.j12, b.r0, b.r1};
+  for (int k = 0; k < 8; k++) {
+    out[(size_t)k * n + i] = va[k];
+    out[(size_t)(8 + k) * n + i] = vb[k];
+  }
+}
+extern "C" int eg3d_probe_gn_div(uint64_t n, const double* num, const double* den, double* out3n) {
+  double *dn, *dd, *dout;
+  PT(hipMalloc(&dn, n * 8));
+  PT(hipMalloc(&dd, n * 8));
+  PT(hipMalloc(&dout, n * 8 * 3));
+  PT(hipMemcpy(dn, num, n * 8, hipMemcpyHostToDevice));
+  PT(hipMemcpy(dd, den, n * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_probe_gn_div, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, n, dn, dd, dout);
+  PT(hipDeviceSynchronize());
+  PT(hipMemcpy(out3n, dout, n * 8 * 3, hipMemcpyDeviceToHost));
+  (void)hipFree(dn);
+  (void)hipFree(dd);
+  (void)hipFree(dout);
+  return 0;
+}
+extern "C" int eg3d_probe_gn_rows(uint64_t n, const float* P16, const float* oxy, const double* X, double* out16n) {
+  float *dP, *dxy;
+  double *dX, *dout;
+  PT(hipMalloc(&dP, n * 64));
+  PT(hipMalloc(&dxy, n * 8));
+  PT(hipMalloc(&dX, n * 24));
+  PT(hipMalloc(&dout, n * 8 * 16));
+  PT(hipMemcpy(dP, P16, n * 64, hipMemcpyHostToDevice));
+  PT(hipMemcpy(dxy, oxy, n * 8, hipMemcpyHostToDevice));
+  PT(hipMemcpy(dX, X, n * 24, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_probe_gn_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, n, dP, dxy, dX, dout);
+  PT(hipDeviceSynchronize());
+  PT(hipMemcpy(out16n, dout, n * 8 * 16, hipMemcpyDeviceToHost));
+  (void)hipFree(dP);
+  (void)hipFree(dxy);
+  (void)hipFree(dX);
+  (void)hipFree(dout);
   return 0;
 }

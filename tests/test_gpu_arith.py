@@ -91,3 +91,58 @@ def _triangulation_check(c, s, ob):
         both_nan = np.isnan(d0).all() and np.isnan(dlt[i]).all()
         assert both_nan or np.array_equal(d0.view(np.uint64), dlt[i].view(np.uint64)), i
     assert n_deg > 0
+
+
+def test_shared_reciprocal_divisions_equal_plain_divisions(ctx):
+    """eg3d_dev_coopgn.h: a Gauss-Newton row divides two numbers by zH and six by zH^2 through TWO refined reciprocals
+    (rcp + 4 fma per divisor, mul + 2 fma per numerator) instead of eight full division sequences — only when a range
+    test guarantees that the full sequence would not rescale its operands. (1) On operand pairs inside the admitted
+    regime — divisor 2^-200..2^200 (zH^2), numerator zero or 2^-253..2^202 — the short form equals `num / den` bit for
+    bit, signs of zero included; (2) whole rows through the guarded path equal the plain rows bit for bit on realistic
+    AND hostile inputs (tiny / huge / zero / NaN coordinates, cameras scaled by 1e+-24 or all zero: the guard must send
+    whatever leaves the regime to the plain divisions)."""
+    c, _ = ctx
+    c.eg3d_probe_gn_div.argtypes = [C.c_uint64, D.f64p, D.f64p, D.f64p]
+    c.eg3d_probe_gn_rows.argtypes = [C.c_uint64, D.f32p, D.f32p, D.f64p, D.f64p]
+    rng = np.random.default_rng(7)
+    n = 2000000
+    den = rng.standard_normal(n) * 2.0 ** rng.uniform(-200, 200, n)
+    den[np.abs(den) < 2.0 ** -200] = 1.5
+    num = rng.standard_normal(n) * 2.0 ** rng.uniform(-253, 202, n)
+    num[: n // 50] = 0.0
+    num[n // 50: n // 25] = -0.0
+    num[n // 25: n // 20] = den[n // 25: n // 20]                      # quotient exactly 1
+    num[n // 20: n // 10] = den[n // 20: n // 10] * rng.integers(1, 1 << 20, n // 10 - n // 20)   # exact quotients
+    # numbers one ulp around representable quotients (rounding ties of the division)
+    num[n // 10: n // 5] = np.nextafter(num[n // 10: n // 5], np.inf)
+    out = np.zeros(3 * n)
+    assert c.eg3d_probe_gn_div(n, D.np_ptr(num, C.c_double), D.np_ptr(den, C.c_double), D.np_ptr(out, C.c_double)) == 0
+    plain, fast = out[:n].view(np.uint64), out[n:2 * n].view(np.uint64)
+    bad = np.nonzero(plain != fast)[0]
+    assert len(bad) == 0, (len(bad), num[bad[:4]], den[bad[:4]], out[:n][bad[:4]], out[n:2 * n][bad[:4]])
+    assert np.array_equal(out[:n].view(np.uint64), (num / den).view(np.uint64))   # and both are the IEEE quotient
+    # ---- whole rows
+    s = host.Synth(4)
+    P = s.scene_np()["cam_P"].reshape(-1, 16)
+    m = 400000
+    Pi = np.ascontiguousarray(P[rng.integers(0, len(P), m)], np.float32)
+    X = rng.uniform(-150, 150, (m, 3))
+    oxy = rng.uniform(0, 1600, (m, 2)).astype(np.float32)
+    # hostile tail: points on / behind the camera plane, absurd magnitudes, zeros, NaN; cameras with tiny / huge / zero / NaN entries
+    k = m // 10
+    X[:k] *= 10.0 ** rng.integers(-40, 40, (k, 1))
+    X[k:2 * k, rng.integers(0, 3)] = 0.0
+    X[2 * k:2 * k + 50] = np.nan
+    X[2 * k + 50:2 * k + 100] = np.inf
+    X[2 * k + 100:2 * k + 200] = 0.0
+    # (camera entries stay zero or within 2^-100 .. 2^100: that half of the guard is eg3d_create's, checked on the host)
+    Pi[3 * k:4 * k] *= (10.0 ** rng.integers(-24, 24, (k, 1))).astype(np.float32)
+    Pi[4 * k:4 * k + 100] = 0.0
+    nz = Pi[:, :12][Pi[:, :12] != 0]
+    assert np.isfinite(Pi).all() and np.abs(nz).min() >= 2.0 ** -100 and np.abs(nz).max() <= 2.0 ** 100
+    X = np.ascontiguousarray(X)
+    out = np.zeros(16 * m)
+    assert c.eg3d_probe_gn_rows(m, D.np_ptr(Pi, C.c_float), D.np_ptr(oxy, C.c_float), D.np_ptr(X, C.c_double), D.np_ptr(out, C.c_double)) == 0
+    a, b = out[:8 * m].view(np.uint64), out[8 * m:].view(np.uint64)
+    same = (a == b) | (np.isnan(out[:8 * m]) & np.isnan(out[8 * m:]))
+    assert same.all(), int((~same).sum())

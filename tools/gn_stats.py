@@ -18,3 +18,6 @@ print("row-iterations useful", b[68], " lane-iterations held", b[67], " utilisat
 print("requests by iterations:", {i: b[i] for i in range(32) if b[i]})
 print("rounds by iterations:  ", {i: b[32 + i] for i in range(32) if b[32 + i]})
 print("long requests", b[102], "long rounds", b[103], "by iterations:", {i: b[70 + i] for i in range(32) if b[70 + i]})
+names = ["rows", "product stores+barrier", "pass-1 sums", "gsum+inverse", "pass-2 products", "pass-2 sums", "update", "round total"]
+tot = b[111] or 1
+print("ticks inside gn_round:", {names[i]: "%.1f%%" % (100.0 * b[104 + i] / tot) for i in range(7)}, "round total %.3e" % b[111], "coop_gn_groups total %.3e (set-up share %.1f%%)" % (b[112], 100.0 * (b[112] - b[111]) / max(1, b[112])))
