@@ -84,8 +84,14 @@ struct GnRow {
 // [70..101] LONG requests by iterations, [102] long requests, [103] long rounds
 __device__ unsigned long long g_gn_dbg[128];
 #define EG3D_GN_DBG(i, v) atomicAdd(&g_gn_dbg[i], (unsigned long long)(v))
+// [104..110] shader-clock ticks inside gn_round: rows (+ their product stores), barrier, pass-1 sums, gsum + inverse,
+// pass-2 products, pass-2 sums, update; [111] whole rounds; [112] coop_gn_groups incl. its set-up
+#define EG3D_GN_T0() unsigned long long gt_ = __builtin_readcyclecounter(), gtn_
+#define EG3D_GN_T(i) (gtn_ = __builtin_readcyclecounter(), gts_[i] += gtn_ - gt_, gt_ = gtn_)
 #else
 #define EG3D_GN_DBG(i, v) ((void)0)
+#define EG3D_GN_T0() ((void)0)
+#define EG3D_GN_T(i) ((void)0)
 #endif
 // ---- the eight divisions of a row with TWO shared reciprocals -------------------------------------------------
 // A correctly rounded FP64 division is, on gfx950, the sequence  sd = div_scale(den), sn = div_scale(num),
@@ -215,10 +221,15 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
   double last_mse = 0;
   const double two_n = (double)(n * 2);
   int dbg_it = 0, dbg_round = 0;
+#if defined(EG3D_SECTION_TIMING)
+  unsigned long long gts_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long gt_begin_ = __builtin_readcyclecounter();
+#endif
   for (int it = 0; it < 30; it++) {
     if (!__any(!done)) break;
     dbg_round++;
     if (!done) dbg_it++;
+    EG3D_GN_T0();
     // ---- pass 1: H (6) and mse; accumulator e lives in group lane e % G, slot e / G
     double acc[4] = {0, 0, 0, 0};
     GnRow w;
@@ -254,7 +265,9 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
         L.prod[12][lane] = w.r0 * w.r0;
         L.prod[13][lane] = w.r1 * w.r1;
       }
+      EG3D_GN_T(0);
       __syncthreads();
+      EG3D_GN_T(1);
       if (!done) {
         int rows = n - c * G;
         rows = rows > G ? G : rows;
@@ -267,6 +280,7 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
         }
       }
       __syncthreads();
+      EG3D_GN_T(2);
     }
     if (!done) {
 #pragma unroll
@@ -306,6 +320,7 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
       }
     }
     __syncthreads();  // the sums are rewritten by pass 2
+    EG3D_GN_T(3);
     if (!__any(!done)) break;
     // ---- pass 2: the update (H^-1 J^T) r, 3 accumulators; rows recomputed unless there is one chunk
     double dac[2] = {0, 0};
@@ -335,6 +350,7 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
         L.prod[5][lane] = ((I20 * w.j10 + I21 * w.j11) + I22 * w.j12) * w.r1;
       }
       __syncthreads();
+      EG3D_GN_T(4);
       if (!done) {
         int rows = n - c * G;
         rows = rows > G ? G : rows;
@@ -347,6 +363,7 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
         }
       }
       __syncthreads();
+      EG3D_GN_T(5);
     }
     if (!done) {
 #pragma unroll
@@ -362,6 +379,7 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
       X[2] += L.gsum[gs][2];
     }
     __syncthreads();
+    EG3D_GN_T(6);
   }
   if (act && !done) ok = last_mse < 9;
 #if defined(__HIP_DEVICE_COMPILE__) && defined(EG3D_SECTION_TIMING)
@@ -377,6 +395,8 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
     }
   }
   if (lane == 0) {
+    for (int q = 0; q < 7; q++) EG3D_GN_DBG(104 + q, gts_[q]);
+    EG3D_GN_DBG(111, __builtin_readcyclecounter() - gt_begin_);
     EG3D_GN_DBG(32 + (dbg_round < 31 ? dbg_round : 31), 1);
     EG3D_GN_DBG(67, 64 * dbg_round * cmax);
     EG3D_GN_DBG(69, 1);
@@ -393,6 +413,9 @@ __device__ __forceinline__ bool coop_gn_groups(const float* cam_P, CoopLds& L, b
                                                bool has_extra, int32_t ex_view, float ex_x, float ex_y,
                                                const float X0[3], float Xout[3]) {
   const int lane = (int)(threadIdx.x & 63u);
+#if defined(EG3D_SECTION_TIMING)
+  const unsigned long long gg_begin_ = __builtin_readcyclecounter();
+#endif
   const int n_req = want ? nblock + (has_extra ? 1 : 0) : 0;
   const bool is_short = want && n_req <= EG3D_GN_PACK_MAX;
   const bool is_long = want && n_req > EG3D_GN_PACK_MAX;
@@ -541,6 +564,9 @@ __device__ __forceinline__ bool coop_gn_groups(const float* cam_P, CoopLds& L, b
   Xout[2] = L.x0[lane][2];
   const bool res = want && L.res_ok[lane] != 0;
   __syncthreads();  // the table may be rewritten by the next window
+#if defined(EG3D_SECTION_TIMING)
+  if (lane == 0) EG3D_GN_DBG(112, __builtin_readcyclecounter() - gg_begin_);
+#endif
   return res;
 }
 
