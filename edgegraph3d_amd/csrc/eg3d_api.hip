@@ -121,6 +121,7 @@ struct HostGrids {
 //   EG3D_NO_LPT=1          launch chains in identity order instead of longest-first (diagnostic)
 struct Tunables {
   int k3a_team = -1, k3a_queue = -1;
+  int k3a_engine = 1, k3a_engine_waves = 0, k3a_engine_lanes = 0;  // EG3D_K3A_ENGINE / _WAVES (per SIMD) / _LANES
   uint32_t arena_cap0 = 0;
   size_t max_scratch = 0;  // 0 = no limit
   bool use_lpt = true;
@@ -128,6 +129,9 @@ struct Tunables {
     Tunables t;
     if (const char* e = getenv("EG3D_K3A_TEAM")) t.k3a_team = atoi(e);
     if (const char* e = getenv("EG3D_K3A_QUEUE")) t.k3a_queue = atoi(e);
+    if (const char* e = getenv("EG3D_K3A_ENGINE")) t.k3a_engine = atoi(e);
+    if (const char* e = getenv("EG3D_K3A_ENGINE_WAVES")) t.k3a_engine_waves = atoi(e);
+    if (const char* e = getenv("EG3D_K3A_ENGINE_LANES")) t.k3a_engine_lanes = atoi(e);
     if (const char* e = getenv("EG3D_ARENA_CAP0")) t.arena_cap0 = (uint32_t)std::max(16, atoi(e));
     if (const char* e = getenv("EG3D_MAX_SCRATCH_MB")) t.max_scratch = (size_t)std::max(1, atoi(e)) << 20;
     if (const char* e = getenv("EG3D_NO_LPT")) t.use_lpt = !(e[0] == '1');
@@ -852,20 +856,31 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
   // small batches are latency-bound by their slowest hypothesis: give each hypothesis a 4-lane team
   const int k3a_mode = c->tune.k3a_team;  // -1 auto, 0 lanes, 1 teams
   const bool team4 = k3a_mode < 0 ? (B.n_hyp <= 131072u) : (k3a_mode != 0);
+  const bool engine = c->tune.k3a_engine != 0;
+  // engine: single-wavefront blocks; a wave's lanes that take work are limited when there is little of it, so that
+  // each working lane gets more of the wave's 64 request slots
+  const uint32_t eng_waves_max = (c->k3a_blocks / 2u) * 4u * (uint32_t)(c->tune.k3a_engine_waves > 0 ? c->tune.k3a_engine_waves : 3);
+  uint32_t eng_lanes = 64;
+  if (c->tune.k3a_engine_lanes > 0)
+    eng_lanes = (uint32_t)std::min(64, c->tune.k3a_engine_lanes);
+  else
+    while (eng_lanes > 8 && (uint64_t)eng_waves_max * (eng_lanes / 2) >= B.n_hyp) eng_lanes /= 2;
+  const uint32_t eng_orient_waves = std::max<uint32_t>(1, std::min<uint32_t>(eng_waves_max, (B.n_hyp + eng_lanes - 1) / eng_lanes));
+  const uint32_t eng_follow_waves = eng_orient_waves;
   const uint32_t k3a_lanes_needed = B.n_hyp * (team4 ? 4u : 1u);
   const uint32_t k3a_blocks =
       std::max<uint32_t>(1, std::min<uint32_t>(c->k3a_blocks * (team4 ? 2u : 1u), (k3a_lanes_needed + 255) / 256));
-  BUF_TRY(c->b_hscratch.ensure(sizeof(HPoint) * 2 * c->hyp_cap * ((size_t)k3a_blocks * 256 / (team4 ? 4 : 1))));
+  if (!engine) BUF_TRY(c->b_hscratch.ensure(sizeof(HPoint) * 2 * c->hyp_cap * ((size_t)k3a_blocks * 256 / (team4 ? 4 : 1))));
   // throughput mode (1 lane per hypothesis): the lists are followed through a lane-level work queue
   // (2 items per hypothesis) — C3' K3a 19.6 -> 17.0 ms; with 4-lane teams (small, latency-bound
   // batches) the team's own two-lane following is faster (C2 2.96 vs 3.34 ms). EG3D_K3A_QUEUE=0/1 forces.
   const int k3a_queue_mode = c->tune.k3a_queue;
-  const bool k3a_queue = k3a_queue_mode < 0 ? !team4 : (k3a_queue_mode != 0);
+  const bool k3a_queue = engine || (k3a_queue_mode < 0 ? !team4 : (k3a_queue_mode != 0));
   const uint32_t follow_blocks =
       std::max<uint32_t>(1, std::min<uint32_t>(c->k3a_blocks * 2u, (uint32_t)(((uint64_t)B.n_hyp * 2 + 255) / 256)));
   if (k3a_queue) {
-    BUF_TRY(c->b_fscratch.ensure(sizeof(HPoint) * c->hyp_cap * ((size_t)follow_blocks * 256)));
-    BUF_TRY(c->b_queue.ensure(sizeof(uint32_t)));
+    BUF_TRY(c->b_fscratch.ensure(sizeof(HPoint) * c->hyp_cap * (engine ? (size_t)eng_follow_waves * 64 : (size_t)follow_blocks * 256)));
+    BUF_TRY(c->b_queue.ensure(2 * sizeof(uint32_t)));
   }
   uint32_t arena_cap = std::max<uint32_t>(1u << 16, std::min<uint64_t>((uint64_t)B.n_hyp * (k3a_queue ? 32 : 24), 1ull << 26));
   if (c->tune.arena_cap0) arena_cap = c->tune.arena_cap0;  // tests: force the overflow-and-retry path
@@ -877,7 +892,12 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
     BUF_TRY(c->b_arena.ensure(sizeof(HPoint) * (size_t)arena_cap));
     HIP_TRY(hipMemsetAsync(c->b_ctr.p, 0, 2 * sizeof(uint32_t), st));  // arena_used, flags (keep bytes)
     HIP_TRY(hipEventRecord(c->ea[3], st));
-    if (k3a_queue) {
+    if (engine) {
+      HIP_TRY(hipMemsetAsync(c->b_queue.p, 0, 2 * sizeof(uint32_t), st));
+      launch_k3a_engine(st, eng_orient_waves, eng_follow_waves, eng_lanes, c->ds, B.a, c->b_tasks.as<TaskDesc>(),
+                        c->b_hyp_off.as<uint32_t>(), B.n_hyp, c->b_res.as<HypResult>(), c->b_fscratch.as<HPoint>(),
+                        c->hyp_cap, c->b_arena.as<HPoint>(), arena_cap, c->b_ctr.as<Counters>(), c->b_queue.as<uint32_t>());
+    } else if (k3a_queue) {
       HIP_TRY(hipMemsetAsync(c->b_queue.p, 0, sizeof(uint32_t), st));
       launch_k3a_queue(st, team4, k3a_blocks, follow_blocks, c->ds, B.a, c->b_tasks.as<TaskDesc>(),
                        c->b_hyp_off.as<uint32_t>(), B.n_hyp, c->b_res.as<HypResult>(), c->b_hscratch.as<HPoint>(),

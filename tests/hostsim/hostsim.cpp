@@ -4,12 +4,15 @@
 // pipeline (task_setup -> hypotheses -> select -> expand -> emit). Purpose: debug the kernel
 // logic against the CPU oracle on machines without a GPU. Stage A (K1/K2) is wave-cooperative
 // HIP code and cannot run here; the harness takes stage-A results as input.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 
 #include "../../include/eg3d.h"
 #include "../../include/eg3d_host.h"
+static unsigned long long g_stat[8], g_hist[2][16], g_hsum[2][16];
+#define EG3D_STAT(i) (g_stat[i]++)
 #include "eg3d_dev_pipeline.h"
 
 using namespace eg3d;
@@ -142,7 +145,18 @@ extern "C" int hostsim_match(const eg3d_scene* sc, const eg3d_seeds* seeds, uint
     for (uint32_t h = hyp_off[t]; h < hyp_off[t + 1]; h++) {
       Obs c[3];
       hypothesis_hits(a, tasks[t], t, h - hyp_off[t], c);
+      const unsigned long long tri_before = g_stat[1], ntri_before = g_stat[3];
       evaluate_hypothesis(HTeamSeq(), ds, c, s1.data(), s2.data(), hyp_cap, res[h]);
+      {  // sequential triangulations of this hypothesis: orientation phase / following (histograms by powers of two)
+        unsigned long long a1 = g_stat[1] - tri_before, a2 = g_stat[3] - ntri_before;
+        int b1 = 0, b2 = 0;
+        while ((1ull << b1) <= a1 && b1 < 15) b1++;
+        while ((1ull << b2) <= a2 && b2 < 15) b2++;
+        g_hist[0][b1]++;
+        g_hist[1][b2]++;
+        g_hsum[0][b1] += a1;
+        g_hsum[1][b2] += a2;
+      }
       flags |= res[h].flags;
       if (res[h].status & HYP_COMPAT) {
         res[h].pts1_off = (uint32_t)arena.size();
@@ -153,6 +167,39 @@ extern "C" int hostsim_match(const eg3d_scene* sc, const eg3d_seeds* seeds, uint
         arena.insert(arena.end(), s2.begin(), s2.begin() + res[h].n2);
       }
     }
+  if (getenv("HOSTSIM_HYP_STATS")) {  // outcome histogram of the hypothesis stage (a tool for sizing K3a's phases)
+    uint64_t n_tri = 0, n_d1 = 0, n_d2 = 0, n_compat = 0, sum_n1 = 0, sum_n2 = 0, h1[8] = {0}, follow_items = 0;
+    for (uint32_t h = 0; h < n_hyp; h++) {
+      const uint32_t st = res[h].status;
+      n_tri += !!(st & HYP_TRI);
+      n_d1 += !!(st & HYP_D1);
+      n_d2 += !!(st & HYP_D2);
+      n_compat += !!(st & HYP_COMPAT);
+      if (st & HYP_D1) {
+        sum_n1 += res[h].n1;
+        h1[res[h].n1 < 7 ? res[h].n1 : 7]++;
+        follow_items++;
+      }
+      if (st & HYP_D2) {
+        sum_n2 += res[h].n2;
+        follow_items++;
+      }
+    }
+    fprintf(stderr,
+            "hostsim hyp stats: tasks %u hyp %u tri %llu d1 %llu d2 %llu compat %llu sum_n1 %llu sum_n2 %llu follow_items %llu "
+            "n1 histogram",
+            nt, n_hyp, (unsigned long long)n_tri, (unsigned long long)n_d1, (unsigned long long)n_d2,
+            (unsigned long long)n_compat, (unsigned long long)sum_n1, (unsigned long long)sum_n2,
+            (unsigned long long)follow_items);
+    for (int i = 0; i < 8; i++) fprintf(stderr, " %llu", (unsigned long long)h1[i]);
+    fprintf(stderr, "; calls: step3 %llu (its triangulations %llu) stepn3 starts %llu (its triangulations %llu)", g_stat[0],
+            g_stat[1], g_stat[2], g_stat[3]);
+    for (int w = 0; w < 2; w++) {
+      fprintf(stderr, "\n  %s: hypotheses (sum of triangulations) with [0], [1], [2-3], [4-7] ... of them:", w ? "following" : "orientation");
+      for (int i = 0; i < 12; i++) fprintf(stderr, " %llu (%llu)", g_hist[w][i], g_hsum[w][i]);
+    }
+    fprintf(stderr, "\n");
+  }
   // K3s
   std::vector<ChainSeed> chains;
   for (uint32_t t = 0; t < nt; t++) {
