@@ -164,7 +164,7 @@ struct eg3d_ctx {
   DevBuf o_X, o_off, o_view, o_pl, o_seg, o_xy, o_key;
   DevBuf f_X, f_off, f_view, f_xy, f_Xo, f_inl;
   DevBuf b_sets_off, b_sets_ids;  // polyline sets of the current eg3d_match_polyline_sets call
-  DevBuf b_fscratch, b_queue;     // K3a following: per-lane staging lists, work-queue head
+  DevBuf b_fscratch, b_queue, b_items;  // K3a following: per-lane staging lists, work-queue heads, the lists to follow
   // K3b: working slices of the resident chains (b_cscratch: 8 XCDs x slots_per_xcd slices), the slot pools,
   // and the staging area finished chains are packed into (sized from the previous launches; grow-only)
   DevBuf b_pools, b_stage_pts, b_stage_obs, b_stage_used;
@@ -615,7 +615,7 @@ extern "C" void eg3d_destroy(eg3d_ctx* c) {
                    &c->b_nhyp, &c->b_hyp_off, &c->b_res, &c->b_hscratch, &c->b_arena, &c->b_ctr, &c->b_cs_task,
                    &c->b_valid, &c->b_chain_off, &c->b_chains, &c->b_cscratch, &c->b_couts, &c->b_cpts, &c->b_cobs,
                    &c->b_cpoff, &c->b_cooff, &c->b_scan_tmp, &c->b_scanchk, &c->b_cost, &c->b_cidx, &c->b_cost2, &c->b_order, &c->o_X, &c->o_off, &c->o_view, &c->o_pl, &c->o_seg,
-                   &c->o_xy, &c->o_key, &c->f_X, &c->f_off, &c->f_view, &c->f_xy, &c->f_Xo, &c->f_inl, &c->b_sets_off, &c->b_sets_ids, &c->b_fscratch, &c->b_queue,
+                   &c->o_xy, &c->o_key, &c->f_X, &c->f_off, &c->f_view, &c->f_xy, &c->f_Xo, &c->f_inl, &c->b_sets_off, &c->b_sets_ids, &c->b_fscratch, &c->b_queue, &c->b_items,
                    &c->b_pools, &c->b_stage_pts, &c->b_stage_obs, &c->b_stage_used};
   for (DevBuf* b : all) b->release();
   if (c->pinned) (void)hipHostFree(c->pinned);
@@ -880,7 +880,8 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
       std::max<uint32_t>(1, std::min<uint32_t>(c->k3a_blocks * 2u, (uint32_t)(((uint64_t)B.n_hyp * 2 + 255) / 256)));
   if (k3a_queue) {
     BUF_TRY(c->b_fscratch.ensure(sizeof(HPoint) * c->hyp_cap * (engine ? (size_t)eng_follow_waves * 64 : (size_t)follow_blocks * 256)));
-    BUF_TRY(c->b_queue.ensure(2 * sizeof(uint32_t)));
+    BUF_TRY(c->b_queue.ensure(4 * sizeof(uint32_t)));
+    if (engine) BUF_TRY(c->b_items.ensure(sizeof(uint32_t) * 2 * ((size_t)B.n_hyp + 1)));
   }
   uint32_t arena_cap = std::max<uint32_t>(1u << 16, std::min<uint64_t>((uint64_t)B.n_hyp * (k3a_queue ? 32 : 24), 1ull << 26));
   if (c->tune.arena_cap0) arena_cap = c->tune.arena_cap0;  // tests: force the overflow-and-retry path
@@ -893,10 +894,11 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
     HIP_TRY(hipMemsetAsync(c->b_ctr.p, 0, 2 * sizeof(uint32_t), st));  // arena_used, flags (keep bytes)
     HIP_TRY(hipEventRecord(c->ea[3], st));
     if (engine) {
-      HIP_TRY(hipMemsetAsync(c->b_queue.p, 0, 2 * sizeof(uint32_t), st));
+      HIP_TRY(hipMemsetAsync(c->b_queue.p, 0, 4 * sizeof(uint32_t), st));
       launch_k3a_engine(st, eng_orient_waves, eng_follow_waves, eng_lanes, c->ds, B.a, c->b_tasks.as<TaskDesc>(),
                         c->b_hyp_off.as<uint32_t>(), B.n_hyp, c->b_res.as<HypResult>(), c->b_fscratch.as<HPoint>(),
-                        c->hyp_cap, c->b_arena.as<HPoint>(), arena_cap, c->b_ctr.as<Counters>(), c->b_queue.as<uint32_t>());
+                        c->hyp_cap, c->b_arena.as<HPoint>(), arena_cap, c->b_ctr.as<Counters>(), c->b_queue.as<uint32_t>(),
+                        c->b_items.as<uint32_t>());
     } else if (k3a_queue) {
       HIP_TRY(hipMemsetAsync(c->b_queue.p, 0, sizeof(uint32_t), st));
       launch_k3a_queue(st, team4, k3a_blocks, follow_blocks, c->ds, B.a, c->b_tasks.as<TaskDesc>(),

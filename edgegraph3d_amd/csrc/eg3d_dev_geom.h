@@ -39,6 +39,10 @@
 #define EG3D_SQRT(x) sqrt(x)
 #endif
 
+#ifndef EG3D_STAT
+#define EG3D_STAT(i) /* call counters of the host simulation (tests/hostsim); nothing on the device */
+#endif
+
 namespace eg3d {
 
 struct f2 {
@@ -308,6 +312,7 @@ EG3D_HD uint32_t walk_by_line(const PlRefT<VPtr>& pl, const PlPt& p, uint32_t di
   uint32_t seg_found = 0;
   bool got = false;
   const LineDir ld = line_dir(la, lb);
+  EG3D_STAT(5);
   if (direction == pl.start) {
     r = seg_line_hit_guarded(p.x, p.y, pl.v[p.seg].x, pl.v[p.seg].y, la, lb, lc, ld, hx, hy);
     if (r & 2u) return WALK_QUASIPARALLEL;
@@ -316,6 +321,7 @@ EG3D_HD uint32_t walk_by_line(const PlRefT<VPtr>& pl, const PlPt& p, uint32_t di
       seg_found = p.seg;
     } else {
       for (uint32_t i = p.seg; i > 0; i--) {
+        EG3D_STAT(6);
         r = seg_line_hit_guarded(pl.v[i].x, pl.v[i].y, pl.v[i - 1].x, pl.v[i - 1].y, la, lb, lc, ld, hx, hy);
         if (r & 2u) return WALK_QUASIPARALLEL;
         if (r & 1u) {
@@ -334,6 +340,7 @@ EG3D_HD uint32_t walk_by_line(const PlRefT<VPtr>& pl, const PlPt& p, uint32_t di
       seg_found = p.seg;
     } else {
       for (uint32_t i = p.seg + 1; i < pl.n - 1; i++) {
+        EG3D_STAT(6);
         r = seg_line_hit_guarded(pl.v[i].x, pl.v[i].y, pl.v[i + 1].x, pl.v[i + 1].y, la, lb, lc, ld, hx, hy);
         if (r & 2u) return WALK_QUASIPARALLEL;
         if (r & 1u) {
@@ -346,6 +353,126 @@ EG3D_HD uint32_t walk_by_line(const PlRefT<VPtr>& pl, const PlPt& p, uint32_t di
     }
   } else {
     return WALK_BAD_DIR;  // Q15: the reference leaves every flag false
+  }
+  out.seg = seg_found;
+  out.x = hx;
+  out.y = hy;
+  if (bounded) {
+    float dsq = dist2(hx, hy, p.x, p.y);
+    if (dsq < (min_d * min_d) || dsq > (max_d * max_d)) return WALK_BOUND;
+  }
+  return WALK_FOUND;
+}
+
+// The two walks with their vertex loads IN FLIGHT: the plain loops above fetch one vertex per segment, each a
+// dependent trip to memory (what a lane of the K3a engine spends its time on: a walk is ~5 segments of ~40
+// instructions, a trip ~1000 cycles). These keep a window of five vertices loaded ahead of the segment being tested
+// (indices clamped to the polyline), so a walk costs about one trip plus a fifth per segment. Same tests in the
+// same order on the same operands: same result, bit for bit (tests/test_cpu_parity.py compares them with the plain
+// walks on random polylines, both directions, every start segment).
+template <class VPtr>
+struct VtxWindow {
+  VPtr v;
+  int32_t first, stepv, hi;
+  f2 w0, w1, w2, w3, w4;
+  EG3D_HD f2 at(int32_t k) const {
+    int32_t j = first + stepv * k;
+    j = j < 0 ? 0 : (j > hi ? hi : j);
+    return v[j];
+  }
+  EG3D_HD void open(VPtr v_, int32_t first_, int32_t stepv_, int32_t hi_) {
+    v = v_;
+    first = first_;
+    stepv = stepv_;
+    hi = hi_;
+    w0 = at(0);
+    w1 = at(1);
+    w2 = at(2);
+    w3 = at(3);
+    w4 = at(4);
+  }
+  EG3D_HD void shift(int32_t k) {  // after the test of (u[k-1], u[k]): w0 becomes u[k]
+    w0 = w1;
+    w1 = w2;
+    w2 = w3;
+    w3 = w4;
+    w4 = at(k + 4);
+  }
+};
+
+template <class VPtr>
+EG3D_HD uint32_t walk_by_distance_pf(const PlRefT<VPtr>& pl, const PlPt& p, uint32_t direction, float distance, PlPt& out) {
+  const bool to_start = direction == pl.start;
+  if (!to_start && direction != pl.end) {
+    out = p;
+    return WALK_EXTREME | WALK_BAD_DIR;
+  }
+  const int32_t n = (int32_t)pl.n;
+  if (!to_start && (int32_t)p.seg >= n - 1) {
+    out.seg = (uint32_t)(n - 2);
+    out.x = pl.v[n - 1].x;
+    out.y = pl.v[n - 1].y;
+    return WALK_EXTREME;
+  }
+  const int32_t first = to_start ? (int32_t)p.seg : (int32_t)p.seg + 1;
+  const int32_t count = to_start ? first + 1 : n - first;  // vertices ahead: u[0] = v[first], ... up to the extreme
+  VtxWindow<VPtr> W;
+  W.open(pl.v, first, to_start ? -1 : 1, n - 1);
+  float prevdist = 0.0f, curdist = dist(W.w0.x, W.w0.y, p.x, p.y), ratio;
+  if (curdist >= distance) {
+    ratio = distance / curdist;
+    out.seg = p.seg;
+    lerp_from(p.x, p.y, W.w0.x, W.w0.y, ratio, out.x, out.y);
+    return WALK_FOUND;
+  }
+  int32_t k;
+  for (k = 1; k < count; k++) {
+    prevdist = curdist;
+    curdist = dist(W.w1.x, W.w1.y, p.x, p.y);
+    if (curdist >= distance) break;
+    W.shift(k);
+  }
+  if (k >= count) {
+    const int32_t e = to_start ? 0 : n - 1;
+    out.seg = to_start ? 0u : (uint32_t)(n - 2);
+    out.x = pl.v[e].x;
+    out.y = pl.v[e].y;
+    return WALK_EXTREME;
+  }
+  ratio = (distance - prevdist) / (curdist - prevdist);
+  out.seg = (uint32_t)(to_start ? first - k : first + k - 1);
+  lerp_from(W.w0.x, W.w0.y, W.w1.x, W.w1.y, ratio, out.x, out.y);
+  return WALK_FOUND;
+}
+
+template <class VPtr>
+EG3D_HD uint32_t walk_by_line_pf(const PlRefT<VPtr>& pl, const PlPt& p, uint32_t direction, float la, float lb, float lc,
+                                 bool bounded, float min_d, float max_d, PlPt& out) {
+  const bool to_start = direction == pl.start;
+  if (!to_start && direction != pl.end) return WALK_BAD_DIR;  // Q15: the reference leaves every flag false
+  const LineDir ld = line_dir(la, lb);
+  const int32_t n = (int32_t)pl.n;
+  const int32_t first = to_start ? (int32_t)p.seg : (int32_t)p.seg + 1;
+  const int32_t count = to_start ? first + 1 : n - first;
+  VtxWindow<VPtr> W;
+  W.open(pl.v, first, to_start ? -1 : 1, n - 1);
+  float hx = 0.0f, hy = 0.0f;
+  uint32_t seg_found = p.seg;
+  uint32_t r = seg_line_hit_guarded(p.x, p.y, W.w0.x, W.w0.y, la, lb, lc, ld, hx, hy);
+  if (r & 2u) return WALK_QUASIPARALLEL;
+  if (!(r & 1u)) {
+    bool got = false;
+    for (int32_t k = 1; k < count; k++) {
+      r = seg_line_hit_guarded(W.w0.x, W.w0.y, W.w1.x, W.w1.y, la, lb, lc, ld, hx, hy);
+      if (r & 2u) return WALK_QUASIPARALLEL;
+      if (r & 1u) {
+        got = true;
+        seg_found = (uint32_t)(to_start ? first - k : first + k - 1);
+        break;
+      }
+      W.shift(k);
+    }
+    if (!got) return WALK_EXTREME;
   }
   out.seg = seg_found;
   out.x = hx;

@@ -29,7 +29,27 @@
 #pragma once
 #include "eg3d_dev_pipeline.h"
 
+#include "eg3d_dev_coopgn.h"
+
 namespace eg3d {
+
+// timing build: shader clocks of a wave's phases, summed over the launch (g_gn_dbg[113 + 7*kernel ..]: advance, serve,
+// consume, iterations, requests served, working lanes, serve passes) — tools/k3a_stats.py
+#ifdef EG3D_SECTION_TIMING
+#define K3A_T0() unsigned long long kt_[3] = {0, 0, 0}, kc_[4] = {0, 0, 0, 0}, kt0_ = __builtin_readcyclecounter(), kt1_
+#define K3A_T(i) (kt1_ = __builtin_readcyclecounter(), kt_[i] += kt1_ - kt0_, kt0_ = kt1_)
+#define K3A_C(i, v) (kc_[i] += (v))
+#define K3A_TEND(kern)                                                \
+  if (lane == 0) {                                                    \
+    for (int q_ = 0; q_ < 3; q_++) EG3D_GN_DBG(113 + 7 * (kern) + q_, kt_[q_]); \
+    for (int q_ = 0; q_ < 4; q_++) EG3D_GN_DBG(116 + 7 * (kern) + q_, kc_[q_]); \
+  }
+#else
+#define K3A_T0() ((void)0)
+#define K3A_T(i) ((void)0)
+#define K3A_C(i, v) ((void)0)
+#define K3A_TEND(kern) ((void)0)
+#endif
 
 #ifndef EG3D_K3A_SPEC
 #define EG3D_K3A_SPEC 8 /* most requests one lane may issue per iteration (look-ahead depth) */
@@ -40,9 +60,11 @@ struct K3aShared {
   float resX[64][3];       // served: the point
   uint32_t resF[64];       // served: bit 0 = valid point, bits 8.. = EG3D_FLAG_* raised by the triangulation
   uint32_t reqM[64];       // issued: bit 0 = slot holds a request; follow: bits 8-9 = starting observation, 16.. = walk flags
-  uint32_t pos[8][3][64];  // per-lane positions (seg, x, y): orientation 0-2 = the hits, 3 = A, 4-5 = B[dir], 6-7 = C[dir];
+  uint32_t pos[6][3][64];  // per-lane positions (seg, x, y): orientation 0 = A, 1-2 = B[dir], 3-4 = C[dir];
                            // following 0-2 = the list's last point, 3-5 = the base the next request is generated from
+  uint32_t plr[3][4][64];  // per-lane polylines of the hypothesis' three views: first vertex, vertex count, start / end node
 };
+static_assert(sizeof(K3aShared) <= 12800, "K3aShared must fit 10 LDS allocation units (12 single-wave blocks per CU)");
 
 struct K3aLane {
   K3aShared* sh;
@@ -58,6 +80,23 @@ struct K3aLane {
     sh->pos[e][0][lane] = p.seg;
     sh->pos[e][1][lane] = __float_as_uint(p.x);
     sh->pos[e][2][lane] = __float_as_uint(p.y);
+  }
+  // the polyline of slot k, looked up once per hypothesis / list (polyline_of is two dependent trips to memory)
+  __device__ __forceinline__ void load_polyline(const DevScene& s, int k, int view, uint32_t pl_id) const {
+    const uint32_t g = s.view_pl_off[view] + pl_id;
+    const uint32_t a = s.pl_vtx_off[g], b = s.pl_vtx_off[g + 1];
+    sh->plr[k][0][lane] = a;
+    sh->plr[k][1][lane] = b - a;
+    sh->plr[k][2][lane] = s.pl_start[g];
+    sh->plr[k][3][lane] = s.pl_end[g];
+  }
+  __device__ __forceinline__ PlRef polyline(const DevScene& s, int k) const {
+    PlRef r;
+    r.v = s.vtx + sh->plr[k][0][lane];
+    r.n = sh->plr[k][1][lane];
+    r.start = sh->plr[k][2][lane];
+    r.end = sh->plr[k][3][lane];
+    return r;
   }
 };
 
@@ -100,64 +139,221 @@ __device__ __forceinline__ HPoint k3a_point_of_slot(const K3aShared& sh, uint32_
 // ---------------------------------------------------------------- orientation --------
 // One lane per hypothesis: triangulate the three hits, orientation search from A's first extreme (and from the
 // other one if that fails), replay of the surviving combination's points into the arena, the single step in the
-// opposite direction. Leaves in res[h] what k3a_follow_spec extends: status (TRI, D1, D2), n1 / n2 and the
-// offsets of the initial lists, the directions, the central point, the flags.
+// opposite direction. Leaves in res[h] what k3a_follow_spec extends — status (TRI, D1, D2), n1 / n2 and the offsets
+// of the initial lists, the directions, the central point, the flags — and appends the lists to follow to `items`.
+//
+// A lane's state machine is run as a PIPELINE, each stage once per iteration and in this order, so that the wave
+// executes every stage's code once however its lanes are spread over the states (a free-running loop executed the
+// walks up to five times per iteration: 77 % of the wave's time): END (evaluate the answers of a round: next round,
+// other extreme, replay, opposite step, or write the result) -> IDLE (take the next hypothesis) -> GEN (walk a round
+// and issue its requests; with slots to spare walk and issue the next rounds too) -> REQ (requests not yet issued).
+// Looking ahead is safe in the search: positions are kept per polyline direction and never depend on which
+// combinations are alive, a dead combination's later answers are ignored, and the two flags a step can raise
+// (direction mismatch, degenerate DLT) depend on the polylines, directions and views only — a looked-ahead round can
+// only repeat flags its first round raised.
 enum : uint32_t { K3A_IDLE = 0, K3A_GEN = 1, K3A_REQ = 2, K3A_END = 3 };
 enum : uint32_t { K3A_TRI0 = 0, K3A_ORIENT = 1, K3A_REPLAY = 2, K3A_OPP = 3 };
 
 __global__ void __launch_bounds__(64, EG3D_K3A_WAVES) k3a_orient(DevScene s, StageAView a, const TaskDesc* tasks,
                                                                  const uint32_t* hyp_off, uint32_t n_hyp, HypResult* res,
                                                                  uint32_t cap, HPoint* arena, uint32_t arena_cap,
-                                                                 Counters* ctr, uint32_t* queue, uint32_t lanes_per_wave) {
+                                                                 Counters* ctr, uint32_t* queue, uint32_t lanes_per_wave,
+                                                                 uint32_t* items, uint32_t* n_items) {
   __shared__ K3aShared sh;
   const uint32_t lane = threadIdx.x;
   const K3aLane L{&sh, lane};
   const unsigned long long lt = (1ull << lane) - 1ull;
   uint32_t st = K3A_IDLE, phase = K3A_TRI0;
   bool exhausted = lane >= lanes_per_wave;  // small batches: fewer working lanes per wave = more slots for each
-  uint32_t h = 0, e = 0, rounds = 0, alive = 0, reqmask = 0, okmask = 0, flags = 0, status = 0;
+  uint32_t h = 0, t_cur = 0, e = 0, rounds = 0, alive = 0, reqmask = 0, okmask = 0, flags = 0, status = 0;
   uint32_t n1 = 0, n2 = 0, i_rep = 0, base = 0xffffffffu;
+  uint32_t dead_round = 0xffffffffu;  // a looked-ahead round in which no combination found its walks
   bool arena_ok = false;
   int32_t view[3] = {0, 0, 0};
   uint32_t pl[3] = {0, 0, 0};
   uint32_t dirA = 0, dirB[2] = {0, 0}, dirC[2] = {0, 0};
   uint32_t d1[3] = {0, 0, 0}, d2[3] = {0, 0, 0};
   float X0[3] = {0.0f, 0.0f, 0.0f};
+  // positions back to the three hits (A; both directions of B and of C)
+  auto to_hits = [&](const Obs c[3]) {
+    PlPt p;
+    p.seg = c[0].seg;
+    p.x = c[0].x;
+    p.y = c[0].y;
+    L.set(0, p);
+    p.seg = c[1].seg;
+    p.x = c[1].x;
+    p.y = c[1].y;
+    L.set(1, p);
+    L.set(2, p);
+    p.seg = c[2].seg;
+    p.x = c[2].x;
+    p.y = c[2].y;
+    L.set(3, p);
+    L.set(4, p);
+  };
+  auto reload_hits = [&]() {  // (restarts are rare: the hits are fetched again instead of being kept)
+    Obs c[3];
+    hypothesis_hits(a, tasks[t_cur], t_cur, h - hyp_off[t_cur], c);
+    to_hits(c);
+  };
+  // request of combination q = 2*b + c from the current positions, tagged with the round it belongs to
+  auto issue = [&](uint32_t slot, int q, uint32_t round_off) {
+    const PlPt pA = L.get(0), pB = L.get(1 + (q >> 1)), pC = L.get(3 + (q & 1));
+    Obs o;
+    o.view = (uint32_t)view[0];
+    o.pl = pl[0];
+    o.seg = pA.seg;
+    o.x = pA.x;
+    o.y = pA.y;
+    sh.req[slot][0] = o;
+    o.view = (uint32_t)view[1];
+    o.pl = pl[1];
+    o.seg = pB.seg;
+    o.x = pB.x;
+    o.y = pB.y;
+    sh.req[slot][1] = o;
+    o.view = (uint32_t)view[2];
+    o.pl = pl[2];
+    o.seg = pC.seg;
+    o.x = pC.x;
+    o.y = pC.y;
+    sh.req[slot][2] = o;
+    sh.reqM[slot] = 1u | ((uint32_t)q << 8) | (round_off << 10);
+  };
+  K3A_T0();
 
   for (;;) {
     const unsigned long long working = __ballot(!(st == K3A_IDLE && exhausted));
     if (!working) break;
+    K3A_C(0, 1);
+    K3A_C(2, __popcll(working));
     const uint32_t K = k3a_slots_per_lane((uint32_t)__popcll(working));
     const uint32_t slot0 = (uint32_t)__popcll(working & lt) * K;
     sh.reqM[lane] = 0;
     __syncthreads();
-    uint32_t n_issued = 0, issued_mask = 0;
-    // ---- (1) + (2): advance until this lane has issued requests for this iteration, or has nothing left to do
-    bool chain = false;  // a replay that walks ahead: keeps advancing although it has issued already
-    while ((n_issued == 0 || chain) && !(st == K3A_IDLE && exhausted)) {
-      if (st == K3A_IDLE) {
-        const uint32_t i = atomicAdd(queue, 1u);
-        if (i >= n_hyp) {
-          exhausted = true;
-          break;
+    uint32_t n_issued = 0;
+    // ---- END: every request of the round has been answered (okmask), or the round had none
+    if (st == K3A_END) {
+      bool finish = false, to_d1 = false, restart = false;
+      if (phase == K3A_TRI0) {
+        if (okmask & 1u) {
+          status |= HYP_TRI;
+          e = 0;
+          phase = K3A_ORIENT;
+          restart = true;
+        } else {
+          finish = true;
         }
+      } else if (phase == K3A_ORIENT) {
+        // (alive / rounds were brought up to date by the consumer)
+        const int amount = __popc(alive);
+        if (amount > 1) {
+          st = K3A_GEN;
+        } else if (amount == 1) {
+          to_d1 = true;
+        } else if (e == 0) {
+          e = 1;
+          reload_hits();
+          restart = true;
+        } else {
+          finish = true;
+        }
+      } else if (phase == K3A_REPLAY) {
+        if (i_rep < n1) {
+          st = K3A_GEN;
+        } else if (e == 0) {
+          // the opposite direction is tested once, and only when A was followed towards its start
+          phase = K3A_OPP;
+          dirA = d2[0];
+          dirB[0] = d2[1];
+          dirC[0] = d2[2];
+          alive = 1u;
+          reload_hits();
+          st = K3A_GEN;
+        } else {
+          finish = true;
+        }
+      } else {  // K3A_OPP
+        finish = true;
+      }
+      if (restart) {  // the search from extreme e
+        rounds = 0;
+        alive = 15u;
+        dirA = sh.plr[0][e == 0 ? 2 : 3][lane];
+        dirB[0] = sh.plr[1][2][lane];
+        dirB[1] = sh.plr[1][3][lane];
+        dirC[0] = sh.plr[2][2][lane];
+        dirC[1] = sh.plr[2][3][lane];
+        st = K3A_GEN;
+      }
+      if (to_d1) {
+        const int qs = __ffs((int)alive) - 1;
+        const PlRef pa = L.polyline(s, 0), pb = L.polyline(s, 1), pc = L.polyline(s, 2);
+        status |= HYP_D1;
+        d1[0] = dirA;
+        d1[1] = dirB[qs >> 1];
+        d1[2] = dirC[qs & 1];
+        d2[0] = (pa.start == d1[0]) ? pa.end : pa.start;
+        d2[1] = (pb.start == d1[1]) ? pb.end : pb.start;
+        d2[2] = (pc.start == d1[2]) ? pc.end : pc.start;
+        if (rounds > cap) flags |= 4u;
+        n1 = rounds < cap ? rounds : cap;
+        const uint32_t need = n1 + (e == 0 ? 1u : 0u);
+        base = atomicAdd(&ctr->arena_used, need);
+        arena_ok = base + need <= arena_cap;
+        if (!arena_ok) atomicOr(&ctr->flags, CTR_ARENA_OVERFLOW);
+        // replay: the surviving combination alone, from the hits
+        phase = K3A_REPLAY;
+        i_rep = 0;
+        dirA = d1[0];
+        dirB[0] = d1[1];
+        dirC[0] = d1[2];
+        alive = 1u;
+        reload_hits();
+        st = K3A_GEN;  // (n1 >= 1: the survivor made at least the round that singled it out)
+      }
+      if (finish) {
+        HypResult r;
+        r.status = status;
+        r.n1 = n1;
+        r.n2 = n2;
+        for (int k = 0; k < 3; k++) {
+          r.dirs1[k] = d1[k];
+          r.dirs2[k] = d2[k];
+          r.X[k] = X0[k];
+        }
+        r.flags = flags;
+        r.pts1_off = ((status & HYP_D1) && arena_ok) ? base : 0xffffffffu;
+        r.pts2_off = ((status & HYP_D2) && arena_ok) ? base + n1 : 0xffffffffu;
+        res[h] = r;
+        if (flags) atomicOr(&ctr->flags, flags);
+        if ((status & HYP_D1) && arena_ok) {  // the lists k3a_follow_spec extends
+          const uint32_t cnt = (status & HYP_D2) ? 2u : 1u;
+          const uint32_t at = atomicAdd(n_items, cnt);
+          items[at] = 2u * h;
+          if (cnt == 2u) items[at + 1] = 2u * h + 1u;
+        }
+        st = K3A_IDLE;
+      }
+    }
+    // ---- IDLE: the next hypothesis; its first request is the triangulation of the hits themselves
+    if (st == K3A_IDLE && !exhausted) {
+      const uint32_t i = atomicAdd(queue, 1u);
+      if (i >= n_hyp) {
+        exhausted = true;
+      } else {
         h = i;
-        const uint32_t t = find_owner(hyp_off, a.n_tasks, h);
-        const TaskDesc d = tasks[t];
+        t_cur = find_owner(hyp_off, a.n_tasks, h);
+        const TaskDesc d = tasks[t_cur];
         Obs c[3];
-        hypothesis_hits(a, d, t, h - hyp_off[t], c);
+        hypothesis_hits(a, d, t_cur, h - hyp_off[t_cur], c);
         for (int k = 0; k < 3; k++) {
           view[k] = (int32_t)c[k].view;
           pl[k] = c[k].pl;
-          PlPt p;
-          p.seg = c[k].seg;
-          p.x = c[k].x;
-          p.y = c[k].y;
-          L.set(k, p);
+          L.load_polyline(s, k, view[k], pl[k]);
         }
-        L.set(3, L.get(0));
-        L.set(4, L.get(1));
-        L.set(6, L.get(2));
+        to_hits(c);
         status = 0;
         flags = 0;
         n1 = n2 = 0;
@@ -169,18 +365,24 @@ __global__ void __launch_bounds__(64, EG3D_K3A_WAVES) k3a_orient(DevScene s, Sta
         reqmask = 1u;
         okmask = 0;
         st = K3A_REQ;
-      } else if (st == K3A_GEN) {
-        // the walks of one round: +10 px on A; next epipolar hit (unbounded) on B / C for every direction a
-        // live combination uses (combination q = 2*b + c)
-        uint32_t fl = 0, m = alive;
-        const PlRef pa = polyline_of(s, view[0], pl[0]);
+      }
+    }
+    // ---- GEN: walk a round and issue its requests; with slots to spare, the rounds behind it too
+    dead_round = 0xffffffffu;
+    if (st == K3A_GEN) {
+      uint32_t walkers = alive;  // the combinations this round is walked for
+      for (uint32_t round_off = 0;; round_off++) {
+        // +10 px on A; next epipolar hit (unbounded) on B / C for every direction a live combination uses
+        // (combination q = 2*b + c; the walk on C is made for the combinations whose walk on B found something)
+        uint32_t fl = 0, m = walkers;
+        const PlRef pa = L.polyline(s, 0);
         PlPt q;
-        const uint32_t w = walk_by_distance(pa, L.get(3), dirA, EG3D_FOLLOW_STEP, q);
+        const uint32_t w = walk_by_distance_pf(pa, L.get(0), dirA, EG3D_FOLLOW_STEP, q);
         if (w & WALK_BAD_DIR) fl |= 8u;
         if (w & WALK_EXTREME) {
           m = 0;
         } else {
-          L.set(3, q);
+          L.set(0, q);
           float la = 0.0f, lb = 0.0f, lc = 0.0f;
           PlRef pk = pa;
 #pragma unroll 1
@@ -192,213 +394,147 @@ __global__ void __launch_bounds__(64, EG3D_K3A_WAVES) k3a_orient(DevScene s, Sta
                 m = 0;  // step3 fails here for every combination
                 break;
               }
-              pk = polyline_of(s, view[k], pl[k]);
+              pk = L.polyline(s, k);
             }
             if (!(m & users)) continue;
             PlPt r;
-            const uint32_t wr = walk_by_line(pk, L.get(2 * k + 2 + j), k == 1 ? dirB[j] : dirC[j], la, lb, lc, false, 0.0f,
-                                             0.0f, r);
+            const uint32_t wr = walk_by_line_pf(pk, L.get(2 * k - 1 + j), k == 1 ? dirB[j] : dirC[j], la, lb, lc, false, 0.0f,
+                                                0.0f, r);
             if (wr & WALK_BAD_DIR) fl |= 8u;
             if (wr & WALK_FOUND)
-              L.set(2 * k + 2 + j, r);
+              L.set(2 * k - 1 + j, r);
             else
               m &= ~users;
           }
         }
-        if (phase != K3A_REPLAY)
-          flags |= fl;  // (the replay repeats steps whose flags are already counted)
-        else if (!m) {
-          n1 = i_rep + n_issued;  // (a replayed walk found nothing: cannot happen; the list ends there)
-          chain = false;
-        }
-        reqmask = m;
-        okmask = 0;
-        st = m ? K3A_REQ : K3A_END;
-      } else if (st == K3A_END) {
-        // all requests of the round are answered (okmask)
-        bool finish = false;
-        bool to_d1 = false;
-        if (phase == K3A_TRI0) {
-          if (okmask & 1u) {
-            status |= HYP_TRI;
-            e = 0;
-            phase = K3A_ORIENT;
-            rounds = 0;
-            alive = 15u;
-            st = K3A_GEN;
-          } else {
-            finish = true;
+        if (phase != K3A_REPLAY) flags |= fl;  // (the replay repeats steps whose flags are already counted)
+        if (round_off == 0) {
+          reqmask = m;
+          okmask = 0;
+          if (!m) {
+            if (phase == K3A_REPLAY) n1 = i_rep;  // (a replayed walk found nothing: cannot happen; the list ends there)
+            if (phase == K3A_ORIENT) {
+              alive = 0;
+              rounds++;
+            }
+            st = K3A_END;
+            break;
           }
-        } else if (phase == K3A_ORIENT) {
-          alive = okmask;
-          rounds++;
-          const int amount = __popc(alive);
-          if (amount > 1) {
-            st = K3A_GEN;
-          } else if (amount == 1) {
-            to_d1 = true;
-          } else if (e == 0) {
-            e = 1;
-            rounds = 0;
-            alive = 15u;
-            L.set(3, L.get(0));
-            L.set(4, L.get(1));
-            L.set(5, L.get(1));
-            L.set(6, L.get(2));
-            L.set(7, L.get(2));
-            st = K3A_GEN;
-          } else {
-            finish = true;
+          st = K3A_REQ;
+          while (reqmask && n_issued < K) {
+            const int qq = __ffs((int)reqmask) - 1;
+            reqmask &= reqmask - 1u;
+            issue(slot0 + n_issued, qq, 0u);
+            n_issued++;
           }
-        } else if (phase == K3A_REPLAY) {
-          if (i_rep < n1) {
-            st = K3A_GEN;
-          } else if (e == 0) {
-            // the opposite direction is tested once, and only when A was followed towards its start
-            phase = K3A_OPP;
-            dirA = d2[0];
-            dirB[0] = d2[1];
-            dirC[0] = d2[2];
-            alive = 1u;
-            L.set(3, L.get(0));
-            L.set(4, L.get(1));
-            L.set(6, L.get(2));
-            st = K3A_GEN;
-          } else {
-            finish = true;
+          if (reqmask) break;  // the rest of this round next iteration
+        } else {
+          if (!m) {
+            if (phase == K3A_REPLAY)
+              n1 = i_rep + round_off;
+            else
+              dead_round = round_off;
+            break;
           }
-        } else {  // K3A_OPP
-          finish = true;
-        }
-        if (phase == K3A_ORIENT && st == K3A_GEN && rounds == 0) {
-          // (re)start of the search: directions of this extreme
-          const PlRef pa = polyline_of(s, view[0], pl[0]);
-          const PlRef pb = polyline_of(s, view[1], pl[1]);
-          const PlRef pc = polyline_of(s, view[2], pl[2]);
-          dirA = e == 0 ? pa.start : pa.end;
-          dirB[0] = pb.start;
-          dirB[1] = pb.end;
-          dirC[0] = pc.start;
-          dirC[1] = pc.end;
-          L.set(5, L.get(1));
-          L.set(7, L.get(2));
-        }
-        if (to_d1) {
-          const int qs = __ffs((int)alive) - 1;
-          const PlRef pa = polyline_of(s, view[0], pl[0]);
-          const PlRef pb = polyline_of(s, view[1], pl[1]);
-          const PlRef pc = polyline_of(s, view[2], pl[2]);
-          status |= HYP_D1;
-          d1[0] = dirA;
-          d1[1] = dirB[qs >> 1];
-          d1[2] = dirC[qs & 1];
-          d2[0] = (pa.start == d1[0]) ? pa.end : pa.start;
-          d2[1] = (pb.start == d1[1]) ? pb.end : pb.start;
-          d2[2] = (pc.start == d1[2]) ? pc.end : pc.start;
-          if (rounds > cap) flags |= 4u;
-          n1 = rounds < cap ? rounds : cap;
-          const uint32_t need = n1 + (e == 0 ? 1u : 0u);
-          base = atomicAdd(&ctr->arena_used, need);
-          arena_ok = base + need <= arena_cap;
-          if (!arena_ok) atomicOr(&ctr->flags, CTR_ARENA_OVERFLOW);
-          // replay: the surviving combination alone, from the hits
-          phase = K3A_REPLAY;
-          i_rep = 0;
-          dirA = d1[0];
-          dirB[0] = d1[1];
-          dirC[0] = d1[2];
-          alive = 1u;
-          L.set(3, L.get(0));
-          L.set(4, L.get(1));
-          L.set(6, L.get(2));
-          st = n1 ? K3A_GEN : K3A_END;
-        }
-        if (finish) {
-          HypResult r;
-          r.status = status;
-          r.n1 = n1;
-          r.n2 = n2;
-          for (int k = 0; k < 3; k++) {
-            r.dirs1[k] = d1[k];
-            r.dirs2[k] = d2[k];
-            r.X[k] = X0[k];
+          uint32_t mm = m;
+          while (mm) {  // (fits: the look-ahead below checked the room)
+            const int qq = __ffs((int)mm) - 1;
+            mm &= mm - 1u;
+            issue(slot0 + n_issued, qq, round_off);
+            n_issued++;
           }
-          r.flags = flags;
-          r.pts1_off = ((status & HYP_D1) && arena_ok) ? base : 0xffffffffu;
-          r.pts2_off = ((status & HYP_D2) && arena_ok) ? base + n1 : 0xffffffffu;
-          res[h] = r;
-          if (flags) atomicOr(&ctr->flags, flags);
-          st = K3A_IDLE;
         }
-      } else {  // K3A_REQ: issue up to K of the round's requests
-        while (reqmask && n_issued < K) {
-          const int q = __ffs((int)reqmask) - 1;
-          reqmask &= reqmask - 1u;
-          const uint32_t slot = slot0 + n_issued;
-          const PlPt pA = L.get(3), pB = L.get(4 + (q >> 1)), pC = L.get(6 + (q & 1));
-          Obs o;
-          o.view = (uint32_t)view[0];
-          o.pl = pl[0];
-          o.seg = pA.seg;
-          o.x = pA.x;
-          o.y = pA.y;
-          sh.req[slot][0] = o;
-          o.view = (uint32_t)view[1];
-          o.pl = pl[1];
-          o.seg = pB.seg;
-          o.x = pB.x;
-          o.y = pB.y;
-          sh.req[slot][1] = o;
-          o.view = (uint32_t)view[2];
-          o.pl = pl[2];
-          o.seg = pC.seg;
-          o.x = pC.x;
-          o.y = pC.y;
-          sh.req[slot][2] = o;
-          sh.reqM[slot] = 1u;
-          issued_mask |= 1u << q;
-          n_issued++;
-        }
-        // a replay knows that its steps succeed: with slots to spare it walks on and issues the next steps too
-        chain = phase == K3A_REPLAY && n_issued < K && i_rep + n_issued < n1;
-        if (chain) st = K3A_GEN;
+        // look ahead? a replay: its next step (known to succeed); the search: the next round of the combinations
+        // that are still walking, if there are at least two and their requests fit
+        const uint32_t cm = (uint32_t)__popc(m);
+        bool more;
+        if (phase == K3A_REPLAY)
+          more = i_rep + round_off + 1u < n1 && n_issued < K;
+        else if (phase == K3A_ORIENT)
+          more = cm >= 2u && n_issued + cm <= K && round_off < 14u;
+        else
+          more = false;
+        if (!more) break;
+        walkers = m;
       }
     }
-    // ---- (3)
+    // ---- REQ: requests of the round that are still to be issued (the first one of a new hypothesis; what did not fit)
+    if (st == K3A_REQ && n_issued == 0) {
+      while (reqmask && n_issued < K) {
+        const int qq = __ffs((int)reqmask) - 1;
+        reqmask &= reqmask - 1u;
+        issue(slot0 + n_issued, qq, 0u);
+        n_issued++;
+      }
+    }
+    // ---- serve
+    K3A_T(0);
+    K3A_C(1, __popcll(__ballot(sh.reqM[lane] & 1u)));
     k3a_serve(sh, s, lane);
-    // ---- (4)
+    K3A_T(1);
+    // ---- the answers
     if (n_issued) {
       if (phase == K3A_REPLAY) {
-        for (uint32_t j = 0; j < n_issued; j++) {
+        for (uint32_t j = 0; j < n_issued; j++)
           if (arena_ok) arena[base + i_rep + j] = k3a_point_of_slot(sh, slot0 + j);
-        }
         i_rep += n_issued;
         st = K3A_END;
-      } else {
-        uint32_t j = 0, m = issued_mask;
-        while (m) {
-          const int q = __ffs((int)m) - 1;
-          m &= m - 1u;
-          const uint32_t f = sh.resF[slot0 + j];
-          flags |= f >> 8;
-          if (f & 1u) {
-            okmask |= 1u << q;
-            if (phase == K3A_TRI0) {
-              X0[0] = sh.resX[slot0 + j][0];
-              X0[1] = sh.resX[slot0 + j][1];
-              X0[2] = sh.resX[slot0 + j][2];
-            } else if (phase == K3A_OPP) {
-              status |= HYP_D2;
-              n2 = 1;
-              if (arena_ok) arena[base + n1] = k3a_point_of_slot(sh, slot0 + j);
+      } else if (phase == K3A_ORIENT) {
+        // rounds in order; a round is closed when the next one's answers begin (or at the end, if it was issued whole)
+        uint32_t cur = 0;
+        bool decided = false;
+        for (uint32_t j = 0; j < n_issued && !decided; j++) {
+          const uint32_t mq = sh.reqM[slot0 + j], f = sh.resF[slot0 + j];
+          const uint32_t q = (mq >> 8) & 3u, ro = mq >> 10;
+          if (ro != cur) {
+            alive = cur == 0 ? okmask : (alive & okmask);
+            okmask = 0;
+            rounds++;
+            cur = ro;
+            if (__popc(alive) <= 1) {
+              decided = true;
+              break;
             }
           }
-          j++;
+          if (cur != 0 && !((alive >> q) & 1u)) continue;  // this combination died in an earlier round
+          flags |= f >> 8;
+          if (f & 1u) okmask |= 1u << q;
         }
-        st = reqmask ? K3A_REQ : K3A_END;
+        if (decided) {
+          st = K3A_END;
+        } else if (reqmask) {
+          st = K3A_REQ;  // round 0 is not complete yet
+        } else {
+          alive = cur == 0 ? okmask : (alive & okmask);
+          okmask = 0;
+          rounds++;
+          if (__popc(alive) > 1 && dead_round != 0xffffffffu) {  // the round behind the last issued one had no walk left
+            alive = 0;
+            rounds++;
+          }
+          st = K3A_END;
+        }
+      } else {  // K3A_TRI0, K3A_OPP: one request
+        const uint32_t f = sh.resF[slot0];
+        flags |= f >> 8;
+        if (f & 1u) {
+          okmask |= 1u;
+          if (phase == K3A_TRI0) {
+            X0[0] = sh.resX[slot0][0];
+            X0[1] = sh.resX[slot0][1];
+            X0[2] = sh.resX[slot0][2];
+          } else {
+            status |= HYP_D2;
+            n2 = 1;
+            if (arena_ok) arena[base + n1] = k3a_point_of_slot(sh, slot0);
+          }
+        }
+        st = K3A_END;
       }
     }
+    K3A_T(2);
   }
+  K3A_TEND(0);
 }
 
 // ---------------------------------------------------------------- following --------
@@ -422,9 +558,9 @@ __device__ __forceinline__ bool k3a_follow_request(const DevScene& s, const K3aL
   for (int st = st_start; st < 3; st++) {
     const int32_t sv = k3a_pick(view3, st);
     const int sd = (sv == ids[0]) ? 0 : (sv == ids[1]) ? 1 : 2;
-    const PlRef ps = polyline_of(s, sv, k3a_pick(pl3, st));
+    const PlRef ps = L.polyline(s, sd);
     PlPt q;
-    const uint32_t w = walk_by_distance(ps, L.get(3 + st), k3a_pick(dirs, sd), EG3D_FOLLOW_STEP, q);
+    const uint32_t w = walk_by_distance_pf(ps, L.get(3 + st), k3a_pick(dirs, sd), EG3D_FOLLOW_STEP, q);
     if (w & WALK_BAD_DIR) fl |= 8u;
     if (w & WALK_EXTREME) continue;
     int found = 0;
@@ -436,10 +572,10 @@ __device__ __forceinline__ bool k3a_follow_request(const DevScene& s, const K3aL
       float la, lb, lc;
       if (!epiline(s.F, s.F_valid, s.n_views, sv, cv, q.x, q.y, la, lb, lc)) continue;
       const int cd = (cv == ids[0]) ? 0 : (cv == ids[1]) ? 1 : 2;
-      const PlRef pk = polyline_of(s, cv, k3a_pick(pl3, i));
+      const PlRef pk = L.polyline(s, cd);
       PlPt r;
       const uint32_t wr =
-          walk_by_line(pk, L.get(3 + i), k3a_pick(dirs, cd), la, lb, lc, true, EG3D_FOLLOW_MIN, EG3D_FOLLOW_MAX, r);
+          walk_by_line_pf(pk, L.get(3 + i), k3a_pick(dirs, cd), la, lb, lc, true, EG3D_FOLLOW_MIN, EG3D_FOLLOW_MAX, r);
       if (wr & WALK_BAD_DIR) fl |= 8u;
       if (wr & WALK_FOUND) {
         found++;
@@ -463,13 +599,14 @@ __global__ void __launch_bounds__(64, EG3D_K3A_WAVES) k3a_follow_spec(DevScene s
                                                                       const uint32_t* hyp_off, uint32_t n_tasks,
                                                                       uint32_t n_hyp, HypResult* res, HPoint* scratch,
                                                                       uint32_t cap, HPoint* arena, uint32_t arena_cap,
-                                                                      Counters* ctr, uint32_t* queue, uint32_t lanes_per_wave) {
+                                                                      Counters* ctr, uint32_t* queue, uint32_t lanes_per_wave,
+                                                                      const uint32_t* items, const uint32_t* n_items_p) {
   __shared__ K3aShared sh;
   const uint32_t lane = threadIdx.x;
   const K3aLane L{&sh, lane};
   const unsigned long long lt = (1ull << lane) - 1ull;
   HPoint* scr = scratch + ((size_t)blockIdx.x * 64 + lane) * cap;  // new points of the current item
-  const uint32_t n_items = n_hyp * 2u;
+  const uint32_t n_items = *n_items_p;  // the lists k3a_orient left to follow: (hypothesis, direction)
   bool have = false, exhausted = lane >= lanes_per_wave;
   uint32_t h = 0, dir = 0, n_init = 0, n_new = 0, init_off = 0, flags = 0;
   int st_start = 0;
@@ -479,6 +616,7 @@ __global__ void __launch_bounds__(64, EG3D_K3A_WAVES) k3a_follow_spec(DevScene s
   // hypothesis' three (view, polyline) pairs
   int32_t cview[3] = {0, 0, 0};
   uint32_t cpl[3] = {0, 0, 0};
+  K3A_T0();
   for (;;) {
     while (!have && !exhausted) {
       const uint32_t i = atomicAdd(queue, 1u);
@@ -486,8 +624,9 @@ __global__ void __launch_bounds__(64, EG3D_K3A_WAVES) k3a_follow_spec(DevScene s
         exhausted = true;
         break;
       }
-      h = i >> 1;
-      dir = i & 1u;
+      const uint32_t item = items[i];
+      h = item >> 1;
+      dir = item & 1u;
       const HypResult& r = res[h];
       const uint32_t stt = r.status;
       if (!(dir == 0 ? (stt & HYP_D1) : (stt & HYP_D2))) continue;
@@ -495,12 +634,13 @@ __global__ void __launch_bounds__(64, EG3D_K3A_WAVES) k3a_follow_spec(DevScene s
       init_off = dir == 0 ? r.pts1_off : r.pts2_off;
       if (n_init == 0 || init_off == 0xffffffffu) continue;  // (arena overflow in the first phase)
       for (int k = 0; k < 3; k++) dirs[k] = dir == 0 ? r.dirs1[k] : r.dirs2[k];
-      const uint32_t t = find_owner(hyp_off, n_tasks, h);
-      for (int k = 0; k < 3; k++) ids[k] = tasks[t].sel_view[k];
+      // (the points of the first phase list their observations in the order of the hypothesis' views: ascending)
       const HPoint last = arena[init_off + n_init - 1];
       for (int k = 0; k < 3; k++) {
         cview[k] = (int32_t)last.o[k].view;
         cpl[k] = last.o[k].pl;
+        ids[k] = cview[k];
+        L.load_polyline(s, k, cview[k], cpl[k]);
         PlPt p;
         p.seg = last.o[k].seg;
         p.x = last.o[k].x;
@@ -567,7 +707,13 @@ __global__ void __launch_bounds__(64, EG3D_K3A_WAVES) k3a_follow_spec(DevScene s
         st0 = 0;
       }
     }
+    K3A_T(0);
+    K3A_C(0, 1);
+    K3A_C(2, __popcll(working));
+    K3A_C(1, __popcll(__ballot(sh.reqM[lane] & 1u)));
+    K3A_C(3, 1);
     k3a_serve(sh, s, lane);
+    K3A_T(1);
     if (have) {
       bool finish = false;
       uint32_t j = 0;
@@ -627,7 +773,9 @@ __global__ void __launch_bounds__(64, EG3D_K3A_WAVES) k3a_follow_spec(DevScene s
         have = false;
       }
     }
+    K3A_T(2);
   }
+  K3A_TEND(1);
 }
 
 }  // namespace eg3d

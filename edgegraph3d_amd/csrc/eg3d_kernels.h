@@ -77,12 +77,12 @@ void launch_k3a_queue(hipStream_t st, bool team4, uint32_t n_blocks, uint32_t fo
                       HPoint* follow_scratch, uint32_t hyp_cap, HPoint* arena, uint32_t arena_cap, Counters* ctr,
                       uint32_t* queue);
 // K3a as a request/serve engine (eg3d_k3a_engine.h): orient_waves / follow_waves single-wavefront blocks, of which
-// the first lanes_per_wave lanes take work; follow_scratch: hyp_cap HPoints per lane of follow_waves x 64; queue2: two
-// zeroed counters
+// the first lanes_per_wave lanes take work; follow_scratch: hyp_cap HPoints per lane of follow_waves x 64; queue3: three
+// zeroed counters (hypotheses taken, lists taken, lists to follow); items: 2 x n_hyp words (the lists to follow)
 void launch_k3a_engine(hipStream_t st, uint32_t orient_waves, uint32_t follow_waves, uint32_t lanes_per_wave, DevScene s,
                        StageAView a, const TaskDesc* tasks, const uint32_t* hyp_off, uint32_t n_hyp, HypResult* res,
                        HPoint* follow_scratch, uint32_t hyp_cap, HPoint* arena, uint32_t arena_cap, Counters* ctr,
-                       uint32_t* queue2);
+                       uint32_t* queue3, uint32_t* items);
 void launch_k3s(hipStream_t st, uint32_t n_tasks, const uint32_t* hyp_off, const HypResult* res, ChainSeed* per_task,
                 uint32_t* valid);
 void launch_compact_chains(hipStream_t st, uint32_t n_tasks, const ChainSeed* per_task, const uint32_t* valid,

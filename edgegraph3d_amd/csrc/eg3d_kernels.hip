@@ -1424,12 +1424,12 @@ void launch_k3a_queue(hipStream_t st, bool team4, uint32_t n_blocks, uint32_t fo
 void launch_k3a_engine(hipStream_t st, uint32_t orient_waves, uint32_t follow_waves, uint32_t lanes_per_wave, DevScene s,
                        StageAView a, const TaskDesc* tasks, const uint32_t* hyp_off, uint32_t n_hyp, HypResult* res,
                        HPoint* follow_scratch, uint32_t hyp_cap, HPoint* arena, uint32_t arena_cap, Counters* ctr,
-                       uint32_t* queue2) {
+                       uint32_t* queue3, uint32_t* items) {
   if (!n_hyp) return;
   hipLaunchKernelGGL(k3a_orient, dim3(orient_waves), dim3(64), 0, st, s, a, tasks, hyp_off, n_hyp, res, hyp_cap, arena,
-                     arena_cap, ctr, queue2, lanes_per_wave);
+                     arena_cap, ctr, queue3, lanes_per_wave, items, queue3 + 2);
   hipLaunchKernelGGL(k3a_follow_spec, dim3(follow_waves), dim3(64), 0, st, s, tasks, hyp_off, a.n_tasks, n_hyp, res,
-                     follow_scratch, hyp_cap, arena, arena_cap, ctr, queue2 + 1, lanes_per_wave);
+                     follow_scratch, hyp_cap, arena, arena_cap, ctr, queue3 + 1, lanes_per_wave, items, queue3 + 2);
   hipLaunchKernelGGL(k3a_finalize, blocks_for(n_hyp, 256), dim3(256), 0, st, n_hyp, res);
 }
 void launch_k3s(hipStream_t st, uint32_t n_tasks, const uint32_t* hyp_off, const HypResult* res, ChainSeed* per_task,

@@ -136,6 +136,7 @@ extern "C" int hostsim_match(const eg3d_scene* sc, const eg3d_seeds* seeds, uint
     hyp_off[t + 1] = hyp_off[t] + tasks[t].n_hyp;
   }
   const uint32_t n_hyp = hyp_off[nt];
+  for (int i = 0; i < 8; i++) g_stat[i] = 0;
   // K3a
   std::vector<HypResult> res(n_hyp ? n_hyp : 1);
   std::vector<HPoint> arena;
@@ -194,6 +195,8 @@ extern "C" int hostsim_match(const eg3d_scene* sc, const eg3d_seeds* seeds, uint
     for (int i = 0; i < 8; i++) fprintf(stderr, " %llu", (unsigned long long)h1[i]);
     fprintf(stderr, "; calls: step3 %llu (its triangulations %llu) stepn3 starts %llu (its triangulations %llu)", g_stat[0],
             g_stat[1], g_stat[2], g_stat[3]);
+    fprintf(stderr, "; line walks %llu, segments scanned beyond the first %llu (%.1f per walk)", g_stat[5], g_stat[6],
+            (double)g_stat[6] / (double)(g_stat[5] ? g_stat[5] : 1));
     for (int w = 0; w < 2; w++) {
       fprintf(stderr, "\n  %s: hypotheses (sum of triangulations) with [0], [1], [2-3], [4-7] ... of them:", w ? "following" : "orientation");
       for (int i = 0; i < 12; i++) fprintf(stderr, " %llu (%llu)", g_hist[w][i], g_hsum[w][i]);
@@ -333,6 +336,36 @@ extern "C" int hostsim_walk_by_line(const float* vtx, int n, uint32_t start, uin
   oxy[0] = o.x;
   oxy[1] = o.y;
   return (int)w;
+}
+// the walks with their loads in flight (walk_by_*_pf) against the plain walks: every start segment of the polyline,
+// both directions and a direction that is neither end; n_q queries (a point near the polyline + a line / a
+// distance each). Returns the number of mismatches (status, segment, coordinate bits).
+extern "C" int hostsim_walk_pf_mismatches(const float* vtx, int n, uint32_t start, uint32_t end, const float* q, int n_q) {
+  PlRef pl;
+  pl.v = reinterpret_cast<const f2*>(vtx);
+  pl.n = (uint32_t)n;
+  pl.start = start;
+  pl.end = end;
+  int bad = 0;
+  const uint32_t dirs[3] = {start, end, 0xfffffff0u};
+  for (int i = 0; i < n_q; i++) {
+    const float* qi = q + 8 * i;  // seg (as float), x, y, la, lb, lc, distance, bounded
+    PlPt p;
+    p.seg = (uint32_t)qi[0];
+    p.x = qi[1];
+    p.y = qi[2];
+    for (int d = 0; d < 3; d++) {
+      PlPt a = p, b = p;
+      const uint32_t wa = walk_by_line(pl, p, dirs[d], qi[3], qi[4], qi[5], qi[7] != 0.0f, 5.0f, 20.0f, a);
+      const uint32_t wb = walk_by_line_pf(pl, p, dirs[d], qi[3], qi[4], qi[5], qi[7] != 0.0f, 5.0f, 20.0f, b);
+      if (wa != wb || ((wa & (WALK_FOUND | WALK_BOUND)) && (a.seg != b.seg || memcmp(&a.x, &b.x, 4) || memcmp(&a.y, &b.y, 4)))) bad++;
+      PlPt c = p, e = p;
+      const uint32_t wc = walk_by_distance(pl, p, dirs[d], qi[6], c);
+      const uint32_t we = walk_by_distance_pf(pl, p, dirs[d], qi[6], e);
+      if (wc != we || c.seg != e.seg || memcmp(&c.x, &e.x, 4) || memcmp(&c.y, &e.y, 4)) bad++;
+    }
+  }
+  return bad;
 }
 extern "C" int hostsim_triangulate(const float* cam_P, const int32_t* views, const float* xy, int n, float* X) {
   std::vector<Obs> a(n);

@@ -21,6 +21,7 @@ def lib():
                                     C.POINTER(D.EdgePoints)]
         L.hostsim_free_edgepoints.argtypes = [C.POINTER(D.EdgePoints)]
         L.hostsim_closest_pruned_mismatches.argtypes = [D.f32p, C.c_int, D.f32p, C.c_int, C.c_uint32, C.c_uint32]
+        L.hostsim_walk_pf_mismatches.argtypes = [D.f32p, C.c_int, C.c_uint32, C.c_uint32, D.f32p, C.c_int]
         L.hostsim_dist2.restype = C.c_float
         L.hostsim_dist2.argtypes = [C.c_float] * 4
         L.hostsim_seg_closest.restype = C.c_float

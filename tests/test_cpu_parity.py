@@ -151,6 +151,54 @@ def test_inconsistent_scenes_are_refused_before_any_device_is_touched():
         assert "eg3d_create" in msg
 
 
+def test_walks_with_vertex_loads_in_flight_equal_the_plain_walks():
+    """eg3d_dev_geom.h walk_by_line_pf / walk_by_distance_pf (what the K3a engine walks with: a window of five vertices
+    loaded ahead of the segment under test) against walk_by_line / walk_by_distance: status, segment and coordinate
+    bits, from every kind of start (first / last segment, on a vertex), towards either end and towards a node that is
+    neither (Q15), lines that cross, miss, graze and run quasi-parallel, bounded and unbounded, polylines of 2..300
+    vertices with repeated vertices."""
+    import ctypes as C
+    import hostsim_binding as hs
+    L = hs.lib()
+    rng = np.random.default_rng(23)
+    total = 0
+    for case in range(80):
+        n = int(rng.integers(2, 300)) if case % 8 else int(rng.integers(2, 7))
+        kind = case % 4
+        if kind == 0:
+            tt = np.linspace(0, rng.uniform(1, 12), n)
+            v = np.stack([np.cos(tt) * tt * 20, np.sin(tt) * tt * 20], 1)
+        elif kind == 1:
+            v = np.cumsum(rng.normal(0, 3, (n, 2)), 0)
+            v[rng.integers(0, n, n // 5)] = v[0]
+        elif kind == 2:
+            v = np.cumsum(np.stack([rng.integers(0, 3, n), rng.integers(0, 3, n)], 1), 0).astype(np.float64)
+        else:
+            v = np.stack([np.linspace(0, 4 * n, n), rng.normal(0, 0.5, n)], 1)   # nearly straight: quasi-parallel lines
+        v = np.ascontiguousarray(v, np.float32)
+        nq = 300
+        seg = rng.integers(0, max(1, n - 1), nq)
+        seg[:3] = [0, max(0, n - 2), max(0, n - 2)]
+        tpar = rng.uniform(0, 1, nq).astype(np.float32)
+        tpar[:40] = 0.0                                                           # exactly on the segment's first vertex
+        a, b = v[seg], v[np.minimum(seg + 1, n - 1)]
+        pts = a + tpar[:, None] * (b - a)
+        ang = rng.uniform(0, np.pi, nq)
+        la, lb = np.cos(ang), np.sin(ang)
+        through = v[rng.integers(0, n, nq)] + rng.normal(0, 6, (nq, 2))           # lines through the neighbourhood
+        lc = -(la * through[:, 0] + lb * through[:, 1])
+        if kind == 3:
+            la[:150], lb[:150] = rng.normal(0, 0.02, 150), 1.0                    # quasi-parallel to the stroke
+            lc[:150] = rng.uniform(-8, 8, 150)
+        dist = rng.choice([10.0, 0.5, 3.0, 50.0, 1e6], nq)
+        q = np.ascontiguousarray(np.stack([seg, pts[:, 0], pts[:, 1], la, lb, lc, dist, rng.integers(0, 2, nq)], 1), np.float32)
+        for start, end in ((1, 2), (7, 7)):                                       # (7, 7): a closed polyline, both ends one node
+            bad = L.hostsim_walk_pf_mismatches(D.np_ptr(v, C.c_float), n, start, end, D.np_ptr(q, C.c_float), nq)
+            assert bad == 0, (case, kind, n, start, end, bad)
+            total += 6 * nq
+    assert total > 200000
+
+
 def test_closest_point_scan_with_box_pretest_equals_the_plain_scan():
     """eg3d_dev_geom.h polyline_closest_pruned (the expand stage's per-view closest-point scan skips blocks of 8 segments
     whose bounding box is farther than the best distance so far) must return the plain scan's result bit for bit: first
