@@ -113,25 +113,24 @@ struct HostGrids {
 
 // Test / tuning knobs, read from the environment ONCE when a context is created (eg3d_create; clones
 // inherit them) — the hot path never calls getenv:
-//   EG3D_K3A_TEAM=0|1      force 1-lane / 4-lane hypothesis teams (default: by batch size)
-//   EG3D_K3A_QUEUE=0|1     force the lane-level following queue off / on
+//   EG3D_K3A_ENGINE_WAVES=n  wavefronts per SIMD the K3a engine launches (default 3)
+//   EG3D_K3A_ENGINE_LANES=n  lanes of a K3a wavefront that take work (default: 64, fewer for small batches)
+//   EG3D_HYP_CAP=n         tests: points per following direction of the hypothesis stage (default 160; a list that would
+//                          outgrow it raises EG3D_FLAG_HYP_OVERFLOW and the call returns EG3D_ERR_CAPACITY)
 //   EG3D_ARENA_CAP0=n      initial hypothesis arena capacity (tests: forces the overflow-and-retry path)
 //   EG3D_MAX_SCRATCH_MB=n  tests: cut the chains of a batch into several K3b launches of at most n MB / slice size
 //                          chains each (default: one launch takes all chains — their working slices are slots)
 //   EG3D_NO_LPT=1          launch chains in identity order instead of longest-first (diagnostic)
 struct Tunables {
-  int k3a_team = -1, k3a_queue = -1;
-  int k3a_engine = 1, k3a_engine_waves = 0, k3a_engine_lanes = 0;  // EG3D_K3A_ENGINE / _WAVES (per SIMD) / _LANES
-  uint32_t arena_cap0 = 0;
+  int k3a_engine_waves = 0, k3a_engine_lanes = 0;
+  uint32_t arena_cap0 = 0, hyp_cap = 0;
   size_t max_scratch = 0;  // 0 = no limit
   bool use_lpt = true;
   static Tunables from_env() {
     Tunables t;
-    if (const char* e = getenv("EG3D_K3A_TEAM")) t.k3a_team = atoi(e);
-    if (const char* e = getenv("EG3D_K3A_QUEUE")) t.k3a_queue = atoi(e);
-    if (const char* e = getenv("EG3D_K3A_ENGINE")) t.k3a_engine = atoi(e);
     if (const char* e = getenv("EG3D_K3A_ENGINE_WAVES")) t.k3a_engine_waves = atoi(e);
     if (const char* e = getenv("EG3D_K3A_ENGINE_LANES")) t.k3a_engine_lanes = atoi(e);
+    if (const char* e = getenv("EG3D_HYP_CAP")) t.hyp_cap = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("EG3D_ARENA_CAP0")) t.arena_cap0 = (uint32_t)std::max(16, atoi(e));
     if (const char* e = getenv("EG3D_MAX_SCRATCH_MB")) t.max_scratch = (size_t)std::max(1, atoi(e)) << 20;
     if (const char* e = getenv("EG3D_NO_LPT")) t.use_lpt = !(e[0] == '1');
@@ -159,7 +158,7 @@ struct eg3d_ctx {
   // work buffers
   DevBuf b_sv_seed, b_map_view, b_map_entry, b_map_n, b_raw_cnt, b_raw_off, b_cand_pl, b_start_hits, b_cand_cnt,
       b_start_cnt, b_task_off, b_task_seed, b_task_entry, b_task_hit, b_task_k, b_task_list_off, b_list_cnt, b_list_ptr,
-      b_hits, b_tasks, b_nhyp, b_hyp_off, b_res, b_hscratch, b_arena, b_ctr, b_cs_task, b_valid, b_chain_off, b_chains,
+      b_hits, b_tasks, b_nhyp, b_hyp_off, b_res, b_arena, b_ctr, b_cs_task, b_valid, b_chain_off, b_chains,
       b_cscratch, b_couts, b_cpts, b_cobs, b_cpoff, b_cooff, b_scan_tmp, b_scanchk, b_cost, b_cidx, b_cost2, b_order;
   DevBuf o_X, o_off, o_view, o_pl, o_seg, o_xy, o_key;
   DevBuf f_X, f_off, f_view, f_xy, f_Xo, f_inl;
@@ -172,7 +171,7 @@ struct eg3d_ctx {
   uint64_t stage_cap_pts = 0, stage_cap_obs = 0;
   hipEvent_t ea[8], eb[8];  // begin/end events per stage: 1 K1, 2 K2, 3 K3a, 4 K3s, 5 K3b, 6 K4, 0 misc, 7 whole call
   uint32_t chain_cap = 384, pool_cap = 0, hyp_cap = 160;
-  uint32_t k3a_blocks = 0;
+  uint32_t n_simd = 0;  // SIMDs of the device (4 per CU): sizes the K3a engine's launch
   void* pinned = nullptr;  // pinned host staging area of the D2H copies of a cloud (grow-only)
   size_t pinned_cap = 0;
   // mailbox for the small read-backs of a step (scan totals, counters): pinned host memory mapped into the
@@ -381,6 +380,7 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
   eg3d_ctx* c = new eg3d_ctx();
   c->device = device;
   c->tune = Tunables::from_env();
+  if (c->tune.hyp_cap) c->hyp_cap = c->tune.hyp_cap;
   c->hg = std::make_shared<HostGrids>();
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   for (int i = 0; i < 8; i++) {
@@ -529,7 +529,7 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
   if (c->pool_cap < 6144) c->pool_cap = 6144;
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
-  c->k3a_blocks = (uint32_t)prop.multiProcessorCount * 2;  // 2 blocks x 4 waves per CU
+  c->n_simd = (uint32_t)prop.multiProcessorCount * 4;
   {
     // working-slice slots per XCD: what can be resident (occupancy query x CUs of an XCD) plus a margin —
     // the occupancy API may be one block per CU off, and a pool must never be smaller than the residency
@@ -592,7 +592,7 @@ extern "C" int eg3d_clone(eg3d_ctx* parent, eg3d_ctx** out) {
   c->chain_cap = parent->chain_cap;
   c->pool_cap = parent->pool_cap;
   c->hyp_cap = parent->hyp_cap;
-  c->k3a_blocks = parent->k3a_blocks;
+  c->n_simd = parent->n_simd;
   c->slots_per_xcd = parent->slots_per_xcd;
   c->stage_cap_pts = parent->stage_cap_pts;  // sizing hints only: the clone allocates its own staging area
   c->stage_cap_obs = parent->stage_cap_obs;
@@ -612,7 +612,7 @@ extern "C" void eg3d_destroy(eg3d_ctx* c) {
                    &c->b_map_entry, &c->b_map_n, &c->b_raw_cnt, &c->b_raw_off, &c->b_cand_pl, &c->b_start_hits,
                    &c->b_cand_cnt, &c->b_start_cnt, &c->b_task_off, &c->b_task_seed, &c->b_task_entry, &c->b_task_hit,
                    &c->b_task_k, &c->b_task_list_off, &c->b_list_cnt, &c->b_list_ptr, &c->b_hits, &c->b_tasks,
-                   &c->b_nhyp, &c->b_hyp_off, &c->b_res, &c->b_hscratch, &c->b_arena, &c->b_ctr, &c->b_cs_task,
+                   &c->b_nhyp, &c->b_hyp_off, &c->b_res, &c->b_arena, &c->b_ctr, &c->b_cs_task,
                    &c->b_valid, &c->b_chain_off, &c->b_chains, &c->b_cscratch, &c->b_couts, &c->b_cpts, &c->b_cobs,
                    &c->b_cpoff, &c->b_cooff, &c->b_scan_tmp, &c->b_scanchk, &c->b_cost, &c->b_cidx, &c->b_cost2, &c->b_order, &c->o_X, &c->o_off, &c->o_view, &c->o_pl, &c->o_seg,
                    &c->o_xy, &c->o_key, &c->f_X, &c->f_off, &c->f_view, &c->f_xy, &c->f_Xo, &c->f_inl, &c->b_sets_off, &c->b_sets_ids, &c->b_fscratch, &c->b_queue, &c->b_items,
@@ -853,37 +853,19 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
   BUF_TRY(scan_total_u32(c, c->b_nhyp.as<uint32_t>(), c->b_hyp_off.as<uint32_t>(), nt + 1, B.n_hyp, "hypotheses"));
   // ---- K3a
   BUF_TRY(c->b_res.ensure(sizeof(HypResult) * (B.n_hyp + 1)));
-  // small batches are latency-bound by their slowest hypothesis: give each hypothesis a 4-lane team
-  const int k3a_mode = c->tune.k3a_team;  // -1 auto, 0 lanes, 1 teams
-  const bool team4 = k3a_mode < 0 ? (B.n_hyp <= 131072u) : (k3a_mode != 0);
-  const bool engine = c->tune.k3a_engine != 0;
-  // engine: single-wavefront blocks; a wave's lanes that take work are limited when there is little of it, so that
-  // each working lane gets more of the wave's 64 request slots
-  const uint32_t eng_waves_max = (c->k3a_blocks / 2u) * 4u * (uint32_t)(c->tune.k3a_engine_waves > 0 ? c->tune.k3a_engine_waves : 3);
+  // K3a engine (eg3d_k3a_engine.h): single-wavefront blocks; the lanes of a wave that take work are limited when there
+  // is little of it, so that each working lane gets more of the wave's 64 request slots
+  const uint32_t eng_waves_max = c->n_simd * (uint32_t)(c->tune.k3a_engine_waves > 0 ? c->tune.k3a_engine_waves : 3);
   uint32_t eng_lanes = 64;
   if (c->tune.k3a_engine_lanes > 0)
     eng_lanes = (uint32_t)std::min(64, c->tune.k3a_engine_lanes);
   else
     while (eng_lanes > 8 && (uint64_t)eng_waves_max * (eng_lanes / 2) >= B.n_hyp) eng_lanes /= 2;
-  const uint32_t eng_orient_waves = std::max<uint32_t>(1, std::min<uint32_t>(eng_waves_max, (B.n_hyp + eng_lanes - 1) / eng_lanes));
-  const uint32_t eng_follow_waves = eng_orient_waves;
-  const uint32_t k3a_lanes_needed = B.n_hyp * (team4 ? 4u : 1u);
-  const uint32_t k3a_blocks =
-      std::max<uint32_t>(1, std::min<uint32_t>(c->k3a_blocks * (team4 ? 2u : 1u), (k3a_lanes_needed + 255) / 256));
-  if (!engine) BUF_TRY(c->b_hscratch.ensure(sizeof(HPoint) * 2 * c->hyp_cap * ((size_t)k3a_blocks * 256 / (team4 ? 4 : 1))));
-  // throughput mode (1 lane per hypothesis): the lists are followed through a lane-level work queue
-  // (2 items per hypothesis) — C3' K3a 19.6 -> 17.0 ms; with 4-lane teams (small, latency-bound
-  // batches) the team's own two-lane following is faster (C2 2.96 vs 3.34 ms). EG3D_K3A_QUEUE=0/1 forces.
-  const int k3a_queue_mode = c->tune.k3a_queue;
-  const bool k3a_queue = engine || (k3a_queue_mode < 0 ? !team4 : (k3a_queue_mode != 0));
-  const uint32_t follow_blocks =
-      std::max<uint32_t>(1, std::min<uint32_t>(c->k3a_blocks * 2u, (uint32_t)(((uint64_t)B.n_hyp * 2 + 255) / 256)));
-  if (k3a_queue) {
-    BUF_TRY(c->b_fscratch.ensure(sizeof(HPoint) * c->hyp_cap * (engine ? (size_t)eng_follow_waves * 64 : (size_t)follow_blocks * 256)));
-    BUF_TRY(c->b_queue.ensure(4 * sizeof(uint32_t)));
-    if (engine) BUF_TRY(c->b_items.ensure(sizeof(uint32_t) * 2 * ((size_t)B.n_hyp + 1)));
-  }
-  uint32_t arena_cap = std::max<uint32_t>(1u << 16, std::min<uint64_t>((uint64_t)B.n_hyp * (k3a_queue ? 32 : 24), 1ull << 26));
+  const uint32_t eng_waves = std::max<uint32_t>(1, std::min<uint32_t>(eng_waves_max, (B.n_hyp + eng_lanes - 1) / eng_lanes));
+  BUF_TRY(c->b_fscratch.ensure(sizeof(HPoint) * c->hyp_cap * ((size_t)eng_waves * 64)));
+  BUF_TRY(c->b_queue.ensure(4 * sizeof(uint32_t)));
+  BUF_TRY(c->b_items.ensure(sizeof(uint32_t) * 2 * ((size_t)B.n_hyp + 1)));
+  uint32_t arena_cap = std::max<uint32_t>(1u << 16, std::min<uint64_t>((uint64_t)B.n_hyp * 32, 1ull << 26));
   if (c->tune.arena_cap0) arena_cap = c->tune.arena_cap0;  // tests: force the overflow-and-retry path
   Counters hc;
   BUF_TRY(c->b_cs_task.ensure(sizeof(ChainSeed) * (nt + 1)));
@@ -893,23 +875,10 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
     BUF_TRY(c->b_arena.ensure(sizeof(HPoint) * (size_t)arena_cap));
     HIP_TRY(hipMemsetAsync(c->b_ctr.p, 0, 2 * sizeof(uint32_t), st));  // arena_used, flags (keep bytes)
     HIP_TRY(hipEventRecord(c->ea[3], st));
-    if (engine) {
-      HIP_TRY(hipMemsetAsync(c->b_queue.p, 0, 4 * sizeof(uint32_t), st));
-      launch_k3a_engine(st, eng_orient_waves, eng_follow_waves, eng_lanes, c->ds, B.a, c->b_tasks.as<TaskDesc>(),
-                        c->b_hyp_off.as<uint32_t>(), B.n_hyp, c->b_res.as<HypResult>(), c->b_fscratch.as<HPoint>(),
-                        c->hyp_cap, c->b_arena.as<HPoint>(), arena_cap, c->b_ctr.as<Counters>(), c->b_queue.as<uint32_t>(),
-                        c->b_items.as<uint32_t>());
-    } else if (k3a_queue) {
-      HIP_TRY(hipMemsetAsync(c->b_queue.p, 0, sizeof(uint32_t), st));
-      launch_k3a_queue(st, team4, k3a_blocks, follow_blocks, c->ds, B.a, c->b_tasks.as<TaskDesc>(),
-                       c->b_hyp_off.as<uint32_t>(), B.n_hyp, c->b_res.as<HypResult>(), c->b_hscratch.as<HPoint>(),
-                       c->b_fscratch.as<HPoint>(), c->hyp_cap, c->b_arena.as<HPoint>(), arena_cap, c->b_ctr.as<Counters>(),
-                       c->b_queue.as<uint32_t>());
-    } else {
-      launch_k3a(st, team4, k3a_blocks, c->ds, B.a, c->b_tasks.as<TaskDesc>(), c->b_hyp_off.as<uint32_t>(), B.n_hyp,
-                 c->b_res.as<HypResult>(), c->b_hscratch.as<HPoint>(), c->hyp_cap, c->b_arena.as<HPoint>(), arena_cap,
-                 c->b_ctr.as<Counters>());
-    }
+    HIP_TRY(hipMemsetAsync(c->b_queue.p, 0, 4 * sizeof(uint32_t), st));
+    launch_k3a_engine(st, eng_waves, eng_waves, eng_lanes, c->ds, B.a, c->b_tasks.as<TaskDesc>(), c->b_hyp_off.as<uint32_t>(),
+                      B.n_hyp, c->b_res.as<HypResult>(), c->b_fscratch.as<HPoint>(), c->hyp_cap, c->b_arena.as<HPoint>(),
+                      arena_cap, c->b_ctr.as<Counters>(), c->b_queue.as<uint32_t>(), c->b_items.as<uint32_t>());
     HIP_TRY(hipEventRecord(c->eb[3], st));
     // ---- K3s and the chain scan are queued right behind K3a; K3a's counters (arena overflow?) and the
     // number of chains come back in ONE read-back. An overflowing attempt is redone from K3a.

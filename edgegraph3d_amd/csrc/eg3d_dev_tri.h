@@ -35,12 +35,15 @@ static_assert(sizeof(Obs) == 16, "Obs must be one 128-bit word");
 EG3D_HD bool epiline(const double* F, const uint8_t* F_valid, int n_views, int from, int to, float x, float y,
                      float& la, float& lb, float& lc) {
   size_t idx = (size_t)from * n_views + to;
-  if (!F_valid[idx]) return false;
   const double* f = F + idx * 9;
+  // the nine entries are requested together with the validity byte (one trip to memory instead of two; the
+  // matrix of an invalid pair is allocated and merely unused)
+  const double f0 = f[0], f1 = f[1], f2_ = f[2], f3 = f[3], f4 = f[4], f5 = f[5], f6 = f[6], f7 = f[7], f8 = f[8];
+  if (!F_valid[idx]) return false;
   double t0 = x, t1 = y;
-  double a = (f[0] * t0 + f[1] * t1) + f[2];
-  double b = (f[3] * t0 + f[4] * t1) + f[5];
-  double c = (f[6] * t0 + f[7] * t1) + f[8];
+  double a = (f0 * t0 + f1 * t1) + f2_;
+  double b = (f3 * t0 + f4 * t1) + f5;
+  double c = (f6 * t0 + f7 * t1) + f8;
   double nu = a * a + b * b;
   nu = (nu != 0.0) ? 1. / EG3D_SQRT(nu) : 1.;
   a *= nu;

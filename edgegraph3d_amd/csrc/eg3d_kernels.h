@@ -67,15 +67,6 @@ void launch_n1_hits(hipStream_t st, bool fill, DevScene s, SetsDev sets, uint32_
                     const uint32_t* task_row0, uint32_t* list_cnt, const uint32_t* list_ptr, Obs* hits, Counters* ctr);
 void launch_task_setup(hipStream_t st, StageAView a, const int32_t* map_view, const uint32_t* map_entry,
                        const uint32_t* map_n, TaskDesc* tasks, uint32_t* n_hyp);
-void launch_k3a(hipStream_t st, bool team4, uint32_t n_blocks, DevScene s, StageAView a, const TaskDesc* tasks,
-                const uint32_t* hyp_off, uint32_t n_hyp, HypResult* res, HPoint* scratch, uint32_t hyp_cap, HPoint* arena,
-                uint32_t arena_cap, Counters* ctr);
-// K3a split: orientation phase (initial lists to the arena), following through a lane-level work
-// queue (follow_scratch: hyp_cap HPoints per lane of follow_blocks x 256), compatibility flags
-void launch_k3a_queue(hipStream_t st, bool team4, uint32_t n_blocks, uint32_t follow_blocks, DevScene s, StageAView a,
-                      const TaskDesc* tasks, const uint32_t* hyp_off, uint32_t n_hyp, HypResult* res, HPoint* scratch,
-                      HPoint* follow_scratch, uint32_t hyp_cap, HPoint* arena, uint32_t arena_cap, Counters* ctr,
-                      uint32_t* queue);
 // K3a as a request/serve engine (eg3d_k3a_engine.h): orient_waves / follow_waves single-wavefront blocks, of which
 // the first lanes_per_wave lanes take work; follow_scratch: hyp_cap HPoints per lane of follow_waves x 64; queue3: three
 // zeroed counters (hypotheses taken, lists taken, lists to follow); items: 2 x n_hyp words (the lists to follow)

@@ -9,7 +9,8 @@
 //   k2_epipolar_hits  1 WAVE / task         epiline x candidate polylines, ballot/popcount
 //                                           ordered compaction (count pass + fill pass)
 //   k_task_setup      1 lane / task         3-view selection, hypothesis count
-//   k3a_hypotheses    1 or 4 lanes / hypothesis  orientation + following (4-lane teams when latency-bound)
+//   k3a_orient, k3a_follow_spec  1 lane / hypothesis, 1 lane / list — the wave SERVES its lanes' triangulation requests
+//                                           densely from 64 slots in LDS (eg3d_k3a_engine.h)
 //   k3s_select        1 lane / task         uniqueness rule -> chain seeds
 //   k3b_expand        1 WAVE / chain        expand-all-views (wave-cooperative Gauss-Newton)
 //   k4_emit           1 WAVE / chain        ordered SoA output (wave prefix sum of obs counts, flat coalesced copy)
@@ -402,160 +403,11 @@ __device__ __forceinline__ uint32_t find_owner(const uint32_t* off, uint32_t n, 
 }
 
 // ------------------------------------------------------------------ K3a --------
-// Hypothesis evaluation. Two instantiations of the same body (eg3d_dev_follow.h):
-//  * HTeamSeq: one lane per hypothesis, wave-synchronous batches of 64 — most work per wave
-//    instruction; used when there are enough hypotheses to fill the chip (throughput-bound).
-//  * HTeam4:   four lanes per hypothesis (16 per wave): the four direction combinations of the
-//    orientation search run on four lanes and the two following directions on two, cutting the
-//    critical path of the slowest hypothesis; used for small, latency-bound batches.
-// Each hypothesis owns two HPoint lists in the scratch arena; finished lists that later stages
-// need are copied to a bump-allocated result arena by the team's lane 0.
-struct HTeam4 {
-  static constexpr int kSize = 4;
-  __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 3u); }
-  __device__ __forceinline__ int sum(int v) const {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    return v;
-  }
-  __device__ __forceinline__ uint32_t or_(uint32_t v) const {
-    v |= (uint32_t)__shfl_xor((int)v, 1, 64);
-    v |= (uint32_t)__shfl_xor((int)v, 2, 64);
-    return v;
-  }
-  __device__ __forceinline__ uint32_t bcast(uint32_t v, int src) const {
-    return (uint32_t)__shfl((int)v, (int)((threadIdx.x & 63u & ~3u) + (uint32_t)src), 64);
-  }
-};
-
+// Hypothesis evaluation: eg3d_k3a_engine.h (k3a_orient, k3a_follow_spec), included below; what it computes is stated
+// sequentially by evaluate_hypothesis in eg3d_dev_follow.h (the host simulation of the tests runs that).
 #ifndef EG3D_K3A_WAVES
-#define EG3D_K3A_WAVES 3 /* waves/SIMD the register allocation of K3a aims at (3: co-resides better with K3b waves of other steps in flight; measured C3 81 -> 77 ms, neutral alone) */
+#define EG3D_K3A_WAVES 3 /* waves/SIMD the register allocation of K3a aims at (also what its LDS allows) */
 #endif
-template <class Team, bool kFollow>
-__global__ void __launch_bounds__(256, EG3D_K3A_WAVES) k3a_hypotheses(DevScene s, StageAView a, const TaskDesc* tasks,
-                                                     const uint32_t* hyp_off, uint32_t n_hyp, HypResult* res,
-                                                     HPoint* scratch, uint32_t hyp_cap, HPoint* arena,
-                                                     uint32_t arena_cap, Counters* ctr) {
-  const uint32_t slot = (blockIdx.x * blockDim.x + threadIdx.x) / Team::kSize;
-  const uint32_t n_slots = (gridDim.x * blockDim.x) / Team::kSize;
-  HPoint* pts1 = scratch + (size_t)slot * 2 * hyp_cap;
-  HPoint* pts2 = pts1 + hyp_cap;
-  Team tm;
-  for (uint32_t h = slot; h < n_hyp; h += n_slots) {
-    const uint32_t t = find_owner(hyp_off, a.n_tasks, h);
-    const TaskDesc d = tasks[t];
-    Obs c[3];
-    hypothesis_hits(a, d, t, h - hyp_off[t], c);
-    HypResult r;
-    evaluate_hypothesis<Team, kFollow>(tm, s, c, pts1, pts2, hyp_cap, r);
-    if (tm.lane() == 0) {
-      // kFollow: the finished lists later stages need; !kFollow: the initial lists k3a_follow extends
-      uint32_t need1 = kFollow ? ((r.status & HYP_COMPAT) ? r.n1 : 0) : ((r.status & HYP_D1) ? r.n1 : 0);
-      uint32_t need2 = (r.status & HYP_D2) ? r.n2 : 0;
-      if (need1 + need2) {
-        uint32_t base = atomicAdd(&ctr->arena_used, need1 + need2);
-        if (base + need1 + need2 <= arena_cap) {
-          r.pts1_off = base;
-          r.pts2_off = base + need1;
-          for (uint32_t i = 0; i < need1; i++) arena[base + i] = pts1[i];
-          for (uint32_t i = 0; i < need2; i++) arena[base + need1 + i] = pts2[i];
-        } else {
-          atomicOr(&ctr->flags, CTR_ARENA_OVERFLOW);
-        }
-      }
-      if (r.flags) atomicOr(&ctr->flags, r.flags);
-      res[h] = r;
-    }
-  }
-}
-
-// Following of the hypotheses' point lists through a LANE-LEVEL WORK QUEUE. An item is
-// (hypothesis, direction); list lengths vary from 1 to ~60 steps, so instead of binding a lane to
-// one hypothesis (the wave then lives as long as its longest list with most lanes idle) every lane
-// pulls the next item as soon as its own list ends: all lanes of the wave execute the same N-view
-// step (stepn3: walks + DLT + Gauss-Newton) on different lists until the queue is empty. A finished
-// list (initial points + the new ones, staged in the lane's scratch) is copied to a fresh arena
-// block. Results do not depend on the order in which items are taken.
-__global__ void __launch_bounds__(256, EG3D_K3A_WAVES) k3a_follow(DevScene s, const TaskDesc* tasks,
-                                                                  const uint32_t* hyp_off, uint32_t n_tasks,
-                                                                  uint32_t n_hyp, HypResult* res, HPoint* scratch,
-                                                                  uint32_t cap, HPoint* arena, uint32_t arena_cap,
-                                                                  Counters* ctr, uint32_t* queue) {
-  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-  HPoint* scr = scratch + (size_t)gid * cap;  // new points of the current item
-  const uint32_t n_items = n_hyp * 2u;
-  bool have = false, exhausted = false, at_cap = false;
-  uint32_t h = 0, dir = 0, n_init = 0, n_new = 0, init_off = 0, flags = 0;
-  uint32_t dirs[3] = {0, 0, 0};
-  int32_t ids[3] = {0, 0, 0};
-  HPoint last;
-  last.nobs = 0;
-  for (;;) {
-    while (!have && !exhausted) {
-      const uint32_t i = atomicAdd(queue, 1u);
-      if (i >= n_items) {
-        exhausted = true;
-        break;
-      }
-      h = i >> 1;
-      dir = i & 1u;
-      const HypResult& r = res[h];
-      const uint32_t st = r.status;
-      if (!(dir == 0 ? (st & HYP_D1) : (st & HYP_D2))) continue;
-      n_init = dir == 0 ? r.n1 : r.n2;
-      init_off = dir == 0 ? r.pts1_off : r.pts2_off;
-      if (n_init == 0 || init_off == 0xffffffffu) continue;  // (arena overflow in the first phase)
-      for (int k = 0; k < 3; k++) dirs[k] = dir == 0 ? r.dirs1[k] : r.dirs2[k];
-      const uint32_t t = find_owner(hyp_off, n_tasks, h);
-      for (int k = 0; k < 3; k++) ids[k] = tasks[t].sel_view[k];
-      last = arena[init_off + n_init - 1];
-      n_new = 0;
-      flags = 0;
-      at_cap = n_init >= cap;
-      have = true;
-    }
-    if (!__any(have)) break;
-    if (have) {
-      HPoint np;
-      const bool ok = stepn3(s, last, dirs, ids, np, flags);
-      bool finish = false;
-      if (at_cap) {
-        if (ok) flags |= 4u;  // the list would outgrow its capacity (follow_list's last probe)
-        finish = true;
-      } else if (ok) {
-        scr[n_new++] = np;
-        last = np;
-        if (n_init + n_new >= cap) at_cap = true;
-      } else {
-        finish = true;
-      }
-      if (finish) {
-        const uint32_t total = n_init + n_new;
-        if (n_new) {
-          const uint32_t base = atomicAdd(&ctr->arena_used, total);
-          if (base + total <= arena_cap) {
-            for (uint32_t k = 0; k < n_init; k++) arena[base + k] = arena[init_off + k];
-            for (uint32_t k = 0; k < n_new; k++) arena[base + n_init + k] = scr[k];
-            if (dir == 0) {
-              res[h].pts1_off = base;
-              res[h].n1 = total;
-            } else {
-              res[h].pts2_off = base;
-              res[h].n2 = total;
-            }
-          } else {
-            atomicOr(&ctr->flags, CTR_ARENA_OVERFLOW);
-          }
-        }
-        if (flags) {
-          atomicOr(&ctr->flags, flags);
-          atomicOr(&res[h].flags, flags);
-        }
-        have = false;
-      }
-    }
-  }
-}
 // compatible <=> direction 1 gave >= 2 points, or direction 2 is valid and gave >= 2
 // (compatible_new_plg_point, plg_matching.cpp:1276-1287)
 __global__ void k3a_finalize(uint32_t n_hyp, HypResult* res) {
@@ -1393,32 +1245,6 @@ void launch_task_setup(hipStream_t st, StageAView a, const int32_t* map_view, co
   if (!a.n_tasks) return;
   hipLaunchKernelGGL(k_task_setup, blocks_for(a.n_tasks, 256), dim3(256), 0, st, a, map_view, map_entry, map_n, tasks,
                      n_hyp);
-}
-void launch_k3a(hipStream_t st, bool team4, uint32_t n_blocks, DevScene s, StageAView a, const TaskDesc* tasks,
-                const uint32_t* hyp_off, uint32_t n_hyp, HypResult* res, HPoint* scratch, uint32_t hyp_cap, HPoint* arena,
-                uint32_t arena_cap, Counters* ctr) {
-  if (!n_hyp) return;
-  if (team4)
-    hipLaunchKernelGGL((k3a_hypotheses<HTeam4, true>), dim3(n_blocks), dim3(256), 0, st, s, a, tasks, hyp_off, n_hyp, res,
-                       scratch, hyp_cap, arena, arena_cap, ctr);
-  else
-    hipLaunchKernelGGL((k3a_hypotheses<HTeamSeq, true>), dim3(n_blocks), dim3(256), 0, st, s, a, tasks, hyp_off, n_hyp,
-                       res, scratch, hyp_cap, arena, arena_cap, ctr);
-}
-void launch_k3a_queue(hipStream_t st, bool team4, uint32_t n_blocks, uint32_t follow_blocks, DevScene s, StageAView a,
-                      const TaskDesc* tasks, const uint32_t* hyp_off, uint32_t n_hyp, HypResult* res, HPoint* scratch,
-                      HPoint* follow_scratch, uint32_t hyp_cap, HPoint* arena, uint32_t arena_cap, Counters* ctr,
-                      uint32_t* queue) {
-  if (!n_hyp) return;
-  if (team4)
-    hipLaunchKernelGGL((k3a_hypotheses<HTeam4, false>), dim3(n_blocks), dim3(256), 0, st, s, a, tasks, hyp_off, n_hyp,
-                       res, scratch, hyp_cap, arena, arena_cap, ctr);
-  else
-    hipLaunchKernelGGL((k3a_hypotheses<HTeamSeq, false>), dim3(n_blocks), dim3(256), 0, st, s, a, tasks, hyp_off, n_hyp,
-                       res, scratch, hyp_cap, arena, arena_cap, ctr);
-  hipLaunchKernelGGL(k3a_follow, dim3(follow_blocks), dim3(256), 0, st, s, tasks, hyp_off, a.n_tasks, n_hyp, res,
-                     follow_scratch, hyp_cap, arena, arena_cap, ctr, queue);
-  hipLaunchKernelGGL(k3a_finalize, blocks_for(n_hyp, 256), dim3(256), 0, st, n_hyp, res);
 }
 // K3a as a request/serve engine (eg3d_k3a_engine.h): one wavefront per block
 void launch_k3a_engine(hipStream_t st, uint32_t orient_waves, uint32_t follow_waves, uint32_t lanes_per_wave, DevScene s,

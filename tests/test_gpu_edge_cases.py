@@ -182,16 +182,72 @@ def test_very_long_polylines_parity():
 def test_hypothesis_arena_overflow_is_retried(monkeypatch):
     """The bump-allocated arena of hypothesis point lists starts from an estimate; when a batch
     outgrows it the kernels flag the overflow and the stage is rerun with a larger arena. Forced
-    here with a tiny initial arena (EG3D_ARENA_CAP0), in both K3a modes."""
+    here with a tiny initial arena (EG3D_ARENA_CAP0): both kernels of the hypothesis stage allocate from it (the
+    first lists of the orientation phase, the followed lists), with full wavefronts and with 8 working lanes each."""
     s = host.Synth(1)
     ref = _oracle(s.scene).match(s.seeds, 0, s.n_seeds, nthreads=8)
     monkeypatch.setenv("EG3D_ARENA_CAP0", "64")
-    for team in ("0", "1"):
-        monkeypatch.setenv("EG3D_K3A_TEAM", team)
+    for lanes in ("64", "8"):
+        monkeypatch.setenv("EG3D_K3A_ENGINE_LANES", lanes)
         ctx = api.Context(s.scene)
         got = ctx.match_refpoints(s.seeds)
         ctx.close()
         assert compare_edgepoints(ref, got, rel_tol=1e-4)["ok"]
+
+
+def test_hypothesis_stage_with_few_working_lanes_looks_ahead(monkeypatch):
+    """With few working lanes per wavefront every lane gets several of the wave's request slots: the orientation
+    rounds, the replays and the followed lists run ahead of their answers (eg3d_k3a_engine.h). The result must not
+    depend on it: 1, 2, 5 and 64 working lanes give the cloud of the oracle, flags included."""
+    s = host.Synth(1)
+    ref = _oracle(s.scene).match(s.seeds, 0, s.n_seeds, nthreads=8)
+    for lanes in ("1", "2", "5", "64"):
+        monkeypatch.setenv("EG3D_K3A_ENGINE_LANES", lanes)
+        ctx = api.Context(s.scene)
+        got = ctx.match_refpoints(s.seeds)
+        ctx.close()
+        rep = compare_edgepoints(ref, got)
+        assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], (lanes, rep["msgs"][:3])
+        assert got["flags"] == ref["flags"], (lanes, got["flags"], ref["flags"])
+
+
+def test_hypothesis_list_capacity_is_reported_not_truncated(monkeypatch):
+    """A following direction of the hypothesis stage holds at most hyp_cap points (160 by default; the reference's
+    vectors have no limit). A list that would outgrow it — its probe past the last point that fits succeeds — must
+    make the call fail with EG3D_FLAG_HYP_OVERFLOW rather than return a truncated cloud; a capacity the longest list
+    just fits must change nothing. Checked with every look-ahead depth (working lanes per wavefront)."""
+    s = host.Synth(1)
+    ref = _oracle(s.scene).match(s.seeds, 0, s.n_seeds, nthreads=8)
+    for lanes in ("64", "2"):
+        monkeypatch.setenv("EG3D_K3A_ENGINE_LANES", lanes)
+        monkeypatch.setenv("EG3D_HYP_CAP", "3")
+        ctx = api.Context(s.scene)
+        with pytest.raises(RuntimeError) as ei:
+            ctx.match_refpoints(s.seeds)
+        assert "capacity" in str(ei.value)
+        ctx.close()
+        # the smallest capacity that passes is the same whatever the look-ahead: bisect it, then check the cloud there
+        lo, hi = 3, 160
+        while hi - lo > 1:
+            mid = (lo + hi) // 2
+            monkeypatch.setenv("EG3D_HYP_CAP", str(mid))
+            ctx = api.Context(s.scene)
+            try:
+                ctx.match_refpoints(s.seeds)
+                hi = mid
+            except RuntimeError:
+                lo = mid
+            ctx.close()
+        monkeypatch.setenv("EG3D_HYP_CAP", str(hi))
+        ctx = api.Context(s.scene)
+        got = ctx.match_refpoints(s.seeds)
+        ctx.close()
+        assert compare_edgepoints(ref, got)["ok"]
+        if lanes == "64":
+            first = hi
+        else:
+            assert hi == first, (hi, first)
+    monkeypatch.delenv("EG3D_HYP_CAP")
 
 
 def test_chain_expansion_in_many_chunks(monkeypatch):
