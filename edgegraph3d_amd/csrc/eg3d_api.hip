@@ -117,6 +117,7 @@ struct HostGrids {
 //   EG3D_K3A_ENGINE_LANES=n  lanes of a K3a wavefront that take work (default: 64, fewer for small batches)
 //   EG3D_HYP_CAP=n         tests: points per following direction of the hypothesis stage (default 160; a list that would
 //                          outgrow it raises EG3D_FLAG_HYP_OVERFLOW and the call returns EG3D_ERR_CAPACITY)
+//   EG3D_SLOTS_PER_XCD=n   tests: working slices of the expand stage per XCD (default: what can be resident + margin)
 //   EG3D_ARENA_CAP0=n      initial hypothesis arena capacity (tests: forces the overflow-and-retry path)
 //   EG3D_MAX_SCRATCH_MB=n  tests: cut the chains of a batch into several K3b launches of at most n MB / slice size
 //                          chains each (default: one launch takes all chains — their working slices are slots)
@@ -541,6 +542,7 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
     }
     const uint32_t cus_per_xcd = ((uint32_t)prop.multiProcessorCount + 7u) / 8u;
     c->slots_per_xcd = ((uint32_t)per_cu + 1u) * cus_per_xcd + 16u;
+    if (const char* e = getenv("EG3D_SLOTS_PER_XCD")) c->slots_per_xcd = (uint32_t)std::max(1, atoi(e));  // tests / experiments
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
   // from here on the scene buffers belong to the (shareable) owner, not to this context

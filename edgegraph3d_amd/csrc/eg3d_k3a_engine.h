@@ -8,12 +8,12 @@
 // wave at 10-16 % active lanes (profiles/r03_c3_rocprof_summary.txt: every lane waits at its own call site while
 // the others walk, fail, or have finished). Here a wavefront is a small server:
 //
-//   every iteration   (1) each lane advances its own state machine — fetch the next hypothesis / list, walk — until
-//                         it holds triangulation REQUESTS (three observations each) or is out of work,
-//                     (2) requests go into the wave's 64 slots in LDS (lanes that are still working are ranked;
+//   every iteration   (1) each lane advances its own state machine — evaluate the answers it got, fetch the next
+//                         hypothesis / list, walk — up to its next triangulation REQUESTS (three observations each),
+//                     (2) the requests go into the wave's 64 slots in LDS (lanes that are still working are ranked;
 //                         each gets K = 64 / #working slots, a power of two),
 //                     (3) ALL 64 lanes serve: lane s triangulates slot s — one call site, dense,
-//                     (4) owners read their results back and move on.
+//                     (4) owners read their results back.
 //
 // Because K grows as lanes run out of work, the tail of a launch parallelises by itself: the 4 direction
 // combinations of an orientation round are served at once, a replay walks K steps ahead (its steps are known to
@@ -34,7 +34,7 @@
 namespace eg3d {
 
 // timing build: shader clocks of a wave's phases, summed over the launch (g_gn_dbg[113 + 7*kernel ..]: advance, serve,
-// consume, iterations, requests served, working lanes, serve passes) — tools/k3a_stats.py
+// read answers; iterations, requests served, working lanes) — tools/k3a_stats.py
 #ifdef EG3D_SECTION_TIMING
 #define K3A_T0() unsigned long long kt_[3] = {0, 0, 0}, kc_[4] = {0, 0, 0, 0}, kt0_ = __builtin_readcyclecounter(), kt1_
 #define K3A_T(i) (kt1_ = __builtin_readcyclecounter(), kt_[i] += kt1_ - kt0_, kt0_ = kt1_)
@@ -711,7 +711,6 @@ __global__ void __launch_bounds__(64, EG3D_K3A_WAVES) k3a_follow_spec(DevScene s
     K3A_C(0, 1);
     K3A_C(2, __popcll(working));
     K3A_C(1, __popcll(__ballot(sh.reqM[lane] & 1u)));
-    K3A_C(3, 1);
     k3a_serve(sh, s, lane);
     K3A_T(1);
     if (have) {

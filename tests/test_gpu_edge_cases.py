@@ -250,6 +250,31 @@ def test_hypothesis_list_capacity_is_reported_not_truncated(monkeypatch):
     monkeypatch.delenv("EG3D_HYP_CAP")
 
 
+def test_slot_pool_size_does_not_matter_and_starvation_fails_loudly(monkeypatch):
+    """The working slices of the expand stage are slots of a fixed arena, taken per XCD from a ring of slot ids
+    (eg3d_kernels.hip pool_pop / pool_push). More slots than waves can be resident change nothing; a pool SMALLER than
+    the residency (forced: EG3D_SLOTS_PER_XCD, a test knob) makes the waves queue for the slots of their XCD: the
+    cloud is still complete, or — if a wave exhausts its bounded wait — the call fails with an error; never a hang,
+    never a cloud with chains missing."""
+    s = host.Synth(1)
+    ref = _oracle(s.scene).match(s.seeds, 0, s.n_seeds, nthreads=8)
+    monkeypatch.setenv("EG3D_SLOTS_PER_XCD", "3000")
+    ctx = api.Context(s.scene)
+    got = ctx.match_refpoints(s.seeds)
+    ctx.close()
+    rep = compare_edgepoints(ref, got)
+    assert rep["ok"] and rep["bitexact_X"], rep["msgs"][:3]
+    monkeypatch.setenv("EG3D_SLOTS_PER_XCD", "2")
+    ctx = api.Context(s.scene)
+    try:  # the waves queue for the two slots of their XCD: either every chain gets its turn, or a wave gives up
+        got = ctx.match_refpoints(s.seeds)
+        rep = compare_edgepoints(ref, got)
+        assert rep["ok"] and rep["bitexact_X"], rep["msgs"][:3]
+    except RuntimeError as e:
+        assert "working slice" in str(e)
+    ctx.close()
+
+
 def test_chain_expansion_in_many_chunks(monkeypatch):
     """Chains are expanded in chunks bounded by the scratch budget (24 GB by default); with a 48 MB
     budget config 1 needs several chunks — the concatenated output must not change."""

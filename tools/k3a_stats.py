@@ -18,8 +18,5 @@ for k, name in ((0, "k3a_orient"), (1, "k3a_follow_spec")):
     adv, srv, con, its, req, work, passes = b[113 + 7 * k: 120 + 7 * k]
     tot = max(1, adv + srv + con)
     print("%-16s wave-clocks: advance %.1f%%  serve %.1f%%  consume %.1f%%  (total %.3e)" % (name, 100 * adv / tot, 100 * srv / tot, 100 * con / tot, tot))
-    if k == 0:
-        print("                 advance-loop passes of the busiest lane per iteration %.2f, of which walking %.2f" % (work / max(1, its), passes / max(1, its)))
-        work = passes = 0
-    print("                 iterations %d  requests %d (%.1f per iteration, %.1f per serve pass)  working lanes per iteration %.1f  clocks per iteration %.0f (serve %.0f)"
-          % (its, req, req / max(1, its), req / max(1, passes), work / max(1, its), tot / max(1, its), srv / max(1, its)))
+    print("                 iterations %d  requests %d (%.1f of 64 slots per iteration)  working lanes per iteration %.1f  clocks per iteration %.0f (serve %.0f)"
+          % (its, req, req / max(1, its), work / max(1, its), tot / max(1, its), srv / max(1, its)))
