@@ -1,3 +1,7 @@
+#!/bin/bash
+# GPU box, repo root: the whole validation + measurement job of a round: GPU test suite, smoke, the four rocprofv3 profile sets
+# (tools/profile_r03.sh), every bench line DESIGN.md quotes (tools/r3_final_numbers.sh), the K3a engine statistics of the timing build
+# (build it first: tools/build_variant.sh timing -DEG3D_SECTION_TIMING). Results under gpurun_out/.
 cd /root/repo
 mkdir -p gpurun_out
 (timeout 2000 python -m pytest tests -m gpu -x -q 2>&1 | tail -5) > gpurun_out/final_pytest.log
