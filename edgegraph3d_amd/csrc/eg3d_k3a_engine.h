@@ -52,7 +52,7 @@ namespace eg3d {
 #endif
 
 #ifndef EG3D_K3A_SPEC
-#define EG3D_K3A_SPEC 32 /* most requests one lane may issue per iteration (look-ahead depth): 4 / 8 / 16 / 32 / 64 -> C3' K3a 5.36 / 4.74 / 4.58 / 4.43 / 4.47 ms */
+#define EG3D_K3A_SPEC 32 /* most requests one lane may issue per iteration (look-ahead depth): 4 / 8 / 16 / 32 / 64 -> C3' K3a 5.36 / 4.74 / 4.58 / 4.43 / 4.47 ms on one box (other boxes: +-0.2 ms) */
 #endif
 
 struct K3aShared {
