@@ -171,6 +171,7 @@ struct eg3d_ctx {
   uint32_t slots_per_xcd = 0;
   uint64_t stage_cap_pts = 0, stage_cap_obs = 0;
   hipEvent_t ea[8], eb[8];  // begin/end events per stage: 1 K1, 2 K2, 3 K3a, 4 K3s, 5 K3b, 6 K4, 0 misc, 7 whole call
+  hipEvent_t ecopy[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // D2H of the cloud: one per output array
   uint32_t chain_cap = 384, pool_cap = 0, hyp_cap = 160;
   uint32_t n_simd = 0;  // SIMDs of the device (4 per CU): sizes the K3a engine's launch
   void* pinned = nullptr;  // pinned host staging area of the D2H copies of a cloud (grow-only)
@@ -388,6 +389,7 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
     HIP_TRY(hipEventCreate(&c->ea[i]));
     HIP_TRY(hipEventCreate(&c->eb[i]));
   }
+  for (int i = 0; i < 7; i++) HIP_TRY(hipEventCreateWithFlags(&c->ecopy[i], hipEventDisableTiming));
   const int V = sc->n_views;
   c->V = V;
   c->W = sc->width;
@@ -570,6 +572,7 @@ extern "C" int eg3d_clone(eg3d_ctx* parent, eg3d_ctx** out) {
     HIP_TRY(hipEventCreate(&c->ea[i]));
     HIP_TRY(hipEventCreate(&c->eb[i]));
   }
+  for (int i = 0; i < 7; i++) HIP_TRY(hipEventCreateWithFlags(&c->ecopy[i], hipEventDisableTiming));
   c->V = parent->V;
   c->W = parent->W;
   c->H = parent->H;
@@ -626,6 +629,8 @@ extern "C" void eg3d_destroy(eg3d_ctx* c) {
     if (c->ea[i]) (void)hipEventDestroy(c->ea[i]);
     if (c->eb[i]) (void)hipEventDestroy(c->eb[i]);
   }
+  for (int i = 0; i < 7; i++)
+    if (c->ecopy[i]) (void)hipEventDestroy(c->ecopy[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1086,9 +1091,10 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
         return EG3D_ERR_ARG;
       }
       H.off.n = p0 + np;  // (one spare slot is kept for the final n_obs sentinel)
-      // D2H through the context's pinned staging area (grow-only): seven async copies at PCIe speed, one
-      // synchronisation, then multi-threaded copies into the caller's pageable arrays. (A pageable
-      // hipMemcpy runs at ~2 GB/s and made the copy 3x the compute time on the dtu006-shaped workload.)
+      // D2H through the context's pinned staging area (grow-only): seven async copies at PCIe speed, each followed
+      // by an event; the multi-threaded copy of an array into the caller's pageable memory starts when ITS event has
+      // fired, while the later arrays are still crossing PCIe. (A pageable hipMemcpy runs at ~2 GB/s and made the
+      // copy 3x the compute time on the dtu006-shaped workload.)
       const size_t sz[7] = {sizeof(float) * 3 * np, sizeof(eg3d_off_t) * np,   sizeof(uint32_t) * 4 * np, sizeof(int32_t) * no,
                             sizeof(uint32_t) * no,  sizeof(uint32_t) * no,      sizeof(float) * 2 * no};
       const void* src[7] = {c->o_X.p, c->o_off.p, c->o_key.p, c->o_view.p, c->o_pl.p, c->o_seg.p, c->o_xy.p};
@@ -1110,13 +1116,21 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
 #ifdef EG3D_COPY_TIMING
       const auto tc0 = std::chrono::steady_clock::now();
 #endif
-      for (int k = 0; k < 7; k++)
+      // (the big observation arrays first: their host copies overlap with the transfers behind them)
+      static const int order[7] = {6, 3, 4, 5, 2, 1, 0};
+      for (int i = 0; i < 7; i++) {
+        const int k = order[i];
         if (sz[k]) HIP_TRY(hipMemcpyAsync((char*)c->pinned + at[k], src[k], sz[k], hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipEventRecord(c->ecopy[i], st));
+      }
 #ifdef EG3D_COPY_TIMING
       const auto tc1 = std::chrono::steady_clock::now();
 #endif
-      for (int k = 0; k < 7; k++) copy_mt(dst[k], (char*)c->pinned + at[k], sz[k]);
+      for (int i = 0; i < 7; i++) {
+        const int k = order[i];
+        HIP_TRY(hipEventSynchronize(c->ecopy[i]));
+        copy_mt(dst[k], (char*)c->pinned + at[k], sz[k]);
+      }
 #ifdef EG3D_COPY_TIMING
       const auto tc2 = std::chrono::steady_clock::now();
       fprintf(stderr, "chunk: p0 %zu o0 %zu np %u no %u nc %u  ", p0, o0, np, no, nc);
