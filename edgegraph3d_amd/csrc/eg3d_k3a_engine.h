@@ -548,12 +548,13 @@ template <class T>
 __device__ __forceinline__ T k3a_pick(const T a[3], int i) {
   return i == 0 ? a[0] : i == 1 ? a[1] : a[2];
 }
-// next request of a step: the base point's observations are entries 3..5 of the lane's positions, their views /
-// polylines in view3 / pl3. Returns the starting observation used and the three new positions in the order the
-// new point lists them (the starting observation, then the other two in index order).
+// next request of a step: the base point's observations are entries 3..5 of the lane's positions, their views in
+// view3 (their polylines: the lane's cached polyline of that view). Returns the starting observation used and the
+// three new positions in the order the new point lists them (the starting observation, then the other two in index
+// order).
 __device__ __forceinline__ bool k3a_follow_request(const DevScene& s, const K3aLane& L, const int32_t view3[3],
-                                                   const uint32_t pl3[3], int st_start, const uint32_t dirs[3],
-                                                   const int32_t ids[3], int& st_used, PlPt sel_pt[3], uint32_t& fl) {
+                                                   int st_start, const uint32_t dirs[3], const int32_t ids[3],
+                                                   int& st_used, PlPt sel_pt[3], uint32_t& fl) {
 #pragma unroll 1
   for (int st = st_start; st < 3; st++) {
     const int32_t sv = k3a_pick(view3, st);
@@ -595,9 +596,7 @@ __device__ __forceinline__ bool k3a_follow_request(const DevScene& s, const K3aL
   return false;
 }
 
-__global__ void __launch_bounds__(64, EG3D_K3A_WAVES) k3a_follow_spec(DevScene s, const TaskDesc* tasks,
-                                                                      const uint32_t* hyp_off, uint32_t n_tasks,
-                                                                      uint32_t n_hyp, HypResult* res, HPoint* scratch,
+__global__ void __launch_bounds__(64, EG3D_K3A_WAVES) k3a_follow_spec(DevScene s, HypResult* res, HPoint* scratch,
                                                                       uint32_t cap, HPoint* arena, uint32_t arena_cap,
                                                                       Counters* ctr, uint32_t* queue, uint32_t lanes_per_wave,
                                                                       const uint32_t* items, const uint32_t* n_items_p) {
@@ -676,7 +675,7 @@ __global__ void __launch_bounds__(64, EG3D_K3A_WAVES) k3a_follow_spec(DevScene s
         int st_used = 0;
         PlPt sel_pt[3];
         uint32_t fl = 0;
-        if (!k3a_follow_request(s, L, bview, bpl, st0, dirs, ids, st_used, sel_pt, fl)) {
+        if (!k3a_follow_request(s, L, bview, st0, dirs, ids, st_used, sel_pt, fl)) {
           ended = true;
           end_fl = fl;
           break;

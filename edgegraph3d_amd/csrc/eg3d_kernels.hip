@@ -1277,8 +1277,7 @@ void launch_k3a_engine(hipStream_t st, uint32_t orient_waves, uint32_t follow_wa
   if (!n_hyp) return;
   hipLaunchKernelGGL(k3a_orient, dim3(orient_waves), dim3(64), 0, st, s, a, tasks, hyp_off, n_hyp, res, hyp_cap, arena,
                      arena_cap, ctr, queue3, lanes_per_wave, items, queue3 + 2);
-  hipLaunchKernelGGL(k3a_follow_spec, dim3(follow_waves), dim3(64), 0, st, s, tasks, hyp_off, a.n_tasks, n_hyp, res,
-                     follow_scratch, hyp_cap, arena, arena_cap, ctr, queue3 + 1, lanes_per_wave, items, queue3 + 2);
+  hipLaunchKernelGGL(k3a_follow_spec, dim3(follow_waves), dim3(64), 0, st, s, res, follow_scratch, hyp_cap, arena, arena_cap, ctr, queue3 + 1, lanes_per_wave, items, queue3 + 2);
   hipLaunchKernelGGL(k3a_finalize, blocks_for(n_hyp, 256), dim3(256), 0, st, n_hyp, res);
 }
 void launch_k3s(hipStream_t st, uint32_t n_tasks, const uint32_t* hyp_off, const HypResult* res, ChainSeed* per_task,
