@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/profile_r03.sh <workload: c3|c2|c4|c3real> [tag=r03]
+# usage (GPU box, repo root): tools/profile_r03.sh <workload: c3|c2|c4|c3real|c2_sets|c3_sets> [tag=r03]
 # (round 3: the C4 counter passes run at the bench's own step size, 8192 seeds, so that roofline.traffic belongs to the
 # bench line; SQ_THREAD_CYCLES_VALU added: active-lane fraction = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU))
 # One rocprofv3 --kernel-trace --stats pass of the bench command the driver runs for that workload, and
@@ -9,6 +9,7 @@ wl=${1:-c3}; tag=${2:-r03}_$wl
 out=$PWD/gpurun_out; mkdir -p $out/tmp; export TMPDIR=$out/tmp
 [ -f $out/pmc_traffic.json ] || cp profiles/pmc_traffic.json $out/pmc_traffic.json  # the other workloads' entries are kept
 case $wl in
+  *_sets) b=${wl%_sets}; kt_args="--workload $b --path sets --steps 6 --warmup 2 --no-cpu-baseline"; pmc_args="--workload $b --path sets --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --no-extras"; pmc_steps=4;;
   c4) kt_args="--workload c4 --steps 3 --warmup 1 --no-cpu-baseline"; pmc_args="--workload c4 --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline --no-extras"; pmc_steps=3;;
   *)  kt_args="--workload $wl --steps 20 --warmup 5 --no-cpu-baseline"; pmc_args="--workload $wl --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --no-extras"; pmc_steps=4;;
 esac

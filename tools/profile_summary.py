@@ -106,6 +106,14 @@ def main():
             for k in out:
                 tot = 2.0 * fs.get(k, {}).get("FETCH_SIZE", 0.0) * 1024.0 + ws.get(k, {}).get("WRITE_SIZE", 0.0) * 1024.0
                 out[k]["hbm_bytes_per_step"] = tot / a.pmc_steps
+                # k3b_expand / k4_emit run once per steady-state step; the first passes of a context repeat the launch
+                # while its capacities and staging area grow (C4: every pass of a 3-pass run): per step = one launch
+                n_l = (counter_stats(a.fetch).get(k, {}).get("FETCH_SIZE") or (0, 0))[1]
+                if k in ("k3b_expand", "k4_emit") and n_l > a.pmc_steps:
+                    out[k]["hbm_bytes_per_step"] = out[k]["hbm_bytes_per_launch"]
+                    out[k]["note_step"] = ("%d launches in %d passes (a context's first passes repeat the launch while its "
+                                           "buffers grow): a steady-state step is ONE launch, per step = the per-launch mean"
+                                           % (n_l, a.pmc_steps))
             path = os.path.join(a.out, "pmc_traffic.json")
             allw = json.load(open(path)) if os.path.exists(path) else {}
             if not isinstance(allw, dict) or any(isinstance(v, dict) and "hbm_bytes_per_launch" in v for v in allw.values()):
