@@ -113,7 +113,7 @@ struct HostGrids {
 
 // Test / tuning knobs, read from the environment ONCE when a context is created (eg3d_create; clones
 // inherit them) — the hot path never calls getenv:
-//   EG3D_K3A_ENGINE_WAVES=n  wavefronts per SIMD the K3a engine launches (default 3)
+//   EG3D_K3A_ENGINE_WAVES=n  wavefronts per SIMD the K3a engine launches (default 2 = what its 256-VGPR build allows)
 //   EG3D_K3A_ENGINE_LANES=n  lanes of a K3a wavefront that take work (default: 64, fewer for small batches)
 //   EG3D_HYP_CAP=n         tests: points per following direction of the hypothesis stage (default 160; a list that would
 //                          outgrow it raises EG3D_FLAG_HYP_OVERFLOW and the call returns EG3D_ERR_CAPACITY)
@@ -862,7 +862,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
   BUF_TRY(c->b_res.ensure(sizeof(HypResult) * (B.n_hyp + 1)));
   // K3a engine (eg3d_k3a_engine.h): single-wavefront blocks; the lanes of a wave that take work are limited when there
   // is little of it, so that each working lane gets more of the wave's 64 request slots
-  const uint32_t eng_waves_max = c->n_simd * (uint32_t)(c->tune.k3a_engine_waves > 0 ? c->tune.k3a_engine_waves : 3);
+  const uint32_t eng_waves_max = c->n_simd * (uint32_t)(c->tune.k3a_engine_waves > 0 ? c->tune.k3a_engine_waves : 2);
   uint32_t eng_lanes = 64;
   if (c->tune.k3a_engine_lanes > 0)
     eng_lanes = (uint32_t)std::min(64, c->tune.k3a_engine_lanes);

@@ -430,7 +430,8 @@ __device__ __forceinline__ uint32_t find_owner(const uint32_t* off, uint32_t n, 
 // Hypothesis evaluation: eg3d_k3a_engine.h (k3a_orient, k3a_follow_spec), included below; what it computes is stated
 // sequentially by evaluate_hypothesis in eg3d_dev_follow.h (the host simulation of the tests runs that).
 #ifndef EG3D_K3A_WAVES
-#define EG3D_K3A_WAVES 3 /* waves/SIMD the register allocation of K3a aims at (also what its LDS allows) */
+#define EG3D_K3A_WAVES 2 /* waves/SIMD the register allocation of K3a aims at: 256 VGPRs, nothing spills (at 3: 168 VGPRs,
+                            86-102 spilled; same speed on C3', K3a 1.50 -> 1.30 ms on C2, half the L2<->fabric traffic) */
 #endif
 // compatible <=> direction 1 gave >= 2 points, or direction 2 is valid and gave >= 2
 // (compatible_new_plg_point, plg_matching.cpp:1276-1287)
