@@ -174,6 +174,7 @@ struct eg3d_ctx {
   hipEvent_t ecopy[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // D2H of the cloud: one per output array
   uint32_t chain_cap = 384, pool_cap = 0, hyp_cap = 160;
   uint32_t n_simd = 0;  // SIMDs of the device (4 per CU): sizes the K3a engine's launch
+  double arena_per_hyp = 12.0;  // hypothesis arena: points per hypothesis to reserve (learned from overflows)
   void* pinned = nullptr;  // pinned host staging area of the D2H copies of a cloud (grow-only)
   size_t pinned_cap = 0;
   // mailbox for the small read-backs of a step (scan totals, counters): pinned host memory mapped into the
@@ -598,6 +599,7 @@ extern "C" int eg3d_clone(eg3d_ctx* parent, eg3d_ctx** out) {
   c->pool_cap = parent->pool_cap;
   c->hyp_cap = parent->hyp_cap;
   c->n_simd = parent->n_simd;
+  c->arena_per_hyp = parent->arena_per_hyp;
   c->slots_per_xcd = parent->slots_per_xcd;
   c->stage_cap_pts = parent->stage_cap_pts;  // sizing hints only: the clone allocates its own staging area
   c->stage_cap_obs = parent->stage_cap_obs;
@@ -872,7 +874,9 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
   BUF_TRY(c->b_fscratch.ensure(sizeof(HPoint) * c->hyp_cap * ((size_t)eng_waves * 64)));
   BUF_TRY(c->b_queue.ensure(4 * sizeof(uint32_t)));
   BUF_TRY(c->b_items.ensure(sizeof(uint32_t) * 2 * ((size_t)B.n_hyp + 1)));
-  uint32_t arena_cap = std::max<uint32_t>(1u << 16, std::min<uint64_t>((uint64_t)B.n_hyp * 32, 1ull << 26));
+  // hypothesis arena: 12 points per hypothesis to start with (the seed path uses 0.4-4.8, the polyline-set path 8.2-8.6;
+  // it was a flat 32: 1.9 GB on C3'), more once an attempt of this context has overflowed (it is redone with room)
+  uint32_t arena_cap = std::max<uint32_t>(1u << 16, std::min<uint64_t>((uint64_t)((double)B.n_hyp * c->arena_per_hyp) + 1, 1ull << 26));
   if (c->tune.arena_cap0) arena_cap = c->tune.arena_cap0;  // tests: force the overflow-and-retry path
   Counters hc;
   BUF_TRY(c->b_cs_task.ensure(sizeof(ChainSeed) * (nt + 1)));
@@ -901,6 +905,10 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
     rb.clear_after(c->b_scanchk.as<uint32_t>());
     BUF_TRY(rb.run());
     memcpy(&hc, rb.item(ic), sizeof(Counters));
+    if (getenv("EG3D_TRACE_ARENA"))
+      fprintf(stderr, "eg3d: hypothesis arena: %u hypotheses, %u points used of %u (%.2f per hypothesis)%s\n", B.n_hyp,
+              hc.arena_used, arena_cap, B.n_hyp ? (double)hc.arena_used / B.n_hyp : 0.0,
+              (hc.flags & CTR_ARENA_OVERFLOW) ? " OVERFLOW" : "");
     if (!(hc.flags & CTR_ARENA_OVERFLOW)) {
       if (*rb.item(iw)) return wrapped_error("chains");
       B.n_chains = *rb.item(it);
@@ -911,6 +919,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
       return EG3D_ERR_CAPACITY;
     }
     arena_cap = std::max<uint32_t>(arena_cap * 2, hc.arena_used + (hc.arena_used >> 2));
+    if (B.n_hyp) c->arena_per_hyp = std::max(c->arena_per_hyp, 1.25 * (double)arena_cap / (double)B.n_hyp);
   }
   H.flags |= (hc.flags & 0xffu);
   BUF_TRY(c->b_chains.ensure(sizeof(ChainSeed) * (B.n_chains + 1)));
