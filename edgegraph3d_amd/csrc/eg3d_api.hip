@@ -118,6 +118,7 @@ struct HostGrids {
 //   EG3D_HYP_CAP=n         tests: points per following direction of the hypothesis stage (default 160; a list that would
 //                          outgrow it raises EG3D_FLAG_HYP_OVERFLOW and the call returns EG3D_ERR_CAPACITY)
 //   EG3D_SLOTS_PER_XCD=n   tests: working slices of the expand stage per XCD (default: what can be resident + margin)
+//   EG3D_TRACE_ARENA=1     print the hypothesis arena's use per batch to stderr
 //   EG3D_ARENA_CAP0=n      initial hypothesis arena capacity (tests: forces the overflow-and-retry path)
 //   EG3D_MAX_SCRATCH_MB=n  tests: cut the chains of a batch into several K3b launches of at most n MB / slice size
 //                          chains each (default: one launch takes all chains — their working slices are slots)
@@ -174,7 +175,7 @@ struct eg3d_ctx {
   hipEvent_t ecopy[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // D2H of the cloud: one per output array
   uint32_t chain_cap = 384, pool_cap = 0, hyp_cap = 160;
   uint32_t n_simd = 0;  // SIMDs of the device (4 per CU): sizes the K3a engine's launch
-  double arena_per_hyp = 12.0;  // hypothesis arena: points per hypothesis to reserve (learned from overflows)
+  double arena_per_hyp = 16.0;  // hypothesis arena: points per hypothesis to reserve (learned from overflows)
   void* pinned = nullptr;  // pinned host staging area of the D2H copies of a cloud (grow-only)
   size_t pinned_cap = 0;
   // mailbox for the small read-backs of a step (scan totals, counters): pinned host memory mapped into the
@@ -871,11 +872,11 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
   else
     while (eng_lanes > 8 && (uint64_t)eng_waves_max * (eng_lanes / 2) >= B.n_hyp) eng_lanes /= 2;
   const uint32_t eng_waves = std::max<uint32_t>(1, std::min<uint32_t>(eng_waves_max, (B.n_hyp + eng_lanes - 1) / eng_lanes));
-  BUF_TRY(c->b_fscratch.ensure(sizeof(HPoint) * c->hyp_cap * ((size_t)eng_waves * 64)));
+  BUF_TRY(c->b_fscratch.ensure(sizeof(HPoint) * std::min<uint32_t>(c->hyp_cap, EG3D_K3A_STAGE_POINTS) * ((size_t)eng_waves * 64)));
   BUF_TRY(c->b_queue.ensure(4 * sizeof(uint32_t)));
   BUF_TRY(c->b_items.ensure(sizeof(uint32_t) * 2 * ((size_t)B.n_hyp + 1)));
-  // hypothesis arena: 12 points per hypothesis to start with (the seed path uses 0.4-4.8, the polyline-set path 8.2-8.6;
-  // it was a flat 32: 1.9 GB on C3'), more once an attempt of this context has overflowed (it is redone with room)
+  // hypothesis arena: 16 points per hypothesis to start with (the seed path uses 0.4-11.6, the polyline-set path 23-24: its
+  // first call overflows once), more once an attempt of this context has overflowed (it is redone with room)
   uint32_t arena_cap = std::max<uint32_t>(1u << 16, std::min<uint64_t>((uint64_t)((double)B.n_hyp * c->arena_per_hyp) + 1, 1ull << 26));
   if (c->tune.arena_cap0) arena_cap = c->tune.arena_cap0;  // tests: force the overflow-and-retry path
   Counters hc;

@@ -51,6 +51,7 @@ namespace eg3d {
 #define K3A_TEND(kern) ((void)0)
 #endif
 
+#define EG3D_K3A_STAGE EG3D_K3A_STAGE_POINTS /* followed points staged per lane before a list moves into the arena (eg3d_kernels.h) */
 #ifndef EG3D_K3A_SPEC
 #define EG3D_K3A_SPEC 32 /* most requests one lane may issue per iteration (look-ahead depth): 4 / 8 / 16 / 32 / 64 -> C3' K3a 5.36 / 4.74 / 4.58 / 4.43 / 4.47 ms on one box (other boxes: +-0.2 ms) */
 #endif
@@ -604,7 +605,12 @@ __global__ void __launch_bounds__(64, EG3D_K3A_WAVES) k3a_follow_spec(DevScene s
   const uint32_t lane = threadIdx.x;
   const K3aLane L{&sh, lane};
   const unsigned long long lt = (1ull << lane) - 1ull;
-  HPoint* scr = scratch + ((size_t)blockIdx.x * 64 + lane) * cap;  // new points of the current item
+  // new points of the current list: the first `stage` are staged per lane (most lists end within a few steps and are
+  // then copied, with their initial points, into an arena block of their exact length); a list that outgrows the
+  // stage moves into an arena block of the full capacity and grows there in place
+  const uint32_t stage = cap < (uint32_t)EG3D_K3A_STAGE ? cap : (uint32_t)EG3D_K3A_STAGE;
+  HPoint* scr = scratch + ((size_t)blockIdx.x * 64 + lane) * stage;
+  uint32_t big_base = 0xffffffffu;  // != none: the list lives at arena[big_base ..]
   const uint32_t n_items = *n_items_p;  // the lists k3a_orient left to follow: (hypothesis, direction)
   bool have = false, exhausted = lane >= lanes_per_wave;
   uint32_t h = 0, dir = 0, n_init = 0, n_new = 0, init_off = 0, flags = 0;
@@ -649,6 +655,7 @@ __global__ void __launch_bounds__(64, EG3D_K3A_WAVES) k3a_follow_spec(DevScene s
       n_new = 0;
       flags = 0;
       st_start = 0;
+      big_base = 0xffffffffu;
       have = true;
     }
     const unsigned long long working = __ballot(have);
@@ -725,7 +732,24 @@ __global__ void __launch_bounds__(64, EG3D_K3A_WAVES) k3a_follow_spec(DevScene s
             finish = true;
             break;
           }
-          scr[n_new++] = k3a_point_of_slot(sh, slot);
+          if (big_base != 0xffffffffu)
+            arena[big_base + n_init + n_new] = k3a_point_of_slot(sh, slot);
+          else
+            scr[n_new] = k3a_point_of_slot(sh, slot);
+          n_new++;
+          if (big_base == 0xffffffffu && n_new == stage && n_init + n_new < cap) {  // outgrew the stage
+            const uint32_t b = atomicAdd(&ctr->arena_used, cap);
+            if (b + cap <= arena_cap) {
+              for (uint32_t k = 0; k < n_init; k++) arena[b + k] = arena[init_off + k];
+              for (uint32_t k = 0; k < n_new; k++) arena[b + n_init + k] = scr[k];
+              big_base = b;
+            } else {  // (the host redoes the stage with a larger arena: this list's result is not used)
+              atomicOr(&ctr->flags, CTR_ARENA_OVERFLOW);
+              n_new = 0;
+              finish = true;
+              break;
+            }
+          }
           for (int k = 0; k < 3; k++) {
             const Obs o = sh.req[slot][k];
             cview[k] = (int32_t)o.view;
@@ -748,7 +772,15 @@ __global__ void __launch_bounds__(64, EG3D_K3A_WAVES) k3a_follow_spec(DevScene s
       }
       if (finish) {
         const uint32_t total = n_init + n_new;
-        if (n_new) {
+        if (n_new && big_base != 0xffffffffu) {
+          if (dir == 0) {
+            res[h].pts1_off = big_base;
+            res[h].n1 = total;
+          } else {
+            res[h].pts2_off = big_base;
+            res[h].n2 = total;
+          }
+        } else if (n_new) {
           const uint32_t base = atomicAdd(&ctr->arena_used, total);
           if (base + total <= arena_cap) {
             for (uint32_t k = 0; k < n_init; k++) arena[base + k] = arena[init_off + k];

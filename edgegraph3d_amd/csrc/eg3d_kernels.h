@@ -68,8 +68,10 @@ void launch_n1_hits(hipStream_t st, bool fill, DevScene s, SetsDev sets, uint32_
 void launch_task_setup(hipStream_t st, StageAView a, const int32_t* map_view, const uint32_t* map_entry,
                        const uint32_t* map_n, TaskDesc* tasks, uint32_t* n_hyp);
 // K3a as a request/serve engine (eg3d_k3a_engine.h): orient_waves / follow_waves single-wavefront blocks, of which
-// the first lanes_per_wave lanes take work; follow_scratch: hyp_cap HPoints per lane of follow_waves x 64; queue3: three
+// the first lanes_per_wave lanes take work; follow_scratch: min(hyp_cap, EG3D_K3A_STAGE_POINTS) HPoints per lane of
+// follow_waves x 64; queue3: three
 // zeroed counters (hypotheses taken, lists taken, lists to follow); items: 2 x n_hyp words (the lists to follow)
+#define EG3D_K3A_STAGE_POINTS 16u /* = EG3D_K3A_STAGE of eg3d_k3a_engine.h */
 void launch_k3a_engine(hipStream_t st, uint32_t orient_waves, uint32_t follow_waves, uint32_t lanes_per_wave, DevScene s,
                        StageAView a, const TaskDesc* tasks, const uint32_t* hyp_off, uint32_t n_hyp, HypResult* res,
                        HPoint* follow_scratch, uint32_t hyp_cap, HPoint* arena, uint32_t arena_cap, Counters* ctr,
