@@ -731,17 +731,16 @@ EG3D_HD bool unique_polyline_4px(const DevScene& s, int view, float x, float y, 
 }
 
 // The speculative central ADD solves of a view's candidates: all chain points at once after the
-// candidate pass ("eager": one big batch, ~1/4 of the solves end up used), or a window of
-// EG3D_SPEC_WINDOW points at a time as the visit reaches them ("lazy"). Eager wins where the solves
-// are short (C2, C3': 8 / 25 views), lazy where points carry dozens of observations and a wasted solve
-// is expensive (C4, 200 views: K3b -9 %). Chosen per scene by the number of views.
+// candidate pass ("eager": one big batch, ~1/4 of the solves end up used), or a window of points at a
+// time as the visit reaches them ("lazy"). Eager wins where the solves are short (C2: 8 views), lazy
+// where a wasted solve is expensive: from 16 views on, in windows of 16 points (C3', 25 views: K3b
+// 54.7 -> 53.6-53.9 ms), of 8 points from 64 views on (C4, 200 views: K3b -9 % against eager; windows
+// of 16 / 32: +1.7 / +3.7 %). Chosen per scene by the number of views.
 #ifndef EG3D_LAZY_PRESOLVE_MIN_VIEWS
-#define EG3D_LAZY_PRESOLVE_MIN_VIEWS 64
-#endif
-#ifndef EG3D_SPEC_WINDOW
-#define EG3D_SPEC_WINDOW 8
+#define EG3D_LAZY_PRESOLVE_MIN_VIEWS 16
 #endif
 EG3D_HD bool lazy_presolve(const DevScene& s) { return s.n_views >= EG3D_LAZY_PRESOLVE_MIN_VIEWS; }
+EG3D_HD int presolve_window(const DevScene& s) { return s.n_views >= 64 ? 8 : 16; }
 // speculative central ADD solve of the chain points [from, to) whose candidate is within 4 px
 template <class Team>
 EG3D_HD_FLAT void central_presolves(const Team& tm, const DevScene& s, Chain& c, int v, int from, int to) {
@@ -903,7 +902,7 @@ EG3D_HD_FLAT void expand_to_view(const Team& tm, const DevScene& s, Chain& c, in
     c.bytes += 8ull * (s.pl_vtx_off[s.view_pl_off[v] + vc.pl + 1] - s.pl_vtx_off[s.view_pl_off[v] + vc.pl]);
     if (vc.d2 > 16.0f) return;  // abandons this view (Q4)
     if (lazy_presolve(s) && c.head + cur >= spec_slot_hi) {
-      int to = cur + EG3D_SPEC_WINDOW;
+      int to = cur + presolve_window(s);
       if (to > c.len) to = c.len;
       const uint64_t tp0 = EG3D_TICK();
       central_presolves(tm, s, c, v, cur, to);
