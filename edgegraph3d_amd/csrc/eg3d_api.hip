@@ -125,8 +125,10 @@ struct HostGrids {
 //   EG3D_NO_LPT=1          launch chains in identity order instead of longest-first (diagnostic)
 struct Tunables {
   int k3a_engine_waves = 0, k3a_engine_lanes = 0;
+  bool trace_arena = false;
   uint32_t arena_cap0 = 0, hyp_cap = 0;
   size_t max_scratch = 0;  // 0 = no limit
+  uint32_t slots_per_xcd = 0;  // 0 = sized from the occupancy query
   bool use_lpt = true;
   static Tunables from_env() {
     Tunables t;
@@ -136,6 +138,8 @@ struct Tunables {
     if (const char* e = getenv("EG3D_ARENA_CAP0")) t.arena_cap0 = (uint32_t)std::max(16, atoi(e));
     if (const char* e = getenv("EG3D_MAX_SCRATCH_MB")) t.max_scratch = (size_t)std::max(1, atoi(e)) << 20;
     if (const char* e = getenv("EG3D_NO_LPT")) t.use_lpt = !(e[0] == '1');
+    if (const char* e = getenv("EG3D_TRACE_ARENA")) t.trace_arena = e[0] == '1';
+    if (const char* e = getenv("EG3D_SLOTS_PER_XCD")) t.slots_per_xcd = (uint32_t)std::max(1, atoi(e));
     return t;
   }
 };
@@ -544,9 +548,14 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
       eg3d_destroy(c);
       return EG3D_ERR_HIP;
     }
-    const uint32_t cus_per_xcd = ((uint32_t)prop.multiProcessorCount + 7u) / 8u;
+    // XCDs of THIS device: 8 on the whole MI355X (32 CUs each), fewer when the GPU is partitioned (CPX: one XCD of 32
+    // CUs appears as a device, DPX / QPX: four / two) — all its blocks then draw from the pools of those XCDs only, so a
+    // pool is sized for CUs / XCDs compute units, not for an eighth of whatever the device reports
+    const uint32_t cus = (uint32_t)prop.multiProcessorCount;
+    const uint32_t n_xcd = std::min(8u, std::max(1u, cus / 32u));
+    const uint32_t cus_per_xcd = (cus + n_xcd - 1u) / n_xcd;
     c->slots_per_xcd = ((uint32_t)per_cu + 1u) * cus_per_xcd + 16u;
-    if (const char* e = getenv("EG3D_SLOTS_PER_XCD")) c->slots_per_xcd = (uint32_t)std::max(1, atoi(e));  // tests / experiments
+    if (c->tune.slots_per_xcd) c->slots_per_xcd = c->tune.slots_per_xcd;  // tests / experiments
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
   // from here on the scene buffers belong to the (shareable) owner, not to this context
@@ -906,7 +915,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
     rb.clear_after(c->b_scanchk.as<uint32_t>());
     BUF_TRY(rb.run());
     memcpy(&hc, rb.item(ic), sizeof(Counters));
-    if (getenv("EG3D_TRACE_ARENA"))
+    if (c->tune.trace_arena)
       fprintf(stderr, "eg3d: hypothesis arena: %u hypotheses, %u points used of %u (%.2f per hypothesis)%s\n", B.n_hyp,
               hc.arena_used, arena_cap, B.n_hyp ? (double)hc.arena_used / B.n_hyp : 0.0,
               (hc.flags & CTR_ARENA_OVERFLOW) ? " OVERFLOW" : "");
@@ -958,7 +967,9 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
       const uint64_t guess_pts = 96ull * nc;
       const uint64_t per_pt = (uint64_t)std::min(100, std::max(8, c->V / 2));
       const uint64_t want_pts = std::max<uint64_t>(c->stage_cap_pts, guess_pts);
-      const uint64_t want_obs = std::max<uint64_t>(c->stage_cap_obs, guess_pts * per_pt);
+      // (the first guess is capped at 8 GB of observations: a launch that needs more reports its exact need and is
+      // repeated once — better than reserving tens of GB per context on a guess for a many-view scene)
+      const uint64_t want_obs = std::max<uint64_t>(c->stage_cap_obs, std::min<uint64_t>(guess_pts * per_pt, (8ull << 30) / sizeof(Obs)));
       BUF_TRY(c->b_stage_pts.ensure(sizeof(StagePt) * (size_t)want_pts));
       BUF_TRY(c->b_stage_obs.ensure(sizeof(Obs) * (size_t)want_obs));
       BUF_TRY(c->b_stage_used.ensure(2 * sizeof(unsigned long long)));

@@ -22,6 +22,11 @@ namespace eg3d {
 #define EG3D_GN_ROW_CYCLES 1400  /* cost model of the longer ones: one row's projection + Jacobian (8 FP64 divisions) */
 #define EG3D_GN_SUM_CYCLES 44    /*   and one row's share of the in-order sums of both passes */
 #endif
+// requests a window holds (request j on lane j < EG3D_COOP_REQ). 64 fills the wave; 32 halves the request table so that
+// CoopLds fits 8 LDS allocation units = 4 single-wave workgroups per SIMD (with EG3D_K3B_WAVES=4)
+#ifndef EG3D_COOP_REQ
+#define EG3D_COOP_REQ 64
+#endif
 #define EG3D_STAGE_VTX 512
 #define EG3D_STAGE_EPI 192
 // 12 784 bytes: gfx950 allocates LDS in 1 280-byte units, 10 units per wave = 12 single-wave
@@ -41,18 +46,26 @@ struct CoopLds {
   int32_t la_m[8];               // look-ahead following: observations kept by step j
   uint32_t la_fl[8];             //   and the diagnostic flags its walks raised
   Obs tmp_a[EG3D_COOP_ROWS];     // the N-view step's candidate observations (Chain::tmp_a) when they fit
-  float x0[EG3D_COOP_ROWS][3];   // in: start point of request j; out: its result
-  const Obs* gbase[EG3D_COOP_ROWS];  // observation array of request j
-  double gsum[32][7];            // per-group sums (G >= 2 => <= 32 groups)
-  int32_t ex_view[EG3D_COOP_ROWS];   // the extra (ADD) observation of request j
-  float ex_x[EG3D_COOP_ROWS], ex_y[EG3D_COOP_ROWS];
-  uint16_t n16[EG3D_COOP_ROWS];  // rows of request j | has-extra << 15
+  float x0[EG3D_COOP_REQ][3];    // in: start point of request j; out: its result
+  const Obs* gbase[EG3D_COOP_REQ];   // observation array of request j
+  int32_t ex_view[EG3D_COOP_REQ];    // the extra (ADD) observation of request j
+  float ex_x[EG3D_COOP_REQ], ex_y[EG3D_COOP_REQ];
+  uint16_t n16[EG3D_COOP_REQ];   // rows of request j | has-extra << 15
   uint8_t row_req[EG3D_COOP_ROWS];   // row (short rounds) / group slot (long rounds) -> request lane
   uint8_t row_k[EG3D_COOP_ROWS];     // row -> its index in the request
-  uint8_t res_ok[EG3D_COOP_ROWS];
+  uint8_t res_ok[EG3D_COOP_REQ];
   uint8_t cams_mid_range;  // DevScene::cams_mid_range (set once per workgroup): enables the shared-reciprocal rows
+  // Per-group sums (G >= 2 => <= 32 groups x 7 doubles). They live in product columns 6..13: a pass's sums are written
+  // after the last chunk's products have been consumed (behind its barrier), pass 2 only writes columns 0..5, and
+  // every lane has read the sums before the next pass writes products again — never live together.
+  __device__ __forceinline__ double& gsum(int g, int e) { return (&prod[6][0])[g * 7 + e]; }
 };
+static_assert(32 * 7 <= 8 * (EG3D_COOP_ROWS + 1), "the per-group sums must fit product columns 6..13");
+#if EG3D_COOP_REQ <= 32
+static_assert(sizeof(CoopLds) <= 10240, "CoopLds must fit 8 LDS allocation units (4 waves per SIMD)");
+#else
 static_assert(sizeof(CoopLds) <= 12800, "CoopLds must fit 10 LDS allocation units (3 waves per SIMD)");
+#endif
 
 
 // ---------------------------------------------------------------------------------------------
@@ -213,6 +226,11 @@ __device__ __forceinline__ double ordered_sum2(double s, const double* __restric
 // at lane gb, the request's n rows (the first nb from a[], the last one the extra observation),
 // start point X (identical on the lanes of a group). cmax = chunks per pass (wave-uniform maximum).
 // Returns the accept flag; X holds the solution.
+// KEEP = chunks of a pass whose rows stay in registers between the two passes of an iteration (16 VGPRs per chunk). 0 =
+// the standard build: a one-chunk round keeps its rows, a multi-chunk round recomputes all of them in the update pass;
+// 4 in the wide build for scenes with long observation lists (V >= 64), where that recomputation was a fifth of the
+// kernel's time. Same values either way (a row is a function of X, which does not change between the passes).
+template <int KEEP>
 __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool act, int l, int G, int gb, int n, int nb,
                                          const Obs* a, int32_t xv, float xx, float xy, int cmax, double X[3]) {
   const int lane = (int)(threadIdx.x & 63u);
@@ -232,9 +250,12 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
     EG3D_GN_T0();
     // ---- pass 1: H (6) and mse; accumulator e lives in group lane e % G, slot e / G
     double acc[4] = {0, 0, 0, 0};
-    GnRow w;
-    w.j00 = w.j01 = w.j02 = w.j10 = w.j11 = w.j12 = w.r0 = w.r1 = 0;
-    for (int c = 0; c < cmax; c++) {
+    constexpr int NK = KEEP > 0 ? KEEP : 1;
+    GnRow wk[NK];
+#pragma unroll
+    for (int q = 0; q < NK; q++) wk[q].j00 = wk[q].j01 = wk[q].j02 = wk[q].j10 = wk[q].j11 = wk[q].j12 = wk[q].r0 = wk[q].r1 = 0;
+    // one chunk of pass 1: the lane's row of the chunk (kept in w), its 14 products, the in-order sums
+    auto pass1_chunk = [&](int c, GnRow& w) {
       const int r = c * G + l;
       const bool rowact = !done && r < n;
       if (rowact) {
@@ -281,20 +302,31 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
       }
       __syncthreads();
       EG3D_GN_T(2);
+    };
+    if constexpr (KEEP == 0) {
+      for (int c = 0; c < cmax; c++) pass1_chunk(c, wk[0]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < KEEP; q++)
+        if (q < cmax) pass1_chunk(q, wk[q]);
+      for (int c = KEEP; c < cmax; c++) {
+        GnRow wt;
+        pass1_chunk(c, wt);
+      }
     }
     if (!done) {
 #pragma unroll
       for (int t = 0; t < 4; t++) {
         const int e = l + t * G;
-        if (e < 7) L.gsum[gs][e] = acc[t];
+        if (e < 7) L.gsum(gs, e) = acc[t];
       }
     }
     __syncthreads();
     double I00 = 0, I01 = 0, I02 = 0, I10 = 0, I11 = 0, I12 = 0, I20 = 0, I21 = 0, I22 = 0;
     if (!done) {
-      const double H00 = L.gsum[gs][0], H01 = L.gsum[gs][1], H02 = L.gsum[gs][2];
-      const double H11 = L.gsum[gs][3], H12 = L.gsum[gs][4], H22 = L.gsum[gs][5];
-      const double mse = L.gsum[gs][6];
+      const double H00 = L.gsum(gs, 0), H01 = L.gsum(gs, 1), H02 = L.gsum(gs, 2);
+      const double H11 = L.gsum(gs, 3), H12 = L.gsum(gs, 4), H22 = L.gsum(gs, 5);
+      const double mse = L.gsum(gs, 6);
       if (absd(mse / two_n - last_mse) < 0.0000005) {
         done = true;
         ok = last_mse < 9;
@@ -324,11 +356,11 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
     if (!__any(!done)) break;
     // ---- pass 2: the update (H^-1 J^T) r, 3 accumulators; rows recomputed unless there is one chunk
     double dac[2] = {0, 0};
-    for (int c = 0; c < cmax; c++) {
+    auto pass2_chunk = [&](int c, GnRow& w, bool recompute) {
       const int r = c * G + l;
       const bool rowact = !done && r < n;
       if (rowact) {
-        if (cmax > 1) {
+        if (recompute) {
           int32_t view;
           float ox, oy;
           if (r < nb) {
@@ -364,19 +396,30 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
       }
       __syncthreads();
       EG3D_GN_T(5);
+    };
+    if constexpr (KEEP == 0) {
+      for (int c = 0; c < cmax; c++) pass2_chunk(c, wk[0], cmax > 1);
+    } else {
+#pragma unroll
+      for (int q = 0; q < KEEP; q++)
+        if (q < cmax) pass2_chunk(q, wk[q], false);
+      for (int c = KEEP; c < cmax; c++) {
+        GnRow wt;
+        pass2_chunk(c, wt, true);
+      }
     }
     if (!done) {
 #pragma unroll
       for (int t = 0; t < 2; t++) {
         const int e = l + t * G;
-        if (e < 3) L.gsum[gs][e] = dac[t];
+        if (e < 3) L.gsum(gs, e) = dac[t];
       }
     }
     __syncthreads();
     if (!done) {
-      X[0] += L.gsum[gs][0];
-      X[1] += L.gsum[gs][1];
-      X[2] += L.gsum[gs][2];
+      X[0] += L.gsum(gs, 0);
+      X[1] += L.gsum(gs, 1);
+      X[2] += L.gsum(gs, 2);
     }
     __syncthreads();
     EG3D_GN_T(6);
@@ -409,27 +452,31 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
 // Must be called by all 64 lanes of the (single-wave) block; every request must have >= 2 rows. On
 // return lane j holds the verdict and solution of ITS request (false when !want); the request
 // table keeps them too (L.res_ok[j], L.x0[j]) until the next call.
-__device__ __forceinline__ bool coop_gn_groups(const float* cam_P, CoopLds& L, bool want, const Obs* base, int nblock,
+template <int KEEP = 0>
+__device__ __forceinline__ bool coop_gn_groups(const float* cam_P, CoopLds& L, bool want_in, const Obs* base, int nblock,
                                                bool has_extra, int32_t ex_view, float ex_x, float ex_y,
                                                const float X0[3], float Xout[3]) {
   const int lane = (int)(threadIdx.x & 63u);
 #if defined(EG3D_SECTION_TIMING)
   const unsigned long long gg_begin_ = __builtin_readcyclecounter();
 #endif
+  const bool want = want_in && lane < EG3D_COOP_REQ;  // the request table has EG3D_COOP_REQ entries (callers keep to it)
   const int n_req = want ? nblock + (has_extra ? 1 : 0) : 0;
   const bool is_short = want && n_req <= EG3D_GN_PACK_MAX;
   const bool is_long = want && n_req > EG3D_GN_PACK_MAX;
   const unsigned long long m_short = __ballot(is_short), m_long = __ballot(is_long);
   if ((m_short | m_long) == 0ull) return false;
-  L.gbase[lane] = base;
-  L.n16[lane] = (uint16_t)(n_req | (has_extra ? 0x8000 : 0));
-  L.ex_view[lane] = ex_view;
-  L.ex_x[lane] = ex_x;
-  L.ex_y[lane] = ex_y;
-  L.x0[lane][0] = X0[0];
-  L.x0[lane][1] = X0[1];
-  L.x0[lane][2] = X0[2];
-  L.res_ok[lane] = 0;
+  if (lane < EG3D_COOP_REQ) {
+    L.gbase[lane] = base;
+    L.n16[lane] = (uint16_t)(n_req | (has_extra ? 0x8000 : 0));
+    L.ex_view[lane] = ex_view;
+    L.ex_x[lane] = ex_x;
+    L.ex_y[lane] = ex_y;
+    L.x0[lane][0] = X0[0];
+    L.x0[lane][1] = X0[1];
+    L.x0[lane][2] = X0[2];
+    L.res_ok[lane] = 0;
+  }
   __syncthreads();
   // ---- short requests: rounds of whole requests packed into <= 64 rows, in lane order
   if (m_short) {
@@ -478,7 +525,7 @@ __device__ __forceinline__ bool coop_gn_groups(const float* cam_P, CoopLds& L, b
         X[1] = (double)L.x0[rq][1];
         X[2] = (double)L.x0[rq][2];
       }
-      const bool ok = gn_round(cam_P, L, act, l, n, lane - l, n, nb, a, xv, xx, xy, 1, X);
+      const bool ok = gn_round<0>(cam_P, L, act, l, n, lane - l, n, nb, a, xv, xx, xy, 1, X);
       if (act && l == 0) {
         L.res_ok[rq] = ok ? 1 : 0;
         L.x0[rq][0] = (float)X[0];
@@ -509,7 +556,9 @@ __device__ __forceinline__ bool coop_gn_groups(const float* cam_P, CoopLds& L, b
           const int Gc = 1 << cand;
           const int k = (mxl + Gc - 1) >> cand;
           const int rounds = (Bl + (64 >> cand) - 1) / (64 >> cand);
-          const unsigned cost = (unsigned)(rounds * k) * (unsigned)((k > 1 ? 2 : 1) * EG3D_GN_ROW_CYCLES + EG3D_GN_SUM_CYCLES * Gc);
+          // rows of the chunks beyond the KEEP kept ones are computed twice per iteration (update pass)
+          const int krow = KEEP == 0 ? (k > 1 ? 2 * k : k) : k + (k > KEEP ? k - KEEP : 0);
+          const unsigned cost = (unsigned)rounds * ((unsigned)krow * EG3D_GN_ROW_CYCLES + (unsigned)k * EG3D_GN_SUM_CYCLES * Gc);
           if (cost < best) {
             best = cost;
             lg = cand;
@@ -548,7 +597,7 @@ __device__ __forceinline__ bool coop_gn_groups(const float* cam_P, CoopLds& L, b
         X[1] = (double)L.x0[rq][1];
         X[2] = (double)L.x0[rq][2];
       }
-      const bool ok = gn_round(cam_P, L, act, l, G, lane - l, n, nb, a, xv, xx, xy, (mxn + G - 1) >> lg, X);
+      const bool ok = gn_round<KEEP>(cam_P, L, act, l, G, lane - l, n, nb, a, xv, xx, xy, (mxn + G - 1) >> lg, X);
       if (act && l == 0) {
         L.res_ok[rq] = ok ? 1 : 0;
         L.x0[rq][0] = (float)X[0];
@@ -559,10 +608,11 @@ __device__ __forceinline__ bool coop_gn_groups(const float* cam_P, CoopLds& L, b
       todo &= ~members;
     }
   }
-  Xout[0] = L.x0[lane][0];
-  Xout[1] = L.x0[lane][1];
-  Xout[2] = L.x0[lane][2];
-  const bool res = want && L.res_ok[lane] != 0;
+  const int tl = lane < EG3D_COOP_REQ ? lane : 0;
+  Xout[0] = L.x0[tl][0];
+  Xout[1] = L.x0[tl][1];
+  Xout[2] = L.x0[tl][2];
+  const bool res = want && L.res_ok[tl] != 0;
   __syncthreads();  // the table may be rewritten by the next window
 #if defined(EG3D_SECTION_TIMING)
   if (lane == 0) EG3D_GN_DBG(112, __builtin_readcyclecounter() - gg_begin_);

@@ -488,7 +488,9 @@ __global__ void k_compact_chains(uint32_t n_tasks, const ChainSeed* per_task, co
 #ifndef EG3D_SPEC_FOLLOW
 #define EG3D_SPEC_FOLLOW 1 /* chain following: walk up to 4 steps ahead, then triangulate them together */
 #endif
-struct TeamWave {
+// GN_KEEP: see gn_round (0 = standard build; 4 = the wide build keeps the rows of up to four chunks in registers)
+template <int GN_KEEP>
+struct TeamWaveT {
   static constexpr bool kSlotStep = EG3D_WAVE_SLOT_STEP != 0;
   static constexpr bool kSpecFollow = EG3D_SPEC_FOLLOW != 0;
   CoopLds* L;
@@ -775,7 +777,7 @@ struct TeamWave {
         const bool want = lane() < Deff;
         const float X0f[3] = {(float)X0[0], (float)X0[1], (float)X0[2]};  // DLT results are float-valued
         float Xr[3];
-        const bool ok = coop_gn_groups(s.cam_P, *L, want, L->tmp_a + (want ? lane() : 0) * n_end,
+        const bool ok = coop_gn_groups<GN_KEEP>(s.cam_P, *L, want, L->tmp_a + (want ? lane() : 0) * n_end,
                                        want ? L->la_m[lane()] : 0, false, 0, 0.f, 0.f, X0f, Xr);
         // results stay in the request table: L->res_ok[j], L->x0[j]
         (void)ok;
@@ -838,7 +840,7 @@ struct TeamWave {
     // one request (lane 0), the whole wave on its rows
     const float X0f[3] = {(float)X0[0], (float)X0[1], (float)X0[2]};  // callers pass float-valued starts
     float Xr[3];
-    const bool ok = coop_gn_groups(s.cam_P, *L, lane() == 0, a, n, false, 0, 0.f, 0.f, X0f, Xr);
+    const bool ok = coop_gn_groups<GN_KEEP>(s.cam_P, *L, lane() == 0, a, n, false, 0, 0.f, 0.f, X0f, Xr);
     Xout[0] = __shfl(Xr[0], 0);
     Xout[1] = __shfl(Xr[1], 0);
     Xout[2] = __shfl(Xr[2], 0);
@@ -848,7 +850,7 @@ struct TeamWave {
                                           float Xout[3]) const {
     const float X0f[3] = {p.X[0], p.X[1], p.X[2]};
     float Xr[3];
-    const bool ok = coop_gn_groups(s.cam_P, *L, lane() == 0, c.pool + p.off, (int)p.nobs, true, extra.view, extra.x,
+    const bool ok = coop_gn_groups<GN_KEEP>(s.cam_P, *L, lane() == 0, c.pool + p.off, (int)p.nobs, true, extra.view, extra.x,
                                    extra.y, X0f, Xr);
     Xout[0] = __shfl(Xr[0], 0);
     Xout[1] = __shfl(Xr[1], 0);
@@ -860,14 +862,14 @@ struct TeamWave {
   // otherwise each lane runs its own solve. Both produce the same bits.
   template <class Get, class Put>
   __device__ __forceinline__ void add_solves(const DevScene& s, Chain& c, int B, Get get, Put put) const {
-    for (int w0 = 0; w0 < B; w0 += 64) {
+    for (int w0 = 0; w0 < B; w0 += EG3D_COOP_REQ) {
       const int j = w0 + lane();
       const ChainPt* pt = nullptr;
       Obs o;
       o.view = 0;
       o.pl = o.seg = 0;
       o.x = o.y = 0.f;
-      const bool want = j < B && get(j, pt, o);
+      const bool want = lane() < EG3D_COOP_REQ && j < B && get(j, pt, o);
       float X[3] = {0.f, 0.f, 0.f};
       float X0[3] = {0.f, 0.f, 0.f};
       if (want) {
@@ -875,12 +877,13 @@ struct TeamWave {
         X0[1] = pt->X[1];
         X0[2] = pt->X[2];
       }
-      const bool ok = coop_gn_groups(s.cam_P, *L, want, want ? c.pool + pt->off : nullptr, want ? (int)pt->nobs : 0, true,
+      const bool ok = coop_gn_groups<GN_KEEP>(s.cam_P, *L, want, want ? c.pool + pt->off : nullptr, want ? (int)pt->nobs : 0, true,
                                      o.view, o.x, o.y, X0, X);
       if (want) put(j, ok, X);
     }
   }
 };
+using TeamWave = TeamWaveT<0>;
 
 #ifndef EG3D_K3B_WAVES
 #define EG3D_K3B_WAVES 3 /* measured: 3 waves/SIMD (168 VGPRs) beats 2 and 4 on C2 and C3 */
@@ -925,21 +928,30 @@ __device__ __forceinline__ uint32_t pool_pop(const SlotPools& P, uint32_t xcc) {
   }
   return EG3D_SLOT_NONE;
 }
-__device__ __forceinline__ void pool_push(const SlotPools& P, uint32_t xcc, uint32_t slot) {
+// false = the cell never emptied within the bound (cannot happen while the ring has more cells than slots; reported as
+// CTR_SLOT_STARVED by the caller rather than silently losing the slot)
+__device__ __forceinline__ bool pool_push(const SlotPools& P, uint32_t xcc, uint32_t slot) {
   uint32_t* b = P.base + (size_t)xcc * P.stride;
   const uint32_t t = atomicAdd(&b[16], 1u);
   uint32_t* cell = &b[32 + (t & (P.ring_n - 1u))];
   for (uint32_t spin = 0; spin < (1u << 22); spin++) {
-    if (atomicCAS(cell, 0u, slot + 1u) == 0u) return;
+    if (atomicCAS(cell, 0u, slot + 1u) == 0u) return true;
     __builtin_amdgcn_s_sleep(4);
   }
+  return false;
 }
 
 // One wavefront per chain, launched longest-first. The finished chain is PACKED into the launch's
 // staging area (point headers + its observations back to back, bump-allocated in order of completion)
 // before the slot is returned: what leaves the kernel is the chain's result, 16 B per point and per
 // observation written once with coalesced stores — not the working slice.
-__global__ void __launch_bounds__(64, EG3D_K3B_WAVES) k3b_expand(DevScene s, StageAView a, const TaskDesc* tasks,
+// <WAVES per SIMD the register allocation aims at, GN_KEEP>: the product instantiates <EG3D_K3B_WAVES, 0>. Round 4 measured a
+// "wide" instantiation <2, 4> (256 registers: nothing spills, the Gauss-Newton rows of up to four chunks stay in registers
+// between the passes of an iteration, so long solves do not recompute them): bit-exact, and SLOWER on every workload
+// (C3' K3b 53.2 -> 68.2 ms, the 8192-seed C4 step 2230 -> 2687 ms): what the third wave per SIMD hides in the walks, the
+// candidate search and the dependent steps of a solve outweighs the row arithmetic saved.
+template <int WAVES, int GN_KEEP>
+__global__ void __launch_bounds__(64, WAVES) k3b_expand_t(DevScene s, StageAView a, const TaskDesc* tasks,
                                                  const ChainSeed* chains, uint32_t n_chains, const uint32_t* hyp_off,
                                                  const HypResult* res, const HPoint* arena, const int32_t* map_view,
                                                  const uint32_t* map_entry, const uint32_t* map_n, ChainLayout L,
@@ -965,7 +977,7 @@ __global__ void __launch_bounds__(64, EG3D_K3B_WAVES) k3b_expand(DevScene s, Sta
     }
     return;
   }
-  TeamWave tm;
+  TeamWaveT<GN_KEEP> tm;
   tm.L = &lds;
   if (lane == 0) lds.cams_mid_range = s.cams_mid_range ? 1 : 0;
   __syncthreads();
@@ -1035,7 +1047,7 @@ __global__ void __launch_bounds__(64, EG3D_K3B_WAVES) k3b_expand(DevScene s, Sta
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
   if (lane == 0) {
-    pool_push(pools, xcc, slot);
+    if (!pool_push(pools, xcc, slot)) atomicOr(&ctr->flags, CTR_SLOT_STARVED);
     outs[j] = co;
     out_points[j] = co.n_points;
     out_obs[j] = co.n_obs;
@@ -1302,6 +1314,7 @@ int gn_dbg_read(unsigned long long* out, int reset) {
   return 0;
 }
 #endif
+static constexpr auto k3b_expand = k3b_expand_t<EG3D_K3B_WAVES, 0>;
 int k3b_blocks_per_cu() {
   int n = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k3b_expand, 64, 0) != hipSuccess || n < 1) return 0;

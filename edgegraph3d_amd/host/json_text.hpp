@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <locale.h>
 #include <string>
 #include <vector>
 
@@ -362,6 +363,13 @@ inline std::string double_text(double d) {
 // precision (correctly rounded; the reference's vendored reader defaults to kParseFullPrecisionFlag), so the C
 // library's strtod gives the same value. Returns the text the writer prints for that value; `ok` = false for a
 // literal the reader would refuse (malformed, or a magnitude beyond the double range).
+// Text -> double, correctly rounded and INDEPENDENT OF THE PROCESS LOCALE: strtod follows LC_NUMERIC (under a locale with
+// a decimal comma "1.5" reads as 1), the reference's reader does not — so the conversion runs in a private "C" locale.
+inline double parse_double(const std::string& text) {
+  static const locale_t c_loc = newlocale(LC_ALL_MASK, "C", (locale_t)0);
+  return c_loc ? strtod_l(text.c_str(), nullptr, c_loc) : strtod(text.c_str(), nullptr);
+}
+
 inline std::string normalize_number(const std::string& text, bool* ok) {
   *ok = true;
   const char* s = text.c_str();
@@ -420,8 +428,7 @@ inline std::string normalize_number(const std::string& text, bool* ok) {
       return buf;
     }
   }
-  char* endp = nullptr;
-  const double d = strtod(text.c_str(), &endp);
+  const double d = parse_double(text);
   if (!(d == d) || d > 1.7976931348623157e308 || d < -1.7976931348623157e308) {  // "number too big" for the reader
     *ok = false;
     return text;

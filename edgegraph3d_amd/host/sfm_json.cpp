@@ -38,7 +38,7 @@ struct JVal {
       if (kv.first == k) return &kv.second;
     return nullptr;
   }
-  double num() const { return t == NUM ? strtod(s.c_str(), nullptr) : 0.0; }
+  double num() const { return t == NUM ? eg3d_json::parse_double(s) : 0.0; }
 };
 
 struct Parser {
@@ -194,6 +194,11 @@ struct Parser {
           }
           default: ok = false; return v;
         }
+      } else if ((unsigned char)*p < 0x20) {
+        // a raw control character inside a string is not JSON (RFC 4627; the reference's reader rejects it too,
+        // external/rapidjson/reader.h:869)
+        ok = false;
+        return v;
       } else
         v.s.push_back(*p++);
     }
@@ -340,7 +345,11 @@ extern "C" int eg3d_sfm_seeds(const eg3d_sfm* s, eg3d_seeds* out) {
 }
 
 extern "C" int eg3d_sfm_add_point(eg3d_sfm* s, const float* X3, int n_obs, const int32_t* views, const float* xy) {
-  if (!s) return -1;
+  if (!s || n_obs < 0) return -1;
+  // the structure's offsets are 32-bit (as are eg3d_gn_filter's and the observation filter's): a point that would
+  // take the observation count past 2^32 - 1 is refused instead of wrapping (a cloud that large has to be added in
+  // parts / filtered first)
+  if ((uint64_t)s->trk_view.size() + (uint64_t)n_obs > 0xffffffffull) return -2;
   s->X.insert(s->X.end(), X3, X3 + 3);
   for (int i = 0; i < n_obs; i++) {
     s->trk_view.push_back(views[i]);
@@ -354,10 +363,21 @@ extern "C" int eg3d_sfm_add_point(eg3d_sfm* s, const float* X3, int n_obs, const
 // add_3dpoints_to_sfmd (output_utilities.cpp:96-111)
 extern "C" int eg3d_sfm_add_edgepoints(eg3d_sfm* s, const eg3d_edgepoints* p, const uint8_t* keep) {
   if (!s || !p) return -1;
+  // all or nothing: count first, so that a cloud whose kept observations do not fit the 32-bit offsets leaves the
+  // structure untouched (-2)
+  uint64_t total = s->trk_view.size();
+  for (uint64_t i = 0; i < p->n_points; i++) {
+    if (keep && !keep[i]) continue;
+    const uint64_t n = p->obs_off[i + 1] - p->obs_off[i];
+    if (n > 0x7fffffffull) return -2;
+    total += n;
+  }
+  if (total > 0xffffffffull) return -2;
   for (uint64_t i = 0; i < p->n_points; i++) {
     if (keep && !keep[i]) continue;
     const uint64_t a = p->obs_off[i], b = p->obs_off[i + 1];
-    eg3d_sfm_add_point(s, p->X + 3 * i, (int)(b - a), p->obs_view + a, p->obs_xy + 2 * (size_t)a);
+    const int rc = eg3d_sfm_add_point(s, p->X + 3 * i, (int)(b - a), p->obs_view + a, p->obs_xy + 2 * (size_t)a);
+    if (rc) return rc;
   }
   return 0;
 }
@@ -442,7 +462,7 @@ static const JVal& at(const JVal& v, size_t i) {
 }
 static double numv(const JVal& v) {
   if (v.t != JVal::NUM) throw Bad();
-  return strtod(v.s.c_str(), nullptr);
+  return eg3d_json::parse_double(v.s);
 }
 static const std::string& strv(const JVal& v) {
   if (v.t != JVal::STR) throw Bad();
@@ -540,6 +560,17 @@ static eg3d_sfm* sfm_read_json_impl(const char* path, eg3d_sfm*& s) {
     return nullptr;
   }
   return s;
+}
+
+// The camera model of the reader / eg3d_sfm_set_camera on bare arrays (include/eg3d_host.h): tests pin it against
+// the reference's vendored glm (tests/test_glm_pin.py)
+extern "C" int eg3d_host_camera_model(uint64_t n, const float* fpp, const float* R9, const float* C3, float* t3, float* P16) {
+  if (!fpp || !R9 || !C3 || !t3 || !P16) return -1;
+  for (uint64_t i = 0; i < n; i++) {
+    eg3dh::translation_from_center(R9 + 9 * i, C3 + 3 * i, t3 + 3 * i);
+    eg3dh::camera_matrix(fpp[3 * i], fpp[3 * i + 1], fpp[3 * i + 2], R9 + 9 * i, t3 + 3 * i, P16 + 16 * i);
+  }
+  return 0;
 }
 
 // Diagnostics of the writer's text rules (include/eg3d_host.h), used by tests/test_json_rapidjson.py

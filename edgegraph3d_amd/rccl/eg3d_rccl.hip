@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -50,8 +51,17 @@ __global__ void k_rebase(uint64_t* obs_off, const uint64_t* bases, int n_ranks, 
 
 }  // namespace
 
+// Largest single ncclSend / ncclRecv / ncclBroadcast: a transfer is cut into pieces of at most this many bytes, the
+// same way on both sides (every rank knows every rank's counts), so that no element count of a collective call comes
+// near 2^31 whatever the library's internal counters are (a 32 768-seed C4 step moves ~3.5 GB per rank).
+#ifndef EG3D_GATHER_CHUNK_BYTES
+#define EG3D_GATHER_CHUNK_BYTES (1ull << 30)
+#endif
+
 struct eg3d_gather {
   int device = 0;
+  int mode = EG3D_GATHER_MODE_SENDRECV;
+  uint64_t chunk = EG3D_GATHER_CHUNK_BYTES;
   Buf cnt_dev, X, off, key, view, pl, seg, xy;
   Buf* field(int f) { return f == 0 ? &X : f == 1 ? &off : f == 2 ? &key : f == 3 ? &view : f == 4 ? &pl : f == 5 ? &seg : &xy; }
   // does [p, p + n) overlap one of the result buffers? (a part that views them cannot be an input)
@@ -67,7 +77,24 @@ extern "C" eg3d_gather* eg3d_gather_create(int device) {
   if (hipSetDevice(device) != hipSuccess) return nullptr;
   eg3d_gather* g = new eg3d_gather();
   g->device = device;
+  // read ONCE, here: EG3D_GATHER_MODE=bcast selects the fallback exchange; EG3D_GATHER_CHUNK_BYTES is a test knob
+  // (small pieces make a small cloud take the multi-piece path)
+  if (const char* e = getenv("EG3D_GATHER_MODE")) g->mode = (e[0] == 'b' || e[0] == '1') ? EG3D_GATHER_MODE_BCAST : EG3D_GATHER_MODE_SENDRECV;
+  if (const char* e = getenv("EG3D_GATHER_CHUNK_BYTES")) {
+    const long long v = atoll(e);
+    if (v >= 16) g->chunk = (uint64_t)v;
+  }
   return g;
+}
+extern "C" int eg3d_gather_set_mode(eg3d_gather* g, int mode) {
+  if (!g || (mode != EG3D_GATHER_MODE_SENDRECV && mode != EG3D_GATHER_MODE_BCAST)) return EG3D_GATHER_ERR_ARG;
+  g->mode = mode;
+  return 0;
+}
+extern "C" int eg3d_gather_set_chunk_bytes(eg3d_gather* g, uint64_t bytes) {
+  if (!g || bytes < 16) return EG3D_GATHER_ERR_ARG;
+  g->chunk = bytes;
+  return 0;
 }
 extern "C" void eg3d_gather_destroy(eg3d_gather* g) {
   if (!g) return;
@@ -181,24 +208,49 @@ extern "C" int eg3d_allgather_edgepoints(eg3d_gather* g, void* nccl_comm, int n_
   // transfers (xGMI links are point-to-point: each pair of ranks uses its own link, all links busy at once).
   // Nothing is packed or padded, so a rank holds the gathered cloud once and nothing else.
   const uint64_t np = local->n_points, no = local->n_obs;
-  for (int f = 0; f < 7; f++) {
-    const uint64_t nb = kFieldBytes[f] * (f < 3 ? np : no);
-    unsigned char* dst = (unsigned char*)g->field(f)->p + kFieldBytes[f] * (f < 3 ? base[rank] : base[R + rank]);
-    if (nb) FATAL_UNLESS(hipMemcpyAsync(dst, field_ptr(local, f), nb, hipMemcpyDeviceToDevice, st) == hipSuccess);
+  const uint64_t CH = g->chunk;
+  if (g->mode == EG3D_GATHER_MODE_SENDRECV || n_ranks == 1) {
+    for (int f = 0; f < 7; f++) {
+      const uint64_t nb = kFieldBytes[f] * (f < 3 ? np : no);
+      unsigned char* dst = (unsigned char*)g->field(f)->p + kFieldBytes[f] * (f < 3 ? base[rank] : base[R + rank]);
+      if (nb) FATAL_UNLESS(hipMemcpyAsync(dst, field_ptr(local, f), nb, hipMemcpyDeviceToDevice, st) == hipSuccess);
+    }
   }
-  if (n_ranks > 1) {
+  if (n_ranks > 1 && g->mode == EG3D_GATHER_MODE_SENDRECV) {
     FATAL_UNLESS(ncclGroupStart() == ncclSuccess);
     bool ok = true;
     for (int q = 0; q < n_ranks && ok; q++) {
       if (q == rank) continue;
       for (int f = 0; f < 7 && ok; f++) {
+        // zero-size fields are skipped on BOTH sides (the receiver knows the sender's counts); pieces in the same
+        // order on both sides
         const uint64_t sb = kFieldBytes[f] * (f < 3 ? np : no);
         const uint64_t rb = kFieldBytes[f] * (f < 3 ? h[3 * q] : h[3 * q + 1]);
         unsigned char* dst = (unsigned char*)g->field(f)->p + kFieldBytes[f] * (f < 3 ? base[q] : base[R + q]);
-        if (sb) ok = ok && ncclSend(field_ptr(local, f), sb, ncclUint8, q, comm, st) == ncclSuccess;
-        if (rb) ok = ok && ncclRecv(dst, rb, ncclUint8, q, comm, st) == ncclSuccess;
+        const unsigned char* src = (const unsigned char*)field_ptr(local, f);
+        for (uint64_t o = 0; o < sb && ok; o += CH)
+          ok = ncclSend(src + o, (size_t)std::min<uint64_t>(CH, sb - o), ncclUint8, q, comm, st) == ncclSuccess;
+        for (uint64_t o = 0; o < rb && ok; o += CH)
+          ok = ncclRecv(dst + o, (size_t)std::min<uint64_t>(CH, rb - o), ncclUint8, q, comm, st) == ncclSuccess;
       }
     }
+    const bool ended = ncclGroupEnd() == ncclSuccess;
+    FATAL_UNLESS(ok && ended);
+  } else if (n_ranks > 1) {
+    // Fallback exchange (EG3D_GATHER_MODE=bcast / eg3d_gather_set_mode): the same all-gather-v as R x 7 broadcasts,
+    // root q's field going from its context's buffers to its final position on every rank (the root's own copy
+    // included: send buffer != receive buffer there). Uses only the library's broadcast collective — the path to take
+    // if the grouped point-to-point transfers misbehave on some RCCL build; still nothing packed or padded.
+    FATAL_UNLESS(ncclGroupStart() == ncclSuccess);
+    bool ok = true;
+    for (int q = 0; q < n_ranks && ok; q++)
+      for (int f = 0; f < 7 && ok; f++) {
+        const uint64_t nb = kFieldBytes[f] * (f < 3 ? h[3 * q] : h[3 * q + 1]);
+        unsigned char* dst = (unsigned char*)g->field(f)->p + kFieldBytes[f] * (f < 3 ? base[q] : base[R + q]);
+        const unsigned char* src = q == rank ? (const unsigned char*)field_ptr(local, f) : dst;
+        for (uint64_t o = 0; o < nb && ok; o += CH)
+          ok = ncclBroadcast(src + o, dst + o, (size_t)std::min<uint64_t>(CH, nb - o), ncclUint8, q, comm, st) == ncclSuccess;
+      }
     const bool ended = ncclGroupEnd() == ncclSuccess;
     FATAL_UNLESS(ok && ended);
   }

@@ -157,6 +157,10 @@ int eg3d_sfm_write_json(const eg3d_sfm* s, const char* in_path_for_passthrough, 
  * notation); a JSON number literal as the reference's reader (default flags) + writer re-print it; the computed
  * Grisu cached power 10^(-348 + 8*index), index 0..86. Return the text length, or -1. Checked against the reference
  * tree's vendored rapidjson by tests/test_json_rapidjson.py. */
+/* The camera model eg3d_sfm_read_json / eg3d_sfm_set_camera apply (OpenMvgParser.cpp:289 t = -center * rotation,
+ * :107-125 cameraMatrix = eMatrix * kMatrix, in glm's float evaluation order), for n cameras on bare arrays:
+ * fpp = [n][3] focal, ppx, ppy; R9 = [n][9] row-major rotation; C3 = [n][3] centre -> t3 [n][3], P16 [n][16]. */
+int eg3d_host_camera_model(uint64_t n, const float* fpp, const float* R9, const float* C3, float* t3, float* P16);
 int eg3d_host_json_double_text(double d, char* buf, int cap);
 int eg3d_host_json_number_text(const char* literal, char* buf, int cap);
 int eg3d_host_json_cached_power(int index, uint64_t* f, int* e);

@@ -36,6 +36,15 @@ void eg3d_comm_destroy(void* comm);
 
 eg3d_gather* eg3d_gather_create(int device);
 void eg3d_gather_destroy(eg3d_gather* g);
+/* How the payload travels. SENDRECV (default): one group of ncclSend / ncclRecv pairs, every pair of ranks on its own
+ * xGMI link. BCAST: the same all-gather-v as one broadcast per (rank, array) — a fallback that uses only RCCL's
+ * broadcast collective, for an RCCL build on which the grouped point-to-point transfers misbehave (the environment
+ * variable EG3D_GATHER_MODE=bcast, read once by eg3d_gather_create, selects it too). Every rank must use the same
+ * mode. Transfers are cut into pieces of at most `bytes` (default 1 GiB) so that no count of a call nears 2^31. */
+#define EG3D_GATHER_MODE_SENDRECV 0
+#define EG3D_GATHER_MODE_BCAST 1
+int eg3d_gather_set_mode(eg3d_gather* g, int mode);
+int eg3d_gather_set_chunk_bytes(eg3d_gather* g, uint64_t bytes);
 
 /* nccl_comm: an initialised ncclComm_t of n_ranks ranks (this process = `rank`); hip_stream: the
  * stream the collective is enqueued on (NULL = the null stream). `local` = this rank's

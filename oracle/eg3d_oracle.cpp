@@ -625,6 +625,29 @@ extern "C" int orc_epiline(const double* F9, float x, float y, float* line) {
   cm.P = nullptr;
   return computeCorrespondEpilineSinglePoint(cm, 0, 0, vec2(x, y), line);
 }
+// batched forms of the probes the glm pin test drives with ~1 M cases (tests/test_glm_pin.py)
+extern "C" void orc_batch_project(uint64_t n, const float* P16, const float* X, float* xy) {
+  for (uint64_t i = 0; i < n; i++) {
+    vec2 r = compute_projection(P16 + 16 * i, vec3(X[3 * i], X[3 * i + 1], X[3 * i + 2]));
+    xy[2 * i] = r.x;
+    xy[2 * i + 1] = r.y;
+  }
+}
+extern "C" void orc_batch_mindist(uint64_t n, const float* pvw /*[n][6]*/, float* out /*[n][3]: d2, proj*/) {
+  for (uint64_t i = 0; i < n; i++) {
+    const float* q = pvw + 6 * i;
+    vec2 pr;
+    out[3 * i] = minimum_distancesq(vec2(q[0], q[1]), vec2(q[2], q[3]), vec2(q[4], q[5]), pr);
+    out[3 * i + 1] = pr.x;
+    out[3 * i + 2] = pr.y;
+  }
+}
+extern "C" void orc_batch_anglecos(uint64_t n, const float* seg_line /*[n][7]: x1 y1 x2 y2 a b c*/, float* out) {
+  for (uint64_t i = 0; i < n; i++) {
+    const float* q = seg_line + 7 * i;
+    out[i] = compute_anglecos(q[0], q[1], q[2], q[3], q + 4);
+  }
+}
 extern "C" void orc_project(const float* P16, const float* X, float* xy) {
   vec2 r = compute_projection(P16, vec3(X[0], X[1], X[2]));
   xy[0] = r.x;

@@ -77,6 +77,10 @@ int orc_intersect_segment_line_nqp(float x1, float y1, float x2, float y2, const
 int orc_cell_from_coords(float cell, float x, float y, int* col, int* row, int* b_row, int* b_col);
 int orc_epiline(const double* F9, float x, float y, float* line);
 void orc_project(const float* P16, const float* X, float* xy);
+/* batched probes (tests/test_glm_pin.py: the oracle's evaluation orders against the reference's vendored glm) */
+void orc_batch_project(uint64_t n, const float* P16 /*[n][16]*/, const float* X /*[n][3]*/, float* xy /*[n][2]*/);
+void orc_batch_mindist(uint64_t n, const float* pvw /*[n][6]*/, float* out /*[n][3]: d2, projection*/);
+void orc_batch_anglecos(uint64_t n, const float* seg_line /*[n][7]: x1 y1 x2 y2 a b c*/, float* out /*[n]*/);
 int orc_triangulate(const float* P /*[n][16]*/, const int* view_ids, const float* xy, int n, float* X, int* degenerate);
 int orc_gn_add(const float* P, const int* view_ids, const float* xy, int n, const float* X0, float* X);
 void orc_dlt(const float* P1, const float* xy1, const float* P2, const float* xy2, double* X0);

@@ -10,6 +10,10 @@ IDS = {3: "dlt6x4", 2: "dlt4x4"}
 
 
 def lib_path(rows):
+    # EG3D_TEST_LIB_6X4 / EG3D_TEST_LIB_4X4: run the suite against an experimental build of that form (tools/build_variant.sh)
+    over = os.environ.get("EG3D_TEST_LIB_6X4" if rows == 3 else "EG3D_TEST_LIB_4X4")
+    if over:
+        return over
     return os.path.join(ROOT, "edgegraph3d_amd", "libeg3d.so" if rows == 3 else "libeg3d_dlt4x4.so")
 
 

@@ -194,6 +194,12 @@ def test_openmvg_reader_rejects_malformed_files_instead_of_crashing():
     assert not reads(bad)
     assert not reads(None, raw="[" * 5000 + "]" * 5000)        # nesting limit, no stack overflow
     assert not reads(None, raw='{"views": [')                  # truncated
+    # a raw control character inside a string is not JSON (the reference's rapidjson reader refuses it, reader.h:869);
+    # the same string with the character escaped reads
+    txt = json.dumps(good)
+    assert '"root_path"' in txt
+    assert not reads(None, raw=txt.replace('"root_path": "', '"root_path": "\x01', 1))
+    assert reads(None, raw=txt.replace('"root_path": "', '"root_path": "\\u0001', 1))
 
 
 def test_analytic_fundamental_matrices_satisfy_the_epipolar_constraint():

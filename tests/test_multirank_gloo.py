@@ -27,7 +27,13 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, cfg, q):
+def _empty_cloud():
+    return {"n_points": 0, "n_obs": 0, "X": np.zeros((0, 3), np.float32), "obs_off": np.zeros(1, np.uint64),
+            "key": np.zeros((0, 4), np.uint32), "obs_view": np.zeros(0, np.int32), "obs_pl": np.zeros(0, np.uint32),
+            "obs_seg": np.zeros(0, np.uint32), "obs_xy": np.zeros((0, 2), np.float32)}
+
+
+def _worker(rank, world, port, cfg, q, empty_rank=-1, failing_rank=None):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "tests")):
@@ -40,14 +46,21 @@ def _worker(rank, world, port, cfg, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     s = host.Synth(cfg)
     o = ob.Oracle(s.scene)
-    b, e = shard_ranges_balanced(s.seeds_np()[0], 0, s.n_seeds, world)[rank]
+    if empty_rank < 0:
+        b, e = shard_ranges_balanced(s.seeds_np()[0], 0, s.n_seeds, world)[rank]
+    else:
+        # one rank owns NO seeds (a step whose batch is smaller than the world, or an unlucky split): the others share
+        # the range, balanced by track length
+        others = shard_ranges_balanced(s.seeds_np()[0], 0, s.n_seeds, world - 1)
+        b, e = (others[empty_rank][0],) * 2 if rank == empty_rank else others[rank - (1 if rank > empty_rank else 0)]
     # stage B = the device code run on the host; its keys carry the global seed index, as the GPU's do
-    r = hs.match(s.scene, s.seeds, b, e, o.candidates_raw(s.seeds, b, e))
+    r = hs.match(s.scene, s.seeds, b, e, o.candidates_raw(s.seeds, b, e)) if e > b else _empty_cloud()
     g = HostCloudGather(dist, world, rank)
     cloud, rc = g.allgather(r)
     assert rc == 0
     # a rank whose match failed still takes part (local = None): EVERY rank gets EG3D_GATHER_ERR_INCOMPLETE
-    none, rc_bad = g.allgather(None if rank == world - 1 else r)
+    bad = world - 1 if failing_rank is None else failing_rank
+    none, rc_bad = g.allgather(None if rank == bad else r)
     assert none is None and rc_bad == -4
     q.put((rank, {k: (np.array(v) if isinstance(v, np.ndarray) else v) for k, v in cloud.items()}))
     dist.barrier()
@@ -82,13 +95,15 @@ def test_shard_ranges_cover_and_balance():
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gloo_allgather_reproduces_single_process_output():
+@pytest.mark.parametrize("world,empty_rank,failing_rank", [(2, -1, None), (4, 1, 2)],
+                         ids=["2 ranks", "4 ranks, rank 1 without seeds, rank 2 failing"])
+def test_gloo_allgather_reproduces_single_process_output(world, empty_rank, failing_rank):
     from oracle import binding as ob
-    cfg, world = 1, 2
+    cfg = 1
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, cfg, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cfg, q, empty_rank, failing_rank)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=240) for _ in range(world))

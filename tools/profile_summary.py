@@ -20,6 +20,9 @@ from collections import defaultdict
 
 
 def short(name):
+    m3 = re.match(r"(?:void )?(?:eg3d::)?k3b_expand_t<(\d+), *(\d+)>", name)
+    if m3:  # the two builds of the expand kernel: <waves per SIMD, Gauss-Newton chunks kept>
+        return "k3b_expand" if m3.group(2) == "0" else "k3b_expand_wide"
     m = re.match(r"(?:void )?(?:eg3d::)?([A-Za-z0-9_]+)(<[a-z]+>)?", name)
     if "rocprim" in name:
         return "rocprim::scan(init)" if "init_lookback" in name else "rocprim::scan"
@@ -109,7 +112,7 @@ def main():
                 # k3b_expand / k4_emit run once per steady-state step; the first passes of a context repeat the launch
                 # while its capacities and staging area grow (C4: every pass of a 3-pass run): per step = one launch
                 n_l = (counter_stats(a.fetch).get(k, {}).get("FETCH_SIZE") or (0, 0))[1]
-                if k in ("k3b_expand", "k4_emit") and n_l > a.pmc_steps:
+                if k in ("k3b_expand", "k3b_expand_wide", "k4_emit") and n_l > a.pmc_steps:
                     out[k]["hbm_bytes_per_step"] = out[k]["hbm_bytes_per_launch"]
                     out[k]["note_step"] = ("%d launches in %d passes (a context's first passes repeat the launch while its "
                                            "buffers grow): a steady-state step is ONE launch, per step = the per-launch mean"
@@ -146,6 +149,26 @@ def main():
         if os.path.exists(sq):
             for k, d in counter_stats(sq).items():
                 merged[k].update({c: v[0] for c, v in d.items()})
+    # vector-ALU figures of the expand kernel go into pmc_traffic.json beside its traffic (bench.py: roofline_valu)
+    if a.workload and merged:
+        path = os.path.join(a.out, "pmc_traffic.json")
+        allw = json.load(open(path)) if os.path.exists(path) else {}
+        ent = allw.setdefault(a.workload, {})
+        kt_avg = {}
+        if a.sq and os.path.exists(a.sq[0]):
+            for k in kernel_stats(a.sq[0]):
+                kt_avg[k["kernel"]] = k["avg_us"] / 1e3
+        for k, d in merged.items():
+            if k.startswith("k3b_expand") and d.get("SQ_THREAD_CYCLES_VALU"):
+                tgt = ent.setdefault(k, {})
+                tgt["valu"] = {c: d.get(c) for c in ("SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
+                                                     "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU") if d.get(c) is not None}
+                tgt["valu"]["active_lane_frac"] = d["SQ_THREAD_CYCLES_VALU"] / (64.0 * d["SQ_ACTIVE_INST_VALU"])
+                tgt["valu"]["kernel_ms"] = kt_avg.get(k)
+                tgt["valu"]["kernel"] = k
+                ent["provenance_valu"] = ("profiles/%s_rocprof_summary.txt: rocprofv3 --kernel-trace --pmc SQ_* passes of `%s`; means per "
+                                          "launch of %s" % (a.tag, a.pmc_cmd, k))
+        json.dump(allw, open(path, "w"), indent=1)
     der = []
     for k, d in merged.items():
         if d.get("SQ_ACTIVE_INST_VALU") and d.get("SQ_THREAD_CYCLES_VALU") and k.startswith("k3"):
