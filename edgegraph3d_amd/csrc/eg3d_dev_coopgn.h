@@ -22,15 +22,16 @@ namespace eg3d {
 #define EG3D_GN_ROW_CYCLES 1400  /* cost model of the longer ones: one row's projection + Jacobian (8 FP64 divisions) */
 #define EG3D_GN_SUM_CYCLES 44    /*   and one row's share of the in-order sums of both passes */
 #endif
-// requests a window holds (request j on lane j < EG3D_COOP_REQ). 64 fills the wave; 32 halves the request table so that
-// CoopLds fits 8 LDS allocation units = 4 single-wave workgroups per SIMD (with EG3D_K3B_WAVES=4)
+// requests a window holds (request j on lane j < EG3D_COOP_REQ). 32 (round 4; it was 64): the request table halves, and
+// with the per-group sums aliased onto the product columns CoopLds fits 8 LDS allocation units = FOUR single-wave
+// workgroups per SIMD (EG3D_K3B_WAVES=4) instead of three. Measured neutral on its own (C3' K3b 53.7 vs 53.7 ms).
 #ifndef EG3D_COOP_REQ
-#define EG3D_COOP_REQ 64
+#define EG3D_COOP_REQ 32
 #endif
 #define EG3D_STAGE_VTX 512
 #define EG3D_STAGE_EPI 192
-// 12 784 bytes: gfx950 allocates LDS in 1 280-byte units, 10 units per wave = 12 single-wave
-// workgroups per CU (3 per SIMD) in 160 KiB.
+// 9 920 bytes: gfx950 allocates LDS in 1 280-byte units, 8 units per wave = 16 single-wave
+// workgroups per CU (4 per SIMD) in 160 KiB. (Rounds 1-3: 12 784 bytes, 3 per SIMD.)
 struct CoopLds {
   union {
     double prod[14][EG3D_COOP_ROWS + 1];  // the rows' products of one chunk (odd stride)

@@ -1,5 +1,6 @@
-// examples/edge_matcher_refpoints.cpp — the reference's `edge_matcher` run for pipeline 3, end to end
-// in C++ over the C ABI (what src/edgegraph3d/edge_matcher.cpp:57-182 + pipelines.cpp:160-176 do):
+// examples/edge_matcher_refpoints.cpp — the reference's `edge_matcher` run, all three stages of
+// edge_reconstruction_pipeline (pipelines.cpp:201-246), end to end in C++ over the C ABI
+// (what src/edgegraph3d/edge_matcher.cpp:57-182 + pipelines.cpp do):
 //
 //   OpenMVG JSON (cameras + SfM points)  +  polyline graphs of every view
 //     -> fundamental matrices            (edge_matcher.cpp:96 -> geometric_utilities.cpp:754-820): pairs of views
@@ -8,8 +9,17 @@
 //                                        least-median-of-squares estimate from the tracks with --estimate-F
 //                                        (the reference's cv::findFundamentalMat(FM_LMEDS) is randomised OpenCV
 //                                        code: not reproducible)
-//     -> plg_matching_from_refpoints     (pipelines.cpp:164)            GPU: eg3d_match_refpoints
-//     -> filter_3d_points_close_2d_array (edge_matcher.cpp:150)         host
+//     -> [pipeline 1] polyline matches of the similarity-graph matcher  (pipelines.cpp:219 -> :68-111)
+//     -> [pipeline 2] polyline matches by closeness to reference points (pipelines.cpp:223 -> :113-158)
+//                                        each match = one set of potentially compatible polylines, given in a
+//                                        file (--sets1 / --sets2; the matchers themselves — Louvain clustering,
+//                                        third party — are out of scope): find_new_3d_points_from_compatible_
+//                                        polylines_expandallviews_parallel per match   GPU: eg3d_match_polyline_sets
+//     -> [pipeline 3] plg_matching_from_refpoints (pipelines.cpp:227 -> :164)    GPU: eg3d_match_refpoints
+//                                        the three results are concatenated in that order (pipelines.cpp:219-227;
+//                                        the matches manager stays empty until pipeline 3 in the parallel build, so
+//                                        the stages do not see each other's matches)
+//     -> filter_3d_points_close_2d_array (pipelines.cpp:236)            host, over the concatenation
 //     -> add_3dpoints_to_sfmd            (edge_matcher.cpp:158)         host
 //     -> [./filter -e] gaussNewtonFiltering + observation filter + removeOutliers   GPU + host
 //     -> output_sfm_data                 (edge_matcher.cpp:169)         OpenMVG JSON out
@@ -20,6 +30,10 @@
 //        builds the polyline graph of every binary edge image (view i = i-th image; SURVEY N2,
 //        edge_matcher.cpp:84-94 convert_edge_images_to_optimized_polyline_graphs) and writes the container
 //   edge_matcher_refpoints <dir>/input.json <dir>/plgs.bin <out.json> [--filter] [--estimate-F] [--all-pairs]
+//                          [--sets1 <polyline matches of pipeline 1>] [--sets2 <... of pipeline 2>]
+//        a match file is text: "eg3d-polyline-sets 1", then "<n_sets> <n_views>", then one line per (set, view):
+//        "<count> <polyline id> ..." with view-local ids (the reference's vector<set<ulong>> per match)
+//        (--make-synthetic also writes <dir>/sets1.txt and <dir>/sets2.txt: the polylines of 3-D curves 0-2 / 3-5)
 //
 // The polyline graphs travel in a container file so that the expensive one-off construction from the
 // edge images (--make-plgs) is separate from the matching run. Build (see tests/test_gpu_edge_cases.py):
@@ -37,6 +51,92 @@ static int fail(const char* what) {
   std::fprintf(stderr, "edge_matcher_refpoints: %s (%s)\n", what, eg3d_last_error());
   return 1;
 }
+
+// ---- polyline match files (input of pipelines 1-2)
+struct MatchSets {
+  uint32_t n_sets = 0;
+  std::vector<uint32_t> row_off{0}, ids;
+};
+static bool read_match_sets(const char* path, int n_views, MatchSets& m) {
+  FILE* f = std::fopen(path, "r");
+  if (!f) return false;
+  char tag[64];
+  int ver = 0;
+  unsigned ns = 0, nv = 0;
+  bool ok = std::fscanf(f, "%63s %d %u %u", tag, &ver, &ns, &nv) == 4 && std::strcmp(tag, "eg3d-polyline-sets") == 0 && ver == 1 &&
+            (int)nv == n_views && ns < (1u << 24);
+  for (uint64_t r = 0; ok && r < (uint64_t)ns * nv; r++) {
+    unsigned k = 0;
+    ok = std::fscanf(f, "%u", &k) == 1 && k < (1u << 24);
+    unsigned long prev = 0;
+    for (unsigned i = 0; ok && i < k; i++) {
+      unsigned long id = 0;
+      ok = std::fscanf(f, "%lu", &id) == 1 && id <= 0xfffffffful && (i == 0 || id > prev);  // a set: ascending, no repeats
+      prev = id;
+      m.ids.push_back((uint32_t)id);
+    }
+    m.row_off.push_back((uint32_t)m.ids.size());
+  }
+  std::fclose(f);
+  m.n_sets = ns;
+  if (m.ids.empty()) m.ids.push_back(0);
+  return ok;
+}
+static bool write_match_sets(const std::string& path, const eg3d_scene* sc, const uint32_t* curve, uint32_t c0, uint32_t c1) {
+  FILE* f = std::fopen(path.c_str(), "w");
+  if (!f) return false;
+  std::fprintf(f, "eg3d-polyline-sets 1\n%u %d\n", c1 - c0, sc->n_views);
+  for (uint32_t c = c0; c < c1; c++)
+    for (int v = 0; v < sc->n_views; v++) {
+      std::vector<uint32_t> ids;
+      for (uint32_t p = sc->view_pl_off[v]; p < sc->view_pl_off[v + 1]; p++)
+        if (curve[p] == c && sc->pl_valid[p] && sc->pl_vtx_off[p + 1] - sc->pl_vtx_off[p] >= 2) ids.push_back(p - sc->view_pl_off[v]);
+      std::fprintf(f, "%zu", ids.size());
+      for (uint32_t id : ids) std::fprintf(f, " %u", id);
+      std::fprintf(f, "\n");
+    }
+  return std::fclose(f) == 0;
+}
+
+// ---- the clouds of the three stages, concatenated in stage order (host arrays in the eg3d_edgepoints layout)
+struct Cloud {
+  std::vector<float> X, xy;
+  std::vector<uint64_t> off{0};
+  std::vector<int32_t> view;
+  std::vector<uint32_t> pl, seg, key;
+  void append(const eg3d_edgepoints& e) {
+    const uint64_t base = (uint64_t)view.size();
+    X.insert(X.end(), e.X, e.X + 3 * e.n_points);
+    key.insert(key.end(), e.key, e.key + 4 * e.n_points);
+    for (uint64_t i = 0; i < e.n_points; i++) off.push_back(base + e.obs_off[i + 1]);
+    view.insert(view.end(), e.obs_view, e.obs_view + e.n_obs);
+    pl.insert(pl.end(), e.obs_pl, e.obs_pl + e.n_obs);
+    seg.insert(seg.end(), e.obs_seg, e.obs_seg + e.n_obs);
+    xy.insert(xy.end(), e.obs_xy, e.obs_xy + 2 * e.n_obs);
+  }
+  eg3d_edgepoints view_as_edgepoints() {
+    eg3d_edgepoints e;
+    std::memset(&e, 0, sizeof(e));
+    e.n_points = off.size() - 1;
+    e.n_obs = view.size();
+    if (X.empty()) X.assign(3, 0.f);  // never hand out null arrays
+    if (key.empty()) key.assign(4, 0);
+    if (view.empty()) {
+      view.assign(1, 0);
+      pl.assign(1, 0);
+      seg.assign(1, 0);
+      xy.assign(2, 0.f);
+    }
+    e.X = X.data();
+    e.obs_off = off.data();
+    e.obs_view = view.data();
+    e.obs_pl = pl.data();
+    e.obs_seg = seg.data();
+    e.obs_xy = xy.data();
+    e.key = key.data();
+    return e;
+  }
+};
 
 static int make_synthetic(int cfg_index, const std::string& dir) {
   eg3d_synth_config cfg;
@@ -60,6 +160,12 @@ static int make_synthetic(int cfg_index, const std::string& dir) {
   }
   int rc = eg3d_sfm_write_json(sfm, nullptr, (dir + "/input.json").c_str());
   if (rc == 0) rc = eg3d_plg_write((dir + "/plgs.bin").c_str(), sc);
+  // stand-ins for the polyline matchers' output: the polylines generated from 3-D curves 0-2 (pipeline 1) and 3-5 (pipeline 2)
+  const uint32_t nc = eg3d_synth_n_curves(syn);
+  const uint32_t c1 = nc < 3 ? nc : 3, c2 = nc < 6 ? nc : 6;
+  if (rc == 0 && !(write_match_sets(dir + "/sets1.txt", sc, eg3d_synth_polyline_curve(syn), 0, c1) &&
+                   write_match_sets(dir + "/sets2.txt", sc, eg3d_synth_polyline_curve(syn), c1, c2)))
+    rc = -1;
   std::printf("wrote %s/input.json (%d views, %u points) and %s/plgs.bin (%u polylines)\n", dir.c_str(), sc->n_views,
               sd->n_seeds, dir.c_str(), sc->view_pl_off[sc->n_views]);
   eg3d_sfm_destroy(sfm);
@@ -103,10 +209,13 @@ int main(int argc, char** argv) {
     return 2;
   }
   bool do_filter = false, estimate_F = false, all_pairs = false;
+  const char* sets_path[2] = {nullptr, nullptr};
   for (int a = 4; a < argc; a++) {
     do_filter |= std::strcmp(argv[a], "--filter") == 0;
     estimate_F |= std::strcmp(argv[a], "--estimate-F") == 0;
     all_pairs |= std::strcmp(argv[a], "--all-pairs") == 0;  // analytic F for every pair, ignoring the 10-point rule
+    if (std::strcmp(argv[a], "--sets1") == 0 && a + 1 < argc) sets_path[0] = argv[++a];
+    else if (std::strcmp(argv[a], "--sets2") == 0 && a + 1 < argc) sets_path[1] = argv[++a];
   }
 
   // ---- inputs (edge_matcher.cpp:64-95)
@@ -140,18 +249,41 @@ int main(int argc, char** argv) {
   sc.F_valid = Fv.data();
   const uint64_t first_edgepoint = eg3d_sfm_n_points(sfm);
 
-  // ---- pipeline 3 on the GPU (pipelines.cpp:160-176)
   eg3d_ctx* ctx = nullptr;
   if (eg3d_create(&sc, 0, &ctx) != EG3D_OK) return fail("eg3d_create");
+  Cloud all_stages;
+  eg3d_stage_times tm;
+  // ---- pipelines 1 and 2 (pipelines.cpp:219-223): the extractor over the polyline matches of each stage, in
+  // match order (one call takes all matches of a stage: eg3d_match_polyline_sets emits them set by set)
+  for (int stage = 0; stage < 2; stage++) {
+    if (!sets_path[stage]) continue;
+    MatchSets ms;
+    if (!read_match_sets(sets_path[stage], V, ms)) return fail("reading a polyline match file");
+    eg3d_polyline_sets ps;
+    ps.n_sets = ms.n_sets;
+    ps.row_off = ms.row_off.data();
+    ps.pl_ids = ms.ids.data();
+    eg3d_edgepoints e;
+    if (eg3d_match_polyline_sets(ctx, &ps, 0, ms.n_sets, 0, &e, &tm) != EG3D_OK) return fail("eg3d_match_polyline_sets");
+    std::printf("pipeline %d: %u polyline matches -> %llu edge-points (%llu observations) in %.2f ms on the GPU\n", stage + 1,
+                ms.n_sets, (unsigned long long)e.n_points, (unsigned long long)e.n_obs, tm.ms_total);
+    all_stages.append(e);
+    eg3d_free_edgepoints(&e);
+  }
+  // ---- pipeline 3 on the GPU (pipelines.cpp:160-176, :227)
   eg3d_seeds seeds;
   eg3d_sfm_seeds(sfm, &seeds);
-  eg3d_edgepoints pts;
-  eg3d_stage_times tm;
-  if (eg3d_match_refpoints(ctx, &seeds, 0, seeds.n_seeds, 0, &pts, &tm) != EG3D_OK) return fail("eg3d_match_refpoints");
-  std::printf("matched %u reference points -> %llu edge-points (%llu observations) in %.2f ms on the GPU\n", seeds.n_seeds,
-              (unsigned long long)pts.n_points, (unsigned long long)pts.n_obs, tm.ms_total);
+  {
+    eg3d_edgepoints e;
+    if (eg3d_match_refpoints(ctx, &seeds, 0, seeds.n_seeds, 0, &e, &tm) != EG3D_OK) return fail("eg3d_match_refpoints");
+    std::printf("matched %u reference points -> %llu edge-points (%llu observations) in %.2f ms on the GPU\n", seeds.n_seeds,
+                (unsigned long long)e.n_points, (unsigned long long)e.n_obs, tm.ms_total);
+    all_stages.append(e);
+    eg3d_free_edgepoints(&e);
+  }
+  eg3d_edgepoints pts = all_stages.view_as_edgepoints();
 
-  // ---- filter_3d_points_close_2d_array + add_3dpoints_to_sfmd (edge_matcher.cpp:150-158)
+  // ---- filter_3d_points_close_2d_array + add_3dpoints_to_sfmd (pipelines.cpp:236-239; edge_matcher.cpp:150-158)
   std::vector<uint8_t> keep(pts.n_points ? pts.n_points : 1);
   if (eg3d_host_filter_close_2d(V, sc.width, sc.height, &pts, keep.data()) != 0) return fail("dedup");
   uint64_t kept = 0;
@@ -159,7 +291,6 @@ int main(int argc, char** argv) {
   if (eg3d_sfm_add_edgepoints(sfm, &pts, keep.data()) != 0) return fail("adding the edge-points");
   std::printf("kept %llu edge-points after the 3 px de-duplication; SfM data now holds %llu points\n",
               (unsigned long long)kept, (unsigned long long)eg3d_sfm_n_points(sfm));
-  eg3d_free_edgepoints(&pts);
 
   // ---- ./filter -e (src/utils/filter.cpp:48-115): Gauss-Newton refinement + observation-count filter
   if (do_filter) {

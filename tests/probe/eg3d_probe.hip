@@ -189,3 +189,39 @@ extern "C" int eg3d_probe_gn_rows(uint64_t n, const float* P16, const float* oxy
   (void)hipFree(dout);
   return 0;
 }
+
+// ---- the 2-D geometry primitives the glm pin test checks (tests/test_glm_pin.py): project_f32, seg_line_cos,
+// seg_closest of the product's headers on the GPU. in = [n][19] / [n][7] / [n][6] floats as tests/glm/glm_driver.cpp takes.
+__global__ void k_probe_geom(uint64_t n, int mode, const float* in, float* out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (mode == 0) {
+    const float* q = in + 19 * i;
+    float u, v;
+    project_f32(q, q[16], q[17], q[18], u, v);
+    out[2 * i] = u;
+    out[2 * i + 1] = v;
+  } else if (mode == 1) {
+    const float* q = in + 7 * i;
+    out[i] = seg_line_cos(q[0], q[1], q[2], q[3], q[4], q[5]);
+  } else {
+    const float* q = in + 6 * i;
+    float qx, qy;
+    out[3 * i] = seg_closest(q[0], q[1], q[2], q[3], q[4], q[5], qx, qy);
+    out[3 * i + 1] = qx;
+    out[3 * i + 2] = qy;
+  }
+}
+extern "C" int eg3d_probe_geom(uint64_t n, int mode, const float* in, float* out) {
+  const size_t rin = mode == 0 ? 19 : mode == 1 ? 7 : 6, rout = mode == 0 ? 2 : mode == 1 ? 1 : 3;
+  float *di, *dout;
+  PT(hipMalloc(&di, n * rin * 4));
+  PT(hipMalloc(&dout, n * rout * 4));
+  PT(hipMemcpy(di, in, n * rin * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_probe_geom, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, n, mode, di, dout);
+  PT(hipDeviceSynchronize());
+  PT(hipMemcpy(out, dout, n * rout * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(di);
+  (void)hipFree(dout);
+  return 0;
+}

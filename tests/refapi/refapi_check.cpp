@@ -146,6 +146,166 @@ int main(int argc, char** argv) {
       eg3d_free_edgepoints(&d);
     }
   }
+  // ---- the reference's EXACT call surface -------------------------------------------------
+  auto same_as_direct = [&](const std::vector<new_3dpoint_plgp_matches>& got, uint64_t first, uint64_t n) {
+    if (got.size() != n) return false;
+    for (uint64_t k = 0; k < n; k++) {
+      const uint64_t i = first + k;
+      if (std::memcmp(&std::get<0>(got[k]), e.X + 3 * i, 12) != 0) return false;
+      const auto& obs = std::get<1>(got[k]);
+      const auto& views = std::get<2>(got[k]);
+      if (obs.size() != e.obs_off[i + 1] - e.obs_off[i]) return false;
+      for (size_t j = 0; j < obs.size(); j++) {
+        const uint64_t o = e.obs_off[i] + (uint64_t)j;
+        if (views[j] != e.obs_view[o] || obs[j].polyline_id != e.obs_pl[o] || obs[j].plp.segment_index != e.obs_seg[o] ||
+            std::memcmp(&obs[j].plp.coords, e.obs_xy + 2 * o, 8) != 0)
+          return false;
+      }
+    }
+    return true;
+  };
+  {
+    // pipelines.cpp:164 verbatim: plg_matching_from_refpoints_parallel(sfmd, em, cm, plgmm) with base-class pointers
+    em.set_batching(301, 3);
+    PLGPCM3ViewsPLGFollowing cm_obj(em);
+    const EdgeManager* em_p = &em;
+    const PLGPConsensusManager* cm_p = &cm_obj;
+    PLGMatchesManager plgmm2;
+    auto exact = plg_matching_from_refpoints_parallel(sfm, em_p, cm_p, plgmm2);
+    auto exact_serial = plg_matching_from_refpoints(sfm, em_p, cm_p, plgmm2);
+    if (!same_as_direct(exact, 0, e.n_points) || !same_as_direct(exact_serial, 0, e.n_points)) {
+      std::printf("FAIL: 4-argument plg_matching_from_refpoints[_parallel] differs from the direct call\n");
+      bad++;
+    }
+    if (plgmm2.get_plg3d().n_nodes != plgmm.get_plg3d().n_nodes || plgmm2.get_plg3d().n_polylines != plgmm.get_plg3d().n_polylines) bad++;
+    // a caller-supplied consensus strategy (here: one that forwards to the path's) goes through the reference's own
+    // per-point loop: plg_matching_from_refpoint(sfmd, em, cm, refpoint) for the first 40 reference points
+    struct Forwarding : PLGPConsensusManager {
+      PLGPCM3ViewsPLGFollowing& inner;
+      int calls = 0;
+      explicit Forwarding(PLGPCM3ViewsPLGFollowing& i) : inner(i) {}
+      points consensus_strategy_single_point(const int a, const int b, const intersections_and_correspondences& p) override {
+        return inner.consensus_strategy_single_point(a, b, p);
+      }
+      std::vector<points> consensus_strategy_single_point_vector(const int a, const int b,
+                                                                 const intersections_and_correspondences& p) override {
+        calls++;
+        return inner.consensus_strategy_single_point_vector(a, b, p);
+      }
+    } fwd(cm_obj);
+    SfMData head = sfm;
+    head.numPoints_ = sfm.numPoints_ < 40 ? sfm.numPoints_ : 40;
+    PLGMatchesManager plgmm3;
+    auto by_point = plg_matching_from_refpoints_parallel(head, em_p, &fwd, plgmm3);
+    uint64_t n_head = 0;
+    while (n_head < e.n_points && e.key[4 * n_head] < (uint32_t)head.numPoints_) n_head++;
+    if (!same_as_direct(by_point, 0, n_head) || fwd.calls == 0) {
+      std::printf("FAIL: per-point loop with a caller-supplied consensus manager: %zu points, expected %llu\n", by_point.size(),
+                  (unsigned long long)n_head);
+      bad++;
+    }
+    std::printf("exact surface: %zu points (batched), %zu (first %d reference points through a caller's consensus manager, %d calls)\n",
+                exact.size(), by_point.size(), head.numPoints_, fwd.calls);
+    // the legacy segment-based virtuals throw, as the reference's PLGEdgeManager does
+    bool threw = false;
+    try {
+      const_cast<EdgeManager*>(em_p)->detect_nearby_edge_intersections(0, 0, 10.0f);
+    } catch (const NotImplementedException&) {
+      threw = true;
+    }
+    if (!threw) bad++;
+  }
+  {
+    // gauss_newton.hpp:20 / outliers_filtering.hpp:18-21 verbatim, on an SfMData that holds the emitted edge-points
+    SfMData cloud;
+    cloud.numCameras_ = V;
+    cloud.imageWidth_ = sc->width;
+    cloud.imageHeight_ = sc->height;
+    cloud.camerasList_ = sfm.camerasList_;
+    const uint64_t np = e.n_points < 20000 ? e.n_points : 20000;
+    for (uint64_t i = 0; i < np; i++) {
+      // every 7th point is pushed off its rays so that the filter has something to reject
+      const float d = (i % 7 == 3) ? 25.0f : 0.0f;
+      cloud.points_.push_back(vec3{e.X[3 * i] + d, e.X[3 * i + 1] - d, e.X[3 * i + 2]});
+      std::vector<int> vs;
+      std::vector<vec2> xy;
+      for (uint64_t j = e.obs_off[i]; j < e.obs_off[i + 1]; j++) {
+        vs.push_back(e.obs_view[j]);
+        xy.push_back(vec2{e.obs_xy[2 * j], e.obs_xy[2 * j + 1]});
+      }
+      cloud.camViewingPointN_.push_back(vs);
+      cloud.point2DoncamViewingPoint_.push_back(xy);
+    }
+    cloud.numPoints_ = (int)cloud.points_.size();
+    // direct C-ABI answer
+    std::vector<float> X(3 * np), Xo(3 * np), xy;
+    std::vector<uint32_t> off(1, 0);
+    std::vector<int32_t> view;
+    for (uint64_t i = 0; i < np; i++) {
+      X[3 * i] = cloud.points_[i].x;
+      X[3 * i + 1] = cloud.points_[i].y;
+      X[3 * i + 2] = cloud.points_[i].z;
+      for (size_t j = 0; j < cloud.camViewingPointN_[i].size(); j++) {
+        view.push_back(cloud.camViewingPointN_[i][j]);
+        xy.push_back(cloud.point2DoncamViewingPoint_[i][j].x);
+        xy.push_back(cloud.point2DoncamViewingPoint_[i][j].y);
+      }
+      off.push_back((uint32_t)view.size());
+    }
+    std::vector<uint8_t> inl(np);
+    if (eg3d_gn_filter(ctx, X.data(), off.data(), view.data(), xy.data(), np, 2.25f, 0, Xo.data(), inl.data(), nullptr) != EG3D_OK) bad++;
+    size_t n_in = 0;
+    for (uint64_t i = 0; i < np; i++) n_in += inl[i];
+    for (int private_ctx = 0; private_ctx < 2; private_ctx++) {
+      PLGEdgeManager* saved = PLGEdgeManager::default_manager();
+      if (private_ctx) PLGEdgeManager::default_manager() = nullptr;  // ./filter has no edge manager: a context from the cameras alone
+      SfMData c1 = cloud;
+      std::vector<bool> inliers;
+      try {
+        gaussNewtonFiltering(c1, inliers, 2.25f);
+      } catch (const Eg3dError& ex) {
+        std::printf("FAIL gaussNewtonFiltering (%s context): %s\n", private_ctx ? "private" : "registered", ex.what());
+        bad++;
+        PLGEdgeManager::default_manager() = saved;
+        continue;
+      }
+      PLGEdgeManager::default_manager() = saved;
+      for (uint64_t i = 0; i < np; i++) {
+        if (inliers[i] != (inl[i] != 0)) bad++;
+        const float* want = inl[i] ? &Xo[3 * i] : &X[3 * i];
+        if (std::memcmp(&c1.points_[i], want, 12) != 0) bad++;
+      }
+    }
+    // filter(): the four overloads against the same steps made by hand
+    auto by_hand = [&](float mse, int forced) {
+      std::vector<uint8_t> k(np);
+      std::vector<float> Xo2(3 * np);
+      if (eg3d_gn_filter(ctx, X.data(), off.data(), view.data(), xy.data(), np, mse, 0, Xo2.data(), k.data(), nullptr) != EG3D_OK) bad++;
+      eg3d_host_observation_filter(V, off.data(), np, np / 2, forced, k.data());
+      std::vector<vec3> pts;
+      for (uint64_t i = 0; i < np; i++)
+        if (k[i]) pts.push_back(vec3{Xo2[3 * i], Xo2[3 * i + 1], Xo2[3 * i + 2]});
+      return pts;
+    };
+    auto same_pts = [&](const SfMData& a, const std::vector<vec3>& b) {
+      return a.points_.size() == b.size() && a.numPoints_ == (int)b.size() && a.camViewingPointN_.size() == b.size() &&
+             (b.empty() || std::memcmp(a.points_.data(), b.data(), 12 * b.size()) == 0);
+    };
+    const int first = (int)(np / 2);
+    SfMData f1 = cloud, f2 = cloud, f3 = cloud, f4 = cloud;
+    filter(f1, first);
+    filter(f2, first, 1.0f);
+    filter(f3, first, 5);
+    filter(f4, first, 4.0f, 2);
+    if (!same_pts(f1, by_hand(2.25f, -1)) || !same_pts(f2, by_hand(1.0f, -1)) || !same_pts(f3, by_hand(2.25f, 5)) ||
+        !same_pts(f4, by_hand(4.0f, 2))) {
+      std::printf("FAIL: filter() overloads differ from gn_filter + observation filter + removal by hand\n");
+      bad++;
+    }
+    if (f1.points_.size() == np || f1.points_.empty()) bad++;  // the filter must have removed something, not everything
+    std::printf("filter surface: %llu points, %zu Gauss-Newton inliers, filter() keeps %zu / %zu / %zu / %zu\n",
+                (unsigned long long)np, n_in, f1.points_.size(), f2.points_.size(), f3.points_.size(), f4.points_.size());
+  }
   // stage A through the reference's per-point entry
   auto cand = em.detect_nearby_intersections_and_correspondences_plgp(0);
   std::printf("%s points=%llu shim_batched=%zu shim_single=%zu track0_entries=%zu\n", bad ? "FAIL" : "OK",

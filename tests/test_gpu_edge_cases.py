@@ -307,7 +307,39 @@ def test_chain_expansion_in_many_chunks(monkeypatch):
     ctx.close()
 
 
-def _check_example_outputs_against_oracle(d, doc, doc_f):
+def _read_match_sets(path):
+    """A polyline match file of the example (text): returns (n_sets, row_off, ids)."""
+    tok = open(path).read().split()
+    assert tok[0] == "eg3d-polyline-sets" and tok[1] == "1"
+    n_sets, n_views = int(tok[2]), int(tok[3])
+    row_off, ids, k = [0], [], 4
+    for _ in range(n_sets * n_views):
+        c = int(tok[k])
+        ids.extend(int(t) for t in tok[k + 1:k + 1 + c])
+        k += 1 + c
+        row_off.append(len(ids))
+    return n_sets, np.asarray(row_off, np.uint32), np.asarray(ids, np.uint32)
+
+
+def _concat_clouds(parts):
+    """Clouds (dicts in the C ABI's layout) back to back, observation offsets rebased."""
+    out = {"X": np.concatenate([p["X"].reshape(-1, 3) for p in parts]),
+           "key": np.concatenate([p["key"].reshape(-1, 4) for p in parts]),
+           "obs_view": np.concatenate([p["obs_view"] for p in parts]),
+           "obs_pl": np.concatenate([p["obs_pl"] for p in parts]),
+           "obs_seg": np.concatenate([p["obs_seg"] for p in parts]),
+           "obs_xy": np.concatenate([p["obs_xy"].reshape(-1, 2) for p in parts])}
+    off, base = [np.zeros(1, np.uint64)], 0
+    for p in parts:
+        off.append(p["obs_off"][1:].astype(np.uint64) + np.uint64(base))
+        base += int(p["n_obs"])
+    out["obs_off"] = np.concatenate(off)
+    out["n_points"] = sum(int(p["n_points"]) for p in parts)
+    out["n_obs"] = base
+    return out
+
+
+def _check_example_outputs_against_oracle(d, doc, doc_f, sets_files=()):
     from oracle import binding as ob
     H = host.lib()
     H.eg3d_sfm_read_json.restype = C.c_void_p
@@ -342,6 +374,14 @@ def _check_example_outputs_against_oracle(d, doc, doc_f):
     n0 = int(seeds.n_seeds)
     o = ob.Oracle(C.byref(sc))
     ref = o.match(C.byref(seeds), 0, n0, os.cpu_count())
+    if sets_files:
+        # pipelines 1 and 2 first, in stage order, then pipeline 3 (pipelines.cpp:219-227)
+        stages = []
+        for path in sets_files:
+            ns, row_off, ids = _read_match_sets(path)
+            stages.append(o.match_polyline_sets(ns, row_off, ids, 0, ns, os.cpu_count()))
+            assert stages[-1]["n_points"] > 0
+        ref = _concat_clouds(stages + [ref])
     ep = D.EdgePointsArrays(ref)
     keep = np.zeros(max(1, ref["n_points"]), np.uint8)
     assert ob.lib().orc_filter_close_2d(o._h, C.byref(ep.c), D.np_ptr(keep, C.c_uint8)) == 0
@@ -430,6 +470,18 @@ def test_cpp_end_to_end_example(tmp_path):
     # -> remove] (filtering_close_plgps.cpp:99-124, output_utilities.cpp:96-111, gauss_newton.cpp:136-178,
     # outliers_filtering.cpp:14-114). Only the file readers are the product's here.
     _check_example_outputs_against_oracle(d, doc, json.load(open(d + "/out_f.json")))
+    # ---- ALL THREE STAGES of edge_reconstruction_pipeline in one run (pipelines.cpp:201-246): polyline matches of
+    # pipelines 1 and 2 from files -> the extractor, then the reference points, concatenated in that order, ONE
+    # de-duplication over the concatenation, append, filter — against the same chain made with the oracle
+    for name, extra in (("out_3", []), ("out_3f", ["--filter"])):
+        o3 = subprocess.run([exe, d + "/input.json", d + "/plgs.bin", d + "/%s.json" % name, "--all-pairs", "--sets1", d + "/sets1.txt",
+                             "--sets2", d + "/sets2.txt"] + extra, capture_output=True, text=True, timeout=300)
+        assert o3.returncode == 0, o3.stdout + o3.stderr
+        assert re.search(r"pipeline 1: 3 polyline matches -> (\d+) edge-points", o3.stdout), o3.stdout
+        assert re.search(r"pipeline 2: 3 polyline matches -> (\d+) edge-points", o3.stdout), o3.stdout
+    doc3 = json.load(open(d + "/out_3.json"))
+    assert len(doc3["structure"]) > len(doc["structure"])     # the two extra stages contributed points
+    _check_example_outputs_against_oracle(d, doc3, json.load(open(d + "/out_3f.json")), (d + "/sets1.txt", d + "/sets2.txt"))
     # N4: the reference's rule for which view pairs have a fundamental matrix (>= 10 common SfM points) — the
     # default — must give what the library gives on the same scene with those pairs switched off; and the
     # matrices estimated from the tracks (--estimate-F) must reproduce most of the cloud
