@@ -88,6 +88,33 @@ static_assert(sizeof(CoopLds) <= 12800, "CoopLds must fit 10 LDS allocation unit
 //     which is what the retired one-lane-per-solve path did — at 1 KB of scratch per lane, the
 //     main source of the expand kernel's former HBM write traffic).
 // Each round iterates until all of its groups have converged.
+// Value of lane `src` (wave-uniform) in every lane: v_readlane_b32 through a scalar register — no trip through the LDS
+// crossbar that the general __shfl (ds_bpermute_b32) takes. All lanes must be active at the call.
+__device__ __forceinline__ int lane_bcast(int v, int src) {
+  return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src));
+}
+__device__ __forceinline__ uint32_t lane_bcast(uint32_t v, int src) { return (uint32_t)lane_bcast((int)v, src); }
+__device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_float(lane_bcast(__float_as_int(v), src)); }
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+  return __hiloint2double(lane_bcast(__double2hiint(v), src), lane_bcast(__double2loint(v), src));
+}
+__device__ __forceinline__ unsigned long long lane_bcast(unsigned long long v, int src) {
+  return ((unsigned long long)(uint32_t)lane_bcast((int)(v >> 32), src) << 32) | (uint32_t)lane_bcast((int)(v & 0xffffffffull), src);
+}
+// Inclusive prefix sum over the 64 lanes with DPP row shifts and row broadcasts (6 vector instructions, no trip
+// through the LDS crossbar; the __shfl_up ladder is 6 dependent ds_bpermute_b32). Integers: exact whatever the order.
+// All lanes must be active at the call.
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  // within each row of 16 lanes (lanes shifted in from outside the row read 0: old = 0, bound_ctrl off)
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+  // across rows: the last lane of row 0 / 2 into rows 1 / 3, then lane 31 into rows 2 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31
+  return v;
+}
 struct GnRow {
   double j00, j01, j02, j10, j11, j12, r0, r1;
 };
@@ -482,17 +509,12 @@ __device__ __forceinline__ bool coop_gn_groups(const float* cam_P, CoopLds& L, b
   // ---- short requests: rounds of whole requests packed into <= 64 rows, in lane order
   if (m_short) {
     const int ns = is_short ? n_req : 0;
-    int pre = ns;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int t = __shfl_up(pre, d);
-      if (lane >= d) pre += t;
-    }
+    const int pre = wave_incl_scan(ns);
     const int excl = pre - ns;
     unsigned long long todo = m_short;
     while (todo) {
       const int q0 = __ffsll((long long)todo) - 1;
-      const int rbase = __shfl(excl, q0);
+      const int rbase = lane_bcast(excl, q0);
       const unsigned long long in_round = __ballot(is_short && lane >= q0 && (excl + ns - rbase) <= EG3D_COOP_ROWS);
       // contiguity: stop at the first short request >= q0 that does not fit
       const unsigned long long nofit = todo & ~in_round & ~((1ull << q0) - 1ull);
@@ -505,7 +527,7 @@ __device__ __forceinline__ bool coop_gn_groups(const float* cam_P, CoopLds& L, b
           L.row_k[excl - rbase + k] = (uint8_t)k;
         }
       const int last = 63 - __builtin_clzll(members);
-      const int rows = __shfl(excl + ns, last) - rbase;
+      const int rows = lane_bcast(excl + ns, last) - rbase;
       __syncthreads();
       const bool act = lane < rows;
       int rq = 0, l = 0, n = 2, nb = 0;

@@ -211,8 +211,11 @@ struct TeamSeq {
   }
   // candidates of one side walk (walk_side_candidates_core); a team may first stage the polyline
   // and the epipolar lines of the chain points ahead in fast memory
-  EG3D_HD int side_walk(const DevScene& s, Chain& c, int view, const Obs& from, uint32_t direction, int lo, int ci,
-                        int hi, bool towards_start, Pending* out) const;
+  // walk_stage() is called once per attachment before its side walks (and again after a solver batch, which may have
+  // overwritten what was staged); a team that keeps nothing staged ignores it
+  EG3D_HD void walk_stage(const DevScene&, Chain&, int, const PlRef&, int, int, int) const {}
+  EG3D_HD int side_walk(const DevScene& s, Chain& c, int view, const PlRef& pl, const Obs& from, uint32_t direction, int lo,
+                        int ci, int hi, bool towards_start, Pending* out) const;
   EG3D_HD bool gn_array(const DevScene& s, const Obs* a, int n, const double X0[3], float Xout[3]) const {
     ArrayCursor cur;
     cur.a = a;
@@ -525,9 +528,8 @@ EG3D_HD int walk_side_candidates_core(const DevScene& s, Chain& c, const PlT& pl
   }
   return cnt;
 }
-EG3D_HD int TeamSeq::side_walk(const DevScene& s, Chain& c, int view, const Obs& from, uint32_t direction, int lo,
-                               int ci, int hi, bool towards_start, Pending* out) const {
-  const PlRef pl = polyline_of(s, view, from.pl);
+EG3D_HD int TeamSeq::side_walk(const DevScene& s, Chain& c, int view, const PlRef& pl, const Obs& from, uint32_t direction,
+                               int lo, int ci, int hi, bool towards_start, Pending* out) const {
   return walk_side_candidates_core(s, c, pl, (const float*)nullptr, 0, view, from, direction, lo, ci, hi,
                                    towards_start, out,
                                    [](const PlRef& p, const PlPt& a, uint32_t d, float la, float lb, float lc, PlPt& nx) {
@@ -535,49 +537,79 @@ EG3D_HD int TeamSeq::side_walk(const DevScene& s, Chain& c, int view, const Obs&
                                    });
 }
 
-// The two side walks of one orientation (towards dS on the chain's start side, towards dE on its
-// end side) and their ADD solves as ONE batch: candidate j of the start side against chain point
-// ci-1-j, of the end side against ci+1+j; n1 / n2 = leading successes of each side — the reference
-// stops a side at its first failed walk or solve (plg_matching.cpp:866-914) and walks the end side
-// only when the start side attached something (:1345-1412). The end-side walk is made before the
-// start side's solves are known (its positions do not depend on them) whenever the start side
-// produced candidates at all; it is discarded if none of those survives its solve.
+// The side walks of an attachment and their ADD solves. One ORIENTATION = the walk towards dS on the chain's start side
+// and towards dE on its end side; candidate j of the start side goes against chain point ci-1-j, of the end side
+// against ci+1+j; n1 / n2 = leading successes of each side — the reference stops a side at its first failed walk or
+// solve (plg_matching.cpp:866-914) and walks the end side only when the start side attached something (:1345-1412).
+// The end-side walk is made before the start side's solves are known (its positions do not depend on them) whenever
+// the start side produced candidates at all; it is discarded if none of those survives its solve. The reference tries
+// the orientation (start, end) first and (end, start) when that one attaches nothing on the start side. Walks do not
+// depend on solves, so: stage once (tm.walk_stage), walk orientation A; if its start side finds NOTHING, orientation
+// B is walked at once from the same staged data (no solver call in between); one batch of solves; only when A found
+// candidates whose first solve failed is B walked and solved on its own (after re-staging: the solver's staging
+// area aliases the walk's). Same walks, same solves that count, same flags as two independent passes.
+// Returns the orientation that attached (0 = none, 1 = A, 2 = B) with n1 / n2.
 template <class Team>
-EG3D_HD_FLAT void walk_sides(const Team& tm, const DevScene& s, Chain& c, int view, const Obs& from, uint32_t dS, uint32_t dE,
-                        int lo, int ci, int hi, int& n1, int& n2) {
-  uint64_t t0 = EG3D_TICK();
-  const int m1 = tm.side_walk(s, c, view, from, dS, lo, ci, hi, true, c.pend1);
-  int m2 = 0;
-  if (m1 > 0 && ci < hi) m2 = tm.side_walk(s, c, view, from, dE, lo, ci, hi, false, c.pend2);
-  tm.sync();
-  uint64_t t1 = EG3D_TICK();
-  c.tsec[2] += t1 - t0;
+EG3D_HD_FLAT int walk_sides_both(const Team& tm, const DevScene& s, Chain& c, int view, const Obs& from, const PlRef& pl, int lo,
+                                 int ci, int hi, int& n1, int& n2) {
   Pending* p1 = c.pend1;
   Pending* p2 = c.pend2;
-  tm.add_solves(
-      s, c, m1 + m2,
-      [&](int j, const ChainPt*& pt, Obs& o) {
-        if (j < m1) {
-          pt = &chain_at(c, ci - 1 - j);
-          o = p1[j].o;
-        } else {
-          pt = &chain_at(c, ci + 1 + (j - m1));
-          o = p2[j - m1].o;
-        }
-        return true;
-      },
-      [&](int j, bool ok, const float* X) {
-        if (!ok) return;
-        Pending& pd = j < m1 ? p1[j] : p2[j - m1];
-        pd.X[0] = X[0];
-        pd.X[1] = X[1];
-        pd.X[2] = X[2];
-        pd.ok = 1;
-      });
-  tm.sync();
-  n1 = tm.leading_true(m1, [&](int j) { return p1[j].ok != 0; });
-  n2 = n1 > 0 ? tm.leading_true(m2, [&](int j) { return p2[j].ok != 0; }) : 0;
-  c.tsec[3] += EG3D_TICK() - t1;
+  auto walks = [&](uint32_t dS, uint32_t dE, int& m1, int& m2) {
+    m1 = tm.side_walk(s, c, view, pl, from, dS, lo, ci, hi, true, p1);
+    m2 = 0;
+    if (m1 > 0 && ci < hi) m2 = tm.side_walk(s, c, view, pl, from, dE, lo, ci, hi, false, p2);
+  };
+  auto solves = [&](int m1, int m2) {
+    tm.sync();
+    const uint64_t t1 = EG3D_TICK();
+    tm.add_solves(
+        s, c, m1 + m2,
+        [&](int j, const ChainPt*& pt, Obs& o) {
+          if (j < m1) {
+            pt = &chain_at(c, ci - 1 - j);
+            o = p1[j].o;
+          } else {
+            pt = &chain_at(c, ci + 1 + (j - m1));
+            o = p2[j - m1].o;
+          }
+          return true;
+        },
+        [&](int j, bool ok, const float* X) {
+          if (!ok) return;
+          Pending& pd = j < m1 ? p1[j] : p2[j - m1];
+          pd.X[0] = X[0];
+          pd.X[1] = X[1];
+          pd.X[2] = X[2];
+          pd.ok = 1;
+        });
+    tm.sync();
+    n1 = tm.leading_true(m1, [&](int j) { return p1[j].ok != 0; });
+    n2 = n1 > 0 ? tm.leading_true(m2, [&](int j) { return p2[j].ok != 0; }) : 0;
+    c.tsec[3] += EG3D_TICK() - t1;
+  };
+  n1 = n2 = 0;
+  uint64_t t0 = EG3D_TICK();
+  tm.walk_stage(s, c, view, pl, lo, ci, hi);
+  int m1, m2;
+  walks(pl.start, pl.end, m1, m2);
+  int which = 1;
+  if (m1 == 0) {  // orientation A cannot reach the lower neighbour: B, from the same staged data
+    which = 2;
+    walks(pl.end, pl.start, m1, m2);
+  }
+  c.tsec[2] += EG3D_TICK() - t0;
+  if (m1 == 0) return 0;
+  solves(m1, m2);
+  if (n1 > 0) return which;
+  if (which == 2) return 0;
+  // A's first start-side solve failed: orientation B on its own
+  t0 = EG3D_TICK();
+  tm.walk_stage(s, c, view, pl, lo, ci, hi);
+  walks(pl.end, pl.start, m1, m2);
+  c.tsec[2] += EG3D_TICK() - t0;
+  if (m1 == 0) return 0;
+  solves(m1, m2);
+  return n1 > 0 ? 2 : 0;
 }
 
 // Try to attach observation `o` of view o.view to chain point ci, then to its neighbours within
@@ -606,19 +638,16 @@ EG3D_HD_FLAT bool attach_view(const Team& tm, const DevScene& s, Chain& c, const
   uint32_t nd1 = 0, nd2 = 0;
   int n1 = 0, n2 = 0;
   if (ci > lo) {
-    walk_sides(tm, s, c, view, o, pl.start, pl.end, lo, ci, hi, n1, n2);
-    if (n1 > 0) {
+    const int which = walk_sides_both(tm, s, c, view, o, pl, lo, ci, hi, n1, n2);
+    if (which == 1) {
       nd1 = pl.start;
       nd2 = pl.end;
-    } else {
-      walk_sides(tm, s, c, view, o, pl.end, pl.start, lo, ci, hi, n1, n2);
-      if (n1 > 0) {
-        nd1 = pl.end;
-        nd2 = pl.start;
-      }
-      // else: neither orientation reaches the lower neighbour; with ci > lo >= 0 the
-      // attachment is rejected below whatever the upper side would give.
+    } else if (which == 2) {
+      nd1 = pl.end;
+      nd2 = pl.start;
     }
+    // else: neither orientation reaches the lower neighbour (n1 = n2 = 0); with ci > lo >= 0 the
+    // attachment is rejected below whatever the upper side would give.
   }
   if (ci > 0 && n1 == 0) return false;
   if (ci < c.len - 1 && n2 == 0) return false;
@@ -740,7 +769,11 @@ EG3D_HD bool unique_polyline_4px(const DevScene& s, int view, float x, float y, 
 #define EG3D_LAZY_PRESOLVE_MIN_VIEWS 16
 #endif
 EG3D_HD bool lazy_presolve(const DevScene& s) { return s.n_views >= EG3D_LAZY_PRESOLVE_MIN_VIEWS; }
-EG3D_HD int presolve_window(const DevScene& s) { return s.n_views >= 64 ? 8 : 16; }
+#ifndef EG3D_PRESOLVE_WINDOW
+#define EG3D_PRESOLVE_WINDOW 16      /* chain points per window of speculative central solves, scenes of 16..63 views */
+#define EG3D_PRESOLVE_WINDOW_MANY 8  /*   ... of 64 views and more */
+#endif
+EG3D_HD int presolve_window(const DevScene& s) { return s.n_views >= 64 ? EG3D_PRESOLVE_WINDOW_MANY : EG3D_PRESOLVE_WINDOW; }
 // speculative central ADD solve of the chain points [from, to) whose candidate is within 4 px
 template <class Team>
 EG3D_HD_FLAT void central_presolves(const Team& tm, const DevScene& s, Chain& c, int v, int from, int to) {

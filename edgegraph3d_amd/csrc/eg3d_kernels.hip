@@ -534,15 +534,18 @@ struct TeamWaveT {
     __syncthreads();
     double r[3] = {0, 0, 0};
     if (lane() == 0) dlt2_mem(P1, x1, y1, P2, x2, y2, (lds_dp)&L->dlt_work[0][0], r);
-    X0[0] = __shfl(r[0], 0);
-    X0[1] = __shfl(r[1], 0);
-    X0[2] = __shfl(r[2], 0);
+    X0[0] = lane_bcast(r[0], 0);
+    X0[1] = lane_bcast(r[1], 0);
+    X0[2] = lane_bcast(r[2], 0);
     __syncthreads();
   }
+  // OR over the lanes of a small flag word (the EG3D_FLAG_* bits 0..4 the expand stage raises): one ballot per bit
   __device__ __forceinline__ uint32_t or_reduce(uint32_t v) const {
+    uint32_t r = 0;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v |= (uint32_t)__shfl_xor((int)v, d);
-    return v;
+    for (uint32_t b = 1; b <= 16u; b <<= 1)
+      if (__ballot((v & b) != 0)) r |= b;
+    return r;
   }
   template <class Pred>
   __device__ __forceinline__ int leading_true(int m, Pred pred) const {
@@ -576,38 +579,43 @@ struct TeamWaveT {
     }
   }
   __device__ __forceinline__ uint32_t excl_scan(uint32_t v, uint32_t& total) const {
-    uint32_t pre = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t t = (uint32_t)__shfl_up((int)pre, d);
-      if (lane() >= d) pre += t;
-    }
-    total = (uint32_t)__shfl((int)pre, 63);
+    const uint32_t pre = (uint32_t)wave_incl_scan((int)v);
+    total = lane_bcast(pre, 63);
     return pre - v;
   }
-  // One side walk: the polyline (when it fits) and the epipolar lines of the chain points ahead
-  // are first copied to LDS by all lanes, then walked through address_space(3) pointers (ds_read).
-  __device__ __forceinline__ int side_walk(const DevScene& s, Chain& c, int view, const Obs& from, uint32_t direction,
-                                           int lo, int ci, int hi, bool towards_start, Pending* out) const {
-    typedef const __attribute__((address_space(3))) float* lds_fp;
-    typedef const __attribute__((address_space(3))) f2* lds_f2p;
-    const PlRef pl = polyline_of(s, view, from.pl);
-    const int first = towards_start ? ci - 1 : ci + 1, step = towards_start ? -1 : 1;
-    const int count = towards_start ? ci - lo : hi - ci - 1;
+  // Staging for the side walks of ONE attachment (all of them walk the same polyline of the same view): the polyline's
+  // vertices (when they fit) and the epipolar lines of the chain points on either side of ci — the lower side
+  // (ci-1, ci-2, ... >= lo) in the first half of the staging area, the upper side (ci+1, ... < hi) in the second —
+  // copied to LDS once by all lanes. (Round 3 staged per side walk: four times per attachment.)
+  static constexpr int kEpiHalf = EG3D_STAGE_EPI / 2;
+  __device__ __forceinline__ void walk_stage(const DevScene& s, Chain& c, int view, const PlRef& pl, int lo, int ci,
+                                             int hi) const {
     __syncthreads();
-    const bool fits = pl.n <= EG3D_STAGE_VTX;
-    if (fits)
+    if (pl.n <= EG3D_STAGE_VTX)
       for (uint32_t i = (uint32_t)lane(); i < pl.n; i += 64) L->walk.vtx[i] = pl.v[i];
-    const int staged = count < EG3D_STAGE_EPI ? (count < 0 ? 0 : count) : EG3D_STAGE_EPI;
-    for (int t = lane(); t < staged; t += 64) {
-      const ViewCand& ve = c.cand[c.head + first + step * t];
-      L->walk.epi[t][0] = ve.eok ? 1.0f : 0.0f;
-      L->walk.epi[t][1] = ve.ea;
-      L->walk.epi[t][2] = ve.eb;
-      L->walk.epi[t][3] = ve.ec;
+    const int n_lo = ci - lo < kEpiHalf ? (ci - lo < 0 ? 0 : ci - lo) : kEpiHalf;
+    const int n_hi = hi - ci - 1 < kEpiHalf ? (hi - ci - 1 < 0 ? 0 : hi - ci - 1) : kEpiHalf;
+    for (int t = lane(); t < n_lo + n_hi; t += 64) {
+      const bool low = t < n_lo;
+      const int pt = low ? ci - 1 - t : ci + 1 + (t - n_lo);
+      const int slot = low ? t : kEpiHalf + (t - n_lo);
+      const ViewCand& ve = c.cand[c.head + pt];
+      L->walk.epi[slot][0] = ve.eok ? 1.0f : 0.0f;
+      L->walk.epi[slot][1] = ve.ea;
+      L->walk.epi[slot][2] = ve.eb;
+      L->walk.epi[slot][3] = ve.ec;
     }
     __syncthreads();
-    const lds_fp epi = (lds_fp)&L->walk.epi[0][0];
+  }
+  // One side walk from the staged data, walked through address_space(3) pointers (ds_read).
+  __device__ __forceinline__ int side_walk(const DevScene& s, Chain& c, int view, const PlRef& pl, const Obs& from,
+                                           uint32_t direction, int lo, int ci, int hi, bool towards_start, Pending* out) const {
+    typedef const __attribute__((address_space(3))) float* lds_fp;
+    typedef const __attribute__((address_space(3))) f2* lds_f2p;
+    const int count = towards_start ? ci - lo : hi - ci - 1;
+    const bool fits = pl.n <= EG3D_STAGE_VTX;
+    const int staged = count < kEpiHalf ? (count < 0 ? 0 : count) : kEpiHalf;
+    const lds_fp epi = (lds_fp)&L->walk.epi[towards_start ? 0 : kEpiHalf][0];
     // next hit of the line towards `direction`, SEGMENT-PARALLEL: lane 0 tests the partial segment
     // from the current position, lane k the k-th whole segment beyond it; the first lane (walking
     // order) whose test reports a hit or a quasi-parallel stop decides — exactly the sequential
@@ -652,11 +660,11 @@ struct TeamWaveT {
         const unsigned long long any = __ballot(r != 0);
         if (any) {
           const int f = __ffsll((long long)any) - 1;
-          const uint32_t rf = (uint32_t)__shfl((int)r, f);
+          const uint32_t rf = lane_bcast(r, f);
           if (rf & 2u) return WALK_QUASIPARALLEL;
-          nx.seg = (uint32_t)__shfl((int)seg, f);
-          nx.x = __shfl(hx, f);
-          nx.y = __shfl(hy, f);
+          nx.seg = lane_bcast(seg, f);
+          nx.x = lane_bcast(hx, f);
+          nx.y = lane_bcast(hy, f);
           return WALK_FOUND;
         }
       }
@@ -787,7 +795,7 @@ struct TeamWaveT {
       c.tsec[6] += EG3D_TICK() - tq2;
       bool redo = false, stop = false;
       for (int j = 0; j < Deff; j++) {
-        const uint32_t dflj = (uint32_t)__shfl((int)dfl, j);
+        const uint32_t dflj = lane_bcast(dfl, j);
         if (L->res_ok[j]) {
           const float X[3] = {L->x0[j][0], L->x0[j][1], L->x0[j][2]};
           c.flags |= L->la_fl[j] | dflj;
@@ -841,10 +849,10 @@ struct TeamWaveT {
     const float X0f[3] = {(float)X0[0], (float)X0[1], (float)X0[2]};  // callers pass float-valued starts
     float Xr[3];
     const bool ok = coop_gn_groups<GN_KEEP>(s.cam_P, *L, lane() == 0, a, n, false, 0, 0.f, 0.f, X0f, Xr);
-    Xout[0] = __shfl(Xr[0], 0);
-    Xout[1] = __shfl(Xr[1], 0);
-    Xout[2] = __shfl(Xr[2], 0);
-    return __shfl(ok ? 1 : 0, 0) != 0;
+    Xout[0] = lane_bcast(Xr[0], 0);
+    Xout[1] = lane_bcast(Xr[1], 0);
+    Xout[2] = lane_bcast(Xr[2], 0);
+    return lane_bcast(ok ? 1 : 0, 0) != 0;
   }
   __device__ __forceinline__ bool add_one(const DevScene& s, const Chain& c, const ChainPt& p, const Obs& extra,
                                           float Xout[3]) const {
@@ -852,10 +860,10 @@ struct TeamWaveT {
     float Xr[3];
     const bool ok = coop_gn_groups<GN_KEEP>(s.cam_P, *L, lane() == 0, c.pool + p.off, (int)p.nobs, true, extra.view, extra.x,
                                    extra.y, X0f, Xr);
-    Xout[0] = __shfl(Xr[0], 0);
-    Xout[1] = __shfl(Xr[1], 0);
-    Xout[2] = __shfl(Xr[2], 0);
-    return __shfl(ok ? 1 : 0, 0) != 0;
+    Xout[0] = lane_bcast(Xr[0], 0);
+    Xout[1] = lane_bcast(Xr[1], 0);
+    Xout[2] = lane_bcast(Xr[2], 0);
+    return lane_bcast(ok ? 1 : 0, 0) != 0;
   }
   // B independent ADD solves, 64 per window, request j on lane j. A window goes cooperative
   // (rows = observations) when that needs fewer row-passes than the longest single solve;
@@ -999,8 +1007,8 @@ __global__ void __launch_bounds__(64, WAVES) k3b_expand_t(DevScene s, StageAView
     pb = atomicAdd(&stage.used[0], (unsigned long long)co.n_points);
     ob = atomicAdd(&stage.used[1], (unsigned long long)co.n_obs);
   }
-  pb = (unsigned long long)__shfl((long long)pb, 0);
-  ob = (unsigned long long)__shfl((long long)ob, 0);
+  pb = lane_bcast(pb, 0);
+  ob = lane_bcast(ob, 0);
   co.spt = pb;
   co.sobs = ob;
   if (pb + co.n_points <= stage.cap_pts && ob + co.n_obs <= stage.cap_obs) {
@@ -1019,13 +1027,8 @@ __global__ void __launch_bounds__(64, WAVES) k3b_expand_t(DevScene s, StageAView
       p.off = 0;
       p.X[0] = p.X[1] = p.X[2] = 0.f;
       if (act) p = pts[i];
-      uint32_t incl = p.nobs;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
-        if ((int)lane >= o) incl += t;
-      }
-      const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+      const uint32_t incl = (uint32_t)wave_incl_scan((int)p.nobs);
+      const uint32_t total = lane_bcast(incl, 63);
       s_excl[lane] = incl - p.nobs;
       s_blk[lane] = p.off;
       if (lane == 63) s_excl[64] = total;
@@ -1102,13 +1105,8 @@ __global__ void __launch_bounds__(64) k4_emit(const TaskDesc* tasks, const Chain
     p.nobs = 0;
     p.X[0] = p.X[1] = p.X[2] = 0.f;
     if (act) p = spt[i];
-    uint32_t incl = p.nobs;  // inclusive wave scan of the observation counts
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
-      if ((int)lane >= o) incl += t;
-    }
-    const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+    const uint32_t incl = (uint32_t)wave_incl_scan((int)p.nobs);  // inclusive wave scan of the observation counts
+    const uint32_t total = lane_bcast(incl, 63);
     if (act) {
       const uint64_t pi = pbase + i;
       X[3 * pi] = p.X[0];
