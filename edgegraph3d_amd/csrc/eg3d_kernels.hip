@@ -893,13 +893,16 @@ struct TeamWaveT {
 };
 using TeamWave = TeamWaveT<0>;
 
+// Waves per SIMD the expand kernel is built for. Round 4: 4 (128 VGPRs) — CoopLds was cut to 8 LDS allocation units
+// (eg3d_dev_coopgn.h) so that four single-wave workgroups really fit a SIMD: rounds 2-3 compared "2 / 3 / 4" with an LDS
+// footprint that capped the residency at 3 whatever the registers, i.e. they never measured 4. At 4 the compiler
+// spills 261 vector registers (352 B of scratch per lane; almost all of them around the inlined solver calls, not
+// inside its loops) against 24 at 3, and the kernel moves 48.9 instead of 29.4 GB per C3' launch — and is faster on
+// every workload: C3' K3b 50.3 vs 52.1 ms (47.3 vs 49.6 ms per step in flight), C2 6.85 vs 7.26 ms, the 8192-seed C4
+// step 2070 vs 2233 ms, one pass over all of C4 22.7 vs 24.7 s. (2 waves with nothing spilled: 68.2 ms / 2687 ms.)
+// What the extra wave hides — the dependent trips of the walks and of a solve's steps — outweighs the spill traffic:
+// occupancy is the lever on this kernel. -DEG3D_K3B_WAVES=3 (tools/build_variant.sh) rebuilds the other one.
 #ifndef EG3D_K3B_WAVES
-// Waves per SIMD the expand kernel is built for. Round 4: 4 (128 VGPRs, CoopLds cut to 8 LDS units so that four
-// single-wave workgroups really fit a SIMD — rounds 2-3 compared "2 / 3 / 4" with an LDS footprint that capped the
-// residency at 3 whatever the registers, i.e. they never measured 4). At 4 the compiler spills 261 vector registers
-// (352 B of scratch per lane) against 24 at 3, almost all of them around the inlined solver calls, not inside its loops:
-// C3' K3b 53.5 vs 53.7 ms, C2 7.0 vs 7.3 ms, the 8192-seed C4 step 2070 vs 2233 ms (-7 %), one pass over all of C4
-// 22.7 vs 24.7 s; 2 waves with nothing spilled: 68.2 ms / 2687 ms. Occupancy is the lever on this kernel, not spills.
 #define EG3D_K3B_WAVES 4
 #endif
 // ---- working slices: a slot-indexed arena ---------------------------------------------------------
