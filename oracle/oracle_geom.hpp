@@ -11,6 +11,9 @@
 // Arithmetic contract (shared with the HIP path, see DESIGN.md "Arithmetic contract"):
 // no FMA contraction, no reassociation, float/double mix exactly as the reference
 // compiles on x86-64 without -march flags (CMakeLists.txt:48).
+// Round 4: compute_anglecos, minimum_distancesq (and squared_2d_distance inside it) are PINNED bit for bit against the
+// reference's own vendored glm (tests/test_glm_pin.py, tests/glm/glm_driver.cpp, tests/golden/glm_pin_v1.npz); everything
+// that does not evaluate through glm — and all OpenCV arithmetic — stays unpinned.
 #pragma once
 #include <cmath>
 #include <cstdint>

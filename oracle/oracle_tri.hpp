@@ -9,6 +9,9 @@
 // (modules/calib3d/src/triangulate.cpp, modules/core/src/lapack.cpp JacobiSVDImpl_,
 // modules/core/src/matmul.cpp GEMMSingleMul, modules/calib3d/src/fundam.cpp). The
 // restatement fixes one evaluation order (documented per function) that the HIP path shares.
+// Round 4: compute_projection (vec4 * mat4 of the vendored glm) is PINNED bit for bit against that glm
+// (tests/test_glm_pin.py); the DLT, the Jacobi SVD and the Gauss-Newton GEMM orders are OpenCV's and stay unpinned —
+// cross-checked numerically against numpy / scipy only (tests/test_dlt_forms.py).
 #pragma once
 #include <cfloat>
 #include <cmath>
