@@ -551,6 +551,8 @@ def main():
         if gstats:
             line.update({"gather_ms": gstats["gather_ms"], "gather_bytes": gstats["gather_bytes"],
                          "overlap_frac": gstats["overlap_frac"], "gather": gstats})
+            line["gather"]["mode"] = getattr(gather, "mode", None)          # "sendrecv" (default) or the "bcast" fallback
+            line["gather"]["preflight"] = getattr(gather, "selftest", None)  # what the pre-flight check of the exchange found
         if tts is not None:
             line["time_to_solution_s"] = tts[0]
             line["time_to_solution"] = {"seconds": tts[0], "edge_points": tts[1], "steps": leg.n_pass_steps(),

@@ -91,6 +91,91 @@ class RcclCloudGather:
         self.stream = C.c_void_p(stream_ptr) if stream_ptr else None
         self.rank_points = (C.c_uint64 * world)()
         self.rank_obs = (C.c_uint64 * world)()
+        self.G.eg3d_gather_set_mode.argtypes = [C.c_void_p, C.c_int]
+        self.mode = "bcast" if os.environ.get("EG3D_GATHER_MODE", "")[:1] in ("b", "1") else "sendrecv"
+        self.selftest = None
+        if world > 1 and dist.get_backend() == "nccl":
+            self._choose_mode(dist, device_index)
+
+    # ---- pre-flight check of the exchange (multi-rank only) -------------------------------------------------
+    def _selftest_once(self, device_index):
+        """A tiny hand-made cloud per rank (rank r: 2 + r points; odd ranks' points carry two observations each, even
+        ranks' none — zero-size arrays on some pairs) through eg3d_allgather_edgepoints; True when this rank holds exactly
+        the concatenation every rank can predict."""
+        import numpy as np
+        import torch as _t
+        C, D = self.C, self.D
+        dev = _t.device("cuda", device_index)
+
+        def cloud(r):
+            n = 2 + r
+            k = 2 if r % 2 else 0
+            X = (np.arange(3 * n, dtype=np.float32) + 1000.0 * r).reshape(n, 3)
+            key = (np.arange(4 * n, dtype=np.int64) + 7 * r).astype(np.uint32).reshape(n, 4)
+            off = (np.arange(n + 1, dtype=np.uint64) * k)
+            m = n * k
+            view = (np.arange(m, dtype=np.int32) + r)
+            pl = (np.arange(m, dtype=np.int64) * 3 + r).astype(np.uint32)
+            seg = (np.arange(m, dtype=np.int64) * 5 + r).astype(np.uint32)
+            xy = (np.arange(2 * m, dtype=np.float32) * 0.5 + r).reshape(m, 2)
+            return X, off, key, view, pl, seg, xy
+
+        mine = cloud(self.rank)
+        keep = [_t.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1).copy()).to(dev) if a.size else
+                _t.zeros(16, dtype=_t.uint8, device=dev) for a in mine]
+        loc = D.DeviceEdgePoints()
+        loc.n_points, loc.n_obs, loc.complete = len(mine[0]), len(mine[3]), 1
+        loc.X, loc.obs_off, loc.key, loc.obs_view, loc.obs_pl, loc.obs_seg, loc.obs_xy = [t.data_ptr() for t in keep]
+        out = D.DeviceEdgePoints()
+        _t.cuda.synchronize(dev)
+        rc = self.G.eg3d_allgather_edgepoints(self.g, self.comm, self.world, self.rank, self.stream, C.byref(loc), C.byref(out),
+                                              self.rank_points, self.rank_obs)
+        if rc != 0:
+            return False
+        parts = [cloud(r) for r in range(self.world)]
+        want_X = np.concatenate([p[0] for p in parts])
+        want_key = np.concatenate([p[2] for p in parts])
+        obase, want_off = 0, [np.zeros(1, np.uint64)]
+        for p in parts:
+            want_off.append(p[1][1:] + np.uint64(obase))
+            obase += len(p[3])
+        want_off = np.concatenate(want_off)
+        want = [want_X, want_off, want_key] + [np.concatenate([p[i] for p in parts]) for i in (3, 4, 5, 6)]
+        if int(out.n_points) != len(want_X) or int(out.n_obs) != obase:
+            return False
+        try:
+            hip = C.CDLL("libamdhip64.so.7")
+        except OSError:
+            hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        ptrs = [out.X, out.obs_off, out.key, out.obs_view, out.obs_pl, out.obs_seg, out.obs_xy]
+        for w, ptr in zip(want, ptrs):
+            w = np.ascontiguousarray(w)
+            got = np.empty_like(w)
+            if w.nbytes and hip.hipMemcpy(got.ctypes.data, C.c_void_p(ptr), w.nbytes, 2) != 0:
+                return False
+            if not np.array_equal(got.view(np.uint8), w.view(np.uint8)):
+                return False
+        return True
+
+    def _choose_mode(self, dist, device_index):
+        """The grouped send/recv exchange is the default; if the pre-flight cloud does not come out right on EVERY rank
+        (an RCCL build on which it misbehaves), all ranks switch to the broadcast fallback together and test that."""
+        import torch as _t
+        dev = _t.device("cuda", device_index)
+        tried = []
+        for mode in ([self.mode] if self.mode == "bcast" else ["sendrecv", "bcast"]):
+            self.G.eg3d_gather_set_mode(self.g, 1 if mode == "bcast" else 0)
+            ok = self._selftest_once(device_index)
+            t = _t.tensor([0 if ok else 1], dtype=_t.int32, device=dev)
+            dist.all_reduce(t)
+            tried.append((mode, int(t.item()) == 0))
+            if tried[-1][1]:
+                self.mode = mode
+                self.selftest = tried
+                return
+        self.selftest = tried
+        raise RuntimeError("eg3d_allgather_edgepoints failed its pre-flight check in every exchange mode: %s" % tried)
 
     def allgather(self, local_dev):
         """local_dev = Context.last_device_output(), or None when this rank has no usable result (its match

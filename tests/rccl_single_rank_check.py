@@ -102,6 +102,14 @@ def main():
     G.eg3d_comm_destroy.argtypes = [C.c_void_p]
     G.eg3d_comm_destroy(comm)
     ctx.close()
+    # the pre-flight check bench.py --gpus N runs before trusting the exchange (edgegraph3d_amd/distributed.py): its
+    # hand-made cloud must come back exactly, in both exchange modes (one rank: the placement / sentinel path)
+    from edgegraph3d_amd.distributed import RcclCloudGather
+    rg = RcclCloudGather(None, 1, 0, 0)
+    for mode in (0, 1):
+        assert rg.G.eg3d_gather_set_mode(rg.g, mode) == 0
+        assert rg._selftest_once(0), "pre-flight cloud differs (mode %d)" % mode
+    rg.close()
 
 
 if __name__ == "__main__":
