@@ -123,9 +123,12 @@ struct HostGrids {
 //   EG3D_MAX_SCRATCH_MB=n  tests: cut the chains of a batch into several K3b launches of at most n MB / slice size
 //                          chains each (default: one launch takes all chains — their working slices are slots)
 //   EG3D_NO_LPT=1          launch chains in identity order instead of longest-first (diagnostic)
+//   EG3D_K3B_FULL=1        always run the full expand kernel (default: scenes of <= 32 views run the build without the
+//                          solver's long-request path)
 struct Tunables {
   int k3a_engine_waves = 0, k3a_engine_lanes = 0;
   bool trace_arena = false;
+  bool k3b_full = false;  // EG3D_K3B_FULL=1: always the full expand kernel (diagnostic)
   uint32_t arena_cap0 = 0, hyp_cap = 0;
   size_t max_scratch = 0;  // 0 = no limit
   uint32_t slots_per_xcd = 0;  // 0 = sized from the occupancy query
@@ -139,6 +142,7 @@ struct Tunables {
     if (const char* e = getenv("EG3D_MAX_SCRATCH_MB")) t.max_scratch = (size_t)std::max(1, atoi(e)) << 20;
     if (const char* e = getenv("EG3D_NO_LPT")) t.use_lpt = !(e[0] == '1');
     if (const char* e = getenv("EG3D_TRACE_ARENA")) t.trace_arena = e[0] == '1';
+    if (const char* e = getenv("EG3D_K3B_FULL")) t.k3b_full = e[0] == '1';
     if (const char* e = getenv("EG3D_SLOTS_PER_XCD")) t.slots_per_xcd = (uint32_t)std::max(1, atoi(e));
     return t;
   }
@@ -1014,7 +1018,8 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
                c->b_hyp_off.as<uint32_t>(), c->b_res.as<HypResult>(), c->b_arena.as<HPoint>(),
                c->b_map_view.as<int32_t>(), c->b_map_entry.as<uint32_t>(), c->b_map_n.as<uint32_t>(), L,
                c->b_cscratch.as<unsigned char>(), pools, stage, c->b_couts.as<ChainOut>(), c->b_cpts.as<uint32_t>(),
-               c->b_cobs.as<uint32_t>(), c->b_ctr.as<Counters>(), c->b_order.as<uint32_t>());
+               c->b_cobs.as<uint32_t>(), c->b_ctr.as<Counters>(), c->b_order.as<uint32_t>(),
+               c->tune.k3b_full ? false : c->V <= EG3D_GN_PACK_MAX_HOST);
     HIP_TRY(hipEventRecord(c->eb[5], st));
     // the two output scans are queued right behind K3b; its counters (capacity overflow?) and both totals
     // come back in ONE read-back
@@ -1036,6 +1041,10 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
       const bool overflow = hc.flags & (EG3D_FLAG_CHAIN_OVERFLOW | EG3D_FLAG_OBS_OVERFLOW);
       if (!overflow && rb.item(iw)[0]) return wrapped_error("edge-points of one chunk");
       if (!overflow && rb.item(iw)[1]) return wrapped_error("observations of one chunk");
+    }
+    if (hc.flags & CTR_LONG_REFUSED) {
+      g_err = "eg3d: internal: the few-views build of the expand kernel met a solve of more than 32 rows";
+      return EG3D_ERR_HIP;
     }
     if (hc.flags & CTR_SLOT_STARVED) {
       g_err = "eg3d: internal: the expand kernel found no free working slice (slot pool smaller than the residency)";

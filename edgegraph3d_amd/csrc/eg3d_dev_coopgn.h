@@ -56,6 +56,7 @@ struct CoopLds {
   uint8_t row_k[EG3D_COOP_ROWS];     // row -> its index in the request
   uint8_t res_ok[EG3D_COOP_REQ];
   uint8_t cams_mid_range;  // DevScene::cams_mid_range (set once per workgroup): enables the shared-reciprocal rows
+  uint8_t long_refused;    // a request of more than EG3D_GN_PACK_MAX rows reached a build without the long-request path
   // Per-group sums (G >= 2 => <= 32 groups x 7 doubles). They live in product columns 6..13: a pass's sums are written
   // after the last chunk's products have been consumed (behind its barrier), pass 2 only writes columns 0..5, and
   // every lane has read the sums before the next pass writes products again — never live together.
@@ -480,7 +481,7 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
 // Must be called by all 64 lanes of the (single-wave) block; every request must have >= 2 rows. On
 // return lane j holds the verdict and solution of ITS request (false when !want); the request
 // table keeps them too (L.res_ok[j], L.x0[j]) until the next call.
-template <int KEEP = 0>
+template <int KEEP = 0, bool LONG_GN = true>
 __device__ __forceinline__ bool coop_gn_groups(const float* cam_P, CoopLds& L, bool want_in, const Obs* base, int nblock,
                                                bool has_extra, int32_t ex_view, float ex_x, float ex_y,
                                                const float X0[3], float Xout[3]) {
@@ -559,8 +560,14 @@ __device__ __forceinline__ bool coop_gn_groups(const float* cam_P, CoopLds& L, b
       todo &= ~members;
     }
   }
-  // ---- long requests: power-of-two groups, several chunks per pass
-  if (m_long) {
+  // ---- long requests: power-of-two groups, several chunks per pass. LONG_GN = false compiles the whole path out: the
+  // kernel instantiated for scenes of at most EG3D_GN_PACK_MAX views, where no point can hold more rows than a packed
+  // round takes (a point has at most one observation per view). A long request that reaches such a build anyway is
+  // refused, loudly (long_refused -> CTR_LONG_REFUSED -> the call fails), never mis-solved.
+  if constexpr (!LONG_GN) {
+    if (m_long) L.long_refused = 1;
+  }
+  if (LONG_GN && m_long) {
     unsigned long long todo = m_long;
     while (todo) {
       const int Bl = __popcll(todo);

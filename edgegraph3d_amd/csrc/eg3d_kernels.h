@@ -13,7 +13,8 @@ struct SeedsDev {
   const float* trk_xy;
 };
 
-enum : uint32_t { CTR_ARENA_OVERFLOW = 0x100u, CTR_SLOT_STARVED = 0x200u /* k3b_expand found no free working slice (internal) */ };
+enum : uint32_t { CTR_ARENA_OVERFLOW = 0x100u, CTR_SLOT_STARVED = 0x200u /* k3b_expand found no free working slice (internal) */,
+                  CTR_LONG_REFUSED = 0x400u /* the few-views build of k3b_expand met a solve of more than 32 rows (internal) */ };
 typedef uint64_t eg3d_off_t;  // element type of obs_off in the output cloud (include/eg3d.h)
 // arguments of k_publish: up to 6 runs of device words copied to the host mailbox, words cleared afterwards
 struct PubArgs {
@@ -86,13 +87,14 @@ struct SlotPools {
   uint32_t* base;
   uint32_t stride, ring_n, slots_per_xcd;
 };
+#define EG3D_GN_PACK_MAX_HOST 32 /* = EG3D_GN_PACK_MAX of eg3d_dev_coopgn.h (static_assert in eg3d_kernels.hip) */
 int k3b_blocks_per_cu();  // resident k3b_expand workgroups per CU (occupancy query; 0 on failure)
 void launch_pool_init(hipStream_t st, SlotPools pools);
 void launch_k3b(hipStream_t st, DevScene s, StageAView a, const TaskDesc* tasks, const ChainSeed* chains,
                 uint32_t n_chains, const uint32_t* hyp_off, const HypResult* res, const HPoint* arena,
                 const int32_t* map_view, const uint32_t* map_entry, const uint32_t* map_n, ChainLayout L,
                 unsigned char* slices, SlotPools pools, StageBuf stage, ChainOut* outs, uint32_t* out_points,
-                uint32_t* out_obs, Counters* ctr, const uint32_t* order);
+                uint32_t* out_obs, Counters* ctr, const uint32_t* order, bool few_views /* <= 32 views: the build without the long-request solver path */);
 void launch_chain_cost(hipStream_t st, StageAView a, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains,
                        uint32_t* cost, uint32_t* idx);
 void launch_k4(hipStream_t st, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains, StageBuf stage,

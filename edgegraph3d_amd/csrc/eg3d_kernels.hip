@@ -489,7 +489,8 @@ __global__ void k_compact_chains(uint32_t n_tasks, const ChainSeed* per_task, co
 #define EG3D_SPEC_FOLLOW 1 /* chain following: walk up to 4 steps ahead, then triangulate them together */
 #endif
 // GN_KEEP: see gn_round (0 = standard build; 4 = the wide build keeps the rows of up to four chunks in registers)
-template <int GN_KEEP>
+// LONG_GN: the solver's long-request path is compiled in (see coop_gn_groups)
+template <int GN_KEEP, bool LONG_GN>
 struct TeamWaveT {
   static constexpr bool kSlotStep = EG3D_WAVE_SLOT_STEP != 0;
   static constexpr bool kSpecFollow = EG3D_SPEC_FOLLOW != 0;
@@ -785,7 +786,7 @@ struct TeamWaveT {
         const bool want = lane() < Deff;
         const float X0f[3] = {(float)X0[0], (float)X0[1], (float)X0[2]};  // DLT results are float-valued
         float Xr[3];
-        const bool ok = coop_gn_groups<GN_KEEP>(s.cam_P, *L, want, L->tmp_a + (want ? lane() : 0) * n_end,
+        const bool ok = coop_gn_groups<GN_KEEP, LONG_GN>(s.cam_P, *L, want, L->tmp_a + (want ? lane() : 0) * n_end,
                                        want ? L->la_m[lane()] : 0, false, 0, 0.f, 0.f, X0f, Xr);
         // results stay in the request table: L->res_ok[j], L->x0[j]
         (void)ok;
@@ -848,7 +849,7 @@ struct TeamWaveT {
     // one request (lane 0), the whole wave on its rows
     const float X0f[3] = {(float)X0[0], (float)X0[1], (float)X0[2]};  // callers pass float-valued starts
     float Xr[3];
-    const bool ok = coop_gn_groups<GN_KEEP>(s.cam_P, *L, lane() == 0, a, n, false, 0, 0.f, 0.f, X0f, Xr);
+    const bool ok = coop_gn_groups<GN_KEEP, LONG_GN>(s.cam_P, *L, lane() == 0, a, n, false, 0, 0.f, 0.f, X0f, Xr);
     Xout[0] = lane_bcast(Xr[0], 0);
     Xout[1] = lane_bcast(Xr[1], 0);
     Xout[2] = lane_bcast(Xr[2], 0);
@@ -858,7 +859,7 @@ struct TeamWaveT {
                                           float Xout[3]) const {
     const float X0f[3] = {p.X[0], p.X[1], p.X[2]};
     float Xr[3];
-    const bool ok = coop_gn_groups<GN_KEEP>(s.cam_P, *L, lane() == 0, c.pool + p.off, (int)p.nobs, true, extra.view, extra.x,
+    const bool ok = coop_gn_groups<GN_KEEP, LONG_GN>(s.cam_P, *L, lane() == 0, c.pool + p.off, (int)p.nobs, true, extra.view, extra.x,
                                    extra.y, X0f, Xr);
     Xout[0] = lane_bcast(Xr[0], 0);
     Xout[1] = lane_bcast(Xr[1], 0);
@@ -885,13 +886,13 @@ struct TeamWaveT {
         X0[1] = pt->X[1];
         X0[2] = pt->X[2];
       }
-      const bool ok = coop_gn_groups<GN_KEEP>(s.cam_P, *L, want, want ? c.pool + pt->off : nullptr, want ? (int)pt->nobs : 0, true,
+      const bool ok = coop_gn_groups<GN_KEEP, LONG_GN>(s.cam_P, *L, want, want ? c.pool + pt->off : nullptr, want ? (int)pt->nobs : 0, true,
                                      o.view, o.x, o.y, X0, X);
       if (want) put(j, ok, X);
     }
   }
 };
-using TeamWave = TeamWaveT<0>;
+using TeamWave = TeamWaveT<0, true>;
 
 // Waves per SIMD the expand kernel is built for. Round 4: 4 (128 VGPRs) — CoopLds was cut to 8 LDS allocation units
 // (eg3d_dev_coopgn.h) so that four single-wave workgroups really fit a SIMD: rounds 2-3 compared "2 / 3 / 4" with an LDS
@@ -967,7 +968,7 @@ __device__ __forceinline__ bool pool_push(const SlotPools& P, uint32_t xcc, uint
 // between the passes of an iteration, so long solves do not recompute them): bit-exact, and SLOWER on every workload
 // (C3' K3b 53.2 -> 68.2 ms, the 8192-seed C4 step 2230 -> 2687 ms): what the third wave per SIMD hides in the walks, the
 // candidate search and the dependent steps of a solve outweighs the row arithmetic saved.
-template <int WAVES, int GN_KEEP>
+template <int WAVES, int GN_KEEP, bool LONG_GN>
 __global__ void __launch_bounds__(64, WAVES) k3b_expand_t(DevScene s, StageAView a, const TaskDesc* tasks,
                                                  const ChainSeed* chains, uint32_t n_chains, const uint32_t* hyp_off,
                                                  const HypResult* res, const HPoint* arena, const int32_t* map_view,
@@ -994,9 +995,12 @@ __global__ void __launch_bounds__(64, WAVES) k3b_expand_t(DevScene s, StageAView
     }
     return;
   }
-  TeamWaveT<GN_KEEP> tm;
+  TeamWaveT<GN_KEEP, LONG_GN> tm;
   tm.L = &lds;
-  if (lane == 0) lds.cams_mid_range = s.cams_mid_range ? 1 : 0;
+  if (lane == 0) {
+    lds.cams_mid_range = s.cams_mid_range ? 1 : 0;
+    lds.long_refused = 0;
+  }
   __syncthreads();
   // wave-uniform descriptors: kept in scalar registers for the chain's whole life (as vector registers they would be
   // 17 of the 168 the kernel may use, and spilled)
@@ -1064,6 +1068,7 @@ __global__ void __launch_bounds__(64, WAVES) k3b_expand_t(DevScene s, StageAView
     out_points[j] = co.n_points;
     out_obs[j] = co.n_obs;
     if (co.flags) atomicOr(&ctr->flags, co.flags);
+    if (!LONG_GN && lds.long_refused) atomicOr(&ctr->flags, CTR_LONG_REFUSED);
     if (co.bytes) atomicAdd(&ctr->bytes, (unsigned long long)co.bytes);
   }
 }
@@ -1321,11 +1326,20 @@ int gn_dbg_read(unsigned long long* out, int reset) {
   return 0;
 }
 #endif
-static constexpr auto k3b_expand = k3b_expand_t<EG3D_K3B_WAVES, 0>;
-int k3b_blocks_per_cu() {
-  int n = 0;
+// Two instantiations (round 4): the full kernel, and one WITHOUT the solver's long-request path for scenes of at most
+// EG3D_GN_PACK_MAX (32) views, where a point cannot hold more rows than a packed round takes. The few-views build is
+// 50.6 k instead of 70.8 k instructions, spills 105 instead of 261 vector registers (256 instead of 352 B of scratch per
+// lane) and runs C3' in 48.0 instead of 50.4 ms (45.4 vs 47.8 ms per step in flight): the kernel's code is ~7x the
+// instruction cache two CUs share (0.8 % of 5.8e9 instruction fetches per C3' launch miss, ~2100 misses per chain), so
+// code that a scene can never execute is not free.
+static_assert(EG3D_GN_PACK_MAX_HOST == EG3D_GN_PACK_MAX, "the host's few-views rule must match the solver's packing limit");
+static constexpr auto k3b_expand = k3b_expand_t<EG3D_K3B_WAVES, 0, true>;
+static constexpr auto k3b_expand_few = k3b_expand_t<EG3D_K3B_WAVES, 0, false>;
+int k3b_blocks_per_cu() {  // the larger residency of the two builds sizes the slot pools
+  int n = 0, m = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k3b_expand, 64, 0) != hipSuccess || n < 1) return 0;
-  return n;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&m, k3b_expand_few, 64, 0) != hipSuccess || m < 1) return 0;
+  return n > m ? n : m;
 }
 void launch_pool_init(hipStream_t st, SlotPools pools) {
   hipLaunchKernelGGL(k_pool_init, dim3(8), dim3(256), 0, st, pools);
@@ -1334,10 +1348,14 @@ void launch_k3b(hipStream_t st, DevScene s, StageAView a, const TaskDesc* tasks,
                 uint32_t n_chains, const uint32_t* hyp_off, const HypResult* res, const HPoint* arena,
                 const int32_t* map_view, const uint32_t* map_entry, const uint32_t* map_n, ChainLayout L,
                 unsigned char* slices, SlotPools pools, StageBuf stage, ChainOut* outs, uint32_t* out_points,
-                uint32_t* out_obs, Counters* ctr, const uint32_t* order) {
+                uint32_t* out_obs, Counters* ctr, const uint32_t* order, bool few_views) {
   if (!n_chains) return;
-  hipLaunchKernelGGL(k3b_expand, dim3(n_chains), dim3(64), 0, st, s, a, tasks, chains, n_chains, hyp_off, res,
-                     arena, map_view, map_entry, map_n, L, slices, pools, stage, outs, out_points, out_obs, ctr, order);
+  if (few_views)
+    hipLaunchKernelGGL(k3b_expand_few, dim3(n_chains), dim3(64), 0, st, s, a, tasks, chains, n_chains, hyp_off, res,
+                       arena, map_view, map_entry, map_n, L, slices, pools, stage, outs, out_points, out_obs, ctr, order);
+  else
+    hipLaunchKernelGGL(k3b_expand, dim3(n_chains), dim3(64), 0, st, s, a, tasks, chains, n_chains, hyp_off, res,
+                       arena, map_view, map_entry, map_n, L, slices, pools, stage, outs, out_points, out_obs, ctr, order);
 }
 void launch_chain_cost(hipStream_t st, StageAView a, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains,
                        uint32_t* cost, uint32_t* idx) {
