@@ -123,8 +123,8 @@ struct HostGrids {
 //   EG3D_MAX_SCRATCH_MB=n  tests: cut the chains of a batch into several K3b launches of at most n MB / slice size
 //                          chains each (default: one launch takes all chains — their working slices are slots)
 //   EG3D_NO_LPT=1          launch chains in identity order instead of longest-first (diagnostic)
-//   EG3D_K3B_FULL=1        always run the full expand kernel (default: scenes of <= 32 views run the build without the
-//                          solver's long-request path)
+//   EG3D_K3B_FULL=1        always run the full expand kernel (default: scenes of <= 32 views whose polylines have <= 512
+//                          vertices run the build without the solver's long-request path and the unstaged side walks)
 struct Tunables {
   int k3a_engine_waves = 0, k3a_engine_lanes = 0;
   bool trace_arena = false;
@@ -178,6 +178,7 @@ struct eg3d_ctx {
   // and the staging area finished chains are packed into (sized from the previous launches; grow-only)
   DevBuf b_pools, b_stage_pts, b_stage_obs, b_stage_used;
   uint32_t slots_per_xcd = 0;
+  uint32_t max_pl_vtx = 0;  // vertices of the scene's longest valid polyline
   uint64_t stage_cap_pts = 0, stage_cap_obs = 0;
   hipEvent_t ea[8], eb[8];  // begin/end events per stage: 1 K1, 2 K2, 3 K3a, 4 K3s, 5 K3b, 6 K4, 0 misc, 7 whole call
   hipEvent_t ecopy[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // D2H of the cloud: one per output array
@@ -536,6 +537,11 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
       }
     d.cams_mid_range = mid ? 1 : 0;
   }
+  // the longest valid polyline of the scene (a scene whose polylines all fit the side walks' LDS staging area, and
+  // that has few views, runs the smaller build of the expand kernel: launch_k3b)
+  c->max_pl_vtx = 0;
+  for (uint32_t p = 0; p < NP; p++)
+    if (sc->pl_valid[p]) c->max_pl_vtx = std::max(c->max_pl_vtx, sc->pl_vtx_off[p + 1] - sc->pl_vtx_off[p]);
   // observation slots per chain (blocks double when they fill, so budget ~3x the live count);
   // grown automatically when a chain overflows
   c->pool_cap = std::min<uint32_t>(32768, 768u * (uint32_t)std::min(V, 32));
@@ -615,6 +621,7 @@ extern "C" int eg3d_clone(eg3d_ctx* parent, eg3d_ctx** out) {
   c->n_simd = parent->n_simd;
   c->arena_per_hyp = parent->arena_per_hyp;
   c->slots_per_xcd = parent->slots_per_xcd;
+  c->max_pl_vtx = parent->max_pl_vtx;
   c->stage_cap_pts = parent->stage_cap_pts;  // sizing hints only: the clone allocates its own staging area
   c->stage_cap_obs = parent->stage_cap_obs;
   *out = c;
@@ -1019,7 +1026,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
                c->b_map_view.as<int32_t>(), c->b_map_entry.as<uint32_t>(), c->b_map_n.as<uint32_t>(), L,
                c->b_cscratch.as<unsigned char>(), pools, stage, c->b_couts.as<ChainOut>(), c->b_cpts.as<uint32_t>(),
                c->b_cobs.as<uint32_t>(), c->b_ctr.as<Counters>(), c->b_order.as<uint32_t>(),
-               c->tune.k3b_full ? false : c->V <= EG3D_GN_PACK_MAX_HOST);
+               c->tune.k3b_full ? false : (c->V <= EG3D_GN_PACK_MAX_HOST && c->max_pl_vtx <= EG3D_STAGE_VTX_HOST));
     HIP_TRY(hipEventRecord(c->eb[5], st));
     // the two output scans are queued right behind K3b; its counters (capacity overflow?) and both totals
     // come back in ONE read-back

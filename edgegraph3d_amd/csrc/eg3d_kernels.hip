@@ -489,7 +489,9 @@ __global__ void k_compact_chains(uint32_t n_tasks, const ChainSeed* per_task, co
 #define EG3D_SPEC_FOLLOW 1 /* chain following: walk up to 4 steps ahead, then triangulate them together */
 #endif
 // GN_KEEP: see gn_round (0 = standard build; 4 = the wide build keeps the rows of up to four chunks in registers)
-// LONG_GN: the solver's long-request path is compiled in (see coop_gn_groups)
+// LONG_GN = the GENERAL build: the solver's long-request path (see coop_gn_groups) and the side walks over polylines that
+// do not fit the LDS staging area are compiled in; false = the build for small scenes (<= 32 views, polylines of <= 512
+// vertices — checked by the host, launch_k3b), which cannot reach either
 template <int GN_KEEP, bool LONG_GN>
 struct TeamWaveT {
   static constexpr bool kSlotStep = EG3D_WAVE_SLOT_STEP != 0;
@@ -592,7 +594,7 @@ struct TeamWaveT {
   __device__ __forceinline__ void walk_stage(const DevScene& s, Chain& c, int view, const PlRef& pl, int lo, int ci,
                                              int hi) const {
     __syncthreads();
-    if (pl.n <= EG3D_STAGE_VTX)
+    if (pl.n <= EG3D_STAGE_VTX)  // (always, in the small-scene build; the test keeps a stray long polyline from overrunning LDS)
       for (uint32_t i = (uint32_t)lane(); i < pl.n; i += 64) L->walk.vtx[i] = pl.v[i];
     const int n_lo = ci - lo < kEpiHalf ? (ci - lo < 0 ? 0 : ci - lo) : kEpiHalf;
     const int n_hi = hi - ci - 1 < kEpiHalf ? (hi - ci - 1 < 0 ? 0 : hi - ci - 1) : kEpiHalf;
@@ -614,7 +616,7 @@ struct TeamWaveT {
     typedef const __attribute__((address_space(3))) float* lds_fp;
     typedef const __attribute__((address_space(3))) f2* lds_f2p;
     const int count = towards_start ? ci - lo : hi - ci - 1;
-    const bool fits = pl.n <= EG3D_STAGE_VTX;
+    const bool fits = !LONG_GN || pl.n <= EG3D_STAGE_VTX;  // the small-scene build: every polyline fits (host-checked)
     const int staged = count < kEpiHalf ? (count < 0 ? 0 : count) : kEpiHalf;
     const lds_fp epi = (lds_fp)&L->walk.epi[towards_start ? 0 : kEpiHalf][0];
     // next hit of the line towards `direction`, SEGMENT-PARALLEL: lane 0 tests the partial segment
@@ -680,6 +682,7 @@ struct TeamWaveT {
       return walk_side_candidates_core(s, c, pls, epi, staged, view, from, direction, lo, ci, hi, towards_start, out,
                                        walk);
     }
+    if constexpr (!LONG_GN) return 0;  // unreachable in the small-scene build (fits is a constant there)
     return walk_side_candidates_core(s, c, pl, epi, staged, view, from, direction, lo, ci, hi, towards_start, out, walk);
   }
   // append a followed point at the chain's front / back (the checks of follow_front / follow_back)
@@ -1332,6 +1335,7 @@ int gn_dbg_read(unsigned long long* out, int reset) {
 // lane) and runs C3' in 48.0 instead of 50.4 ms (45.4 vs 47.8 ms per step in flight): the kernel's code is ~7x the
 // instruction cache two CUs share (0.8 % of 5.8e9 instruction fetches per C3' launch miss, ~2100 misses per chain), so
 // code that a scene can never execute is not free.
+static_assert(EG3D_STAGE_VTX_HOST == EG3D_STAGE_VTX, "the host's small-scene rule must match the side walks' staging capacity");
 static_assert(EG3D_GN_PACK_MAX_HOST == EG3D_GN_PACK_MAX, "the host's few-views rule must match the solver's packing limit");
 static constexpr auto k3b_expand = k3b_expand_t<EG3D_K3B_WAVES, 0, true>;
 static constexpr auto k3b_expand_few = k3b_expand_t<EG3D_K3B_WAVES, 0, false>;
@@ -1348,9 +1352,9 @@ void launch_k3b(hipStream_t st, DevScene s, StageAView a, const TaskDesc* tasks,
                 uint32_t n_chains, const uint32_t* hyp_off, const HypResult* res, const HPoint* arena,
                 const int32_t* map_view, const uint32_t* map_entry, const uint32_t* map_n, ChainLayout L,
                 unsigned char* slices, SlotPools pools, StageBuf stage, ChainOut* outs, uint32_t* out_points,
-                uint32_t* out_obs, Counters* ctr, const uint32_t* order, bool few_views) {
+                uint32_t* out_obs, Counters* ctr, const uint32_t* order, bool small_scene) {
   if (!n_chains) return;
-  if (few_views)
+  if (small_scene)
     hipLaunchKernelGGL(k3b_expand_few, dim3(n_chains), dim3(64), 0, st, s, a, tasks, chains, n_chains, hyp_off, res,
                        arena, map_view, map_entry, map_n, L, slices, pools, stage, outs, out_points, out_obs, ctr, order);
   else
