@@ -65,6 +65,32 @@ def test_full_path_parity(have_gpu, cfg):
     ctx.close()
 
 
+def test_small_scene_and_general_builds_of_the_expand_kernel_agree(have_gpu, monkeypatch):
+    """libeg3d.so carries two instantiations of k3b_expand: the general one and one for small scenes (<= 32 views,
+    polylines of <= 512 vertices) without the solver's long-request path and the unstaged side walks, chosen by
+    eg3d_create's scene (launch_k3b). EG3D_K3B_FULL=1 (read once, by eg3d_create) forces the general kernel: both must
+    give the same cloud bit for bit — on the seed path and on the polyline-set path — and the small build must not
+    have met a request it cannot solve (the call would fail)."""
+    s = host.Synth(1)
+    small = api.Context(s.scene)
+    a = small.match_refpoints(s.seeds)
+    n_sets, row_off, ids = s.polyline_sets(3)
+    sa = small.match_polyline_sets(n_sets, row_off, ids)
+    small.close()
+    monkeypatch.setenv("EG3D_K3B_FULL", "1")
+    general = api.Context(s.scene)
+    b = general.match_refpoints(s.seeds)
+    sb = general.match_polyline_sets(n_sets, row_off, ids)
+    general.close()
+    for x, y in ((a, b), (sa, sb)):
+        assert x["n_points"] == y["n_points"] > 0 and x["n_obs"] == y["n_obs"]
+        for k in ("obs_off", "key", "obs_view", "obs_pl", "obs_seg"):
+            assert np.array_equal(x[k], y[k]), k
+        assert np.array_equal(x["X"].view(np.uint32), y["X"].view(np.uint32))
+        assert np.array_equal(x["obs_xy"].view(np.uint32), y["obs_xy"].view(np.uint32))
+        assert x["flags"] == y["flags"]
+
+
 def test_seed_range_concatenation(have_gpu):
     """Ranges are independent: [0,n/2) + [n/2,n) == [0,n) (the multi-GPU sharding property)."""
     s = host.Synth(1)
