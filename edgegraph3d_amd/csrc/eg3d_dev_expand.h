@@ -167,6 +167,7 @@ EG3D_HD bool add_observation_solve(const DevScene& s, const Chain& c, const Chai
 // batch of B independent ADD solves, request j described by get(j, point, extra) -> wanted and
 // answered through put(j, ok, X). The sequential team runs them one after the other; the
 // wavefront team spreads the observations of the solves over its lanes (eg3d_dev_coopgn.h).
+EG3D_HD bool lazy_presolve(const DevScene& s);  // defined below (central pre-solves)
 struct TeamSeq {
   static constexpr bool kSlotStep = false;  // N-view step: plain sequential candidates
   static constexpr bool kSpecFollow = false; // chain following: one step at a time
@@ -211,6 +212,9 @@ struct TeamSeq {
   }
   // candidates of one side walk (walk_side_candidates_core); a team may first stage the polyline
   // and the epipolar lines of the chain points ahead in fast memory
+  // windowed (lazy) or all-at-once (eager) speculative central solves for this scene (a team built for a class of
+  // scenes may know the answer at compile time)
+  EG3D_HD bool lazy_presolve(const DevScene& s) const { return eg3d::lazy_presolve(s); }
   // walk_stage() is called once per attachment before its side walks (and again after a solver batch, which may have
   // overwritten what was staged); a team that keeps nothing staged ignores it
   EG3D_HD void walk_stage(const DevScene&, Chain&, int, const PlRef&, int, int, int) const {}
@@ -862,7 +866,7 @@ EG3D_HD_FLAT void view_candidates(const Team& tm, const DevScene& s, Chain& c, i
   }
   tm.sync();
   c.tsec[0] += EG3D_TICK() - tc0;
-  if (!lazy_presolve(s)) {
+  if (!tm.lazy_presolve(s)) {
     const uint64_t tp0 = EG3D_TICK();
     central_presolves(tm, s, c, v, from, c.len);
     c.tsec[10] += EG3D_TICK() - tp0;  // (diagnostic: all speculative central solves are booked with the epc pre-solves)
@@ -934,7 +938,7 @@ EG3D_HD_FLAT void expand_to_view(const Team& tm, const DevScene& s, Chain& c, in
     if (!vc.valid) continue;
     c.bytes += 8ull * (s.pl_vtx_off[s.view_pl_off[v] + vc.pl + 1] - s.pl_vtx_off[s.view_pl_off[v] + vc.pl]);
     if (vc.d2 > 16.0f) return;  // abandons this view (Q4)
-    if (lazy_presolve(s) && c.head + cur >= spec_slot_hi) {
+    if (tm.lazy_presolve(s) && c.head + cur >= spec_slot_hi) {
       int to = cur + presolve_window(s);
       if (to > c.len) to = c.len;
       const uint64_t tp0 = EG3D_TICK();

@@ -87,7 +87,7 @@ struct SlotPools {
   uint32_t* base;
   uint32_t stride, ring_n, slots_per_xcd;
 };
-#define EG3D_GN_PACK_MAX_HOST 32 /* = EG3D_GN_PACK_MAX of eg3d_dev_coopgn.h (static_assert in eg3d_kernels.hip) */
+#define EG3D_SMALL_SCENE_VIEWS_HOST 28 /* the last view count whose N-view step lists fit LDS (2 V + 8 <= 64; static_assert in eg3d_kernels.hip) */
 #define EG3D_STAGE_VTX_HOST 512 /* = EG3D_STAGE_VTX: vertices of a polyline the side walks stage in LDS */
 int k3b_blocks_per_cu();  // resident k3b_expand workgroups per CU (occupancy query; 0 on failure)
 void launch_pool_init(hipStream_t st, SlotPools pools);
@@ -95,7 +95,7 @@ void launch_k3b(hipStream_t st, DevScene s, StageAView a, const TaskDesc* tasks,
                 uint32_t n_chains, const uint32_t* hyp_off, const HypResult* res, const HPoint* arena,
                 const int32_t* map_view, const uint32_t* map_entry, const uint32_t* map_n, ChainLayout L,
                 unsigned char* slices, SlotPools pools, StageBuf stage, ChainOut* outs, uint32_t* out_points,
-                uint32_t* out_obs, Counters* ctr, const uint32_t* order, bool small_scene /* <= 32 views and polylines of <= 512 vertices: the build without the paths such a scene cannot reach */);
+                uint32_t* out_obs, Counters* ctr, const uint32_t* order, int scene_class /* 0 small (<= 28 views, polylines of <= 512 vertices), 1 general, 2 many views (>= 29): the build of the kernel without the paths such a scene cannot reach */);
 void launch_chain_cost(hipStream_t st, StageAView a, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains,
                        uint32_t* cost, uint32_t* idx);
 void launch_k4(hipStream_t st, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains, StageBuf stage,

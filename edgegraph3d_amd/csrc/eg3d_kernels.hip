@@ -489,19 +489,32 @@ __global__ void k_compact_chains(uint32_t n_tasks, const ChainSeed* per_task, co
 #define EG3D_SPEC_FOLLOW 1 /* chain following: walk up to 4 steps ahead, then triangulate them together */
 #endif
 // GN_KEEP: see gn_round (0 = standard build; 4 = the wide build keeps the rows of up to four chunks in registers)
-// LONG_GN = the GENERAL build: the solver's long-request path (see coop_gn_groups) and the side walks over polylines that
-// do not fit the LDS staging area are compiled in; false = the build for small scenes (<= 32 views, polylines of <= 512
-// vertices — checked by the host, launch_k3b), which cannot reach either
-template <int GN_KEEP, bool LONG_GN>
+// SCENE = the class of scenes an instantiation serves (the host picks it per context, launch_k3b):
+//   0  small: <= 28 views and polylines of <= 512 vertices — the solver's long-request path (a point has at most one
+//      observation per view, so no solve exceeds a packed round) and the side walks over polylines that do not fit
+//      the LDS staging area are compiled out;
+//   1  general: everything;
+//   2  many views (>= 29): the N-view step's lists never fit LDS there (2 V + 8 > 64 observations), so chain
+//      following is always one step at a time — the look-ahead rounds are compiled out — and the speculative
+//      central solves are always windowed.
+// What a scene cannot execute is not free in a 45-70 k-instruction kernel: register allocation and the instruction
+// cache both see it (C3': 50.4 -> 47.5 ms with SCENE 0; C4: 1828 -> 1732 ms per step in flight with SCENE 2).
+template <int GN_KEEP, int SCENE>
 struct TeamWaveT {
+  static constexpr bool LONG_GN = SCENE != 0;
   static constexpr bool kSlotStep = EG3D_WAVE_SLOT_STEP != 0;
-  static constexpr bool kSpecFollow = EG3D_SPEC_FOLLOW != 0;
+  static constexpr bool kSpecFollow = EG3D_SPEC_FOLLOW != 0 && SCENE != 2;
   CoopLds* L;
   __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
   __device__ __forceinline__ int size() const { return 64; }
   __device__ __forceinline__ void sync() const { __syncthreads(); }
   __device__ __forceinline__ void bind(Chain& c) const {
-    if (c.tmp_cap <= EG3D_COOP_ROWS) c.tmp_a = L->tmp_a;
+    if constexpr (SCENE != 2)
+      if (c.tmp_cap <= EG3D_COOP_ROWS) c.tmp_a = L->tmp_a;
+  }
+  __device__ __forceinline__ bool lazy_presolve(const DevScene& s) const {
+    if constexpr (SCENE == 2) return true;
+    return eg3d::lazy_presolve(s);
   }
   __device__ __forceinline__ int rank(bool flag, int& total) const {
     const unsigned long long m = __ballot(flag);
@@ -895,7 +908,7 @@ struct TeamWaveT {
     }
   }
 };
-using TeamWave = TeamWaveT<0, true>;
+using TeamWave = TeamWaveT<0, 1>;
 
 // Waves per SIMD the expand kernel is built for. Round 4: 4 (128 VGPRs) — CoopLds was cut to 8 LDS allocation units
 // (eg3d_dev_coopgn.h) so that four single-wave workgroups really fit a SIMD: rounds 2-3 compared "2 / 3 / 4" with an LDS
@@ -971,7 +984,7 @@ __device__ __forceinline__ bool pool_push(const SlotPools& P, uint32_t xcc, uint
 // between the passes of an iteration, so long solves do not recompute them): bit-exact, and SLOWER on every workload
 // (C3' K3b 53.2 -> 68.2 ms, the 8192-seed C4 step 2230 -> 2687 ms): what the third wave per SIMD hides in the walks, the
 // candidate search and the dependent steps of a solve outweighs the row arithmetic saved.
-template <int WAVES, int GN_KEEP, bool LONG_GN>
+template <int WAVES, int GN_KEEP, int SCENE>
 __global__ void __launch_bounds__(64, WAVES) k3b_expand_t(DevScene s, StageAView a, const TaskDesc* tasks,
                                                  const ChainSeed* chains, uint32_t n_chains, const uint32_t* hyp_off,
                                                  const HypResult* res, const HPoint* arena, const int32_t* map_view,
@@ -998,7 +1011,7 @@ __global__ void __launch_bounds__(64, WAVES) k3b_expand_t(DevScene s, StageAView
     }
     return;
   }
-  TeamWaveT<GN_KEEP, LONG_GN> tm;
+  TeamWaveT<GN_KEEP, SCENE> tm;
   tm.L = &lds;
   if (lane == 0) {
     lds.cams_mid_range = s.cams_mid_range ? 1 : 0;
@@ -1071,7 +1084,7 @@ __global__ void __launch_bounds__(64, WAVES) k3b_expand_t(DevScene s, StageAView
     out_points[j] = co.n_points;
     out_obs[j] = co.n_obs;
     if (co.flags) atomicOr(&ctr->flags, co.flags);
-    if (!LONG_GN && lds.long_refused) atomicOr(&ctr->flags, CTR_LONG_REFUSED);
+    if (SCENE == 0 && lds.long_refused) atomicOr(&ctr->flags, CTR_LONG_REFUSED);
     if (co.bytes) atomicAdd(&ctr->bytes, (unsigned long long)co.bytes);
   }
 }
@@ -1329,21 +1342,24 @@ int gn_dbg_read(unsigned long long* out, int reset) {
   return 0;
 }
 #endif
-// Two instantiations (round 4): the full kernel, and one WITHOUT the solver's long-request path for scenes of at most
-// EG3D_GN_PACK_MAX (32) views, where a point cannot hold more rows than a packed round takes. The few-views build is
-// 50.6 k instead of 70.8 k instructions, spills 105 instead of 261 vector registers (256 instead of 352 B of scratch per
-// lane) and runs C3' in 48.0 instead of 50.4 ms (45.4 vs 47.8 ms per step in flight): the kernel's code is ~7x the
-// instruction cache two CUs share (0.8 % of 5.8e9 instruction fetches per C3' launch miss, ~2100 misses per chain), so
-// code that a scene can never execute is not free.
+// Three instantiations (round 4), see TeamWaveT: small scenes (50.6 k -> 45 k instructions, 116 instead of 262 spilled
+// vector registers), general, many views.
 static_assert(EG3D_STAGE_VTX_HOST == EG3D_STAGE_VTX, "the host's small-scene rule must match the side walks' staging capacity");
-static_assert(EG3D_GN_PACK_MAX_HOST == EG3D_GN_PACK_MAX, "the host's few-views rule must match the solver's packing limit");
-static constexpr auto k3b_expand = k3b_expand_t<EG3D_K3B_WAVES, 0, true>;
-static constexpr auto k3b_expand_few = k3b_expand_t<EG3D_K3B_WAVES, 0, false>;
-int k3b_blocks_per_cu() {  // the larger residency of the two builds sizes the slot pools
-  int n = 0, m = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k3b_expand, 64, 0) != hipSuccess || n < 1) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&m, k3b_expand_few, 64, 0) != hipSuccess || m < 1) return 0;
-  return n > m ? n : m;
+static_assert(EG3D_GN_PACK_MAX >= EG3D_SMALL_SCENE_VIEWS_HOST, "a small scene's solves must fit a packed round");
+static_assert(2 * EG3D_SMALL_SCENE_VIEWS_HOST + 8 <= EG3D_COOP_ROWS && 2 * (EG3D_SMALL_SCENE_VIEWS_HOST + 1) + 8 > EG3D_COOP_ROWS,
+              "EG3D_SMALL_SCENE_VIEWS_HOST must be the last view count whose N-view step lists fit LDS");
+static constexpr auto k3b_expand_small = k3b_expand_t<EG3D_K3B_WAVES, 0, 0>;
+static constexpr auto k3b_expand = k3b_expand_t<EG3D_K3B_WAVES, 0, 1>;
+static constexpr auto k3b_expand_many = k3b_expand_t<EG3D_K3B_WAVES, 0, 2>;
+int k3b_blocks_per_cu() {  // the largest residency of the builds sizes the slot pools
+  int best = 0;
+  for (int k = 0; k < 3; k++) {
+    int n = 0;
+    const void* f = k == 0 ? (const void*)k3b_expand_small : k == 1 ? (const void*)k3b_expand : (const void*)k3b_expand_many;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, f, 64, 0) != hipSuccess || n < 1) return 0;
+    best = n > best ? n : best;
+  }
+  return best;
 }
 void launch_pool_init(hipStream_t st, SlotPools pools) {
   hipLaunchKernelGGL(k_pool_init, dim3(8), dim3(256), 0, st, pools);
@@ -1352,10 +1368,13 @@ void launch_k3b(hipStream_t st, DevScene s, StageAView a, const TaskDesc* tasks,
                 uint32_t n_chains, const uint32_t* hyp_off, const HypResult* res, const HPoint* arena,
                 const int32_t* map_view, const uint32_t* map_entry, const uint32_t* map_n, ChainLayout L,
                 unsigned char* slices, SlotPools pools, StageBuf stage, ChainOut* outs, uint32_t* out_points,
-                uint32_t* out_obs, Counters* ctr, const uint32_t* order, bool small_scene) {
+                uint32_t* out_obs, Counters* ctr, const uint32_t* order, int scene_class) {
   if (!n_chains) return;
-  if (small_scene)
-    hipLaunchKernelGGL(k3b_expand_few, dim3(n_chains), dim3(64), 0, st, s, a, tasks, chains, n_chains, hyp_off, res,
+  if (scene_class == 0)
+    hipLaunchKernelGGL(k3b_expand_small, dim3(n_chains), dim3(64), 0, st, s, a, tasks, chains, n_chains, hyp_off, res,
+                       arena, map_view, map_entry, map_n, L, slices, pools, stage, outs, out_points, out_obs, ctr, order);
+  else if (scene_class == 2)
+    hipLaunchKernelGGL(k3b_expand_many, dim3(n_chains), dim3(64), 0, st, s, a, tasks, chains, n_chains, hyp_off, res,
                        arena, map_view, map_entry, map_n, L, slices, pools, stage, outs, out_points, out_obs, ctr, order);
   else
     hipLaunchKernelGGL(k3b_expand, dim3(n_chains), dim3(64), 0, st, s, a, tasks, chains, n_chains, hyp_off, res,

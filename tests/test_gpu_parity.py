@@ -65,13 +65,19 @@ def test_full_path_parity(have_gpu, cfg):
     ctx.close()
 
 
-def test_small_scene_and_general_builds_of_the_expand_kernel_agree(have_gpu, monkeypatch):
-    """libeg3d.so carries two instantiations of k3b_expand: the general one and one for small scenes (<= 32 views,
-    polylines of <= 512 vertices) without the solver's long-request path and the unstaged side walks, chosen by
-    eg3d_create's scene (launch_k3b). EG3D_K3B_FULL=1 (read once, by eg3d_create) forces the general kernel: both must
-    give the same cloud bit for bit — on the seed path and on the polyline-set path — and the small build must not
-    have met a request it cannot solve (the call would fail)."""
-    s = host.Synth(1)
+@pytest.mark.parametrize("n_views", [0, 31, 70], ids=["small scene", "31 views", "70 views"])
+def test_scene_class_builds_of_the_expand_kernel_agree_with_the_general_one(have_gpu, monkeypatch, n_views):
+    """libeg3d.so carries three instantiations of k3b_expand, chosen per context by the scene's class (launch_k3b): small
+    scenes (<= 28 views, polylines of <= 512 vertices: no long-request solver path, no unstaged side walks), many views
+    (>= 29: chain following one step at a time, windowed central pre-solves), and the general one. EG3D_K3B_FULL=1
+    (read once, by eg3d_create) forces the general kernel: both must give the same cloud bit for bit — on the seed path
+    and on the polyline-set path — and the small build must not have met a request it cannot solve (the call would fail)."""
+    if n_views:
+        cfg = host.default_config(1)
+        cfg.rng_seed, cfg.n_views, cfg.n_curves, cfg.max_track, cfg.n_seeds = 13 + n_views, n_views, 24, n_views, 80
+        s = host.Synth(cfg)
+    else:
+        s = host.Synth(1)
     small = api.Context(s.scene)
     a = small.match_refpoints(s.seeds)
     n_sets, row_off, ids = s.polyline_sets(3)
