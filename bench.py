@@ -334,7 +334,7 @@ def _rooflines(wkey, bytes_alg, excl_ms, inflight_ms):
     ONE step on the GPU at a time when that was measured (so that kernel time <= the serial step time); with several
     steps in flight the launches of different steps share the GPU and the event duration is an overlapped wall time."""
     ent = _pmc_entry(wkey)
-    dom = ent.get(DOM_NAME + "_wide") or ent.get(DOM_NAME, {})  # scenes with >= 64 views run the wide build of the kernel
+    dom = ent.get(DOM_NAME, {})
     primary_ms, basis = (excl_ms, "one step on the GPU at a time") if excl_ms else (inflight_ms, "steps in flight (no exclusive measurement in this run)")
     ach = (bytes_alg / (primary_ms * 1e-3)) / 1e9 if primary_ms and primary_ms > 0 else 0.0
     roof = {"bound": "hbm", "kernel": DOM_NAME, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -20,9 +20,10 @@ from collections import defaultdict
 
 
 def short(name):
-    m3 = re.match(r"(?:void )?(?:eg3d::)?k3b_expand_t<(\d+), *(\d+)>", name)
-    if m3:  # the two builds of the expand kernel: <waves per SIMD, Gauss-Newton chunks kept>
-        return "k3b_expand" if m3.group(2) == "0" else "k3b_expand_wide"
+    if re.match(r"(?:void )?(?:eg3d::)?k3b_expand_t<", name):
+        # the instantiations of the expand kernel <waves per SIMD, Gauss-Newton chunks kept, scene class>: a context runs
+        # exactly one of them, so they share the row "k3b_expand"
+        return "k3b_expand"
     m = re.match(r"(?:void )?(?:eg3d::)?([A-Za-z0-9_]+)(<[a-z]+>)?", name)
     if "rocprim" in name:
         return "rocprim::scan(init)" if "init_lookback" in name else "rocprim::scan"
@@ -112,7 +113,7 @@ def main():
                 # k3b_expand / k4_emit run once per steady-state step; the first passes of a context repeat the launch
                 # while its capacities and staging area grow (C4: every pass of a 3-pass run): per step = one launch
                 n_l = (counter_stats(a.fetch).get(k, {}).get("FETCH_SIZE") or (0, 0))[1]
-                if k in ("k3b_expand", "k3b_expand_wide", "k4_emit") and n_l > a.pmc_steps:
+                if k in ("k3b_expand", "k4_emit") and n_l > a.pmc_steps:
                     out[k]["hbm_bytes_per_step"] = out[k]["hbm_bytes_per_launch"]
                     out[k]["note_step"] = ("%d launches in %d passes (a context's first passes repeat the launch while its "
                                            "buffers grow): a steady-state step is ONE launch, per step = the per-launch mean"
