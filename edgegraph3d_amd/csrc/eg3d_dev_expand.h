@@ -228,6 +228,16 @@ struct TeamSeq {
     cur.i = 0;
     return gauss_newton_f64(s.cam_P, cur, X0, Xout);
   }
+  // one ADD solve of a plain observation array (the greedy phase of the 3-subset fallback): rows a[0..n) + extra, from X0
+  EG3D_HD bool add_array(const DevScene& s, const Obs* a, int n, const Obs& extra, const float X0[3], float Xout[3]) const {
+    ArrayCursor cur;
+    cur.a = a;
+    cur.n = n;
+    cur.extra = &extra;
+    cur.i = 0;
+    const double X0d[3] = {(double)X0[0], (double)X0[1], (double)X0[2]};
+    return gauss_newton_f64(s.cam_P, cur, X0d, Xout);
+  }
   // one ADD solve inside a uniform section
   EG3D_HD bool add_one(const DevScene& s, const Chain& c, const ChainPt& p, const Obs& extra, float Xout[3]) const {
     return add_observation_solve(s, c, p, extra, Xout);
@@ -344,18 +354,51 @@ EG3D_HD bool triangulate_array_team(const Team& tm, const DevScene& s, const Obs
 }
 
 // Triangulation fallback of a candidate whose all-observation solve failed: first valid 3-subset
-// + greedy ADD (triangulation.cpp:1105-1158); compacts sel to the kept observations.
+// + greedy ADD (triangulation.cpp:1105-1158); compacts sel to the kept observations. Every solve goes through the TEAM
+// (round 4): the 3-subset triangulations and the ADD solves of the greedy phase are the same requests the rest of the
+// expand stage issues, so a wavefront team spreads their rows over its lanes instead of running a sequential solver
+// redundantly on all 64 — same additions in the same order, same bits (the subsets are enumerated in the order
+// prev_permutation visits {1,1,1,0,...}: ascending (i, j, k), k fastest).
 template <class Team>
 EG3D_HD int stepn_fallback(const Team& tm, const DevScene& s, Obs* sel, int m, Obs* tmp, uint8_t* mask, float Xout[3],
                            uint32_t& flags) {
   if (m <= 3) return 0;
-  struct TeamDlt {
-    const Team& tm;
-    EG3D_HD void operator()(const float* P1, float x1, float y1, const float* P2, float x2, float y2, double X0[3]) const {
-      tm.dlt_rare(P1, x1, y1, P2, x2, y2, X0);
+  bool valid = false;
+  int bi = 0, bj = 0, bk = 0;
+  for (int i = 0; i < m - 2 && !valid; i++)
+    for (int j = i + 1; j < m - 1 && !valid; j++)
+      for (int k = j + 1; k < m && !valid; k++) {
+        tmp[0] = sel[i];
+        tmp[1] = sel[j];
+        tmp[2] = sel[k];
+        tm.sync();
+        if (triangulate_array_team(tm, s, tmp, 3, Xout, flags)) {
+          valid = true;
+          bi = i;
+          bj = j;
+          bk = k;
+        }
+      }
+  if (!valid) return 0;
+  for (int i = 0; i < m; i++) mask[i] = (i == bi || i == bj || i == bk) ? 1 : 0;
+  tmp[0] = sel[bi];
+  tmp[1] = sel[bj];
+  tmp[2] = sel[bk];
+  int kept = 3;
+  for (int i = 0; i < m; i++) {
+    if (!mask[i]) {
+      tm.sync();
+      float Xn[3];
+      if (tm.add_array(s, tmp, kept, sel[i], Xout, Xn)) {
+        mask[i] = 1;
+        Xout[0] = Xn[0];
+        Xout[1] = Xn[1];
+        Xout[2] = Xn[2];
+        tmp[kept++] = sel[i];
+      }
     }
-  };
-  if (!triangulate_combinations<0>(s.cam_P, sel, m, tmp, mask, Xout, flags, TeamDlt{tm})) return 0;
+  }
+  tm.sync();
   int k = 0;
   for (int i = 0; i < m; i++)
     if (mask[i]) sel[k++] = sel[i];

@@ -871,6 +871,15 @@ struct TeamWaveT {
     Xout[2] = lane_bcast(Xr[2], 0);
     return lane_bcast(ok ? 1 : 0, 0) != 0;
   }
+  __device__ __forceinline__ bool add_array(const DevScene& s, const Obs* a, int n, const Obs& extra, const float X0[3],
+                                            float Xout[3]) const {
+    float Xr[3];
+    const bool ok = coop_gn_groups<GN_KEEP, LONG_GN>(s.cam_P, *L, lane() == 0, a, n, true, extra.view, extra.x, extra.y, X0, Xr);
+    Xout[0] = lane_bcast(Xr[0], 0);
+    Xout[1] = lane_bcast(Xr[1], 0);
+    Xout[2] = lane_bcast(Xr[2], 0);
+    return lane_bcast(ok ? 1 : 0, 0) != 0;
+  }
   __device__ __forceinline__ bool add_one(const DevScene& s, const Chain& c, const ChainPt& p, const Obs& extra,
                                           float Xout[3]) const {
     const float X0f[3] = {p.X[0], p.X[1], p.X[2]};
