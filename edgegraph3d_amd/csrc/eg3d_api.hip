@@ -124,7 +124,7 @@ struct HostGrids {
 //                          chains each (default: one launch takes all chains — their working slices are slots)
 //   EG3D_NO_LPT=1          launch chains in identity order instead of longest-first (diagnostic)
 //   EG3D_K3B_FULL=1        always run the general build of the expand kernel (default: the build for the scene's class —
-//                          small: <= 28 views and polylines of <= 512 vertices; many views: >= 29; general otherwise)
+//                          polylines of <= 512 vertices and <= 28 views: small, >= 29 views: many views; general otherwise)
 struct Tunables {
   int k3a_engine_waves = 0, k3a_engine_lanes = 0;
   bool trace_arena = false;
@@ -1026,7 +1026,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
                c->b_map_view.as<int32_t>(), c->b_map_entry.as<uint32_t>(), c->b_map_n.as<uint32_t>(), L,
                c->b_cscratch.as<unsigned char>(), pools, stage, c->b_couts.as<ChainOut>(), c->b_cpts.as<uint32_t>(),
                c->b_cobs.as<uint32_t>(), c->b_ctr.as<Counters>(), c->b_order.as<uint32_t>(),
-               c->tune.k3b_full ? 1 : c->V > EG3D_SMALL_SCENE_VIEWS_HOST ? 2 : c->max_pl_vtx <= EG3D_STAGE_VTX_HOST ? 0 : 1);
+               (c->tune.k3b_full || c->max_pl_vtx > EG3D_STAGE_VTX_HOST) ? 1 : c->V > EG3D_SMALL_SCENE_VIEWS_HOST ? 2 : 0);
     HIP_TRY(hipEventRecord(c->eb[5], st));
     // the two output scans are queued right behind K3b; its counters (capacity overflow?) and both totals
     // come back in ONE read-back

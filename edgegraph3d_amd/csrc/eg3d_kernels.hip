@@ -494,9 +494,9 @@ __global__ void k_compact_chains(uint32_t n_tasks, const ChainSeed* per_task, co
 //      observation per view, so no solve exceeds a packed round) and the side walks over polylines that do not fit
 //      the LDS staging area are compiled out;
 //   1  general: everything;
-//   2  many views (>= 29): the N-view step's lists never fit LDS there (2 V + 8 > 64 observations), so chain
-//      following is always one step at a time — the look-ahead rounds are compiled out — and the speculative
-//      central solves are always windowed.
+//   2  many views (>= 29) and polylines of <= 512 vertices: the N-view step's lists never fit LDS there (2 V + 8 > 64
+//      observations), so chain following is always one step at a time — the look-ahead rounds are compiled out —,
+//      the speculative central solves are always windowed, and the unstaged side walks are compiled out as in 0.
 // What a scene cannot execute is not free in a 45-70 k-instruction kernel: register allocation and the instruction
 // cache both see it (C3': 50.4 -> 47.5 ms with SCENE 0; C4: 1828 -> 1732 ms per step in flight with SCENE 2).
 template <int GN_KEEP, int SCENE>
@@ -629,7 +629,7 @@ struct TeamWaveT {
     typedef const __attribute__((address_space(3))) float* lds_fp;
     typedef const __attribute__((address_space(3))) f2* lds_f2p;
     const int count = towards_start ? ci - lo : hi - ci - 1;
-    const bool fits = !LONG_GN || pl.n <= EG3D_STAGE_VTX;  // the small-scene build: every polyline fits (host-checked)
+    const bool fits = SCENE != 1 || pl.n <= EG3D_STAGE_VTX;  // scene classes 0 and 2: every polyline fits (host-checked)
     const int staged = count < kEpiHalf ? (count < 0 ? 0 : count) : kEpiHalf;
     const lds_fp epi = (lds_fp)&L->walk.epi[towards_start ? 0 : kEpiHalf][0];
     // next hit of the line towards `direction`, SEGMENT-PARALLEL: lane 0 tests the partial segment
@@ -695,7 +695,7 @@ struct TeamWaveT {
       return walk_side_candidates_core(s, c, pls, epi, staged, view, from, direction, lo, ci, hi, towards_start, out,
                                        walk);
     }
-    if constexpr (!LONG_GN) return 0;  // unreachable in the small-scene build (fits is a constant there)
+    if constexpr (SCENE != 1) return 0;  // unreachable in those builds (fits is a constant there)
     return walk_side_candidates_core(s, c, pl, epi, staged, view, from, direction, lo, ci, hi, towards_start, out, walk);
   }
   // append a followed point at the chain's front / back (the checks of follow_front / follow_back)
