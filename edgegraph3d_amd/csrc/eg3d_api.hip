@@ -761,7 +761,7 @@ int run_stage_a(eg3d_ctx* c, BatchState& B, eg3d_stage_times* tm) {
   HIP_TRY(hipEventRecord(c->ea[1], st));
   launch_k1(st, c->ds, B.sd, B.sv_base, n_sv, c->b_sv_seed.as<uint32_t>(), c->b_raw_off.as<uint32_t>(),
             c->b_cand_pl.as<uint32_t>(), c->b_start_hits.as<Obs>(), c->b_cand_cnt.as<uint32_t>(),
-            c->b_start_cnt.as<uint32_t>(), c->b_ctr.as<Counters>());
+            c->b_start_cnt.as<uint32_t>(), c->b_raw_cnt.as<uint32_t>() /* dead after its scan: reused for K1's vertex counts */);
   HIP_TRY(hipEventRecord(c->eb[1], st));
   BUF_TRY(scan_total_u32(c, c->b_start_cnt.as<uint32_t>(), c->b_task_off.as<uint32_t>(), n_sv + 1, B.n_tasks, "tasks"));
   const uint32_t nt = B.n_tasks;
@@ -773,7 +773,7 @@ int run_stage_a(eg3d_ctx* c, BatchState& B, eg3d_stage_times* tm) {
   HIP_TRY(hipMemsetAsync(c->b_task_k.as<uint32_t>() + nt, 0, sizeof(uint32_t), st));
   launch_task_fill(st, B.sd, B.sv_base, n_sv, c->b_sv_seed.as<uint32_t>(), c->b_start_cnt.as<uint32_t>(),
                    c->b_task_off.as<uint32_t>(), c->b_task_seed.as<uint32_t>(), c->b_task_entry.as<uint32_t>(),
-                   c->b_task_hit.as<uint32_t>(), c->b_task_k.as<uint32_t>());
+                   c->b_task_hit.as<uint32_t>(), c->b_task_k.as<uint32_t>(), c->b_raw_cnt.as<uint32_t>(), c->b_ctr.as<Counters>());
   BUF_TRY(scan_total_u32(c, c->b_task_k.as<uint32_t>(), c->b_task_list_off.as<uint32_t>(), nt + 1, B.n_lists, "hit lists"));
   BUF_TRY(c->b_list_cnt.ensure(sizeof(uint32_t) * (B.n_lists + 1)));
   BUF_TRY(c->b_list_ptr.ensure(sizeof(uint32_t) * (B.n_lists + 1)));

@@ -37,10 +37,10 @@ void launch_k1_count_raw(hipStream_t st, DevScene s, SeedsDev sd, uint32_t sv_ba
                          uint32_t* raw_cnt);
 void launch_k1(hipStream_t st, DevScene s, SeedsDev sd, uint32_t sv_base, uint32_t n_sv, const uint32_t* sv_seed,
                const uint32_t* raw_off, uint32_t* cand_pl, Obs* start_hits, uint32_t* cand_cnt, uint32_t* start_cnt,
-               Counters* ctr);
+               uint32_t* sv_vtx);
 void launch_task_fill(hipStream_t st, SeedsDev sd, uint32_t sv_base, uint32_t n_sv, const uint32_t* sv_seed,
                       const uint32_t* start_cnt, const uint32_t* task_off, uint32_t* task_seed, uint32_t* task_entry,
-                      uint32_t* task_hit, uint32_t* task_k);
+                      uint32_t* task_hit, uint32_t* task_k, const uint32_t* sv_vtx, Counters* ctr);
 #ifndef EG3D_K2_LDS
 #define EG3D_K2_LDS 0
 #endif

@@ -45,6 +45,19 @@ __device__ __forceinline__ float wave_min_f32(float v) {
   return v;
 }
 
+// Wave minimum through DPP (row_shr 1/2/4/8, row_bcast 15/31: lane 63 ends up with the minimum of all lanes) and one
+// v_readlane — seven short instructions instead of six dependent trips through the LDS crossbar. All lanes active.
+__device__ __forceinline__ uint32_t wave_min_u32_dpp(uint32_t v) {
+  auto mn = [](uint32_t x, int y) { return (uint32_t)y < x ? (uint32_t)y : x; };
+  v = mn(v, __builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xf, 0xf, false));
+  v = mn(v, __builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xf, 0xf, false));
+  v = mn(v, __builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xf, 0xf, false));
+  v = mn(v, __builtin_amdgcn_update_dpp(-1, (int)v, 0x118, 0xf, 0xf, false));
+  v = mn(v, __builtin_amdgcn_update_dpp(-1, (int)v, 0x142, 0xa, 0xf, false));
+  v = mn(v, __builtin_amdgcn_update_dpp(-1, (int)v, 0x143, 0xc, 0xf, false));
+  return (uint32_t)lane_bcast((int)v, 63);
+}
+
 // ------------------------------------------------------------------ prep -------
 __global__ void k_seed_prep(SeedsDev sd, uint32_t seed_begin, uint32_t n_seeds, uint32_t sv_base, uint32_t* sv_seed,
                             int32_t* map_view, uint32_t* map_entry, uint32_t* map_n) {
@@ -96,7 +109,7 @@ __global__ void k1_count_raw(DevScene s, SeedsDev sd, uint32_t sv_base, uint32_t
 __global__ void __launch_bounds__(256) k1_seed_candidates(DevScene s, SeedsDev sd, uint32_t sv_base, uint32_t n_sv,
                                                          const uint32_t* sv_seed, const uint32_t* raw_off,
                                                          uint32_t* cand_pl, Obs* start_hits, uint32_t* cand_cnt,
-                                                         uint32_t* start_cnt, Counters* ctr) {
+                                                         uint32_t* start_cnt, uint32_t* sv_vtx) {
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t lane = threadIdx.x & 63;
   if (wave >= n_sv) return;
@@ -119,63 +132,125 @@ __global__ void __launch_bounds__(256) k1_seed_candidates(DevScene s, SeedsDev s
   }
   const uint32_t out_base = raw_off[sv];
   uint32_t nc = 0, ns = 0;
-  unsigned long long vbytes = 0;
+  uint32_t nvtx = 0;
+  // Candidates are taken in batches of up to 64 ids (phase A: the k-way merge, one wave-minimum per id, the lanes' list
+  // heads loaded eight at a time); the segments of a whole batch are then scanned as ONE flat sequence (phase B) — a
+  // pass per candidate paid the dependent look-ups id -> vertex range -> vertices and three wave reductions per
+  // candidate with ~25 of 64 lanes busy. The first closest segment of a candidate (smallest distance, then smallest
+  // index) is the minimum of the 64-bit keys (distance bits : segment) in the candidate's LDS slot: squared distances
+  // are >= +0, so their bit patterns order like the values; NaN / infinite distances are never submitted (the plain
+  // scan's `d < best` with best = +inf).
+  __shared__ unsigned long long k1_best[4][64];
+  unsigned long long* const slot = k1_best[threadIdx.x >> 6];
+  const uint32_t gview = s.view_pl_off[view];
+  const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  uint32_t h0 = 0xffffffffu, h1 = 0xffffffffu, h2 = 0xffffffffu, h3 = 0xffffffffu, h4 = 0xffffffffu, h5 = 0xffffffffu,
+           h6 = 0xffffffffu, h7 = 0xffffffffu;
+  uint32_t hn = 0;  // ids of this lane's list held in h0..h7
   for (;;) {
-    const uint32_t head = (a < b) ? s.g30_ids[a] : 0xffffffffu;
-    const uint32_t m = wave_min_u32(head);
-    if (m == 0xffffffffu) break;
-    if (head == m) a++;
-    const PlRef pl = polyline_of(s, view, m);
-    vbytes += 8ull * pl.n;
-    float best = __builtin_huge_valf();
-    uint32_t bj = 0xffffffffu;
-    float bx = 0.f, by = 0.f;
-    for (uint32_t j = lane; j + 1 < pl.n; j += 64) {
-      const f2 v0 = pl.v[j], v1 = pl.v[j + 1];
-      float qx, qy;
-      const float d = seg_closest(px, py, v0.x, v0.y, v1.x, v1.y, qx, qy);
-      if (d < best) {
-        best = d;
-        bj = j;
-        bx = qx;
-        by = qy;
+    uint32_t my_id = 0xffffffffu, nb = 0;
+    while (nb < 64) {
+      if (hn == 0 && a < b) {  // refill: up to eight ids of the lane's cell list, their loads in flight together
+        const uint32_t r = b - a;
+        h0 = s.g30_ids[a];
+        h1 = r > 1 ? s.g30_ids[a + 1] : 0xffffffffu;
+        h2 = r > 2 ? s.g30_ids[a + 2] : 0xffffffffu;
+        h3 = r > 3 ? s.g30_ids[a + 3] : 0xffffffffu;
+        h4 = r > 4 ? s.g30_ids[a + 4] : 0xffffffffu;
+        h5 = r > 5 ? s.g30_ids[a + 5] : 0xffffffffu;
+        h6 = r > 6 ? s.g30_ids[a + 6] : 0xffffffffu;
+        h7 = r > 7 ? s.g30_ids[a + 7] : 0xffffffffu;
+        hn = r > 8 ? 8 : r;
+        a += hn;
+      }
+      const uint32_t head = hn ? h0 : 0xffffffffu;
+      const uint32_t m = wave_min_u32_dpp(head);
+      if (m == 0xffffffffu) break;
+      if (head == m) {
+        h0 = h1, h1 = h2, h2 = h3, h3 = h4, h4 = h5, h5 = h6, h6 = h7, h7 = 0xffffffffu;
+        hn--;
+      }
+      if (lane == nb) my_id = m;
+      nb++;
+    }
+    if (nb == 0) break;
+    uint32_t my_a = 0, my_n = 0;
+    if (lane < nb) {
+      const uint32_t v0 = s.pl_vtx_off[gview + my_id], v1 = s.pl_vtx_off[gview + my_id + 1];
+      my_a = v0;
+      my_n = v1 - v0;
+    }
+    const uint32_t my_ns = my_n >= 2u ? my_n - 1u : 0u;
+    nvtx += (uint32_t)lane_bcast(wave_incl_scan((int)my_n), 63);
+    const uint32_t incl = (uint32_t)wave_incl_scan((int)my_ns);
+    const uint32_t total = (uint32_t)lane_bcast((int)incl, 63);
+    slot[lane] = ~0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t base = 0; base < total; base += 64) {
+      const uint32_t f = base + lane;
+      uint32_t pos = 0;  // owner of flat segment f: the first lane whose inclusive count exceeds f
+#pragma unroll
+      for (uint32_t step = 32; step; step >>= 1) {
+        const uint32_t v = (uint32_t)__shfl((int)incl, (int)(pos + step - 1), 64);
+        if (v <= f) pos += step;
+      }
+      const uint32_t o_incl = (uint32_t)__shfl((int)incl, (int)pos, 64);
+      const uint32_t o_ns = (uint32_t)__shfl((int)my_ns, (int)pos, 64);
+      const uint32_t o_a = (uint32_t)__shfl((int)my_a, (int)pos, 64);
+      if (f < total) {
+        const uint32_t j = f - (o_incl - o_ns);
+        const f2 v0 = s.vtx[o_a + j], v1 = s.vtx[o_a + j + 1];
+        float qx, qy;
+        const float d = seg_closest(px, py, v0.x, v0.y, v1.x, v1.y, qx, qy);
+        if (d < __builtin_huge_valf())
+          atomicMin(&slot[pos], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)j);
       }
     }
-    const float dmin = wave_min_f32(best);
-    const uint32_t jmin = wave_min_u32(best == dmin ? bj : 0xffffffffu);
-    const unsigned long long win = __ballot(best == dmin && bj == jmin);
-    if (win == 0ull) continue;  // degenerate (NaN) polyline: never a candidate
-    const int wl = __ffsll((long long)win) - 1;
-    const float hx = __shfl(bx, wl, 64), hy = __shfl(by, wl, 64);
-    if (dmin <= 100.0f) {
-      if (lane == 0) {
-        cand_pl[out_base + nc] = m;
-        Obs o;
-        o.view = view;
-        o.pl = m;
-        o.seg = jmin;
-        o.x = hx;
-        o.y = hy;
-        start_hits[out_base + ns] = o;
-      }
-      nc++;
-      ns++;
-    } else if (dmin <= 900.0f) {
-      if (lane == 0) cand_pl[out_base + nc] = m;
-      nc++;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long key = slot[lane];
+    const bool valid = lane < nb && key != ~0ull;  // no finite distance (degenerate polyline): never a candidate
+    const float dmin = __uint_as_float((uint32_t)(key >> 32));
+    const uint32_t jmin = (uint32_t)key;
+    const bool is_start = valid && dmin <= 100.0f;
+    const bool is_cand = valid && dmin <= 900.0f;
+    const unsigned long long mc = __ballot(is_cand), ms = __ballot(is_start);
+    if (is_cand) cand_pl[out_base + nc + __popcll(mc & lt_mask)] = my_id;
+    if (is_start) {
+      const f2 v0 = s.vtx[my_a + jmin], v1 = s.vtx[my_a + jmin + 1];
+      Obs o;
+      o.view = view;
+      o.pl = my_id;
+      o.seg = jmin;
+      (void)seg_closest(px, py, v0.x, v0.y, v1.x, v1.y, o.x, o.y);  // the winning segment's closest point again: same inputs, same bits
+      start_hits[out_base + ns + __popcll(ms & lt_mask)] = o;
     }
+    nc += __popcll(mc);
+    ns += __popcll(ms);
+    __builtin_amdgcn_wave_barrier();
+    if (nb < 64) break;
   }
   if (lane == 0) {
     cand_cnt[sv] = nc;
     start_cnt[sv] = ns;
-    if (vbytes) atomicAdd(&ctr->bytes, vbytes);
+    // the vertices this entry's scans touched (algorithmic bytes): summed by k_task_fill, one atomic per
+    // wave of entries — one atomic per entry on the one counter serialised at the memory side and was 3/4 of this
+    // kernel's time (0.51 -> 0.13 ms on C3')
+    sv_vtx[sv] = nvtx;
   }
 }
 
 __global__ void k_task_fill(SeedsDev sd, uint32_t sv_base, uint32_t n_sv, const uint32_t* sv_seed,
                             const uint32_t* start_cnt, const uint32_t* task_off, uint32_t* task_seed,
-                            uint32_t* task_entry, uint32_t* task_hit, uint32_t* task_k) {
+                            uint32_t* task_entry, uint32_t* task_hit, uint32_t* task_k, const uint32_t* sv_vtx,
+                            Counters* ctr) {
   uint32_t sv = blockIdx.x * blockDim.x + threadIdx.x;
+  {  // K1's vertex counts -> the byte counter, one atomic per wave of entries
+    unsigned long long v = sv < n_sv ? (unsigned long long)sv_vtx[sv] : 0ull;
+    for (int d = 32; d; d >>= 1) v += (unsigned long long)__shfl_xor((long long)v, d, 64);
+    if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&ctr->bytes, 8ull * v);
+  }
   if (sv >= n_sv) return;
   const uint32_t seed = sv_seed[sv];
   const uint32_t t0 = sd.trk_off[seed], k = sd.trk_off[seed + 1] - t0;
@@ -231,28 +306,72 @@ __global__ void __launch_bounds__(256) k2_epipolar_hits(DevScene s, SeedsDev sd,
         const float sx = sd.trk_xy[2 * (t0 + i)], sy = sd.trk_xy[2 * (t0 + i) + 1];
         const uint32_t cbase = raw_off[sv0 + i], ncand = cand_cnt[sv0 + i];
         const uint32_t wbase = FILL ? list_ptr[lo + i] : 0;
-        for (uint32_t c = 0; c < ncand; c++) {
-          const uint32_t pl_id = cand_pl[cbase + c];
-          const PlRef pl = polyline_of(s, cur_view, pl_id);
-          for (uint32_t base = 1; base < pl.n; base += 64) {
-            const uint32_t ii = base + lane;
-            bool ok = false;
-            float hx = 0.f, hy = 0.f;
-            if (ii < pl.n) {
-              const f2 v1 = pl.v[ii], v0 = pl.v[ii - 1];
-              if (seg_line_hit(v1.x, v1.y, v0.x, v0.y, la, lb, lc, hx, hy)) ok = dist2(sx, sy, hx, hy) <= detsq;
+        // The segments of up to 64 candidate polylines are dealt to the lanes as ONE flat sequence (candidate-major,
+        // segment-minor = the order of the per-candidate loops): polylines average ~25 vertices, so a pass per
+        // candidate left 60 % of the lanes idle and paid its dependent look-ups (candidate id -> vertex range ->
+        // vertices) once per candidate; here the look-ups of all candidates are in flight together.
+        const uint32_t gview = s.view_pl_off[cur_view];
+        for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
+          const uint32_t c = c0 + lane;
+          uint32_t my_id = 0, my_a = 0, my_ns = 0;
+          if (c < ncand) {
+            my_id = cand_pl[cbase + c];
+            const uint32_t a = s.pl_vtx_off[gview + my_id], b = s.pl_vtx_off[gview + my_id + 1];
+            my_a = a;
+            my_ns = (b - a) >= 2u ? (b - a) - 1u : 0u;
+          }
+          const uint32_t incl = (uint32_t)wave_incl_scan((int)my_ns);
+          const uint32_t total = (uint32_t)lane_bcast((int)incl, 63);
+          const uint32_t excl = incl - my_ns;
+          // four chunks of 64 flat segments per trip: their owner searches and vertex loads are independent and in
+          // flight together (one chunk at a time, a wave waited out one memory latency per chunk)
+          constexpr int U = 4;
+          for (uint32_t base = 0; base < total; base += 64 * U) {
+            f2 v0[U], v1[U];
+            uint32_t oid[U], seg[U];
+            bool in[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+              const uint32_t f = base + 64u * u + lane;
+              in[u] = f < total;
+              oid[u] = seg[u] = 0;
+              v0[u].x = v0[u].y = v1[u].x = v1[u].y = 0.f;
+              if (base + 64u * u < total) {  // wave-uniform
+                uint32_t pos = 0;  // owner of flat segment f: the first lane whose inclusive count exceeds f
+#pragma unroll
+                for (uint32_t step = 32; step; step >>= 1) {
+                  const uint32_t v = (uint32_t)__shfl((int)incl, (int)(pos + step - 1), 64);
+                  if (v <= f) pos += step;
+                }
+                const uint32_t o_excl = (uint32_t)__shfl((int)excl, (int)pos, 64);
+                const uint32_t o_a = (uint32_t)__shfl((int)my_a, (int)pos, 64);
+                oid[u] = (uint32_t)__shfl((int)my_id, (int)pos, 64);
+                if (in[u]) {
+                  seg[u] = f - o_excl;
+                  v0[u] = s.vtx[o_a + seg[u]];
+                  v1[u] = s.vtx[o_a + seg[u] + 1];
+                }
+              }
             }
-            const unsigned long long mask = __ballot(ok);
-            if (FILL && ok) {
-              Obs o;
-              o.view = cur_view;
-              o.pl = pl_id;
-              o.seg = ii - 1;
-              o.x = hx;
-              o.y = hy;
-              hits[wbase + cnt + __popcll(mask & lt_mask)] = o;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+              if (base + 64u * u >= total) break;  // wave-uniform
+              bool ok = false;
+              float hx = 0.f, hy = 0.f;
+              if (in[u] && seg_line_hit(v1[u].x, v1[u].y, v0[u].x, v0[u].y, la, lb, lc, hx, hy))
+                ok = dist2(sx, sy, hx, hy) <= detsq;
+              const unsigned long long mask = __ballot(ok);
+              if (FILL && ok) {
+                Obs o;
+                o.view = cur_view;
+                o.pl = oid[u];
+                o.seg = seg[u];
+                o.x = hx;
+                o.y = hy;
+                hits[wbase + cnt + __popcll(mask & lt_mask)] = o;
+              }
+              cnt += __popcll(mask);
             }
-            cnt += __popcll(mask);
           }
         }
       }
@@ -1002,6 +1121,7 @@ __global__ void __launch_bounds__(64, WAVES) k3b_expand_t(DevScene s, StageAView
                                                  uint32_t* out_points, uint32_t* out_obs, Counters* ctr,
                                                  const uint32_t* order) {
   if (blockIdx.x >= n_chains) return;
+  EG3D_SETPRIO_REST();
   __shared__ CoopLds lds;
   const uint32_t lane = threadIdx.x;
   const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)order[blockIdx.x]);  // longest-first schedule; results stay indexed by chain
@@ -1263,17 +1383,17 @@ void launch_k1_count_raw(hipStream_t st, DevScene s, SeedsDev sd, uint32_t sv_ba
 }
 void launch_k1(hipStream_t st, DevScene s, SeedsDev sd, uint32_t sv_base, uint32_t n_sv, const uint32_t* sv_seed,
                const uint32_t* raw_off, uint32_t* cand_pl, Obs* start_hits, uint32_t* cand_cnt, uint32_t* start_cnt,
-               Counters* ctr) {
+               uint32_t* sv_vtx) {
   if (!n_sv) return;
   hipLaunchKernelGGL(k1_seed_candidates, blocks_for((uint64_t)n_sv * 64, 256), dim3(256), 0, st, s, sd, sv_base, n_sv,
-                     sv_seed, raw_off, cand_pl, start_hits, cand_cnt, start_cnt, ctr);
+                     sv_seed, raw_off, cand_pl, start_hits, cand_cnt, start_cnt, sv_vtx);
 }
 void launch_task_fill(hipStream_t st, SeedsDev sd, uint32_t sv_base, uint32_t n_sv, const uint32_t* sv_seed,
                       const uint32_t* start_cnt, const uint32_t* task_off, uint32_t* task_seed, uint32_t* task_entry,
-                      uint32_t* task_hit, uint32_t* task_k) {
+                      uint32_t* task_hit, uint32_t* task_k, const uint32_t* sv_vtx, Counters* ctr) {
   if (!n_sv) return;
   hipLaunchKernelGGL(k_task_fill, blocks_for(n_sv, 256), dim3(256), 0, st, sd, sv_base, n_sv, sv_seed, start_cnt,
-                     task_off, task_seed, task_entry, task_hit, task_k);
+                     task_off, task_seed, task_entry, task_hit, task_k, sv_vtx, ctr);
 }
 void launch_k2(hipStream_t st, bool fill, DevScene s, SeedsDev sd, uint32_t seed_begin, uint32_t n_seeds, uint32_t sv_base,
                uint32_t n_tasks, const uint32_t* task_off, const uint32_t* task_seed, const uint32_t* task_entry,
