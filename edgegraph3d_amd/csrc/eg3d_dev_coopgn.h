@@ -259,21 +259,6 @@ __device__ __forceinline__ double ordered_sum2(double s, const double* __restric
 // the standard build: a one-chunk round keeps its rows, a multi-chunk round recomputes all of them in the update pass;
 // 4 in the wide build for scenes with long observation lists (V >= 64), where that recomputation was a fifth of the
 // kernel's time. Same values either way (a row is a function of X, which does not change between the passes).
-// Experiment hook (off unless -DEG3D_PRIO_GN=<0..3>): the wave's issue priority inside a solver round / outside it.
-#if defined(EG3D_PRIO_GN) && defined(__HIP_DEVICE_COMPILE__)
-#define EG3D_SETPRIO_GN() __builtin_amdgcn_s_setprio(EG3D_PRIO_GN)
-#define EG3D_SETPRIO_REST() __builtin_amdgcn_s_setprio(EG3D_PRIO_REST)
-#else
-#define EG3D_SETPRIO_GN() ((void)0)
-#define EG3D_SETPRIO_REST() ((void)0)
-#endif
-#if defined(EG3D_PRIO_ROWS) && defined(__HIP_DEVICE_COMPILE__)  // ... or only around the rows' arithmetic
-#define EG3D_SETPRIO_ROWS() __builtin_amdgcn_s_setprio(EG3D_PRIO_ROWS)
-#define EG3D_SETPRIO_ROWS_END() __builtin_amdgcn_s_setprio(EG3D_PRIO_REST)
-#else
-#define EG3D_SETPRIO_ROWS() ((void)0)
-#define EG3D_SETPRIO_ROWS_END() ((void)0)
-#endif
 template <int KEEP>
 __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool act, int l, int G, int gb, int n, int nb,
                                          const Obs* a, int32_t xv, float xx, float xy, int cmax, double X[3]) {
@@ -283,7 +268,6 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
   double last_mse = 0;
   const double two_n = (double)(n * 2);
   int dbg_it = 0, dbg_round = 0;
-  EG3D_SETPRIO_GN();
 #if defined(EG3D_SECTION_TIMING)
   unsigned long long gts_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long gt_begin_ = __builtin_readcyclecounter();
@@ -303,7 +287,6 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
     auto pass1_chunk = [&](int c, GnRow& w) {
       const int r = c * G + l;
       const bool rowact = !done && r < n;
-      EG3D_SETPRIO_ROWS();
       if (rowact) {
         int32_t view;
         float ox, oy;
@@ -332,7 +315,6 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
         L.prod[12][lane] = w.r0 * w.r0;
         L.prod[13][lane] = w.r1 * w.r1;
       }
-      EG3D_SETPRIO_ROWS_END();
       EG3D_GN_T(0);
       __syncthreads();
       EG3D_GN_T(1);
@@ -472,7 +454,6 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
     EG3D_GN_T(6);
   }
   if (act && !done) ok = last_mse < 9;
-  EG3D_SETPRIO_REST();
 #if defined(__HIP_DEVICE_COMPILE__) && defined(EG3D_SECTION_TIMING)
   if (act && l == 0) {
     EG3D_GN_DBG(dbg_it < 31 ? dbg_it : 31, 1);

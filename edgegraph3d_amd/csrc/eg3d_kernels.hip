@@ -306,6 +306,7 @@ __global__ void __launch_bounds__(256) k2_epipolar_hits(DevScene s, SeedsDev sd,
         const float sx = sd.trk_xy[2 * (t0 + i)], sy = sd.trk_xy[2 * (t0 + i) + 1];
         const uint32_t cbase = raw_off[sv0 + i], ncand = cand_cnt[sv0 + i];
         const uint32_t wbase = FILL ? list_ptr[lo + i] : 0;
+        if (FILL && list_ptr[lo + i + 1] == wbase) continue;  // the count pass found nothing for this list
         // The segments of up to 64 candidate polylines are dealt to the lanes as ONE flat sequence (candidate-major,
         // segment-minor = the order of the per-candidate loops): polylines average ~25 vertices, so a pass per
         // candidate left 60 % of the lanes idle and paid its dependent look-ups (candidate id -> vertex range ->
@@ -1121,7 +1122,6 @@ __global__ void __launch_bounds__(64, WAVES) k3b_expand_t(DevScene s, StageAView
                                                  uint32_t* out_points, uint32_t* out_obs, Counters* ctr,
                                                  const uint32_t* order) {
   if (blockIdx.x >= n_chains) return;
-  EG3D_SETPRIO_REST();
   __shared__ CoopLds lds;
   const uint32_t lane = threadIdx.x;
   const uint32_t j = (uint32_t)__builtin_amdgcn_readfirstlane((int)order[blockIdx.x]);  // longest-first schedule; results stay indexed by chain
