@@ -179,6 +179,65 @@ def test_very_long_polylines_parity():
     ctx.close()
 
 
+def test_crowded_neighbourhoods_more_than_64_candidate_polylines():
+    """K1 takes the candidate polylines of a (seed, entry) in batches of 64 ids and scans a batch's segments as one flat
+    sequence; K2 deals the segments of all candidates of a list to the lanes the same way. The tiny scene with clutter:
+    around the observations of the first seeds every view gets 70-200 extra 2- and 3-vertex polylines within the 30 px
+    window (some within the 10 px start radius, some of them degenerate: repeated vertices), so that entries have more
+    than 64 and more than 128 candidates. Stage A and the whole path must equal the oracle bit for bit."""
+    s = host.Synth(0)
+    sc = s.scene_np()
+    off, view, xy = s.seeds_np()
+    rng = np.random.default_rng(64128)
+    V = int(sc["n_views"])
+    vpo, pvo, vtx = sc["view_pl_off"], sc["pl_vtx_off"], sc["vtx_xy"]
+    node0 = int(max(sc["pl_start"].max(), sc["pl_end"].max())) + 1
+    n_vpo, n_pvo, n_vtx, n_st, n_en, n_val = [0], [0], [], [], [], []
+    for v in range(V):
+        for g in range(int(vpo[v]), int(vpo[v + 1])):   # the view's own polylines, unchanged
+            n_vtx.extend(vtx[pvo[g]:pvo[g + 1]])
+            n_pvo.append(len(n_vtx))
+            n_st.append(sc["pl_start"][g]); n_en.append(sc["pl_end"][g]); n_val.append(sc["pl_valid"][g])
+        centres = [xy[e] for p in range(min(6, len(off) - 1)) for e in range(int(off[p]), int(off[p + 1])) if view[e] == v]
+        for ci, c in enumerate(centres):
+            for k in range(70 if ci % 2 else 200):
+                r = np.float32(rng.uniform(0.5, 9.0) if k % 3 == 0 else rng.uniform(9.0, 27.0))
+                a = rng.uniform(0, 2 * np.pi)
+                p0 = (c + r * np.array([np.cos(a), np.sin(a)])).astype(np.float32)
+                d = rng.normal(0, 1.5, 2).astype(np.float32)
+                pts = [p0, p0 + d] if k % 5 else [p0, p0, p0 + d]   # every fifth starts with a zero-length segment
+                if k % 11 == 0:
+                    pts.append(p0 + d + rng.normal(0, 1.5, 2).astype(np.float32))
+                n_vtx.extend(pts)
+                n_pvo.append(len(n_vtx))
+                n_st.append(node0); n_en.append(node0 + 1); n_val.append(1)
+                node0 += 2
+        n_vpo.append(len(n_pvo) - 1)
+    sc["view_pl_off"] = np.asarray(n_vpo, np.uint32)
+    sc["pl_vtx_off"] = np.asarray(n_pvo, np.uint32)
+    sc["vtx_xy"] = np.asarray(n_vtx, np.float32).reshape(-1, 2)
+    sc["pl_start"], sc["pl_end"] = np.asarray(n_st, np.uint32), np.asarray(n_en, np.uint32)
+    sc["pl_valid"] = np.asarray(n_val, np.uint8)
+    sa = host.SceneArrays(sc)
+    ctx, orc = api.Context(C.byref(sa.c)), _oracle(C.byref(sa.c))
+    ca, cb = ctx.candidates(s.seeds, 0, s.n_seeds), orc.candidates(s.seeds, 0, s.n_seeds)
+    per_entry = np.diff(cb["cand_off"])
+    assert per_entry.max() > 128 and (per_entry > 64).sum() >= 4, per_entry.max()
+    for k in cb:
+        x, y = ca[k], cb[k]
+        if isinstance(y, np.ndarray):
+            bits = (lambda a: a.view(np.uint32) if a.dtype == np.float32 else a)
+            assert np.array_equal(bits(x), bits(y)), k
+        else:
+            assert x == y, (k, x, y)
+    got = ctx.match_refpoints(s.seeds, 0, s.n_seeds)
+    ref = orc.match(s.seeds, 0, s.n_seeds, nthreads=8)
+    rep = compare_edgepoints(ref, got, rel_tol=1e-4)
+    assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], rep["msgs"][:3]
+    assert got["flags"] == ref["flags"] and got["times"]["bytes_algorithmic"] == ref["stats"]["bytes_algorithmic"]
+    ctx.close()
+
+
 def test_hypothesis_arena_overflow_is_retried(monkeypatch):
     """The bump-allocated arena of hypothesis point lists starts from an estimate; when a batch
     outgrows it the kernels flag the overflow and the stage is rerun with a larger arena. Forced
