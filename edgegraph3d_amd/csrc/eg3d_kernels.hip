@@ -3,11 +3,11 @@
 // Phase pipeline (DESIGN.md "Kernels"):
 //   k_seed_prep       1 lane / seed       view map of the track, (seed,entry) of every track entry
 //   k1_count_raw      1 lane / (seed,entry)  upper bound of candidate polylines (sizes the slots)
-//   k1_seed_candidates 1 WAVE / (seed,entry) k-way merge of the 30 px grid cells + cooperative
-//                                           closest-point scan of each candidate polyline
-//   k_task_fill       1 lane / (seed,entry)  enumerates (seed, start view, start hit) tasks
-//   k2_epipolar_hits  1 WAVE / task         epiline x candidate polylines, ballot/popcount
-//                                           ordered compaction (count pass + fill pass)
+//   k1_seed_candidates 1 WAVE / (seed,entry) k-way merge of the 30 px grid cells into batches of 64 candidate ids +
+//                                           closest-point scan of a batch's segments as one flat sequence
+//   k_task_fill       1 lane / (seed,entry)  enumerates (seed, start view, start hit) tasks; sums K1's byte counts
+//   k2_epipolar_hits  1 WAVE / task         epiline x the segments of all candidate polylines of a list (flat),
+//                                           ballot/popcount ordered compaction (count pass + fill pass)
 //   k_task_setup      1 lane / task         3-view selection, hypothesis count
 //   k3a_orient, k3a_follow_spec  1 lane / hypothesis, 1 lane / list — the wave SERVES its lanes' triangulation requests
 //                                           densely from 64 slots in LDS (eg3d_k3a_engine.h)
@@ -103,9 +103,11 @@ __global__ void k1_count_raw(DevScene s, SeedsDev sd, uint32_t sv_base, uint32_t
 // ------------------------------------------------------------------ K1 ---------
 // One wavefront per (seed, track entry). Lanes 0..8 each own one grid cell of the (shrunk)
 // 3x3 window and k-way-merge the ascending id lists (wave-min of the heads) so candidates
-// come out ascending and unique with no LDS cap; for every candidate all 64 lanes scan its
-// segments (coalesced 8-byte vertex loads) and an argmin reduction picks the first closest
-// segment. Outputs go to the slot [raw_off[sv], raw_off[sv+1]) sized by k1_count_raw.
+// come out ascending and unique, 64 at a time; the segments of such a batch are scanned as one
+// flat sequence over the 64 lanes and the first closest segment of every candidate falls out of
+// an LDS minimum (below). Outputs go to the slot [raw_off[sv], raw_off[sv+1]) sized by
+// k1_count_raw. (Reference: PLGEdgeManager::detect_nearby_intersections_and_correspondences_plgp,
+// plg_edge_manager.cpp:261-300, its per-view polyline search polyLine_2d_map_search.cpp:46-77.)
 __global__ void __launch_bounds__(256) k1_seed_candidates(DevScene s, SeedsDev sd, uint32_t sv_base, uint32_t n_sv,
                                                          const uint32_t* sv_seed, const uint32_t* raw_off,
                                                          uint32_t* cand_pl, Obs* start_hits, uint32_t* cand_cnt,
