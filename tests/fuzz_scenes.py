@@ -5,8 +5,9 @@ import numpy as np
 from edgegraph3d_amd import host
 
 
-def draw(case):
-    rng = np.random.default_rng(0xE63D + case)
+def draw(case, salt=0):
+    """salt != 0: another random stream for the same case shape (tools/fuzz_campaign.py)."""
+    rng = np.random.default_rng(0xE63D + case + 100003 * salt)
     cfg = host.default_config(1)
     cfg.n_views = int(rng.integers(3, 28))
     cfg.n_seeds = int(rng.integers(40, 160))
