@@ -49,6 +49,34 @@ def test_point_segment_distance_clamps_and_degenerate(L):
     assert hs.lib().hostsim_seg_closest(13, 4, 0, 0, 10, 0, D.np_ptr(q, C.c_float)) == 25.0 and tuple(q) == (10.0, 0.0)
 
 
+def test_point_segment_distances_are_never_negative_so_their_bits_order_like_their_values(L):
+    """K1 picks a candidate polyline's first closest segment as the minimum of 64-bit keys (bits of the squared distance :
+    segment index) in LDS. That is the oracle's `d < best` scan (smallest distance, then smallest index) iff the squared
+    distances are >= +0 — never -0, never negative — because only then do IEEE-754 bit patterns order like the values.
+    minimum_distancesq returns dx*dx + dy*dy of single-precision differences: checked here on random and edge inputs
+    (zero-length segments, the point on the segment, on a vertex, huge and tiny coordinates), on the oracle and on the
+    device-side body."""
+    rng = np.random.default_rng(20240929)
+    n = 200000
+    scale = rng.choice(np.float32([1e-30, 1e-3, 1.0, 1e3, 1e7]), n)
+    P = (rng.normal(0, 1, (n, 6)).astype(np.float32) * scale[:, None]).astype(np.float32)
+    P[::7, 4:6] = P[::7, 2:4]          # zero-length segments
+    P[::11, 0:2] = P[::11, 2:4]        # the point on the first vertex
+    P[::13, 0:2] = (P[::13, 2:4] + P[::13, 4:6]) * np.float32(0.5)   # (about) on the segment
+    proj = f32(0, 0)
+    H = hs.lib()
+    d_or = np.array([L.orc_minimum_distancesq(*map(float, r), D.np_ptr(proj, C.c_float)) for r in P[:20000]], np.float32)
+    d_dev = np.array([H.hostsim_seg_closest(*map(float, r), D.np_ptr(proj, C.c_float)) for r in P[:20000]], np.float32)
+    assert np.array_equal(d_or.view(np.uint32), d_dev.view(np.uint32))
+    assert not np.signbit(d_or).any() and not np.isnan(d_or).any()
+    # the ordering claim itself, on all non-negative single-precision values incl. +0, subnormals and +inf
+    a = np.abs(rng.normal(0, 1, n).astype(np.float32) * scale)
+    a[:4] = [0.0, np.float32(1e-45), np.finfo(np.float32).max, np.inf]
+    b = np.roll(a, 1)
+    assert np.array_equal(a < b, a.view(np.uint32) < b.view(np.uint32))
+    assert np.array_equal(a == b, a.view(np.uint32) == b.view(np.uint32))
+
+
 def test_segment_line_intersection_endpoints_and_parallel(L):
     inter = f32(0, 0)
     par, ovl = C.c_int(), C.c_int()
