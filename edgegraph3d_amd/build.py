@@ -21,10 +21,15 @@ HIP_LIB = os.path.join(PKG, "libeg3d.so")
 # -ffp-contract=off everywhere: decisions on the path are float threshold tests and the
 # arithmetic contract forbids FMA formation on host and device alike.
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-Wall"]
-# -O2, not -O3: the expand kernel of the small-scene class is 2-3 % faster (C3': 46.1-46.2 against 47.1-47.5 ms one step at a
-# time, 43.3-43.9 against 44.0-44.5 ms per step in flight; the other kernels and workloads are the same within noise) — the
-# extra unrolling / inlining of -O3 costs this register-bound kernel more than it buys. Results are bit-identical.
-HIP_FLAGS = ["--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+# Optimisation switches of the device code, chosen by measurement on the MI355X. The expand
+# kernel is register-bound at its 128 VGPRs (4 waves per SIMD): what lengthens live ranges or adds induction variables costs
+# it more than it buys. Each step below was kept because the kernel got faster (C3', one step at a time: -O3 47.1-47.5 ms;
+# -O2 46.0-46.3; vectorizers off 45.3-45.4; no machine LICM 45.0-45.4; no loop strength reduction 43.7-44.3; no GVN-PRE,
+# no pre-RA machine scheduler 43.6-43.7; C4's step in flight 1737 -> 1673 ms); the other kernels are the same within
+# noise. Results are bit-identical (the whole GPU suite runs on this build).
+HIP_OPT_FLAGS = ["-O2", "-fno-slp-vectorize", "-fno-vectorize", "-mllvm", "-disable-machine-licm", "-mllvm", "-disable-lsr",
+                 "-mllvm", "-enable-pre=false", "-mllvm", "-enable-load-pre=false", "-mllvm", "-enable-misched=false"]
+HIP_FLAGS = ["--offload-arch=gfx950"] + HIP_OPT_FLAGS + ["-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
              "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-rdc",
              "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 
