@@ -181,7 +181,7 @@ EG3D_HD bool select_task(const HypResult* res, uint32_t h0, uint32_t h1, ChainSe
 // Scratch slice layout of one chain (bytes); all sub-arrays 16-byte aligned (Obs is one 128-bit word).
 struct ChainLayout {
   uint32_t cap_pts, pool_cap, tmp_cap, n_views;
-  size_t off_pts, off_pool, off_sdir, off_edir, off_p1, off_p2, off_cand, off_slots, off_epc, off_ta, off_tb, off_tm, total;
+  size_t off_pts, off_pool, off_sdir, off_edir, off_p1, off_p2, off_cand, off_slots, off_epc, off_ta, off_tb, off_tm, off_mbox, total;
 };
 EG3D_HD size_t align8(size_t v) { return (v + 15) & ~(size_t)15; }  // (name kept: 16-byte alignment)
 EG3D_HD ChainLayout chain_layout(uint32_t cap_pts, uint32_t pool_cap, uint32_t n_views) {
@@ -215,6 +215,8 @@ EG3D_HD ChainLayout chain_layout(uint32_t cap_pts, uint32_t pool_cap, uint32_t n
   o = align8(o + sizeof(Obs) * L.tmp_cap);
   L.off_tm = o;
   o = align8(o + L.tmp_cap);
+  L.off_mbox = o;  // answer of a single solve of the chain state machine (eg3d_chain_sm.h: SmMbox, 16 bytes)
+  o = align8(o + 16);
   L.total = o;
   return L;
 }

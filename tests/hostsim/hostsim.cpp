@@ -14,6 +14,7 @@
 static unsigned long long g_stat[8], g_hist[2][16], g_hsum[2][16];
 #define EG3D_STAT(i) (g_stat[i]++)
 #include "eg3d_dev_pipeline.h"
+#include "eg3d_chain_sm.h"
 
 using namespace eg3d;
 
@@ -62,6 +63,62 @@ static int build_dev_scene(const eg3d_scene* sc, HostScene& hs) {
   d.g4_off = hs.g4_off.data();
   d.g4_ids = hs.g4_ids.data();
   return 0;
+}
+
+// The expand stage as the chain STATE MACHINE of eg3d_chain_sm.h (what the engine kernel k3c runs, one lane per
+// chain) with a sequential server: requests are answered one after the other by the plain solver / candidate code.
+static unsigned long long g_sm[16];  // advances, GN batches, GN requests, rows, closest batches, closest items, by batch kind [8..]
+static void run_chain_machine(const DevScene& ds, const StageAView& a, const TaskDesc& d, const ChainSeed& cs, uint32_t hyp_base,
+                              const HypResult* res, const HPoint* arena, const int32_t* map_view, const uint32_t* map_entry,
+                              const uint32_t* map_n, const ChainLayout& L, unsigned char* slice, ChainOut& out) {
+  SmChain q;
+  sm_begin(ds, a, d, cs, hyp_base, res, arena, map_view, map_entry, map_n, L, slice, (SmMbox*)(slice + L.off_mbox), q);
+  const SmEnvSeq env;
+  for (;;) {
+    sm_advance(env, ds, a, q);
+    g_sm[0]++;
+    if (q.k.wait == SM_DONE) break;
+    if (q.k.wait == SM_WAIT_GN) {
+      g_sm[1]++;
+      g_sm[8 + (q.k.gn_kind & 7)]++;
+      for (int j = q.k.gn_issued; j < q.k.gn_count; j++) {
+        SmGnReq r;
+        if (!sm_gn_request(q, j, r)) continue;
+        g_sm[2]++;
+        g_sm[3] += (unsigned long long)(r.nblock + (r.has_extra ? 1 : 0));
+        Obs ex;
+        ex.view = (uint32_t)r.ex_view;
+        ex.pl = 0;
+        ex.seg = 0;
+        ex.x = r.ex_x;
+        ex.y = r.ex_y;
+        ArrayCursor cur;
+        cur.a = r.base;
+        cur.n = r.nblock;
+        cur.extra = r.has_extra ? &ex : nullptr;
+        cur.i = 0;
+        const double X0[3] = {(double)r.X0[0], (double)r.X0[1], (double)r.X0[2]};
+        float X[3] = {0.f, 0.f, 0.f};
+        const bool ok = gauss_newton_f64(ds.cam_P, cur, X0, X);
+        *r.resOk = ok ? 1u : 0u;
+        if (ok) {
+          r.resX[0] = X[0];
+          r.resX[1] = X[1];
+          r.resX[2] = X[2];
+        }
+      }
+      q.k.gn_issued = q.k.gn_count;
+      q.k.wait = SM_RUN;
+    } else if (q.k.wait == SM_WAIT_CL) {
+      g_sm[4]++;
+      for (int i = q.k.cl_from; i < q.k.cl_to; i++) {
+        sm_closest_item(ds, q.c, q.k.v, i);
+        g_sm[5]++;
+      }
+      q.k.wait = SM_RUN;
+    }
+  }
+  sm_finish(q, out);
 }
 
 extern "C" int hostsim_match(const eg3d_scene* sc, const eg3d_seeds* seeds, uint32_t b, uint32_t e,
@@ -137,6 +194,7 @@ extern "C" int hostsim_match(const eg3d_scene* sc, const eg3d_seeds* seeds, uint
   }
   const uint32_t n_hyp = hyp_off[nt];
   for (int i = 0; i < 8; i++) g_stat[i] = 0;
+  for (int i = 0; i < 16; i++) g_sm[i] = 0;
   // K3a
   std::vector<HypResult> res(n_hyp ? n_hyp : 1);
   std::vector<HPoint> arena;
@@ -215,9 +273,13 @@ extern "C" int hostsim_match(const eg3d_scene* sc, const eg3d_seeds* seeds, uint
   std::vector<unsigned char> scratch(L.total * (chains.size() ? chains.size() : 1));
   std::vector<ChainOut> couts(chains.size() ? chains.size() : 1);
   uint64_t np = 0, no = 0;
+  const unsigned long long sm_walks0 = g_stat[5], sm_segs0 = g_stat[6];
   for (size_t j = 0; j < chains.size(); j++) {
     const ChainSeed& cs = chains[j];
-    if (slot_step)
+    if (slot_step == 2)
+      run_chain_machine(ds, a, tasks[cs.task], cs, hyp_off[cs.task], res.data(), arena.data(), map_view.data(),
+                        map_entry.data(), map_n.data(), L, scratch.data() + L.total * j, couts[j]);
+    else if (slot_step)
       expand_chain(TeamSeqSlots(), ds, a, tasks[cs.task], cs, hyp_off[cs.task], res.data(), arena.data(),
                    map_view.data(), map_entry.data(), map_n.data(), L, scratch.data() + L.total * j, couts[j]);
     else
@@ -226,6 +288,17 @@ extern "C" int hostsim_match(const eg3d_scene* sc, const eg3d_seeds* seeds, uint
     flags |= couts[j].flags;
     np += couts[j].n_points;
     no += couts[j].n_obs;
+  }
+  if (slot_step == 2 && getenv("HOSTSIM_SM_STATS")) {  // stage 0 of the engine: what the chains ask for, per chain
+    const double nc = chains.size() ? (double)chains.size() : 1.0;
+    fprintf(stderr,
+            "hostsim chain machine: %zu chains, %llu points; per chain: %.1f blocking points (GN batches %.1f, CLOSEST batches %.1f), "
+            "%.1f solves of %.2f rows, %.1f closest items; GN batches by kind epc %.2f presolve %.2f central %.2f sides %.2f list %.2f "
+            "listadd %.2f; line walks %.1f (+%.2f segments beyond the first each)\n",
+            chains.size(), (unsigned long long)np, g_sm[0] / nc, g_sm[1] / nc, g_sm[4] / nc, g_sm[2] / nc,
+            g_sm[2] ? (double)g_sm[3] / (double)g_sm[2] : 0.0, g_sm[5] / nc, g_sm[8 + SMB_EPC] / nc, g_sm[8 + SMB_PRESOLVE] / nc,
+            g_sm[8 + SMB_CENTRAL] / nc, g_sm[8 + SMB_SIDES] / nc, g_sm[8 + SMB_LIST] / nc, g_sm[8 + SMB_LISTADD] / nc,
+            (g_stat[5] - sm_walks0) / nc, (g_stat[5] - sm_walks0) ? (double)(g_stat[6] - sm_segs0) / (double)(g_stat[5] - sm_walks0) : 0.0);
   }
   // K4
   out->n_points = np;

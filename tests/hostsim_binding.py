@@ -40,7 +40,7 @@ def lib():
 def match(scene_ptr, seeds_ptr, begin, end, cand_struct, hyp_cap=192, chain_cap=768, pool_cap=8192, slot_step=False):
     e = D.EdgePoints()
     rc = lib().hostsim_match(scene_ptr, seeds_ptr, begin, end, C.byref(cand_struct), hyp_cap, chain_cap, pool_cap,
-                             1 if slot_step else 0, C.byref(e))
+                             int(slot_step), C.byref(e))
     if rc != 0:
         raise RuntimeError("hostsim_match rc=%d" % rc)
     d = D.edgepoints_to_dict(e)

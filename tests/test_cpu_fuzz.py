@@ -18,10 +18,13 @@ def test_random_mutated_scene_hostsim_vs_oracle(case):
     o = ob.Oracle(C.byref(sa.c))
     ref = o.match(C.byref(seeds.c), 0, n, 1)
     cand = o.candidates_raw(C.byref(seeds.c), 0, n)
-    got = hs.match(C.byref(sa.c), C.byref(seeds.c), 0, n, cand, slot_step=bool(case & 1))
-    rep = compare_edgepoints(ref, got)
-    assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], (case, rep["msgs"][:3])
-    assert got["n_chains"] == ref["stats"]["n_chains"] and got["n_tasks"] == ref["stats"]["n_tasks"]
+    # the team form of the expand stage (plain / slot step by case), then the chain state machine the engine kernel runs
+    for mode in (int(bool(case & 1)), 2):
+        got = hs.match(C.byref(sa.c), C.byref(seeds.c), 0, n, cand, slot_step=mode)
+        rep = compare_edgepoints(ref, got)
+        assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], (case, mode, rep["msgs"][:3])
+        assert got["n_chains"] == ref["stats"]["n_chains"] and got["n_tasks"] == ref["stats"]["n_tasks"]
+        assert got["flags"] == ref["flags"], (case, mode)
 
 
 @pytest.mark.parametrize("case", range(6))
@@ -33,9 +36,10 @@ def test_hostile_numeric_inputs_hostsim_vs_oracle(case):
     o = ob.Oracle(C.byref(sa.c))
     ref = o.match(C.byref(seeds.c), 0, n, 1)
     cand = o.candidates_raw(C.byref(seeds.c), 0, n)
-    got = hs.match(C.byref(sa.c), C.byref(seeds.c), 0, n, cand)
-    rep = compare_edgepoints(ref, got)
-    assert rep["ok"] and rep["bitexact_X"], (case, rep["msgs"][:3])
+    for mode in (0, 2):
+        got = hs.match(C.byref(sa.c), C.byref(seeds.c), 0, n, cand, slot_step=mode)
+        rep = compare_edgepoints(ref, got)
+        assert rep["ok"] and rep["bitexact_X"], (case, mode, rep["msgs"][:3])
 
 
 def _mutated_cloud(case):
