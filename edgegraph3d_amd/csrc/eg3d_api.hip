@@ -115,6 +115,9 @@ struct HostGrids {
 // inherit them) — the hot path never calls getenv:
 //   EG3D_K3A_ENGINE_WAVES=n  wavefronts per SIMD the K3a engine launches (default 2 = what its 256-VGPR build allows)
 //   EG3D_K3A_ENGINE_LANES=n  lanes of a K3a wavefront that take work (default: 64, fewer for small batches)
+#ifndef EG3D_K3B_ENGINE_DEFAULT
+#define EG3D_K3B_ENGINE_DEFAULT 0
+#endif
 //   EG3D_HYP_CAP=n         tests: points per following direction of the hypothesis stage (default 160; a list that would
 //                          outgrow it raises EG3D_FLAG_HYP_OVERFLOW and the call returns EG3D_ERR_CAPACITY)
 //   EG3D_SLOTS_PER_XCD=n   tests: working slices of the expand stage per XCD (default: what can be resident + margin)
@@ -125,8 +128,14 @@ struct HostGrids {
 //   EG3D_NO_LPT=1          launch chains in identity order instead of longest-first (diagnostic)
 //   EG3D_K3B_FULL=1        always run the general build of the expand kernel (default: the build for the scene's class —
 //                          polylines of <= 512 vertices and <= 28 views: small, >= 29 views: many views; general otherwise)
+//   EG3D_K3B_ENGINE=0|1    expand stage: 1 = the lane-per-chain engine (k3c_engine, eg3d_k3c_engine.h), 0 = one wavefront per
+//                          chain (k3b_expand). EG3D_K3C_WAVES=n waves per SIMD of the engine's grid, EG3D_K3C_LANES=n lanes of a
+//                          wave that own a chain (default: as many waves as fit, then as few lanes as cover the chains)
 struct Tunables {
   int k3a_engine_waves = 0, k3a_engine_lanes = 0;
+  int k3b_engine = EG3D_K3B_ENGINE_DEFAULT, k3c_waves = 0, k3c_lanes = 0;
+  bool assume_short = false;  // EG3D_K3B_ASSUME_SHORT=1 (tests): start with the few-views builds whatever the view count, so that
+                              // the CTR_LONG_REFUSED -> general build retry runs
   bool trace_arena = false;
   bool k3b_full = false;  // EG3D_K3B_FULL=1: always the full expand kernel (diagnostic)
   uint32_t arena_cap0 = 0, hyp_cap = 0;
@@ -137,6 +146,10 @@ struct Tunables {
     Tunables t;
     if (const char* e = getenv("EG3D_K3A_ENGINE_WAVES")) t.k3a_engine_waves = atoi(e);
     if (const char* e = getenv("EG3D_K3A_ENGINE_LANES")) t.k3a_engine_lanes = atoi(e);
+    if (const char* e = getenv("EG3D_K3B_ENGINE")) t.k3b_engine = atoi(e);
+    if (const char* e = getenv("EG3D_K3C_WAVES")) t.k3c_waves = atoi(e);
+    if (const char* e = getenv("EG3D_K3C_LANES")) t.k3c_lanes = atoi(e);
+    if (const char* e = getenv("EG3D_K3B_ASSUME_SHORT")) t.assume_short = e[0] == '1';
     if (const char* e = getenv("EG3D_HYP_CAP")) t.hyp_cap = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("EG3D_ARENA_CAP0")) t.arena_cap0 = (uint32_t)std::max(16, atoi(e));
     if (const char* e = getenv("EG3D_MAX_SCRATCH_MB")) t.max_scratch = (size_t)std::max(1, atoi(e)) << 20;
@@ -178,6 +191,8 @@ struct eg3d_ctx {
   // and the staging area finished chains are packed into (sized from the previous launches; grow-only)
   DevBuf b_pools, b_stage_pts, b_stage_obs, b_stage_used;
   uint32_t slots_per_xcd = 0;
+  int k3c_per_cu = 0;            // resident blocks per CU of the lane-per-chain engine (occupancy query)
+  bool k3b_long_latched = false; // a launch of a few-views build met a solve of > 32 rows: the context runs the general builds from then on
   uint32_t max_pl_vtx = 0;  // vertices of the scene's longest valid polyline
   uint64_t stage_cap_pts = 0, stage_cap_obs = 0;
   hipEvent_t ea[8], eb[8];  // begin/end events per stage: 1 K1, 2 K2, 3 K3a, 4 K3s, 5 K3b, 6 K4, 0 misc, 7 whole call
@@ -566,6 +581,12 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
     const uint32_t cus_per_xcd = (cus + n_xcd - 1u) / n_xcd;
     c->slots_per_xcd = ((uint32_t)per_cu + 1u) * cus_per_xcd + 16u;
     if (c->tune.slots_per_xcd) c->slots_per_xcd = c->tune.slots_per_xcd;  // tests / experiments
+    c->k3c_per_cu = k3c_blocks_per_cu();
+    if (c->k3c_per_cu < 1) {
+      g_err = "eg3d_create: occupancy query of the expand engine failed";
+      eg3d_destroy(c);
+      return EG3D_ERR_HIP;
+    }
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
   // from here on the scene buffers belong to the (shareable) owner, not to this context
@@ -621,6 +642,8 @@ extern "C" int eg3d_clone(eg3d_ctx* parent, eg3d_ctx** out) {
   c->n_simd = parent->n_simd;
   c->arena_per_hyp = parent->arena_per_hyp;
   c->slots_per_xcd = parent->slots_per_xcd;
+  c->k3c_per_cu = parent->k3c_per_cu;
+  c->k3b_long_latched = parent->k3b_long_latched;
   c->max_pl_vtx = parent->max_pl_vtx;
   c->stage_cap_pts = parent->stage_cap_pts;  // sizing hints only: the clone allocates its own staging area
   c->stage_cap_obs = parent->stage_cap_obs;
@@ -963,15 +986,34 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
     uint32_t* const saved_bytes = c->b_scanchk.as<uint32_t>() + 4;  // device copy of the byte counter before this chunk
     HIP_TRY(hipMemcpyAsync(saved_bytes, &c->b_ctr.as<Counters>()->bytes, sizeof(unsigned long long),
                            hipMemcpyDeviceToDevice, st));
-    BUF_TRY(c->b_cscratch.ensure(L.total * 8 * (size_t)c->slots_per_xcd));
+    // the expand stage's two forms: one wavefront per chain on XCD-affine slots (k3b_expand), or the lane-per-chain
+    // engine (k3c_engine): n_waves single-wave blocks whose first eng_lanes lanes own a working slice each
+    const bool engine = c->tune.k3b_engine != 0;
+    uint32_t eng_waves = 0, eng_lanes = 64;
     SlotPools pools;
-    pools.slots_per_xcd = c->slots_per_xcd;
-    pools.ring_n = 1;
-    while (pools.ring_n <= c->slots_per_xcd) pools.ring_n <<= 1;
-    pools.stride = 32 + pools.ring_n;
-    BUF_TRY(c->b_pools.ensure(sizeof(uint32_t) * 8 * (size_t)pools.stride));
-    pools.base = c->b_pools.as<uint32_t>();
-    launch_pool_init(st, pools);
+    pools.base = nullptr;
+    pools.stride = pools.ring_n = pools.slots_per_xcd = 0;
+    if (engine) {
+      const uint32_t per_simd = (uint32_t)(c->tune.k3c_waves > 0 ? c->tune.k3c_waves : std::max(1, c->k3c_per_cu / 4));
+      const uint32_t waves_max = c->n_simd * per_simd;
+      if (c->tune.k3c_lanes > 0)
+        eng_lanes = (uint32_t)std::min(64, c->tune.k3c_lanes);
+      else
+        while (eng_lanes > 8 && (uint64_t)waves_max * (eng_lanes / 2) >= nc) eng_lanes /= 2;
+      eng_waves = std::max<uint32_t>(1, std::min<uint32_t>(waves_max, (nc + eng_lanes - 1) / eng_lanes));
+      BUF_TRY(c->b_cscratch.ensure(L.total * (size_t)eng_waves * eng_lanes));
+      BUF_TRY(c->b_queue.ensure(4 * sizeof(uint32_t)));
+      HIP_TRY(hipMemsetAsync(c->b_queue.p, 0, 4 * sizeof(uint32_t), st));
+    } else {
+      BUF_TRY(c->b_cscratch.ensure(L.total * 8 * (size_t)c->slots_per_xcd));
+      pools.slots_per_xcd = c->slots_per_xcd;
+      pools.ring_n = 1;
+      while (pools.ring_n <= c->slots_per_xcd) pools.ring_n <<= 1;
+      pools.stride = 32 + pools.ring_n;
+      BUF_TRY(c->b_pools.ensure(sizeof(uint32_t) * 8 * (size_t)pools.stride));
+      pools.base = c->b_pools.as<uint32_t>();
+      launch_pool_init(st, pools);
+    }
     // staging area: what the previous launches needed, or a first guess (an overflowing launch is repeated once
     // with the exact need, which the output scans report)
     {
@@ -1021,12 +1063,25 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
     if (!use_lpt)  // identity order (diagnostic): chain j runs in block j
       HIP_TRY(hipMemcpyAsync(c->b_order.p, c->b_cidx.p, sizeof(uint32_t) * nc, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipEventRecord(c->ea[5], st));
+    // scene class of the launch: solves of more than 32 rows (EG3D_GN_PACK_MAX) need the builds with the solver's
+    // long-request path. Few views normally means none (one observation per view), and the smaller builds run; a point
+    // that repeats a view can exceed it — the kernel then raises CTR_LONG_REFUSED and the chunk is redone with the general
+    // build (k3b_full latched for the context), like the capacity overflows below.
+    const bool general = c->tune.k3b_full || c->k3b_long_latched || c->max_pl_vtx > EG3D_STAGE_VTX_HOST;
+    if (engine)
+      launch_k3c(st, eng_waves, eng_lanes, c->ds, B.a, c->b_tasks.as<TaskDesc>(), c->b_chains.as<ChainSeed>() + c0, nc,
+                 c->b_hyp_off.as<uint32_t>(), c->b_res.as<HypResult>(), c->b_arena.as<HPoint>(), c->b_map_view.as<int32_t>(),
+                 c->b_map_entry.as<uint32_t>(), c->b_map_n.as<uint32_t>(), L, c->b_cscratch.as<unsigned char>(), stage,
+                 c->b_couts.as<ChainOut>(), c->b_cpts.as<uint32_t>(), c->b_cobs.as<uint32_t>(), c->b_ctr.as<Counters>(),
+                 c->b_order.as<uint32_t>(), c->b_queue.as<uint32_t>(),
+                 (c->tune.k3b_full || c->k3b_long_latched || (c->V > EG3D_SMALL_SCENE_VIEWS_HOST && !c->tune.assume_short)) ? 1 : 0);
+    else
     launch_k3b(st, c->ds, B.a, c->b_tasks.as<TaskDesc>(), c->b_chains.as<ChainSeed>() + c0, nc,
                c->b_hyp_off.as<uint32_t>(), c->b_res.as<HypResult>(), c->b_arena.as<HPoint>(),
                c->b_map_view.as<int32_t>(), c->b_map_entry.as<uint32_t>(), c->b_map_n.as<uint32_t>(), L,
                c->b_cscratch.as<unsigned char>(), pools, stage, c->b_couts.as<ChainOut>(), c->b_cpts.as<uint32_t>(),
                c->b_cobs.as<uint32_t>(), c->b_ctr.as<Counters>(), c->b_order.as<uint32_t>(),
-               (c->tune.k3b_full || c->max_pl_vtx > EG3D_STAGE_VTX_HOST) ? 1 : c->V > EG3D_SMALL_SCENE_VIEWS_HOST ? 2 : 0);
+               general ? 1 : (c->V > EG3D_SMALL_SCENE_VIEWS_HOST && !c->tune.assume_short) ? 2 : 0);
     HIP_TRY(hipEventRecord(c->eb[5], st));
     // the two output scans are queued right behind K3b; its counters (capacity overflow?) and both totals
     // come back in ONE read-back
@@ -1050,8 +1105,18 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
       if (!overflow && rb.item(iw)[1]) return wrapped_error("observations of one chunk");
     }
     if (hc.flags & CTR_LONG_REFUSED) {
-      g_err = "eg3d: internal: the few-views build of the expand kernel met a solve of more than 32 rows";
-      return EG3D_ERR_HIP;
+      // a point of a few-views scene carries more than 32 observations (a view repeated on a track): valid input — the
+      // general build solves it. Latch it for the context, restore the byte counter and redo this chunk.
+      if (c->k3b_long_latched) {
+        g_err = "eg3d: internal: the general build of the expand kernel refused a solve";
+        return EG3D_ERR_HIP;
+      }
+      c->k3b_long_latched = true;
+      HIP_TRY(hipMemcpyAsync(&c->b_ctr.as<Counters>()->bytes, saved_bytes, sizeof(unsigned long long),
+                             hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      chunk = 0;  // do not advance
+      continue;
     }
     if (hc.flags & CTR_SLOT_STARVED) {
       g_err = "eg3d: internal: the expand kernel found no free working slice (slot pool smaller than the residency)";

@@ -223,7 +223,7 @@ EG3D_HD bool sm_gn_request(SmChain& q, int j, SmGnReq& r) {
 
 // CLOSEST item: the candidate of chain point i in view v (view_candidates of eg3d_dev_expand.h with one member per
 // point), stored in the candidate array.
-EG3D_HD void sm_closest_item(const DevScene& s, Chain& c, int v, int i) {
+EG3D_HD void sm_closest_item(const DevScene& s, const ChainPt* pts, const Obs* pool, ViewCand* cand, int head, int v, int i) {
   const float* P = s.cam_P + (size_t)v * 16;
   ViewCand vc;
   vc.valid = 0;
@@ -234,8 +234,8 @@ EG3D_HD void sm_closest_item(const DevScene& s, Chain& c, int v, int i) {
   vc.cX[0] = vc.cX[1] = vc.cX[2] = 0.0f;
   vc.eok = 0;
   vc.ea = vc.eb = vc.ec = 0.0f;
-  const ChainPt& pt = chain_at(c, i);
-  const Obs first = c.pool[pt.off];
+  const ChainPt pt = pts[head + i];
+  const Obs first = pool[pt.off];
   vc.eok = epiline(s.F, s.F_valid, s.n_views, first.view, v, first.x, first.y, vc.ea, vc.eb, vc.ec) ? 1u : 0u;
   float u, w;
   project_f32(P, pt.X[0], pt.X[1], pt.X[2], u, w);
@@ -253,8 +253,9 @@ EG3D_HD void sm_closest_item(const DevScene& s, Chain& c, int v, int i) {
     vc.x = cp.x;
     vc.y = cp.y;
   }
-  c.cand[c.head + i] = vc;
+  cand[head + i] = vc;
 }
+EG3D_HD void sm_closest_item(const DevScene& s, Chain& c, int v, int i) { sm_closest_item(s, c.pts, c.pool, c.cand, c.head, v, i); }
 
 // Build the initial chain (expand_chain's first part) and put the machine before its first view.
 EG3D_HD void sm_begin(const DevScene& s, const StageAView& a, const TaskDesc& d, const ChainSeed& cs, uint32_t hyp_base,
@@ -338,6 +339,14 @@ EG3D_HD void sm_begin(const DevScene& s, const StageAView& a, const TaskDesc& d,
   k.gn_from = 0;
   k.gn_list = nullptr;
   k.gn_m = 0;
+  k.gn_extra.view = 0;
+  k.gn_extra.pl = 0;
+  k.gn_extra.seg = 0;
+  k.gn_extra.x = k.gn_extra.y = 0.0f;
+  k.gn_X0[0] = k.gn_X0[1] = k.gn_X0[2] = 0.0f;
+  k.o = k.gn_extra;
+  k.Xc[0] = k.Xc[1] = k.Xc[2] = 0.0f;
+  k.X[0] = k.X[1] = k.X[2] = 0.0f;
   k.cl_from = k.cl_to = 0;
   k.v = -1;
   k.j = 0;

@@ -478,35 +478,17 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
   return ok;
 }
 
-// Must be called by all 64 lanes of the (single-wave) block; every request must have >= 2 rows. On
-// return lane j holds the verdict and solution of ITS request (false when !want); the request
-// table keeps them too (L.res_ok[j], L.x0[j]) until the next call.
+// The solver proper: the request table (gbase, n16, ex_*, x0) of this window is ALREADY in LDS — written by
+// coop_gn_groups below (request j by lane j) or by the engine kernel (eg3d_k3c_engine.h: entries written by whichever
+// lanes own the requests) and made visible by a barrier. Lane j < EG3D_COOP_REQ passes want / n_req of entry j. Must be
+// called by all 64 lanes; every request must have >= 2 rows. On return the table holds verdict and solution of every
+// entry (L.res_ok[j], L.x0[j]) until the next call; lane j also gets its own as the return value / Xout.
 template <int KEEP = 0, bool LONG_GN = true>
-__device__ __forceinline__ bool coop_gn_groups(const float* cam_P, CoopLds& L, bool want_in, const Obs* base, int nblock,
-                                               bool has_extra, int32_t ex_view, float ex_x, float ex_y,
-                                               const float X0[3], float Xout[3]) {
+__device__ __forceinline__ bool coop_gn_run(const float* cam_P, CoopLds& L, bool want, int n_req, float Xout[3]) {
   const int lane = (int)(threadIdx.x & 63u);
-#if defined(EG3D_SECTION_TIMING)
-  const unsigned long long gg_begin_ = __builtin_readcyclecounter();
-#endif
-  const bool want = want_in && lane < EG3D_COOP_REQ;  // the request table has EG3D_COOP_REQ entries (callers keep to it)
-  const int n_req = want ? nblock + (has_extra ? 1 : 0) : 0;
   const bool is_short = want && n_req <= EG3D_GN_PACK_MAX;
   const bool is_long = want && n_req > EG3D_GN_PACK_MAX;
   const unsigned long long m_short = __ballot(is_short), m_long = __ballot(is_long);
-  if ((m_short | m_long) == 0ull) return false;
-  if (lane < EG3D_COOP_REQ) {
-    L.gbase[lane] = base;
-    L.n16[lane] = (uint16_t)(n_req | (has_extra ? 0x8000 : 0));
-    L.ex_view[lane] = ex_view;
-    L.ex_x[lane] = ex_x;
-    L.ex_y[lane] = ex_y;
-    L.x0[lane][0] = X0[0];
-    L.x0[lane][1] = X0[1];
-    L.x0[lane][2] = X0[2];
-    L.res_ok[lane] = 0;
-  }
-  __syncthreads();
   // ---- short requests: rounds of whole requests packed into <= 64 rows, in lane order
   if (m_short) {
     const int ns = is_short ? n_req : 0;
@@ -644,6 +626,36 @@ __device__ __forceinline__ bool coop_gn_groups(const float* cam_P, CoopLds& L, b
   Xout[2] = L.x0[tl][2];
   const bool res = want && L.res_ok[tl] != 0;
   __syncthreads();  // the table may be rewritten by the next window
+  return res;
+}
+
+// Must be called by all 64 lanes of the (single-wave) block; every request must have >= 2 rows. On
+// return lane j holds the verdict and solution of ITS request (false when !want); the request
+// table keeps them too (L.res_ok[j], L.x0[j]) until the next call.
+template <int KEEP = 0, bool LONG_GN = true>
+__device__ __forceinline__ bool coop_gn_groups(const float* cam_P, CoopLds& L, bool want_in, const Obs* base, int nblock,
+                                               bool has_extra, int32_t ex_view, float ex_x, float ex_y,
+                                               const float X0[3], float Xout[3]) {
+  const int lane = (int)(threadIdx.x & 63u);
+#if defined(EG3D_SECTION_TIMING)
+  const unsigned long long gg_begin_ = __builtin_readcyclecounter();
+#endif
+  const bool want = want_in && lane < EG3D_COOP_REQ;  // the request table has EG3D_COOP_REQ entries (callers keep to it)
+  const int n_req = want ? nblock + (has_extra ? 1 : 0) : 0;
+  if (__ballot(want) == 0ull) return false;
+  if (lane < EG3D_COOP_REQ) {
+    L.gbase[lane] = base;
+    L.n16[lane] = (uint16_t)(n_req | (has_extra ? 0x8000 : 0));
+    L.ex_view[lane] = ex_view;
+    L.ex_x[lane] = ex_x;
+    L.ex_y[lane] = ex_y;
+    L.x0[lane][0] = X0[0];
+    L.x0[lane][1] = X0[1];
+    L.x0[lane][2] = X0[2];
+    L.res_ok[lane] = 0;
+  }
+  __syncthreads();
+  const bool res = coop_gn_run<KEEP, LONG_GN>(cam_P, L, want, n_req, Xout);
 #if defined(EG3D_SECTION_TIMING)
   if (lane == 0) EG3D_GN_DBG(112, __builtin_readcyclecounter() - gg_begin_);
 #endif

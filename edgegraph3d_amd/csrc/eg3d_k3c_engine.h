@@ -1,0 +1,247 @@
+// eg3d_k3c_engine.h — the expand stage as a LANE-PER-CHAIN engine (gfx950 only; included by eg3d_kernels.hip).
+//
+// k3b_expand (rounds 1-4) gives a chain a whole wavefront: its Gauss-Newton solves and candidate searches spread over
+// the 64 lanes, everything else — every side-walk step, every step of the chain following, every 2-view DLT, all the
+// bookkeeping — is executed wave-uniformly, 64 lanes doing one chain's work. The counters of round 4 put that at 475 k
+// vector instructions per C3' chain against ~90 k of useful work at full density
+// (profiles/r05_experiments/stage0_chain_machine_counts.txt).
+//
+// Here ONE LANE owns a chain. The chain's program is the state machine of eg3d_chain_sm.h, whose only blocking points
+// are batches of Gauss-Newton solves and of candidate searches. A wavefront is a small bulk-synchronous machine:
+//
+//   every iteration   (0) idle lanes take the next chain of the launch (longest first) and build its initial state,
+//                     (1) every lane ADVANCES its machine to its next blocking point — lane-private walks, DLTs, commits,
+//                     (2) lanes whose chain is finished pack it into the launch's staging area,
+//                     (3) the wave DRAINS all pending solves: windows of EG3D_COOP_REQ requests, entries written by
+//                         whichever lanes own them (each owner gets K = 32 / #owners slots per window), solved by the
+//                         lane-group solver of eg3d_dev_coopgn.h — rows of different chains' requests side by side,
+//                         ordered sums => the bits of the sequential solver — answers stored where the machines read them,
+//                     (4) the wave DRAINS all pending candidate items as one flat sequence dealt to the 64 lanes.
+//
+// Results are those of the sequential statement whatever the interleaving: requests are pure functions of a chain's own
+// state, and a machine only resumes when its whole batch is answered.
+#pragma once
+#include "eg3d_chain_sm.h"
+#include "eg3d_dev_coopgn.h"
+
+namespace eg3d {
+
+#ifndef EG3D_K3C_WAVES
+#define EG3D_K3C_WAVES 2 /* waves per SIMD the register allocation aims at (256 VGPRs) */
+#endif
+
+struct K3cShared {
+  CoopLds gn;
+  float* resX[EG3D_COOP_REQ];      // where the answer of window entry j goes
+  uint32_t* resOk[EG3D_COOP_REQ];
+  unsigned char* cl_slice[64];     // candidate drain: working slice, chain head, first point and view of each owner
+  uint32_t cl_excl[65];
+  int32_t cl_head[64], cl_from[64], cl_view[64];
+};
+
+#ifdef EG3D_SECTION_TIMING
+#define K3C_T0() unsigned long long ct_[6] = {0, 0, 0, 0, 0, 0}, cc_[4] = {0, 0, 0, 0}, ct0_ = __builtin_readcyclecounter(), ct1_
+#define K3C_T(i) (ct1_ = __builtin_readcyclecounter(), ct_[i] += ct1_ - ct0_, ct0_ = ct1_)
+#define K3C_C(i, v) (cc_[i] += (v))
+#else
+#define K3C_T0() ((void)0)
+#define K3C_T(i) ((void)0)
+#define K3C_C(i, v) ((void)0)
+#endif
+
+template <bool LONG_GN>
+__global__ void __launch_bounds__(64, EG3D_K3C_WAVES) k3c_engine_t(DevScene s, StageAView a, const TaskDesc* tasks,
+                                                                  const ChainSeed* chains, uint32_t n_chains,
+                                                                  const uint32_t* hyp_off, const HypResult* res,
+                                                                  const HPoint* arena, const int32_t* map_view,
+                                                                  const uint32_t* map_entry, const uint32_t* map_n,
+                                                                  ChainLayout L, unsigned char* slices, StageBuf stage,
+                                                                  ChainOut* outs, uint32_t* out_points, uint32_t* out_obs,
+                                                                  Counters* ctr, const uint32_t* order, uint32_t* queue,
+                                                                  uint32_t lanes_per_wave) {
+  __shared__ K3cShared sh;
+  const uint32_t lane = threadIdx.x;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  unsigned char* const slice = slices + L.total * ((size_t)blockIdx.x * lanes_per_wave + (lane < lanes_per_wave ? lane : 0u));
+  if (lane == 0) {
+    sh.gn.cams_mid_range = s.cams_mid_range ? 1 : 0;
+    sh.gn.long_refused = 0;
+  }
+  __syncthreads();
+  SmChain q;
+  q.k.wait = SM_DONE;
+  q.k.gn_count = q.k.gn_issued = 0;
+  q.k.cl_from = q.k.cl_to = 0;
+  bool have = false, exhausted = lane >= lanes_per_wave;
+  uint32_t jchain = 0, flags_acc = 0;
+  unsigned long long bytes_acc = 0;
+  const SmEnvSeq env;
+  K3C_T0();
+  for (;;) {
+    // ---- (0) the next chain
+    if (!have && !exhausted) {
+      const uint32_t i = atomicAdd(queue, 1u);
+      if (i >= n_chains) {
+        exhausted = true;
+      } else {
+        jchain = order[i];
+        const ChainSeed cs = chains[jchain];
+        sm_begin(s, a, tasks[cs.task], cs, hyp_off[cs.task], res, arena, map_view, map_entry, map_n, L, slice,
+                 (SmMbox*)(slice + L.off_mbox), q);
+        have = true;
+      }
+    }
+    if (!__ballot(have)) break;
+    K3C_T(0);
+    K3C_C(0, 1);
+    K3C_C(1, __popcll(__ballot(have)));
+    // ---- (1) advance
+    if (have) sm_advance(env, s, a, q);
+    K3C_T(1);
+    // ---- (2) finished chains: pack (point headers + observations back to back), report
+    if (have && q.k.wait == SM_DONE) {
+      ChainOut co;
+      sm_finish(q, co);
+      const unsigned long long pb = atomicAdd(&stage.used[0], (unsigned long long)co.n_points);
+      const unsigned long long ob = atomicAdd(&stage.used[1], (unsigned long long)co.n_obs);
+      co.spt = pb;
+      co.sobs = ob;
+      if (pb + co.n_points <= stage.cap_pts && ob + co.n_obs <= stage.cap_obs) {
+        const ChainPt* pts = q.c.pts + q.c.head;
+        StagePt* spt = stage.pts + pb;
+        Obs* sob = stage.obs + ob;
+        for (uint32_t i = 0; i < co.n_points; i++) {
+          const ChainPt p = pts[i];
+          StagePt sp;
+          sp.X[0] = p.X[0];
+          sp.X[1] = p.X[1];
+          sp.X[2] = p.X[2];
+          sp.nobs = p.nobs;
+          spt[i] = sp;
+          const Obs* src = q.c.pool + p.off;
+          for (uint32_t k = 0; k < p.nobs; k++) sob[k] = src[k];
+          sob += p.nobs;
+        }
+      }
+      outs[jchain] = co;
+      out_points[jchain] = co.n_points;
+      out_obs[jchain] = co.n_obs;
+      flags_acc |= co.flags;
+      bytes_acc += co.bytes;
+      have = false;
+    }
+    K3C_T(2);
+    // ---- (3) drain the solves
+    for (;;) {
+      const bool has = have && q.k.wait == SM_WAIT_GN && q.k.gn_issued < q.k.gn_count;
+      const unsigned long long mask = __ballot(has);
+      if (!mask) break;
+      const uint32_t nl = (uint32_t)__popcll(mask);
+      uint32_t K = 1;
+      while (K * 2 * nl <= (uint32_t)EG3D_COOP_REQ) K *= 2;
+      const uint32_t r = (uint32_t)__popcll(mask & lt);
+      const bool taking = has && r * K < (uint32_t)EG3D_COOP_REQ;
+      if (lane < EG3D_COOP_REQ) {
+        sh.gn.n16[lane] = 0;
+        sh.gn.res_ok[lane] = 0;
+      }
+      __syncthreads();
+      if (taking) {
+        uint32_t filled = 0;
+        while (filled < K && q.k.gn_issued < q.k.gn_count) {
+          SmGnReq rq;
+          if (sm_gn_request(q, q.k.gn_issued, rq)) {
+            const uint32_t slot = r * K + filled;
+            sh.gn.gbase[slot] = rq.base;
+            sh.gn.n16[slot] = (uint16_t)((uint32_t)(rq.nblock + (rq.has_extra ? 1 : 0)) | (rq.has_extra ? 0x8000u : 0u));
+            sh.gn.ex_view[slot] = rq.ex_view;
+            sh.gn.ex_x[slot] = rq.ex_x;
+            sh.gn.ex_y[slot] = rq.ex_y;
+            sh.gn.x0[slot][0] = rq.X0[0];
+            sh.gn.x0[slot][1] = rq.X0[1];
+            sh.gn.x0[slot][2] = rq.X0[2];
+            sh.resX[slot] = rq.resX;
+            sh.resOk[slot] = rq.resOk;
+            filled++;
+          }
+          q.k.gn_issued++;
+        }
+      }
+      __syncthreads();
+      {
+        const int n_req = lane < EG3D_COOP_REQ ? (int)(sh.gn.n16[lane] & 0x7fff) : 0;
+        K3C_C(2, __popcll(__ballot(n_req != 0)));
+        float Xr[3];
+        coop_gn_run<0, LONG_GN>(s.cam_P, sh.gn, n_req != 0, n_req, Xr);
+        // answers: the table keeps them until the next window
+        if (n_req != 0) {
+          const uint32_t ok = sh.gn.res_ok[lane];
+          *sh.resOk[lane] = ok;
+          if (ok) {
+            float* X = sh.resX[lane];
+            X[0] = sh.gn.x0[lane][0];
+            X[1] = sh.gn.x0[lane][1];
+            X[2] = sh.gn.x0[lane][2];
+          }
+        }
+      }
+      __syncthreads();  // (answers stored: s_waitcnt vmcnt(0) + barrier, as between a solver batch and its readers in k3b_expand)
+    }
+    if (have && q.k.wait == SM_WAIT_GN) q.k.wait = SM_RUN;
+    K3C_T(3);
+    // ---- (4) drain the candidate items: all of them as one flat sequence
+    {
+      const int cnt = (have && q.k.wait == SM_WAIT_CL) ? q.k.cl_to - q.k.cl_from : 0;
+      if (__ballot(cnt > 0)) {
+        const int incl = wave_incl_scan(cnt);
+        const int total = lane_bcast(incl, 63);
+        sh.cl_excl[lane] = (uint32_t)(incl - cnt);
+        if (lane == 63) sh.cl_excl[64] = (uint32_t)total;
+        sh.cl_slice[lane] = slice;
+        sh.cl_head[lane] = q.c.head;
+        sh.cl_from[lane] = q.k.cl_from;
+        sh.cl_view[lane] = q.k.v;
+        __syncthreads();
+        K3C_C(3, total);
+        for (int f0 = 0; f0 < total; f0 += 64) {
+          const int f = f0 + (int)lane;
+          if (f < total) {
+            uint32_t lo = 0;  // the owner whose range holds f: largest o with excl[o] <= f (owners without items skipped)
+#pragma unroll
+            for (uint32_t step = 32; step; step >>= 1)
+              if (sh.cl_excl[lo + step] <= (uint32_t)f) lo += step;
+            unsigned char* const sl = sh.cl_slice[lo];
+            sm_closest_item(s, (const ChainPt*)(sl + L.off_pts), (const Obs*)(sl + L.off_pool), (ViewCand*)(sl + L.off_cand),
+                            sh.cl_head[lo], sh.cl_view[lo], sh.cl_from[lo] + (f - (int)sh.cl_excl[lo]));
+          }
+        }
+        __syncthreads();
+      }
+      if (have && q.k.wait == SM_WAIT_CL) q.k.wait = SM_RUN;
+    }
+    K3C_T(4);
+  }
+  // ---- the wave's flags and byte count: one atomic each
+  {
+    uint32_t fl = 0;
+#pragma unroll
+    for (uint32_t b = 1; b <= 16u; b <<= 1)
+      if (__ballot((flags_acc & b) != 0)) fl |= b;
+    unsigned long long bsum = bytes_acc;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) bsum += (unsigned long long)__shfl_xor((long long)bsum, d);
+    if (lane == 0) {
+      if (fl) atomicOr(&ctr->flags, fl);
+      if (!LONG_GN && sh.gn.long_refused) atomicOr(&ctr->flags, CTR_LONG_REFUSED);
+      if (bsum) atomicAdd(&ctr->bytes, bsum);
+    }
+  }
+#ifdef EG3D_SECTION_TIMING
+  if (lane == 0) {
+    for (int q_ = 0; q_ < 5; q_++) EG3D_GN_DBG(113 + q_, ct_[q_]);  // (the K3a engine's diagnostic slots are reused by tools/k3c_stats.py builds)
+    for (int q_ = 0; q_ < 4; q_++) EG3D_GN_DBG(120 + q_, cc_[q_]);
+  }
+#endif
+}
+
+}  // namespace eg3d

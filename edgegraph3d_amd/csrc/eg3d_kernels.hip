@@ -1511,6 +1511,34 @@ void launch_k3b(hipStream_t st, DevScene s, StageAView a, const TaskDesc* tasks,
     hipLaunchKernelGGL(k3b_expand, dim3(n_chains), dim3(64), 0, st, s, a, tasks, chains, n_chains, hyp_off, res,
                        arena, map_view, map_entry, map_n, L, slices, pools, stage, outs, out_points, out_obs, ctr, order);
 }
+}  // namespace eg3d
+#include "eg3d_k3c_engine.h"
+namespace eg3d {
+// The expand stage as a lane-per-chain engine (eg3d_k3c_engine.h): n_waves single-wavefront blocks whose first
+// lanes_per_wave lanes each own a working slice (slices: [n_waves * lanes_per_wave] x L.total bytes) and take chains from
+// the launch's queue (*queue zeroed by the caller) until it is empty. long_gn = 0: scenes whose solves all fit a packed
+// round of the solver (<= 32 rows); a longer request raises CTR_LONG_REFUSED and the host repeats the launch with 1.
+static constexpr auto k3c_engine_short = k3c_engine_t<false>;
+static constexpr auto k3c_engine_long = k3c_engine_t<true>;
+int k3c_blocks_per_cu() {
+  int a = 0, b = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, (const void*)k3c_engine_short, 64, 0) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (const void*)k3c_engine_long, 64, 0) != hipSuccess) return 0;
+  return a < b ? a : b;
+}
+void launch_k3c(hipStream_t st, uint32_t n_waves, uint32_t lanes_per_wave, DevScene s, StageAView a, const TaskDesc* tasks,
+                const ChainSeed* chains, uint32_t n_chains, const uint32_t* hyp_off, const HypResult* res, const HPoint* arena,
+                const int32_t* map_view, const uint32_t* map_entry, const uint32_t* map_n, ChainLayout L, unsigned char* slices,
+                StageBuf stage, ChainOut* outs, uint32_t* out_points, uint32_t* out_obs, Counters* ctr, const uint32_t* order,
+                uint32_t* queue, int long_gn) {
+  if (!n_chains) return;
+  if (long_gn)
+    hipLaunchKernelGGL(k3c_engine_long, dim3(n_waves), dim3(64), 0, st, s, a, tasks, chains, n_chains, hyp_off, res, arena,
+                       map_view, map_entry, map_n, L, slices, stage, outs, out_points, out_obs, ctr, order, queue, lanes_per_wave);
+  else
+    hipLaunchKernelGGL(k3c_engine_short, dim3(n_waves), dim3(64), 0, st, s, a, tasks, chains, n_chains, hyp_off, res, arena,
+                       map_view, map_entry, map_n, L, slices, stage, outs, out_points, out_obs, ctr, order, queue, lanes_per_wave);
+}
 void launch_chain_cost(hipStream_t st, StageAView a, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains,
                        uint32_t* cost, uint32_t* idx) {
   if (!n_chains) return;

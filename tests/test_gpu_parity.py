@@ -97,6 +97,29 @@ def test_scene_class_builds_of_the_expand_kernel_agree_with_the_general_one(have
         assert x["flags"] == y["flags"]
 
 
+@pytest.mark.parametrize("engine", [0, 1])
+def test_solve_longer_than_a_packed_round_is_redone_by_the_general_build(have_gpu, monkeypatch, engine):
+    """A few-views build of the expand stage (k3b_expand small scenes / the engine without the solver's long-request
+    path) that meets a solve of more than 32 rows must not fail the call: it raises CTR_LONG_REFUSED, the host latches
+    the general build for the context and redoes the chunk (eg3d_api.hip run_stage_b). Forced here with
+    EG3D_K3B_ASSUME_SHORT=1 on a 40-view scene whose points carry up to 40 observations; cloud == oracle, twice (the
+    second call runs the latched general build from the start)."""
+    cfg = host.default_config(1)
+    cfg.n_views, cfg.n_seeds, cfg.n_curves, cfg.max_track = 40, 60, 14, 12
+    s = host.Synth(cfg)
+    ref = _oracle(s.scene).match(s.seeds, 0, s.n_seeds, nthreads=8)
+    assert int(np.diff(ref["obs_off"].astype(np.int64)).max()) > 33
+    monkeypatch.setenv("EG3D_K3B_ASSUME_SHORT", "1")
+    monkeypatch.setenv("EG3D_K3B_ENGINE", str(engine))
+    ctx = api.Context(s.scene)
+    for _ in range(2):
+        got = ctx.match_refpoints(s.seeds)
+        rep = compare_edgepoints(ref, got)
+        assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], rep["msgs"][:3]
+        assert got["times"]["bytes_algorithmic"] == ref["stats"]["bytes_algorithmic"]
+    ctx.close()
+
+
 def test_seed_range_concatenation(have_gpu):
     """Ranges are independent: [0,n/2) + [n/2,n) == [0,n) (the multi-GPU sharding property)."""
     s = host.Synth(1)
