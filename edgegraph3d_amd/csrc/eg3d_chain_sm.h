@@ -37,11 +37,13 @@ enum : uint32_t {
   SMB_PRESOLVE = 2,  // request j: chain[from + j] + its candidate   -> cand[head + from + j].cok / cX (skipped: no candidate within 4 px)
   SMB_CENTRAL = 3,   // chain[ci] + o                                 -> mbox
   SMB_SIDES = 4,     // j < m1: chain[ci-1-j] + pend1[j].o, else chain[ci+1+(j-m1)] + pend2[j-m1].o -> pendX[j].X / .ok
-  SMB_LIST = 5,      // rows list[0..m) from X0                       -> mbox
-  SMB_LISTADD = 6    // rows list[0..m) + extra from X0               -> mbox
+  SMB_LIST_A = 5,    // rows tmp_a[0..m) from X (the N-view step's candidate list) -> mbox
+  SMB_LISTADD = 6,   // rows tmp_b[0..kept) + tmp_a[fb_i] from X (greedy phase of the fallback) -> mbox
+  SMB_LIST_B = 7     // rows tmp_b[0..3) from X (a 3-subset of the fallback)     -> mbox
 };
 enum : uint32_t {
   SMS_VIEW_NEXT = 0,
+  SMS_EPC_POST,
   SMS_EPC_LOOP,
   SMS_CAND_POST,
   SMS_CAND_DONE,
@@ -70,10 +72,8 @@ enum : uint32_t { SMR_EPC = 0, SMR_VISIT = 1 };
 
 // What a chain is made from (constant for its life).
 struct SmTask {
-  TaskDesc d;
-  ChainSeed cs;
-  uint32_t hyp_base;
-  const int32_t* mv;   // the seed's view map
+  int32_t sel_view[3];  // the three views of the hypothesis (not offered)
+  const int32_t* mv;    // the seed's view map
   const uint32_t* me;
   uint32_t n_map, list_lo;
 };
@@ -85,12 +85,10 @@ struct SmCtl {
   uint32_t gn_kind;
   int32_t gn_count, gn_issued;
   int32_t gn_from;        // PRESOLVE: first chain point of the window
-  const Obs* gn_list;     // LIST / LISTADD: the rows
-  int32_t gn_m;           //   their number
-  Obs gn_extra;           // LISTADD: the extra observation
-  float gn_X0[3];         // LIST / LISTADD: start point
-  // pending CLOSEST batch: chain points [cl_from, cl_to) in view v
+  // pending CLOSEST batch: chain points [cl_from, cl_to) in view v; cl_epi_only: just the epipolar lines of the points'
+  // first observations (before the epipolar hits of a view are tried), not the candidates
   int32_t cl_from, cl_to;
+  uint32_t cl_epi_only;
   // view loop
   int32_t v;
   uint32_t j;
@@ -104,14 +102,14 @@ struct SmCtl {
   Obs o;
   int32_t lo, ci, hi;
   uint32_t ret_to, pre_kind;  // pre_kind: 0 = no speculative central solve, 1 = epcres[e], 2 = cand[head + cur]
-  float Xc[3];
   int32_t which, n1, n2, m1, m2;
-  uint32_t b_alone;  // orientation B walked after A's first solve failed
   uint32_t nd1, nd2;
   int32_t to_start, to_end;
   uint32_t attach_ok;
   // following
   int32_t side, added, st_obs, m;
+  // attach_view: the central solve's point (until the commit); following: start point / result of the step's solve and
+  // the fallback's running point (after the commit) — never live together
   float X[3];
   // 3-subset fallback
   int32_t fi, fj, fk, kept, fb_i;
@@ -195,17 +193,23 @@ EG3D_HD bool sm_gn_request(SmChain& q, int j, SmGnReq& r) {
       r.resOk = &pd->ok;
       break;
     }
-    case SMB_LIST:
+    case SMB_LIST_A:
+    case SMB_LIST_B:
     case SMB_LISTADD: {
-      r.base = k.gn_list;
-      r.nblock = k.gn_m;
+      r.base = k.gn_kind == SMB_LIST_A ? c.tmp_a : c.tmp_b;
+      r.nblock = k.gn_kind == SMB_LIST_A ? k.m : k.gn_kind == SMB_LIST_B ? 3 : k.kept;
       r.has_extra = k.gn_kind == SMB_LISTADD ? 1u : 0u;
-      r.ex_view = (int32_t)k.gn_extra.view;
-      r.ex_x = k.gn_extra.x;
-      r.ex_y = k.gn_extra.y;
-      r.X0[0] = k.gn_X0[0];
-      r.X0[1] = k.gn_X0[1];
-      r.X0[2] = k.gn_X0[2];
+      r.ex_view = 0;
+      r.ex_x = r.ex_y = 0.0f;
+      if (k.gn_kind == SMB_LISTADD) {
+        const Obs ex = c.tmp_a[k.fb_i];
+        r.ex_view = (int32_t)ex.view;
+        r.ex_x = ex.x;
+        r.ex_y = ex.y;
+      }
+      r.X0[0] = k.X[0];
+      r.X0[1] = k.X[1];
+      r.X0[2] = k.X[2];
       r.resX = q.mbox->X;
       r.resOk = &q.mbox->ok;
       return true;
@@ -256,6 +260,17 @@ EG3D_HD void sm_closest_item(const DevScene& s, const ChainPt* pts, const Obs* p
   cand[head + i] = vc;
 }
 EG3D_HD void sm_closest_item(const DevScene& s, Chain& c, int v, int i) { sm_closest_item(s, c.pts, c.pool, c.cand, c.head, v, i); }
+// ... only the epipolar line of the point's first observation (the other fields of the candidate are left alone)
+EG3D_HD void sm_epiline_item(const DevScene& s, const ChainPt* pts, const Obs* pool, ViewCand* cand, int head, int v, int i) {
+  const Obs first = pool[pts[head + i].off];
+  float ea = 0.0f, eb = 0.0f, ec = 0.0f;
+  const uint32_t eok = epiline(s.F, s.F_valid, s.n_views, first.view, v, first.x, first.y, ea, eb, ec) ? 1u : 0u;
+  ViewCand& vc = cand[head + i];
+  vc.eok = eok;
+  vc.ea = ea;
+  vc.eb = eb;
+  vc.ec = ec;
+}
 
 // Build the initial chain (expand_chain's first part) and put the machine before its first view.
 EG3D_HD void sm_begin(const DevScene& s, const StageAView& a, const TaskDesc& d, const ChainSeed& cs, uint32_t hyp_base,
@@ -295,37 +310,43 @@ EG3D_HD void sm_begin(const DevScene& s, const StageAView& a, const TaskDesc& d,
       L1 = (int)(c.pool_cap / 4u);
     }
     const uint32_t p2 = cs.pts2_src != 0xffffffffu ? res[cs.pts2_src].pts2_off : 0u;
-    for (int i = 0; i < L1; i++) {
-      HPoint hp;
-      if (i < centre0) {
-        hp = arena[w.pts1_off + (uint32_t)(centre0 - 1 - i)];
-      } else if (i == centre0) {
-        hypothesis_hits(a, d, cs.task, cs.winner - hyp_base, hp.o);
-        hp.X[0] = w.X[0];
-        hp.X[1] = w.X[1];
-        hp.X[2] = w.X[2];
-        hp.nobs = 3;
-        hp.pad = 0;
-      } else {
-        hp = arena[p2 + (uint32_t)(i - centre0 - 1)];
+    for (int i0 = 0; i0 < L1; i0 += 4) {  // four points requested together (the lane builds its chain alone)
+      HPoint hp[4];
+      for (int b = 0; b < 4; b++) {
+        const int i = i0 + b < L1 ? i0 + b : i0;
+        if (i < centre0) {
+          hp[b] = arena[w.pts1_off + (uint32_t)(centre0 - 1 - i)];
+        } else if (i == centre0) {
+          hypothesis_hits(a, d, cs.task, cs.winner - hyp_base, hp[b].o);
+          hp[b].X[0] = w.X[0];
+          hp[b].X[1] = w.X[1];
+          hp[b].X[2] = w.X[2];
+          hp[b].nobs = 3;
+          hp[b].pad = 0;
+        } else {
+          hp[b] = arena[p2 + (uint32_t)(i - centre0 - 1)];
+        }
       }
-      ChainPt p;
-      p.X[0] = hp.X[0];
-      p.X[1] = hp.X[1];
-      p.X[2] = hp.X[2];
-      p.off = 4u * (uint32_t)i;
-      p.cap = 4;
-      p.nobs = hp.nobs;
-      for (uint32_t k = 0; k < hp.nobs; k++) c.pool[p.off + k] = hp.o[k];
-      c.pts[c.head + i] = p;
+      for (int b = 0; b < 4 && i0 + b < L1; b++) {
+        const int i = i0 + b;
+        ChainPt p;
+        p.X[0] = hp[b].X[0];
+        p.X[1] = hp[b].X[1];
+        p.X[2] = hp[b].X[2];
+        p.off = 4u * (uint32_t)i;
+        p.cap = 4;
+        p.nobs = hp[b].nobs;
+        for (uint32_t k = 0; k < hp[b].nobs; k++) c.pool[p.off + k] = hp[b].o[k];
+        c.pts[c.head + i] = p;
+      }
     }
     c.len = L1;
     c.pool_used = 4u * (uint32_t)L1;
   }
   SmTask& t = q.t;
-  t.d = d;
-  t.cs = cs;
-  t.hyp_base = hyp_base;
+  t.sel_view[0] = d.sel_view[0];
+  t.sel_view[1] = d.sel_view[1];
+  t.sel_view[2] = d.sel_view[2];
   const uint32_t base = track_base(a, d.seed);
   t.n_map = track_n_views(a, map_n, d.seed);
   t.mv = map_view + base;
@@ -337,17 +358,13 @@ EG3D_HD void sm_begin(const DevScene& s, const StageAView& a, const TaskDesc& d,
   k.gn_kind = 0;
   k.gn_count = k.gn_issued = 0;
   k.gn_from = 0;
-  k.gn_list = nullptr;
-  k.gn_m = 0;
-  k.gn_extra.view = 0;
-  k.gn_extra.pl = 0;
-  k.gn_extra.seg = 0;
-  k.gn_extra.x = k.gn_extra.y = 0.0f;
-  k.gn_X0[0] = k.gn_X0[1] = k.gn_X0[2] = 0.0f;
-  k.o = k.gn_extra;
-  k.Xc[0] = k.Xc[1] = k.Xc[2] = 0.0f;
+  k.o.view = 0;
+  k.o.pl = 0;
+  k.o.seg = 0;
+  k.o.x = k.o.y = 0.0f;
   k.X[0] = k.X[1] = k.X[2] = 0.0f;
   k.cl_from = k.cl_to = 0;
+  k.cl_epi_only = 0;
   k.v = -1;
   k.j = 0;
   k.epc = nullptr;
@@ -362,12 +379,38 @@ EG3D_HD void sm_begin(const DevScene& s, const StageAView& a, const TaskDesc& d,
   k.ret_to = 0;
   k.pre_kind = 0;
   k.which = k.n1 = k.n2 = k.m1 = k.m2 = 0;
-  k.b_alone = 0;
   k.nd1 = k.nd2 = 0;
   k.to_start = k.to_end = 0;
   k.attach_ok = 0;
   k.side = k.added = k.st_obs = k.m = 0;
   k.fi = k.fj = k.fk = k.kept = k.fb_i = 0;
+}
+
+// dst[0..n) = src[0..n) (disjoint), four observations requested at a time
+EG3D_HD void sm_copy_obs(Obs* dst, const Obs* src, uint32_t n) {
+  uint32_t i = 0;
+  for (; i + 4 <= n; i += 4) {
+    const Obs a0 = src[i], a1 = src[i + 1], a2 = src[i + 2], a3 = src[i + 3];
+    dst[i] = a0;
+    dst[i + 1] = a1;
+    dst[i + 2] = a2;
+    dst[i + 3] = a3;
+  }
+  for (; i < n; i++) dst[i] = src[i];
+}
+// leading candidates of a side whose solve succeeded; the verdicts are requested eight at a time (a lane scans alone:
+// one trip to memory per eight candidates instead of one each)
+EG3D_HD int sm_leading_ok(const Pending* pd, int m) {
+  int cnt = 0;
+  while (cnt < m) {
+    uint32_t ok[8];
+    for (int b = 0; b < 8; b++) ok[b] = cnt + b < m ? pd[cnt + b].ok : 0u;
+    int b = 0;
+    while (b < 8 && ok[b] != 0) b++;
+    cnt += b;
+    if (b < 8) break;
+  }
+  return cnt;
 }
 
 // presolve policy of the machine: windows of points as the visit reaches them (lazy) or the whole view at once
@@ -451,7 +494,7 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
       for (;;) {
         k.v++;
         if (k.v >= s.n_views) break;
-        if (k.v == t.d.sel_view[0] || k.v == t.d.sel_view[1] || k.v == t.d.sel_view[2]) continue;
+        if (k.v == t.sel_view[0] || k.v == t.sel_view[1] || k.v == t.sel_view[2]) continue;
         break;
       }
       if (k.v >= s.n_views) {
@@ -469,18 +512,19 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
         k.n_pre = k.n_epc < c.cap_pts ? k.n_epc : c.cap_pts;
         k.e = 0;
         if (k.n_epc > 0) {
-          // epipolar lines of every chain point in view v (the side walks read them)
-          for (int i = 0; i < c.len; i++) {
-            const Obs first = c.pool[chain_at(c, i).off];
-            ViewCand& vc = c.cand[c.head + i];
-            vc.eok = epiline(s.F, s.F_valid, s.n_views, first.view, k.v, first.x, first.y, vc.ea, vc.eb, vc.ec) ? 1u : 0u;
-          }
-          sm_post_gn(k, SMB_EPC, k.n_pre, SMS_EPC_LOOP);
+          // epipolar lines of every chain point in view v (the side walks read them): an epi-only CLOSEST batch, then
+          // the speculative central solves of the view's epipolar hits
+          k.cl_from = 0;
+          k.cl_to = c.len;
+          k.cl_epi_only = 1;
+          k.st = SMS_EPC_POST;
+          if (k.cl_to > k.cl_from) k.wait = SM_WAIT_CL;
         } else {
           k.st = SMS_CAND_POST;
         }
       }
     }
+    if (k.st == SMS_EPC_POST && k.wait == SM_RUN) sm_post_gn(k, SMB_EPC, k.n_pre, SMS_EPC_LOOP);
     // ---------------- the task's epipolar hits in this view, in order, against the central point
     if (k.st == SMS_EPC_LOOP && k.wait == SM_RUN) {
       if (k.e >= k.n_epc) {
@@ -500,6 +544,7 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
       k.last_matched = -1;
       k.cl_from = 0;
       k.cl_to = c.len;
+      k.cl_epi_only = 0;
       k.st = SMS_CAND_DONE;
       if (k.cl_to > k.cl_from) k.wait = SM_WAIT_CL;
     }
@@ -573,9 +618,9 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
         if (!ok) {
           k.st = SMS_ATTACH_RET;
         } else {
-          k.Xc[0] = X[0];
-          k.Xc[1] = X[1];
-          k.Xc[2] = X[2];
+          k.X[0] = X[0];
+          k.X[1] = X[1];
+          k.X[2] = X[2];
           k.st = SMS_ATTACH_SIDES;
         }
       } else {
@@ -586,9 +631,9 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
       if (!q.mbox->ok) {
         k.st = SMS_ATTACH_RET;
       } else {
-        k.Xc[0] = q.mbox->X[0];
-        k.Xc[1] = q.mbox->X[1];
-        k.Xc[2] = q.mbox->X[2];
+        k.X[0] = q.mbox->X[0];
+        k.X[1] = q.mbox->X[1];
+        k.X[2] = q.mbox->X[2];
         k.st = SMS_ATTACH_SIDES;
       }
     }
@@ -596,7 +641,6 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
       k.nd1 = k.nd2 = 0;
       k.n1 = k.n2 = 0;
       k.which = 0;
-      k.b_alone = 0;
       if (k.ci > k.lo) {
         const PlRef pl = polyline_of(s, (int)k.o.view, k.o.pl);
         env.walk_stage(s, c, (int)k.o.view, pl, k.lo, k.ci, k.hi);
@@ -617,11 +661,8 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
       }
     }
     if (k.st == SMS_SIDES_DONE && k.wait == SM_RUN) {
-      int n1 = 0;
-      while (n1 < k.m1 && c.pend1[n1].ok != 0) n1++;
-      int n2 = 0;
-      if (n1 > 0)
-        while (n2 < k.m2 && c.pend2[n2].ok != 0) n2++;
+      const int n1 = sm_leading_ok(c.pend1, k.m1);
+      const int n2 = n1 > 0 ? sm_leading_ok(c.pend2, k.m2) : 0;
       k.n1 = n1;
       k.n2 = n2;
       if (n1 > 0) {
@@ -653,46 +694,66 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
           k.nd1 = k.which == 1 ? pl.start : pl.end;
           k.nd2 = k.which == 1 ? pl.end : pl.start;
         }
-        // commit: the 1 + n1 + n2 touched points, in the order of the sequential statement
+        // commit: the 1 + n1 + n2 touched points, in the order of the sequential statement. The points are distinct, so
+        // the headers and pending observations of four of them are requested together (one trip to memory per four
+        // points instead of one per point: the lane commits alone).
         const int T = 1 + n1 + n2;
-        for (int tt = 0; tt < T; tt++) {
-          ChainPt* p;
-          const Pending* pd = nullptr;
-          if (tt == 0)
-            p = &chain_at(c, ci);
-          else if (tt <= n1) {
-            p = &chain_at(c, ci - tt);
-            pd = &c.pend1[tt - 1];
-          } else {
-            p = &chain_at(c, ci + (tt - n1));
-            pd = &c.pend2[tt - n1 - 1];
+        bool overflow = false;
+        for (int t0 = 0; t0 < T && !overflow; t0 += 4) {
+          ChainPt* pp[4];
+          uint32_t hn[4], hc[4], ho[4];
+          Obs po[4];
+          float pX[4][3];
+          for (int b = 0; b < 4; b++) {
+            const int tt = t0 + b < T ? t0 + b : t0;
+            const Pending* pd = nullptr;
+            if (tt == 0)
+              pp[b] = &chain_at(c, ci);
+            else if (tt <= n1) {
+              pp[b] = &chain_at(c, ci - tt);
+              pd = &c.pend1[tt - 1];
+            } else {
+              pp[b] = &chain_at(c, ci + (tt - n1));
+              pd = &c.pend2[tt - n1 - 1];
+            }
+            hn[b] = pp[b]->nobs;
+            hc[b] = pp[b]->cap;
+            ho[b] = pp[b]->off;
+            if (pd) {
+              po[b] = pd->o;
+              pX[b][0] = pd->X[0];
+              pX[b][1] = pd->X[1];
+              pX[b][2] = pd->X[2];
+            } else {
+              po[b] = k.o;
+              pX[b][0] = k.X[0];
+              pX[b][1] = k.X[1];
+              pX[b][2] = k.X[2];
+            }
           }
-          uint32_t nobs = p->nobs, cap = p->cap, off = p->off, need = 0;
-          if (nobs == cap) need = cap ? cap * 2 : 4;
-          if (c.pool_used + need > c.pool_cap) {
-            c.flags |= 2u;
-            break;
+          for (int b = 0; b < 4 && t0 + b < T; b++) {
+            ChainPt* p = pp[b];
+            uint32_t nobs = hn[b], off = ho[b], need = 0;
+            if (nobs == hc[b]) need = hc[b] ? hc[b] * 2 : 4;
+            if (c.pool_used + need > c.pool_cap) {
+              c.flags |= 2u;  // the host enlarges the pool and reruns the chunk
+              overflow = true;
+              break;
+            }
+            if (need) {
+              const uint32_t noff = c.pool_used;
+              sm_copy_obs(c.pool + noff, c.pool + off, nobs);
+              off = noff;
+              p->off = noff;
+              p->cap = need;
+            }
+            c.pool[off + nobs] = po[b];
+            p->X[0] = pX[b][0];
+            p->X[1] = pX[b][1];
+            p->X[2] = pX[b][2];
+            p->nobs = nobs + 1;
+            c.pool_used += need;
           }
-          if (need) {
-            const uint32_t noff = c.pool_used;
-            for (uint32_t i = 0; i < nobs; i++) c.pool[noff + i] = c.pool[off + i];
-            off = noff;
-            p->off = noff;
-            p->cap = need;
-          }
-          if (pd) {
-            c.pool[off + nobs] = pd->o;
-            p->X[0] = pd->X[0];
-            p->X[1] = pd->X[1];
-            p->X[2] = pd->X[2];
-          } else {
-            c.pool[off + nobs] = k.o;
-            p->X[0] = k.Xc[0];
-            p->X[1] = k.Xc[1];
-            p->X[2] = k.Xc[2];
-          }
-          p->nobs = nobs + 1;
-          c.pool_used += need;
         }
         k.to_start = n1;
         k.to_end = n2;
@@ -774,10 +835,8 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
       k.st = SMS_STEP_TRI;
     }
     if (k.st == SMS_STEP_TRI) {
-      sm_list_dlt(env, s, c.tmp_a, k.m, c.flags, k.gn_X0);
-      k.gn_list = c.tmp_a;
-      k.gn_m = k.m;
-      sm_post_gn(k, SMB_LIST, 1, SMS_STEP_TRI_DONE);
+      sm_list_dlt(env, s, c.tmp_a, k.m, c.flags, k.X);
+      sm_post_gn(k, SMB_LIST_A, 1, SMS_STEP_TRI_DONE);
     }
     if (k.st == SMS_STEP_TRI_DONE && k.wait == SM_RUN) {
       if (q.mbox->ok) {
@@ -831,10 +890,8 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
       c.tmp_b[0] = c.tmp_a[k.fi];
       c.tmp_b[1] = c.tmp_a[k.fj];
       c.tmp_b[2] = c.tmp_a[k.fk];
-      sm_list_dlt(env, s, c.tmp_b, 3, c.flags, k.gn_X0);
-      k.gn_list = c.tmp_b;
-      k.gn_m = 3;
-      sm_post_gn(k, SMB_LIST, 1, SMS_FB_TRI_DONE);
+      sm_list_dlt(env, s, c.tmp_b, 3, c.flags, k.X);
+      sm_post_gn(k, SMB_LIST_B, 1, SMS_FB_TRI_DONE);
     }
     if (k.st == SMS_FB_ADD_DONE && k.wait == SM_RUN) {
       if (q.mbox->ok) {
@@ -850,12 +907,6 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
     if (k.st == SMS_FB_ADD) {
       while (k.fb_i < k.m && c.tmp_mask[k.fb_i]) k.fb_i++;
       if (k.fb_i < k.m) {
-        k.gn_list = c.tmp_b;
-        k.gn_m = k.kept;
-        k.gn_extra = c.tmp_a[k.fb_i];
-        k.gn_X0[0] = k.X[0];
-        k.gn_X0[1] = k.X[1];
-        k.gn_X0[2] = k.X[2];
         sm_post_gn(k, SMB_LISTADD, 1, SMS_FB_ADD_DONE);
       } else {
         int kk = 0;
@@ -884,6 +935,187 @@ EG3D_HD void sm_finish(const SmChain& q, ChainOut& out) {
   for (int k = 0; k < 12; k++) out.tsec[k] = 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The side walk of walk_side_candidates_core with its memory trips taken out of the dependent chain (the engine kernel's
+// lanes walk alone: nothing else hides a trip). Same tests in the same order on the same operands as the plain walk
+// (walk_by_line per chain point) => same candidates, same flags:
+//   * the epipolar lines of the next EG3D_SM_EPI_AHEAD chain points are requested together;
+//   * the polyline's vertices ahead of the current position live in a window of five (VtxWindow, as walk_by_line_pf)
+//     that is carried FROM ONE WALK TO THE NEXT: a walk that ends on segment k of the window leaves the window shifted
+//     to that segment, so a side walk opens the window once and every later vertex is requested four tests before it
+//     is needed.
+#define EG3D_SM_EPI_AHEAD 4
+EG3D_HD int sm_side_walk_stream(const DevScene& s, Chain& c, int view, const PlRef& pl, const Obs& from, uint32_t direction,
+                                int lo, int ci, int hi, bool towards_start, Pending* out) {
+  (void)s;
+  const int step_i = towards_start ? -1 : 1;
+  int i = towards_start ? ci - 1 : ci + 1;
+  int remaining = towards_start ? i - lo + 1 : hi - i;
+  if (remaining <= 0) return 0;
+  const bool to_start = direction == pl.start;
+  const bool bad_dir = !to_start && direction != pl.end;  // Q15: every walk fails (after the epipolar line was checked)
+  const int32_t n = (int32_t)pl.n;
+  PlPt actual;
+  actual.seg = from.seg;
+  actual.x = from.x;
+  actual.y = from.y;
+  VtxWindow<const f2*> W;
+  int32_t first = to_start ? (int32_t)actual.seg : (int32_t)actual.seg + 1;
+  if (!bad_dir) W.open(pl.v, first, to_start ? -1 : 1, n - 1);
+  int cnt = 0;
+  while (remaining > 0) {
+    // the lines of the next few chain points, requested together
+    float eok[EG3D_SM_EPI_AHEAD], ea[EG3D_SM_EPI_AHEAD], eb[EG3D_SM_EPI_AHEAD], ec[EG3D_SM_EPI_AHEAD];
+    const int nb = remaining < EG3D_SM_EPI_AHEAD ? remaining : EG3D_SM_EPI_AHEAD;
+    for (int b = 0; b < EG3D_SM_EPI_AHEAD; b++) {
+      const int ib = b < nb ? i + step_i * b : i;
+      const ViewCand& ve = c.cand[c.head + ib];
+      eok[b] = ve.eok ? 1.0f : 0.0f;
+      ea[b] = ve.ea;
+      eb[b] = ve.eb;
+      ec[b] = ve.ec;
+    }
+    for (int b = 0; b < nb; b++) {
+      if (eok[b] == 0.0f) return cnt;
+      if (bad_dir) {
+        c.flags |= 8u;
+        return cnt;
+      }
+      const float la = ea[b], lb = eb[b], lc = ec[b];
+      // ---- next hit of the line from `actual` towards `direction` (walk_by_line_pf on the carried window)
+      const LineDir ld = line_dir(la, lb);
+      const int32_t count = to_start ? first + 1 : n - first;  // vertices ahead: u[0] = v[first], ...
+      float hx = 0.0f, hy = 0.0f;
+      uint32_t seg_found = actual.seg;
+      uint32_t r = seg_line_hit_guarded(actual.x, actual.y, W.w0.x, W.w0.y, la, lb, lc, ld, hx, hy);
+      if (r & 2u) return cnt;  // quasi-parallel: the side walk ends
+      if (!(r & 1u)) {
+        bool got = false;
+        int32_t kk = 1;
+        for (; kk < count; kk++) {
+          r = seg_line_hit_guarded(W.w0.x, W.w0.y, W.w1.x, W.w1.y, la, lb, lc, ld, hx, hy);
+          if (r & 2u) return cnt;
+          if (r & 1u) {
+            got = true;
+            seg_found = (uint32_t)(to_start ? first - kk : first + kk - 1);
+            break;
+          }
+          W.shift(kk);
+        }
+        if (!got) return cnt;  // reached the extreme
+        // the next walk starts on the segment of the hit: its u[0] is this walk's u[kk]
+        W.shift(kk);
+        first += W.stepv * kk;
+        W.first = first;
+      }
+      Pending& pd = out[cnt++];
+      pd.o.view = (uint32_t)view;
+      pd.o.pl = from.pl;
+      pd.o.seg = seg_found;
+      pd.o.x = hx;
+      pd.o.y = hy;
+      pd.ok = 0;
+      actual.seg = seg_found;
+      actual.x = hx;
+      actual.y = hy;
+    }
+    i += step_i * nb;
+    remaining -= nb;
+  }
+  return cnt;
+}
+
+// The walk phase of one candidate of the N-view step (stepn_walks with one member) with its memory trips batched: the
+// observations are taken four at a time and every stage of the four — the observations themselves; their epipolar lines,
+// directions and polyline indices; the polyline descriptors; the first vertices ahead — is requested together before
+// the next stage needs it. Same walks (walk_by_distance_pf / walk_by_line_pf: the tests of the plain walks in the same
+// order, tests/test_cpu_parity.py) in observation order => same list, same flags.
+#define EG3D_SM_STEP_CHUNK 4
+EG3D_HD int sm_step_walks_stream(const DevScene& s, const Obs* co_all, int n, int st, const uint32_t* dirs, Obs* sel,
+                                 int sel_cap, uint32_t& flags) {
+  const Obs so = co_all[st];
+  const PlRef ps = polyline_of(s, (int)so.view, so.pl);
+  PlPt p, q;
+  p.seg = so.seg;
+  p.x = so.x;
+  p.y = so.y;
+  const uint32_t w = walk_by_distance_pf(ps, p, dirs[so.view], EG3D_FOLLOW_STEP, q);
+  if (w & WALK_BAD_DIR) flags |= 8u;
+  if (w & WALK_EXTREME) return 0;
+  int m = 0;
+  sel[m].view = so.view;
+  sel[m].pl = so.pl;
+  sel[m].seg = q.seg;
+  sel[m].x = q.x;
+  sel[m].y = q.y;
+  m++;
+  uint32_t fl = 0;
+  bool full = false;
+  constexpr int CH = EG3D_SM_STEP_CHUNK;
+  for (int i0 = 0; i0 < n && !full; i0 += CH) {
+    Obs co[CH];
+    bool use[CH], eok[CH], open[CH];
+    float la[CH], lb[CH], lc[CH];
+    uint32_t dir[CH], g[CH];
+    PlRef pk[CH];
+    VtxWindow<const f2*> W[CH];
+    for (int b = 0; b < CH; b++) {
+      const int i = i0 + b;
+      use[b] = i < n && i != st;
+      co[b] = co_all[use[b] ? i : st];
+    }
+    for (int b = 0; b < CH; b++) {
+      eok[b] = epiline(s.F, s.F_valid, s.n_views, (int)so.view, (int)co[b].view, q.x, q.y, la[b], lb[b], lc[b]) && use[b];
+      dir[b] = dirs[co[b].view];
+      g[b] = s.view_pl_off[co[b].view] + co[b].pl;
+    }
+    for (int b = 0; b < CH; b++) {
+      const uint32_t va = s.pl_vtx_off[g[b]], vb = s.pl_vtx_off[g[b] + 1];
+      pk[b].v = s.vtx + va;
+      pk[b].n = vb - va;
+      pk[b].start = s.pl_start[g[b]];
+      pk[b].end = s.pl_end[g[b]];
+    }
+    for (int b = 0; b < CH; b++) {
+      PlPt cp;
+      cp.seg = co[b].seg;
+      cp.x = co[b].x;
+      cp.y = co[b].y;
+      open[b] = walk_by_line_open(pk[b], cp, dir[b], W[b]);
+    }
+    for (int b = 0; b < CH; b++) {
+      if (!eok[b]) continue;
+      if (!open[b]) {
+        fl |= 8u;  // WALK_BAD_DIR
+        continue;
+      }
+      PlPt cp, rp;
+      cp.seg = co[b].seg;
+      cp.x = co[b].x;
+      cp.y = co[b].y;
+      const uint32_t wr = walk_by_line_run(pk[b], cp, dir[b], la[b], lb[b], lc[b], true, EG3D_FOLLOW_MIN, EG3D_FOLLOW_MAX, W[b], rp);
+      if (wr & WALK_FOUND) {
+        if (m < sel_cap) {
+          sel[m].view = co[b].view;
+          sel[m].pl = co[b].pl;
+          sel[m].seg = rp.seg;
+          sel[m].x = rp.x;
+          sel[m].y = rp.y;
+        }
+        if (m + 1 > sel_cap) {
+          flags |= 2u;
+          m = sel_cap;
+          full = true;
+          break;
+        }
+        m++;
+      }
+    }
+  }
+  flags |= fl;
+  return m < 3 ? 0 : m;
+}
+
 // Lane-private primitives of the machine in their plain (sequential) form: what the host simulation uses, and the
 // engine kernel unless it overrides one.
 struct SmEnvSeq {
@@ -898,6 +1130,25 @@ struct SmEnvSeq {
   EG3D_HD int step_walks(const DevScene& s, const Obs* co_all, int n, int st, const uint32_t* dirs, Obs* sel, int sel_cap,
                          uint32_t& flags) const {
     return stepn_walks(TeamSeq(), s, co_all, n, st, dirs, sel, sel_cap, flags);
+  }
+};
+
+// ... with the memory trips of the lane-private loops taken out of the dependent chains (what the engine kernel runs;
+// hostsim mode 3 runs it on the CPU against the oracle)
+struct SmEnvStream : SmEnvSeq {
+  // the 2-view DLT with its matrices in lane-private MEMORY (dlt2_mem: same operations in the same order as dlt2): the
+  // decomposition's 44 doubles would otherwise sit in registers on top of the machine's whole state
+  EG3D_HD void dlt(const float* P1, float x1, float y1, const float* P2, float x2, float y2, double X0[3]) const {
+    double work[EG3D_DLT_WORK_DOUBLES];
+    dlt2_mem(P1, x1, y1, P2, x2, y2, (double*)work, X0);
+  }
+  EG3D_HD int side_walk(const DevScene& s, Chain& c, int view, const PlRef& pl, const Obs& from, uint32_t direction, int lo,
+                        int ci, int hi, bool towards_start, Pending* out) const {
+    return sm_side_walk_stream(s, c, view, pl, from, direction, lo, ci, hi, towards_start, out);
+  }
+  EG3D_HD int step_walks(const DevScene& s, const Obs* co_all, int n, int st, const uint32_t* dirs, Obs* sel, int sel_cap,
+                         uint32_t& flags) const {
+    return sm_step_walks_stream(s, co_all, n, st, dirs, sel, sel_cap, flags);
   }
 };
 

@@ -259,10 +259,23 @@ __device__ __forceinline__ double ordered_sum2(double s, const double* __restric
 // the standard build: a one-chunk round keeps its rows, a multi-chunk round recomputes all of them in the update pass;
 // 4 in the wide build for scenes with long observation lists (V >= 64), where that recomputation was a fifth of the
 // kernel's time. Same values either way (a row is a function of X, which does not change between the passes).
-template <int KEEP>
+// HOIST: a one-chunk round requests the lane's observation ONCE, before the iterations (the engine kernel: its rows come
+// from the slices of many chains and miss the caches — a trip per iteration was most of a round there; k3b_expand, whose
+// chain is cache-resident, measured the three extra live registers as a loss and keeps the load per iteration).
+template <int KEEP, bool HOIST = false>
 __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool act, int l, int G, int gb, int n, int nb,
                                          const Obs* a, int32_t xv, float xx, float xy, int cmax, double X[3]) {
   const int lane = (int)(threadIdx.x & 63u);
+  int32_t hview = xv;
+  float hox = xx, hoy = xy;
+  if constexpr (HOIST) {
+    if (cmax == 1 && act && l < nb) {
+      const Obs o = a[l];
+      hview = (int32_t)o.view;
+      hox = o.x;
+      hoy = o.y;
+    }
+  }
   const int gs = gb >> 1;  // slot of the group's sums (G >= 2 => distinct)
   bool done = !act, ok = false;
   double last_mse = 0;
@@ -290,7 +303,11 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
       if (rowact) {
         int32_t view;
         float ox, oy;
-        if (r < nb) {
+        if (HOIST && cmax == 1) {
+          view = hview;
+          ox = hox;
+          oy = hoy;
+        } else if (r < nb) {
           view = a[r].view;
           ox = a[r].x;
           oy = a[r].y;
@@ -483,7 +500,7 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
 // lanes own the requests) and made visible by a barrier. Lane j < EG3D_COOP_REQ passes want / n_req of entry j. Must be
 // called by all 64 lanes; every request must have >= 2 rows. On return the table holds verdict and solution of every
 // entry (L.res_ok[j], L.x0[j]) until the next call; lane j also gets its own as the return value / Xout.
-template <int KEEP = 0, bool LONG_GN = true>
+template <int KEEP = 0, bool LONG_GN = true, bool HOIST = false>
 __device__ __forceinline__ bool coop_gn_run(const float* cam_P, CoopLds& L, bool want, int n_req, float Xout[3]) {
   const int lane = (int)(threadIdx.x & 63u);
   const bool is_short = want && n_req <= EG3D_GN_PACK_MAX;
@@ -531,7 +548,7 @@ __device__ __forceinline__ bool coop_gn_run(const float* cam_P, CoopLds& L, bool
         X[1] = (double)L.x0[rq][1];
         X[2] = (double)L.x0[rq][2];
       }
-      const bool ok = gn_round<0>(cam_P, L, act, l, n, lane - l, n, nb, a, xv, xx, xy, 1, X);
+      const bool ok = gn_round<0, HOIST>(cam_P, L, act, l, n, lane - l, n, nb, a, xv, xx, xy, 1, X);
       if (act && l == 0) {
         L.res_ok[rq] = ok ? 1 : 0;
         L.x0[rq][0] = (float)X[0];

@@ -445,17 +445,25 @@ EG3D_HD uint32_t walk_by_distance_pf(const PlRefT<VPtr>& pl, const PlPt& p, uint
   return WALK_FOUND;
 }
 
+// walk_by_line_pf in two halves, so that a caller with several walks to make can OPEN all their windows first (the
+// vertex requests of all of them in flight together) and then run them: open = request the five vertices ahead of the
+// position; run = the tests. walk_by_line_pf is the two back to back.
 template <class VPtr>
-EG3D_HD uint32_t walk_by_line_pf(const PlRefT<VPtr>& pl, const PlPt& p, uint32_t direction, float la, float lb, float lc,
-                                 bool bounded, float min_d, float max_d, PlPt& out) {
+EG3D_HD bool walk_by_line_open(const PlRefT<VPtr>& pl, const PlPt& p, uint32_t direction, VtxWindow<VPtr>& W) {
   const bool to_start = direction == pl.start;
-  if (!to_start && direction != pl.end) return WALK_BAD_DIR;  // Q15: the reference leaves every flag false
+  if (!to_start && direction != pl.end) return false;  // Q15: the reference leaves every flag false
+  const int32_t first = to_start ? (int32_t)p.seg : (int32_t)p.seg + 1;
+  W.open(pl.v, first, to_start ? -1 : 1, (int32_t)pl.n - 1);
+  return true;
+}
+template <class VPtr>
+EG3D_HD uint32_t walk_by_line_run(const PlRefT<VPtr>& pl, const PlPt& p, uint32_t direction, float la, float lb, float lc,
+                                  bool bounded, float min_d, float max_d, VtxWindow<VPtr>& W, PlPt& out) {
+  const bool to_start = direction == pl.start;
   const LineDir ld = line_dir(la, lb);
   const int32_t n = (int32_t)pl.n;
   const int32_t first = to_start ? (int32_t)p.seg : (int32_t)p.seg + 1;
   const int32_t count = to_start ? first + 1 : n - first;
-  VtxWindow<VPtr> W;
-  W.open(pl.v, first, to_start ? -1 : 1, n - 1);
   float hx = 0.0f, hy = 0.0f;
   uint32_t seg_found = p.seg;
   uint32_t r = seg_line_hit_guarded(p.x, p.y, W.w0.x, W.w0.y, la, lb, lc, ld, hx, hy);
@@ -482,6 +490,13 @@ EG3D_HD uint32_t walk_by_line_pf(const PlRefT<VPtr>& pl, const PlPt& p, uint32_t
     if (dsq < (min_d * min_d) || dsq > (max_d * max_d)) return WALK_BOUND;
   }
   return WALK_FOUND;
+}
+template <class VPtr>
+EG3D_HD uint32_t walk_by_line_pf(const PlRefT<VPtr>& pl, const PlPt& p, uint32_t direction, float la, float lb, float lc,
+                                 bool bounded, float min_d, float max_d, PlPt& out) {
+  VtxWindow<VPtr> W;
+  if (!walk_by_line_open(pl, p, direction, W)) return WALK_BAD_DIR;
+  return walk_by_line_run(pl, p, direction, la, lb, lc, bounded, min_d, max_d, W, out);
 }
 
 // Closest point of a whole polyline, first minimal segment wins (polyline_graph_2d.cpp:845-862).

@@ -190,11 +190,11 @@ EG3D_HD ChainLayout chain_layout(uint32_t cap_pts, uint32_t pool_cap, uint32_t n
   L.pool_cap = pool_cap;
   L.n_views = n_views;
   L.tmp_cap = 2 * n_views + 8;
+  // the small arrays first, the observation pool (of which a chain touches the beginning) last: what a chain keeps
+  // warm is then one compact region at the start of its slice
   size_t o = 0;
   L.off_pts = o;
   o = align8(o + sizeof(ChainPt) * cap_pts);
-  L.off_pool = o;
-  o = align8(o + sizeof(Obs) * pool_cap);
   L.off_sdir = o;
   o = align8(o + sizeof(uint32_t) * n_views);
   L.off_edir = o;
@@ -217,6 +217,8 @@ EG3D_HD ChainLayout chain_layout(uint32_t cap_pts, uint32_t pool_cap, uint32_t n
   o = align8(o + L.tmp_cap);
   L.off_mbox = o;  // answer of a single solve of the chain state machine (eg3d_chain_sm.h: SmMbox, 16 bytes)
   o = align8(o + 16);
+  L.off_pool = o;
+  o = align8(o + sizeof(Obs) * pool_cap);
   L.total = o;
   return L;
 }

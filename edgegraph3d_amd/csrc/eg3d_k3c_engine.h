@@ -30,20 +30,42 @@ namespace eg3d {
 #define EG3D_K3C_WAVES 2 /* waves per SIMD the register allocation aims at (256 VGPRs) */
 #endif
 
+// LDS of a wave: the solver's block (CoopLds, 8 allocation units => four waves per SIMD fit) and, aliased onto parts of it
+// that the engine does not use at the same time: the answer addresses of a window's entries in CoopLds::tmp_a (the
+// N-view step's list of k3b_expand — the machine keeps its lists in the slice), the owner table of the candidate drain
+// in the product columns (never live during a solve).
+struct K3cOwners {
+  unsigned char* slice[64];  // candidate drain: working slice, chain head, first point, view (| epi-only << 16) of each owner
+  uint32_t excl[65];
+  int32_t head[64], from[64], view[64];
+};
+struct K3cAnswers {
+  float* resX[EG3D_COOP_REQ];  // where the answer of window entry j goes
+  uint32_t* resOk[EG3D_COOP_REQ];
+};
+static_assert(sizeof(K3cOwners) <= sizeof(((CoopLds*)nullptr)->prod), "the owner table must fit the product columns");
+static_assert(sizeof(K3cAnswers) <= sizeof(((CoopLds*)nullptr)->tmp_a), "the answer addresses must fit CoopLds::tmp_a");
 struct K3cShared {
   CoopLds gn;
-  float* resX[EG3D_COOP_REQ];      // where the answer of window entry j goes
-  uint32_t* resOk[EG3D_COOP_REQ];
-  unsigned char* cl_slice[64];     // candidate drain: working slice, chain head, first point and view of each owner
-  uint32_t cl_excl[65];
-  int32_t cl_head[64], cl_from[64], cl_view[64];
+  __device__ __forceinline__ K3cOwners& own() { return *(K3cOwners*)&gn.prod[0][0]; }
+  __device__ __forceinline__ K3cAnswers& ans() { return *(K3cAnswers*)&gn.tmp_a[0]; }
 };
 
 #ifdef EG3D_SECTION_TIMING
-#define K3C_T0() unsigned long long ct_[6] = {0, 0, 0, 0, 0, 0}, cc_[4] = {0, 0, 0, 0}, ct0_ = __builtin_readcyclecounter(), ct1_
+// timing build: shader clocks of a wave's phases summed over the launch — [0] fetch, [1] advance, [2] pack, [3] solve
+// drain, [4] candidate drain; [8] iterations, [9] lanes with a chain (summed over iterations), [10] solves served,
+// [11] candidate items, [12] solver windows, [13] lanes blocked on solves / [14] on candidates (summed over iterations)
+__device__ unsigned long long g_k3c_dbg[32];
+#define K3C_T0() unsigned long long ct_[6] = {0, 0, 0, 0, 0, 0}, cc_[7] = {0, 0, 0, 0, 0, 0, 0}, ct0_ = __builtin_readcyclecounter(), ct1_
 #define K3C_T(i) (ct1_ = __builtin_readcyclecounter(), ct_[i] += ct1_ - ct0_, ct0_ = ct1_)
 #define K3C_C(i, v) (cc_[i] += (v))
+#define K3C_TEND()                                                                   \
+  if (lane == 0) {                                                                   \
+    for (int q_ = 0; q_ < 5; q_++) atomicAdd(&g_k3c_dbg[q_], ct_[q_]);               \
+    for (int q_ = 0; q_ < 7; q_++) atomicAdd(&g_k3c_dbg[8 + q_], cc_[q_]);           \
+  }
 #else
+#define K3C_TEND() ((void)0)
 #define K3C_T0() ((void)0)
 #define K3C_T(i) ((void)0)
 #define K3C_C(i, v) ((void)0)
@@ -75,7 +97,7 @@ __global__ void __launch_bounds__(64, EG3D_K3C_WAVES) k3c_engine_t(DevScene s, S
   bool have = false, exhausted = lane >= lanes_per_wave;
   uint32_t jchain = 0, flags_acc = 0;
   unsigned long long bytes_acc = 0;
-  const SmEnvSeq env;
+  const SmEnvStream env;
   K3C_T0();
   for (;;) {
     // ---- (0) the next chain
@@ -98,29 +120,46 @@ __global__ void __launch_bounds__(64, EG3D_K3C_WAVES) k3c_engine_t(DevScene s, S
     // ---- (1) advance
     if (have) sm_advance(env, s, a, q);
     K3C_T(1);
+    K3C_C(5, __popcll(__ballot(have && q.k.wait == SM_WAIT_GN)));
+    K3C_C(6, __popcll(__ballot(have && q.k.wait == SM_WAIT_CL)));
     // ---- (2) finished chains: pack (point headers + observations back to back), report
     if (have && q.k.wait == SM_DONE) {
+      // (the point headers are requested eight at a time, the observations of a point four at a time: the lane packs alone)
       ChainOut co;
-      sm_finish(q, co);
+      const ChainPt* pts = q.c.pts + q.c.head;
+      const uint32_t np = (uint32_t)q.c.len;
+      uint32_t nobs_total = 0;
+      for (uint32_t i0 = 0; i0 < np; i0 += 8) {
+        uint32_t nn[8];
+        for (uint32_t b = 0; b < 8; b++) nn[b] = i0 + b < np ? pts[i0 + b].nobs : 0u;
+        for (uint32_t b = 0; b < 8; b++) nobs_total += nn[b];
+      }
+      co.n_points = np;
+      co.n_obs = nobs_total;
+      co.flags = q.c.flags;
+      co.head = (uint32_t)q.c.head;
+      co.bytes = q.c.bytes;
+      for (int k = 0; k < 12; k++) co.tsec[k] = 0;
       const unsigned long long pb = atomicAdd(&stage.used[0], (unsigned long long)co.n_points);
       const unsigned long long ob = atomicAdd(&stage.used[1], (unsigned long long)co.n_obs);
       co.spt = pb;
       co.sobs = ob;
       if (pb + co.n_points <= stage.cap_pts && ob + co.n_obs <= stage.cap_obs) {
-        const ChainPt* pts = q.c.pts + q.c.head;
         StagePt* spt = stage.pts + pb;
         Obs* sob = stage.obs + ob;
-        for (uint32_t i = 0; i < co.n_points; i++) {
-          const ChainPt p = pts[i];
-          StagePt sp;
-          sp.X[0] = p.X[0];
-          sp.X[1] = p.X[1];
-          sp.X[2] = p.X[2];
-          sp.nobs = p.nobs;
-          spt[i] = sp;
-          const Obs* src = q.c.pool + p.off;
-          for (uint32_t k = 0; k < p.nobs; k++) sob[k] = src[k];
-          sob += p.nobs;
+        for (uint32_t i0 = 0; i0 < np; i0 += 4) {
+          ChainPt hp[4];
+          for (uint32_t b = 0; b < 4; b++) hp[b] = pts[i0 + b < np ? i0 + b : i0];
+          for (uint32_t b = 0; b < 4 && i0 + b < np; b++) {
+            StagePt sp;
+            sp.X[0] = hp[b].X[0];
+            sp.X[1] = hp[b].X[1];
+            sp.X[2] = hp[b].X[2];
+            sp.nobs = hp[b].nobs;
+            spt[i0 + b] = sp;
+            sm_copy_obs(sob, q.c.pool + hp[b].off, hp[b].nobs);
+            sob += hp[b].nobs;
+          }
         }
       }
       outs[jchain] = co;
@@ -160,8 +199,8 @@ __global__ void __launch_bounds__(64, EG3D_K3C_WAVES) k3c_engine_t(DevScene s, S
             sh.gn.x0[slot][0] = rq.X0[0];
             sh.gn.x0[slot][1] = rq.X0[1];
             sh.gn.x0[slot][2] = rq.X0[2];
-            sh.resX[slot] = rq.resX;
-            sh.resOk[slot] = rq.resOk;
+            sh.ans().resX[slot] = rq.resX;
+            sh.ans().resOk[slot] = rq.resOk;
             filled++;
           }
           q.k.gn_issued++;
@@ -171,14 +210,15 @@ __global__ void __launch_bounds__(64, EG3D_K3C_WAVES) k3c_engine_t(DevScene s, S
       {
         const int n_req = lane < EG3D_COOP_REQ ? (int)(sh.gn.n16[lane] & 0x7fff) : 0;
         K3C_C(2, __popcll(__ballot(n_req != 0)));
+        K3C_C(4, 1);
         float Xr[3];
-        coop_gn_run<0, LONG_GN>(s.cam_P, sh.gn, n_req != 0, n_req, Xr);
+        coop_gn_run<0, LONG_GN, true>(s.cam_P, sh.gn, n_req != 0, n_req, Xr);
         // answers: the table keeps them until the next window
         if (n_req != 0) {
           const uint32_t ok = sh.gn.res_ok[lane];
-          *sh.resOk[lane] = ok;
+          *sh.ans().resOk[lane] = ok;
           if (ok) {
-            float* X = sh.resX[lane];
+            float* X = sh.ans().resX[lane];
             X[0] = sh.gn.x0[lane][0];
             X[1] = sh.gn.x0[lane][1];
             X[2] = sh.gn.x0[lane][2];
@@ -195,12 +235,13 @@ __global__ void __launch_bounds__(64, EG3D_K3C_WAVES) k3c_engine_t(DevScene s, S
       if (__ballot(cnt > 0)) {
         const int incl = wave_incl_scan(cnt);
         const int total = lane_bcast(incl, 63);
-        sh.cl_excl[lane] = (uint32_t)(incl - cnt);
-        if (lane == 63) sh.cl_excl[64] = (uint32_t)total;
-        sh.cl_slice[lane] = slice;
-        sh.cl_head[lane] = q.c.head;
-        sh.cl_from[lane] = q.k.cl_from;
-        sh.cl_view[lane] = q.k.v;
+        K3cOwners& ow = sh.own();
+        ow.excl[lane] = (uint32_t)(incl - cnt);
+        if (lane == 63) ow.excl[64] = (uint32_t)total;
+        ow.slice[lane] = slice;
+        ow.head[lane] = q.c.head;
+        ow.from[lane] = q.k.cl_from;
+        ow.view[lane] = q.k.v | (int32_t)(q.k.cl_epi_only << 16);
         __syncthreads();
         K3C_C(3, total);
         for (int f0 = 0; f0 < total; f0 += 64) {
@@ -209,10 +250,16 @@ __global__ void __launch_bounds__(64, EG3D_K3C_WAVES) k3c_engine_t(DevScene s, S
             uint32_t lo = 0;  // the owner whose range holds f: largest o with excl[o] <= f (owners without items skipped)
 #pragma unroll
             for (uint32_t step = 32; step; step >>= 1)
-              if (sh.cl_excl[lo + step] <= (uint32_t)f) lo += step;
-            unsigned char* const sl = sh.cl_slice[lo];
-            sm_closest_item(s, (const ChainPt*)(sl + L.off_pts), (const Obs*)(sl + L.off_pool), (ViewCand*)(sl + L.off_cand),
-                            sh.cl_head[lo], sh.cl_view[lo], sh.cl_from[lo] + (f - (int)sh.cl_excl[lo]));
+              if (ow.excl[lo + step] <= (uint32_t)f) lo += step;
+            unsigned char* const sl = ow.slice[lo];
+            const int vw = ow.view[lo];
+            const int idx = ow.from[lo] + (f - (int)ow.excl[lo]);
+            if (vw >> 16)
+              sm_epiline_item(s, (const ChainPt*)(sl + L.off_pts), (const Obs*)(sl + L.off_pool), (ViewCand*)(sl + L.off_cand),
+                              ow.head[lo], vw & 0xffff, idx);
+            else
+              sm_closest_item(s, (const ChainPt*)(sl + L.off_pts), (const Obs*)(sl + L.off_pool), (ViewCand*)(sl + L.off_cand),
+                              ow.head[lo], vw & 0xffff, idx);
           }
         }
         __syncthreads();
@@ -236,12 +283,7 @@ __global__ void __launch_bounds__(64, EG3D_K3C_WAVES) k3c_engine_t(DevScene s, S
       if (bsum) atomicAdd(&ctr->bytes, bsum);
     }
   }
-#ifdef EG3D_SECTION_TIMING
-  if (lane == 0) {
-    for (int q_ = 0; q_ < 5; q_++) EG3D_GN_DBG(113 + q_, ct_[q_]);  // (the K3a engine's diagnostic slots are reused by tools/k3c_stats.py builds)
-    for (int q_ = 0; q_ < 4; q_++) EG3D_GN_DBG(120 + q_, cc_[q_]);
-  }
-#endif
+  K3C_TEND();
 }
 
 }  // namespace eg3d

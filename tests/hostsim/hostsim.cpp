@@ -68,12 +68,13 @@ static int build_dev_scene(const eg3d_scene* sc, HostScene& hs) {
 // The expand stage as the chain STATE MACHINE of eg3d_chain_sm.h (what the engine kernel k3c runs, one lane per
 // chain) with a sequential server: requests are answered one after the other by the plain solver / candidate code.
 static unsigned long long g_sm[16];  // advances, GN batches, GN requests, rows, closest batches, closest items, by batch kind [8..]
+template <class Env>
 static void run_chain_machine(const DevScene& ds, const StageAView& a, const TaskDesc& d, const ChainSeed& cs, uint32_t hyp_base,
                               const HypResult* res, const HPoint* arena, const int32_t* map_view, const uint32_t* map_entry,
                               const uint32_t* map_n, const ChainLayout& L, unsigned char* slice, ChainOut& out) {
   SmChain q;
   sm_begin(ds, a, d, cs, hyp_base, res, arena, map_view, map_entry, map_n, L, slice, (SmMbox*)(slice + L.off_mbox), q);
-  const SmEnvSeq env;
+  const Env env;
   for (;;) {
     sm_advance(env, ds, a, q);
     g_sm[0]++;
@@ -112,7 +113,10 @@ static void run_chain_machine(const DevScene& ds, const StageAView& a, const Tas
     } else if (q.k.wait == SM_WAIT_CL) {
       g_sm[4]++;
       for (int i = q.k.cl_from; i < q.k.cl_to; i++) {
-        sm_closest_item(ds, q.c, q.k.v, i);
+        if (q.k.cl_epi_only)
+          sm_epiline_item(ds, q.c.pts, q.c.pool, q.c.cand, q.c.head, q.k.v, i);
+        else
+          sm_closest_item(ds, q.c, q.k.v, i);
         g_sm[5]++;
       }
       q.k.wait = SM_RUN;
@@ -276,8 +280,11 @@ extern "C" int hostsim_match(const eg3d_scene* sc, const eg3d_seeds* seeds, uint
   const unsigned long long sm_walks0 = g_stat[5], sm_segs0 = g_stat[6];
   for (size_t j = 0; j < chains.size(); j++) {
     const ChainSeed& cs = chains[j];
-    if (slot_step == 2)
-      run_chain_machine(ds, a, tasks[cs.task], cs, hyp_off[cs.task], res.data(), arena.data(), map_view.data(),
+    if (slot_step == 3)  // the machine with the streaming forms of its lane-private loops (what the engine kernel runs)
+      run_chain_machine<SmEnvStream>(ds, a, tasks[cs.task], cs, hyp_off[cs.task], res.data(), arena.data(), map_view.data(),
+                                     map_entry.data(), map_n.data(), L, scratch.data() + L.total * j, couts[j]);
+    else if (slot_step == 2)
+      run_chain_machine<SmEnvSeq>(ds, a, tasks[cs.task], cs, hyp_off[cs.task], res.data(), arena.data(), map_view.data(),
                         map_entry.data(), map_n.data(), L, scratch.data() + L.total * j, couts[j]);
     else if (slot_step)
       expand_chain(TeamSeqSlots(), ds, a, tasks[cs.task], cs, hyp_off[cs.task], res.data(), arena.data(),
@@ -297,7 +304,7 @@ extern "C" int hostsim_match(const eg3d_scene* sc, const eg3d_seeds* seeds, uint
             "listadd %.2f; line walks %.1f (+%.2f segments beyond the first each)\n",
             chains.size(), (unsigned long long)np, g_sm[0] / nc, g_sm[1] / nc, g_sm[4] / nc, g_sm[2] / nc,
             g_sm[2] ? (double)g_sm[3] / (double)g_sm[2] : 0.0, g_sm[5] / nc, g_sm[8 + SMB_EPC] / nc, g_sm[8 + SMB_PRESOLVE] / nc,
-            g_sm[8 + SMB_CENTRAL] / nc, g_sm[8 + SMB_SIDES] / nc, g_sm[8 + SMB_LIST] / nc, g_sm[8 + SMB_LISTADD] / nc,
+            g_sm[8 + SMB_CENTRAL] / nc, g_sm[8 + SMB_SIDES] / nc, (g_sm[8 + SMB_LIST_A] + g_sm[8 + SMB_LIST_B]) / nc, g_sm[8 + SMB_LISTADD] / nc,
             (g_stat[5] - sm_walks0) / nc, (g_stat[5] - sm_walks0) ? (double)(g_stat[6] - sm_segs0) / (double)(g_stat[5] - sm_walks0) : 0.0);
   }
   // K4

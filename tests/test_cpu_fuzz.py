@@ -19,7 +19,7 @@ def test_random_mutated_scene_hostsim_vs_oracle(case):
     ref = o.match(C.byref(seeds.c), 0, n, 1)
     cand = o.candidates_raw(C.byref(seeds.c), 0, n)
     # the team form of the expand stage (plain / slot step by case), then the chain state machine the engine kernel runs
-    for mode in (int(bool(case & 1)), 2):
+    for mode in (int(bool(case & 1)), 2, 3):
         got = hs.match(C.byref(sa.c), C.byref(seeds.c), 0, n, cand, slot_step=mode)
         rep = compare_edgepoints(ref, got)
         assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], (case, mode, rep["msgs"][:3])
@@ -36,7 +36,7 @@ def test_hostile_numeric_inputs_hostsim_vs_oracle(case):
     o = ob.Oracle(C.byref(sa.c))
     ref = o.match(C.byref(seeds.c), 0, n, 1)
     cand = o.candidates_raw(C.byref(seeds.c), 0, n)
-    for mode in (0, 2):
+    for mode in (0, 2, 3):
         got = hs.match(C.byref(sa.c), C.byref(seeds.c), 0, n, cand, slot_step=mode)
         rep = compare_edgepoints(ref, got)
         assert rep["ok"] and rep["bitexact_X"], (case, mode, rep["msgs"][:3])

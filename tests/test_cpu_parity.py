@@ -26,7 +26,7 @@ def test_host_grid_builder_matches_oracle(cfg):
             assert ids.size > 0
 
 
-@pytest.mark.parametrize("slot_step", [False, True, 2])  # 2 = the chain state machine of the engine kernel (eg3d_chain_sm.h), sequential server
+@pytest.mark.parametrize("slot_step", [False, True, 2, 3])  # 2 = the chain state machine of the engine kernel (eg3d_chain_sm.h) with a sequential server, 3 = with the streaming forms of its lane-private loops (what the kernel runs)
 @pytest.mark.parametrize("cfg", [0, 1])
 def test_kernel_bodies_hostsim_vs_oracle(cfg, slot_step):
     s = host.Synth(cfg)
