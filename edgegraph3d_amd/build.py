@@ -74,6 +74,7 @@ def build_hip(force=False, out=None, defines=()):
         extra = os.environ.get("EG3D_EXTRA_HIPFLAGS", "").split()
         _run([hipcc] + HIP_FLAGS + extra + list(defines) + ["-I", INC_DIR, "-I", CSRC_DIR, "-I", HOST_DIR, "-o", out]
              + srcs + host_srcs)
+        check_resources(out)
     return out
 
 
@@ -115,6 +116,58 @@ def build_rccl(force=False):
         _run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", INC_DIR, src,
               "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib", "-o", RCCL_LIB])
     return RCCL_LIB
+
+
+# ---- build guard -----------------------------------------------------------------------------------------------------
+# HIP_OPT_FLAGS holds unversioned LLVM switches that were chosen because they cut the expand kernel's register spills. A
+# toolchain bump can silently change what they do; that must show at BUILD time, not weeks later in a bench regression.
+# After every HIP build the register / spill / scratch / LDS figures are read from the code object's own metadata
+# (tools/kernel_resources.py), written to profiles/kernel_resources_<lib>.json, and compared with the committed bounds
+# below (measured figures of the round-5 build + a margin of a few registers). EG3D_NO_BUILD_GUARD=1 skips the check
+# (experimental variants built with other switches).
+RESOURCE_BOUNDS = {
+    # kernel (substring of the demangled name): {metadata field: largest accepted value}
+    "k3b_expand_t<4, 0, 0>": {"vgpr_spill_count": 40, "private_segment_fixed_size": 192, "group_segment_fixed_size": 10240},
+    "k3b_expand_t<4, 0, 1>": {"vgpr_spill_count": 180, "private_segment_fixed_size": 320, "group_segment_fixed_size": 10240},
+    "k3b_expand_t<4, 0, 2>": {"vgpr_spill_count": 40, "private_segment_fixed_size": 192, "group_segment_fixed_size": 10240},
+    "k3a_orient": {"vgpr_spill_count": 0, "group_segment_fixed_size": 12800},
+    "k3a_follow_spec": {"vgpr_spill_count": 0, "group_segment_fixed_size": 12800},
+    "k3c_engine_t<false>": {"vgpr_spill_count": 160, "group_segment_fixed_size": 10240},
+    "k3c_engine_t<true>": {"vgpr_spill_count": 160, "group_segment_fixed_size": 10240},
+    "k5_gn_filter": {"vgpr_spill_count": 0},
+    "k2_epipolar_hits": {"vgpr_spill_count": 0},
+    "k1_seed_candidates": {"vgpr_spill_count": 0},
+}
+
+
+def check_resources(lib, strict=True):
+    """Reads the kernels' resource figures from `lib`, stores them under profiles/, returns the list of violated bounds
+    (and raises if strict)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import kernel_resources as kr
+    finally:
+        sys.path.pop(0)
+    res = {n: r for n, r in kr.kernel_resources(lib).items() if n.startswith("eg3d::")}
+    out = os.path.join(ROOT, "profiles", "kernel_resources_%s.json" % os.path.splitext(os.path.basename(lib))[0])
+    try:
+        import json
+        with open(out, "w") as f:
+            json.dump(res, f, indent=1, sort_keys=True)
+            f.write("\n")
+    except OSError:
+        pass  # (a read-only tree: the check below still runs)
+    for n in sorted(res):
+        if any(k in n for k in ("k3a_orient", "k3a_follow", "k3b_expand", "k3c_engine")):
+            r = res[n]
+            print("  %-28s vgpr %3d  spilled vgpr %3d  spilled sgpr %3d  scratch %4d B  lds %5d B" % (
+                n.replace("eg3d::", ""), r["vgpr_count"], r["vgpr_spill_count"], r["sgpr_spill_count"],
+                r["private_segment_fixed_size"], r["group_segment_fixed_size"]), flush=True)
+    bad = kr.check_bounds(res, RESOURCE_BOUNDS)
+    if bad and strict and os.environ.get("EG3D_NO_BUILD_GUARD") != "1":
+        raise RuntimeError("build guard: kernel resources exceed the committed bounds (edgegraph3d_amd/build.py "
+                           "RESOURCE_BOUNDS):\n  " + "\n  ".join(bad))
+    return bad
 
 
 def build_oracle(force=False):

@@ -1730,9 +1730,6 @@ extern "C" int eg3d_probe_sections(eg3d_ctx* c, double* sum, double* slowest, ui
 // Gauss-Newton diagnostics of the expand kernel since the last reset (eg3d_dev_coopgn.h g_gn_dbg)
 namespace eg3d { int gn_dbg_read(unsigned long long* out, int reset); }
 extern "C" int eg3d_probe_gn(unsigned long long* out128, int reset) { return eg3d::gn_dbg_read(out128, reset); }
-// ... and of the lane-per-chain engine (eg3d_k3c_engine.h g_k3c_dbg)
-namespace eg3d { int k3c_dbg_read(unsigned long long* out, int reset); }
-extern "C" int eg3d_probe_k3c(unsigned long long* out32, int reset) { return eg3d::k3c_dbg_read(out32, reset); }
 
 extern "C" int eg3d_probe_hyp_sections(eg3d_ctx* c, double* sum, double* slowest, uint32_t* counts) {
   if (!c || !sum || !slowest || !counts) return EG3D_ERR_ARG;
@@ -1758,4 +1755,10 @@ extern "C" int eg3d_probe_hyp_sections(eg3d_ctx* c, double* sum, double* slowest
   return EG3D_OK;
 }
 
-#endif  // EG3D_SECTION_TIMING
+#endif
+#if defined(EG3D_SECTION_TIMING) || defined(EG3D_K3C_TIMING)
+// ... and of the lane-per-chain engine (eg3d_k3c_engine.h g_k3c_dbg)
+namespace eg3d { int k3c_dbg_read(unsigned long long* out, int reset); }
+extern "C" int eg3d_probe_k3c(unsigned long long* out128, int reset) { return eg3d::k3c_dbg_read(out128, reset); }
+#endif
+  // EG3D_SECTION_TIMING

@@ -447,6 +447,14 @@ EG3D_HD void sm_walks(const Env& env, const DevScene& s, SmChain& q, const PlRef
   if (k.m1 > 0 && k.ci < k.hi) k.m2 = env.side_walk(s, c, (int)k.o.view, pl, k.o, dE, k.lo, k.ci, k.hi, false, c.pend2);
 }
 
+// timing builds of the engine kernel: clocks per block of sm_advance (the Env counts; the plain Envs do nothing)
+template <class Env>
+struct SmProf {
+  const Env& e;
+  uint32_t id;
+  EG3D_HD SmProf(const Env& env, uint32_t i) : e(env), id(i) { e.prof_begin(id); }
+  EG3D_HD ~SmProf() { e.prof_end(id); }
+};
 // Run the machine until it blocks (k.wait != SM_RUN). The blocks below are in flow order, so that a machine passes
 // through as many of them as it can in one trip of the loop (on the GPU a trip executes every block some lane is in).
 template <class Env>
@@ -457,6 +465,7 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
   while (k.wait == SM_RUN) {
     // ---------------- result of an attachment, back in the loop that tried it
     if (k.st == SMS_ATTACH_RET) {
+      const SmProf<Env> prof_(env, SMS_ATTACH_RET);
       if (k.ret_to == SMR_EPC) {
         if (k.attach_ok) {
           k.epc_matched = 1;
@@ -491,6 +500,7 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
     }
     // ---------------- next view
     if (k.st == SMS_VIEW_NEXT) {
+      const SmProf<Env> prof_(env, SMS_VIEW_NEXT);
       for (;;) {
         k.v++;
         if (k.v >= s.n_views) break;
@@ -527,6 +537,7 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
     if (k.st == SMS_EPC_POST && k.wait == SM_RUN) sm_post_gn(k, SMB_EPC, k.n_pre, SMS_EPC_LOOP);
     // ---------------- the task's epipolar hits in this view, in order, against the central point
     if (k.st == SMS_EPC_LOOP && k.wait == SM_RUN) {
+      const SmProf<Env> prof_(env, SMS_EPC_LOOP);
       if (k.e >= k.n_epc) {
         k.st = SMS_CAND_POST;
       } else {
@@ -541,6 +552,7 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
     }
     // ---------------- candidates of all chain points in view v
     if (k.st == SMS_CAND_POST) {
+      const SmProf<Env> prof_(env, SMS_CAND_POST);
       k.last_matched = -1;
       k.cl_from = 0;
       k.cl_to = c.len;
@@ -549,6 +561,7 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
       if (k.cl_to > k.cl_from) k.wait = SM_WAIT_CL;
     }
     if (k.st == SMS_CAND_DONE && k.wait == SM_RUN) {
+      const SmProf<Env> prof_(env, SMS_CAND_DONE);
       k.spec_slot_hi = 0;
       k.cur = 0;
       if (!sm_lazy_presolve(s)) {
@@ -560,6 +573,7 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
     }
     // ---------------- visit the chain points in order
     if (k.st == SMS_VISIT && k.wait == SM_RUN) {
+      const SmProf<Env> prof_(env, SMS_VISIT);
       for (;;) {
         if (k.cur >= c.len) {
           k.st = SMS_VIEW_NEXT;
@@ -594,6 +608,7 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
       }
     }
     if (k.st == SMS_VISIT_ATTACH && k.wait == SM_RUN) {
+      const SmProf<Env> prof_(env, SMS_VISIT_ATTACH);
       const ViewCand& vc = c.cand[c.head + k.cur];
       k.o.view = (uint32_t)k.v;
       k.o.pl = vc.pl;
@@ -609,6 +624,7 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
     }
     // ---------------- attach_view
     if (k.st == SMS_ATTACH_BEGIN) {
+      const SmProf<Env> prof_(env, SMS_ATTACH_BEGIN);
       k.to_start = 0;
       k.to_end = 0;
       k.attach_ok = 0;
@@ -628,6 +644,7 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
       }
     }
     if (k.st == SMS_CENTRAL_DONE && k.wait == SM_RUN) {
+      const SmProf<Env> prof_(env, SMS_CENTRAL_DONE);
       if (!q.mbox->ok) {
         k.st = SMS_ATTACH_RET;
       } else {
@@ -638,6 +655,7 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
       }
     }
     if (k.st == SMS_ATTACH_SIDES) {
+      const SmProf<Env> prof_(env, SMS_ATTACH_SIDES);
       k.nd1 = k.nd2 = 0;
       k.n1 = k.n2 = 0;
       k.which = 0;
@@ -661,6 +679,7 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
       }
     }
     if (k.st == SMS_SIDES_DONE && k.wait == SM_RUN) {
+      const SmProf<Env> prof_(env, SMS_SIDES_DONE);
       const int n1 = sm_leading_ok(c.pend1, k.m1);
       const int n2 = n1 > 0 ? sm_leading_ok(c.pend2, k.m2) : 0;
       k.n1 = n1;
@@ -685,6 +704,7 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
       }
     }
     if (k.st == SMS_ATTACH_CHECK) {
+      const SmProf<Env> prof_(env, SMS_ATTACH_CHECK);
       const int n1 = k.n1, n2 = k.n2, ci = k.ci;
       if ((ci > 0 && n1 == 0) || (ci < c.len - 1 && n2 == 0)) {
         k.st = SMS_ATTACH_RET;
@@ -764,6 +784,7 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
     }
     // ---------------- grow the chain at the front, then at the back
     if (k.st == SMS_FOLLOW_END) {
+      const SmProf<Env> prof_(env, SMS_FOLLOW_END);
       if (k.side == 0) {
         k.to_start += k.added;
         k.ci += k.added;
@@ -774,6 +795,7 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
       k.st = SMS_FOLLOW_SIDE;
     }
     if (k.st == SMS_FOLLOW_SIDE) {
+      const SmProf<Env> prof_(env, SMS_FOLLOW_SIDE);
       for (; k.side < 2; k.side++) {
         const bool front = k.side == 0;
         if (front ? !(k.n1 > 0 && k.n1 == k.ci) : !(k.n2 > 0 && k.n2 == (c.len - k.ci - 1))) continue;
@@ -788,6 +810,7 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
       if (k.side >= 2) k.st = SMS_ATTACH_RET;
     }
     if (k.st == SMS_STEP_OK) {
+      const SmProf<Env> prof_(env, SMS_STEP_OK);
       const bool front = k.side == 0;
       bool stop = false;
       if (front ? (c.head <= 0) : (c.head + c.len >= c.cap_pts)) {
@@ -812,11 +835,13 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
       if (stop) continue;  // (SMS_FOLLOW_END is above)
     }
     if (k.st == SMS_FOLLOW_STEP) {
+      const SmProf<Env> prof_(env, SMS_FOLLOW_STEP);
       k.st_obs = 0;
       k.st = SMS_STEP_CAND;
     }
     // ---------------- N-view step: candidates in observation order
     if (k.st == SMS_STEP_CAND) {
+      const SmProf<Env> prof_(env, SMS_STEP_CAND);
       const bool front = k.side == 0;
       const ChainPt& cur = front ? chain_at(c, 0) : chain_at(c, c.len - 1);
       const uint32_t* dirs = front ? c.start_dirs : c.end_dirs;
@@ -835,10 +860,12 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
       k.st = SMS_STEP_TRI;
     }
     if (k.st == SMS_STEP_TRI) {
+      const SmProf<Env> prof_(env, SMS_STEP_TRI);
       sm_list_dlt(env, s, c.tmp_a, k.m, c.flags, k.X);
       sm_post_gn(k, SMB_LIST_A, 1, SMS_STEP_TRI_DONE);
     }
     if (k.st == SMS_STEP_TRI_DONE && k.wait == SM_RUN) {
+      const SmProf<Env> prof_(env, SMS_STEP_TRI_DONE);
       if (q.mbox->ok) {
         k.X[0] = q.mbox->X[0];
         k.X[1] = q.mbox->X[1];
@@ -858,6 +885,7 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
       k.st = SMS_FB_NEXT;
     }
     if (k.st == SMS_FB_TRI_DONE && k.wait == SM_RUN) {
+      const SmProf<Env> prof_(env, SMS_FB_TRI_DONE);
       if (q.mbox->ok) {
         k.X[0] = q.mbox->X[0];
         k.X[1] = q.mbox->X[1];
@@ -882,6 +910,7 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
       }
     }
     if (k.st == SMS_FB_NEXT) {
+      const SmProf<Env> prof_(env, SMS_FB_NEXT);
       if (k.fi >= k.m - 2) {  // no valid 3-subset: this candidate is dead
         k.st_obs++;
         k.st = SMS_STEP_CAND;
@@ -894,6 +923,7 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
       sm_post_gn(k, SMB_LIST_B, 1, SMS_FB_TRI_DONE);
     }
     if (k.st == SMS_FB_ADD_DONE && k.wait == SM_RUN) {
+      const SmProf<Env> prof_(env, SMS_FB_ADD_DONE);
       if (q.mbox->ok) {
         c.tmp_mask[k.fb_i] = 1;
         k.X[0] = q.mbox->X[0];
@@ -905,6 +935,7 @@ EG3D_HD_FLAT void sm_advance(const Env& env, const DevScene& s, const StageAView
       k.st = SMS_FB_ADD;
     }
     if (k.st == SMS_FB_ADD) {
+      const SmProf<Env> prof_(env, SMS_FB_ADD);
       while (k.fb_i < k.m && c.tmp_mask[k.fb_i]) k.fb_i++;
       if (k.fb_i < k.m) {
         sm_post_gn(k, SMB_LISTADD, 1, SMS_FB_ADD_DONE);
@@ -1119,6 +1150,8 @@ EG3D_HD int sm_step_walks_stream(const DevScene& s, const Obs* co_all, int n, in
 // Lane-private primitives of the machine in their plain (sequential) form: what the host simulation uses, and the
 // engine kernel unless it overrides one.
 struct SmEnvSeq {
+  EG3D_HD void prof_begin(uint32_t) const {}
+  EG3D_HD void prof_end(uint32_t) const {}
   EG3D_HD void dlt(const float* P1, float x1, float y1, const float* P2, float x2, float y2, double X0[3]) const {
     dlt2(P1, x1, y1, P2, x2, y2, X0);
   }

@@ -51,20 +51,45 @@ struct K3cShared {
   __device__ __forceinline__ K3cAnswers& ans() { return *(K3cAnswers*)&gn.tmp_a[0]; }
 };
 
-#ifdef EG3D_SECTION_TIMING
-// timing build: shader clocks of a wave's phases summed over the launch — [0] fetch, [1] advance, [2] pack, [3] solve
+#if defined(EG3D_SECTION_TIMING) && !defined(EG3D_K3C_TIMING)
+#define EG3D_K3C_TIMING 1
+#endif
+#ifdef EG3D_K3C_TIMING
+// timing build (-DEG3D_K3C_TIMING: the engine's own clocks only, light; -DEG3D_SECTION_TIMING adds the solver's): shader clocks of a wave's phases summed over the launch — [0] fetch, [1] advance, [2] pack, [3] solve
 // drain, [4] candidate drain; [8] iterations, [9] lanes with a chain (summed over iterations), [10] solves served,
 // [11] candidate items, [12] solver windows, [13] lanes blocked on solves / [14] on candidates (summed over iterations)
 __device__ unsigned long long g_k3c_dbg[32];
+// ... and per block of sm_advance (index = SMS_* state): [3 s] wall clocks of the wave inside the block, [3 s + 1] the same
+// times the lanes that were in it, [3 s + 2] entries
+__device__ unsigned long long g_k3c_prof[96];
+struct SmEnvProf : SmEnvStream {
+  mutable unsigned long long t0 = 0;
+  unsigned long long* acc = nullptr;  // the wave's 96 counters in LDS
+  __device__ void prof_begin(uint32_t) const { t0 = __builtin_readcyclecounter(); }
+  __device__ void prof_end(uint32_t id) const {
+    const unsigned long long dt = __builtin_readcyclecounter() - t0;
+    const unsigned long long m = __ballot(1);
+    if ((int)(threadIdx.x & 63u) == __ffsll((long long)m) - 1) {
+      acc[3 * id] += dt;
+      acc[3 * id + 1] += dt * (unsigned long long)__popcll(m);
+      acc[3 * id + 2] += 1ull;
+    }
+  }
+};
+#define K3C_ENV SmEnvProf
 #define K3C_T0() unsigned long long ct_[6] = {0, 0, 0, 0, 0, 0}, cc_[7] = {0, 0, 0, 0, 0, 0, 0}, ct0_ = __builtin_readcyclecounter(), ct1_
 #define K3C_T(i) (ct1_ = __builtin_readcyclecounter(), ct_[i] += ct1_ - ct0_, ct0_ = ct1_)
 #define K3C_C(i, v) (cc_[i] += (v))
 #define K3C_TEND()                                                                   \
+  __syncthreads();                                                                   \
+  for (uint32_t i_ = lane; i_ < 96; i_ += 64)                                        \
+    if (prof_acc[i_]) atomicAdd(&g_k3c_prof[i_], prof_acc[i_]);                      \
   if (lane == 0) {                                                                   \
     for (int q_ = 0; q_ < 5; q_++) atomicAdd(&g_k3c_dbg[q_], ct_[q_]);               \
     for (int q_ = 0; q_ < 7; q_++) atomicAdd(&g_k3c_dbg[8 + q_], cc_[q_]);           \
   }
 #else
+#define K3C_ENV SmEnvStream
 #define K3C_TEND() ((void)0)
 #define K3C_T0() ((void)0)
 #define K3C_T(i) ((void)0)
@@ -97,7 +122,15 @@ __global__ void __launch_bounds__(64, EG3D_K3C_WAVES) k3c_engine_t(DevScene s, S
   bool have = false, exhausted = lane >= lanes_per_wave;
   uint32_t jchain = 0, flags_acc = 0;
   unsigned long long bytes_acc = 0;
-  const SmEnvStream env;
+#ifdef EG3D_K3C_TIMING
+  __shared__ unsigned long long prof_acc[96];
+  for (uint32_t i_ = lane; i_ < 96; i_ += 64) prof_acc[i_] = 0;
+  __syncthreads();
+  K3C_ENV env;
+  env.acc = prof_acc;
+#else
+  const K3C_ENV env;
+#endif
   K3C_T0();
   for (;;) {
     // ---- (0) the next chain

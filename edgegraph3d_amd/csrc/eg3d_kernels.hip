@@ -1539,12 +1539,14 @@ void launch_k3c(hipStream_t st, uint32_t n_waves, uint32_t lanes_per_wave, DevSc
     hipLaunchKernelGGL(k3c_engine_short, dim3(n_waves), dim3(64), 0, st, s, a, tasks, chains, n_chains, hyp_off, res, arena,
                        map_view, map_entry, map_n, L, slices, stage, outs, out_points, out_obs, ctr, order, queue, lanes_per_wave);
 }
-#ifdef EG3D_SECTION_TIMING
-int k3c_dbg_read(unsigned long long* out, int reset) {
+#if defined(EG3D_SECTION_TIMING) || defined(EG3D_K3C_TIMING)
+int k3c_dbg_read(unsigned long long* out, int reset) {  // out[128]: g_k3c_dbg[32] then g_k3c_prof[96]
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k3c_dbg), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out + 32, HIP_SYMBOL(g_k3c_prof), sizeof(unsigned long long) * 96) != hipSuccess) return -1;
   if (reset) {
-    unsigned long long z[32] = {0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_k3c_dbg), z, sizeof(z)) != hipSuccess) return -1;
+    unsigned long long z[96] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_k3c_dbg), z, sizeof(unsigned long long) * 32) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_k3c_prof), z, sizeof(z)) != hipSuccess) return -1;
   }
   return 0;
 }

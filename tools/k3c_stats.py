@@ -9,11 +9,11 @@ cfg = int(sys.argv[1]); ns = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 s = host.Synth(cfg)
 ctx = api.Context(s.scene); ctx.upload_seeds(s.seeds)
 n = ns or s.n_seeds
-L = api.lib(); buf = (C.c_ulonglong * 32)(); gn = (C.c_ulonglong * 128)()
+L = api.lib(); buf = (C.c_ulonglong * 128)(); gn = (C.c_ulonglong * 128)()
 ctx.match_resident(0, n, device_only=True)
-L.eg3d_probe_k3c(buf, 1); L.eg3d_probe_gn(gn, 1)
+L.eg3d_probe_k3c(buf, 1); (hasattr(L, "eg3d_probe_gn") and L.eg3d_probe_gn(gn, 1))
 r = ctx.match_resident(0, n, device_only=True)
-L.eg3d_probe_k3c(buf, 1); L.eg3d_probe_gn(gn, 1)
+L.eg3d_probe_k3c(buf, 1); (hasattr(L, "eg3d_probe_gn") and L.eg3d_probe_gn(gn, 1))
 b = list(buf); g = list(gn)
 names = ["fetch", "advance", "pack", "solve drain", "candidate drain"]
 tot = max(1, sum(b[:5]))
@@ -26,3 +26,17 @@ rounds = max(1, g[69])
 print("  solver: %d requests in %d rounds (%.2f per round), rows per request %.2f, row fill %.2f of 64, "
       "clocks per round %.0f; share of solve drain inside rounds %.1f%%"
       % (g[64], g[69], g[64] / rounds, g[66] / max(1, g[64]), g[68] / max(1.0, g[67] / 64.0) , g[111] / rounds, 100.0 * g[111] / max(1, b[3])))
+
+STATES = ["VIEW_NEXT", "EPC_POST", "EPC_LOOP", "CAND_POST", "CAND_DONE", "VISIT", "VISIT_ATTACH", "ATTACH_BEGIN", "CENTRAL_DONE",
+          "ATTACH_SIDES", "SIDES_DONE", "ATTACH_CHECK", "FOLLOW_SIDE", "FOLLOW_STEP", "STEP_CAND", "STEP_TRI", "STEP_TRI_DONE",
+          "FB_NEXT", "FB_TRI_DONE", "FB_ADD", "FB_ADD_DONE", "STEP_OK", "FOLLOW_END", "ATTACH_RET", "FINISH"]
+adv = max(1, b[1])
+print("  blocks of the advance (share of its wall clocks; lanes inside; clocks per entry):")
+for i, nm in enumerate(STATES):
+    w, l, n = b[32 + 3 * i: 35 + 3 * i]
+    if n:
+        print("    %-14s %5.1f%%  lanes %.2f  entries %9d  clocks/entry %8.0f" % (nm, 100.0 * w / adv, l / max(1, w), n, w / n))
+t = g[104:113]
+tt = max(1, g[111])
+print("  inside solver rounds: rows %.1f%%  barrier %.1f%%  sums-1 %.1f%%  inverse %.1f%%  products-2 %.1f%%  sums-2 %.1f%%  update %.1f%%"
+      % tuple(100.0 * x / tt for x in t[:7]))
