@@ -132,8 +132,8 @@ RESOURCE_BOUNDS = {
     "k3b_expand_t<4, 0, 2>": {"vgpr_spill_count": 40, "private_segment_fixed_size": 192, "group_segment_fixed_size": 10240},
     "k3a_orient": {"vgpr_spill_count": 0, "group_segment_fixed_size": 12800},
     "k3a_follow_spec": {"vgpr_spill_count": 0, "group_segment_fixed_size": 12800},
-    "k3c_engine_t<false>": {"vgpr_spill_count": 160, "group_segment_fixed_size": 10240},
-    "k3c_engine_t<true>": {"vgpr_spill_count": 160, "group_segment_fixed_size": 10240},
+    "k3c_engine_t<false>": {"vgpr_spill_count": 256, "group_segment_fixed_size": 10240},
+    "k3c_engine_t<true>": {"vgpr_spill_count": 256, "group_segment_fixed_size": 10240},
     "k5_gn_filter": {"vgpr_spill_count": 0},
     "k2_epipolar_hits": {"vgpr_spill_count": 0},
     "k1_seed_candidates": {"vgpr_spill_count": 0},

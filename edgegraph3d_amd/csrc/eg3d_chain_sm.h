@@ -1169,12 +1169,9 @@ struct SmEnvSeq {
 // ... with the memory trips of the lane-private loops taken out of the dependent chains (what the engine kernel runs;
 // hostsim mode 3 runs it on the CPU against the oracle)
 struct SmEnvStream : SmEnvSeq {
-  // the 2-view DLT with its matrices in lane-private MEMORY (dlt2_mem: same operations in the same order as dlt2): the
-  // decomposition's 44 doubles would otherwise sit in registers on top of the machine's whole state
-  EG3D_HD void dlt(const float* P1, float x1, float y1, const float* P2, float x2, float y2, double X0[3]) const {
-    double work[EG3D_DLT_WORK_DOUBLES];
-    dlt2_mem(P1, x1, y1, P2, x2, y2, (double*)work, X0);
-  }
+  // (the 2-view DLT stays in registers, SmEnvSeq::dlt: with its matrices in lane-private memory — dlt2_mem on a scratch
+  // array, which frees ~80 registers — a decomposition took 150 k clocks, 37 % of the engine's advance phase:
+  // profiles/r05_experiments/engine_blocks_c3.txt)
   EG3D_HD int side_walk(const DevScene& s, Chain& c, int view, const PlRef& pl, const Obs& from, uint32_t direction, int lo,
                         int ci, int hi, bool towards_start, Pending* out) const {
     return sm_side_walk_stream(s, c, view, pl, from, direction, lo, ci, hi, towards_start, out);

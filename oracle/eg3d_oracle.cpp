@@ -101,6 +101,7 @@ extern "C" int orc_set_dlt_rows(int rows) {
 extern "C" int orc_get_dlt_rows(void) { return orc::g_dlt_rows; }
 // test hook (tests/test_quirks.py): bit q makes the restatement "fix" quirk Qq (4, 12, 13); 0 = reference behaviour
 extern "C" void orc_set_quirk_fixes(unsigned mask) { orc::g_quirk_fix = mask; }
+extern "C" void orc_set_conventions(unsigned mask) { orc::g_conv = mask; }
 
 extern "C" int orc_get_grid(orc_ctx* c, int view, int which, uint32_t* ncols, uint32_t* nrows,
                             const uint32_t** cell_off, const uint32_t** ids) {
@@ -204,7 +205,7 @@ extern "C" int orc_match_refpoints(orc_ctx* c, const eg3d_seeds* seeds, uint32_t
   std::vector<Stats> tstats(nthreads);
   c->sc.dir_mismatch = 0;
   auto t0 = std::chrono::steady_clock::now();
-#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
   for (uint32_t i = 0; i < n; i++) {
     int t = omp_get_thread_num();
     SeedView sv = seed_view(seeds, b + i);

@@ -27,6 +27,8 @@ int orc_set_dlt_rows(int rows);
 int orc_get_dlt_rows(void);
 /* test hook: bit q = behave as a "corrected" implementation of quirk Qq would (q = 4, 12, 13); 0 = reference */
 void orc_set_quirk_fixes(unsigned mask);
+/* TEST HOOK: arithmetic conventions of the unpinned OpenCV routines (oracle_tri.hpp g_conv); 0 = the restatement */
+void orc_set_conventions(unsigned mask);
 orc_ctx* orc_create(const eg3d_scene* scene);
 void orc_destroy(orc_ctx*);
 int orc_get_grid(orc_ctx*, int view, int which, uint32_t* ncols, uint32_t* nrows, const uint32_t** cell_off,

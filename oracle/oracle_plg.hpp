@@ -32,7 +32,9 @@ struct Scene {
   mutable uint32_t dir_mismatch;
 };
 
-struct Stats {
+// (one per thread, in a vector: its own cache lines — the counters are bumped on every solve, and 256 threads sharing
+// lines two by two was most of what kept the all-core run of the oracle at 7x one thread)
+struct alignas(128) Stats {
   TriStats tri;
   uint64_t n_tasks = 0, n_hyp = 0, n_chains = 0;
   uint64_t bytes_algorithmic = 0;

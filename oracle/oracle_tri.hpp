@@ -30,6 +30,44 @@ struct Cameras {
 
 // geometric_utilities.cpp:824-843 -> cv::computeCorrespondEpilines(points, 1, F, lines):
 // l = F * (x, y, 1)^T in double, scaled by 1/sqrt(a^2+b^2), rounded to float.
+// TEST HOOK (tools/convention_report.py, orc_set_conventions): how exposed the results are to conventions of the OpenCV
+// routines that this restatement could not pin (no OpenCV in the image). 0 = the restatement as is. Bits:
+//   1   GEMM sums (J^T J and (H^-1 J^T) r) with TWO interleaved accumulators (even / odd terms), added at the end
+//   2   ... with FOUR interleaved accumulators
+//   4   Jacobi SVD: gamma = hypot(p, beta) instead of sqrt(p*p + beta*beta)
+//   8   Jacobi SVD: rotation pairs visited in the opposite order (i descending, j descending)
+//   16  epipolar line normalised by division (a / sqrt(nu)) instead of multiplication by 1 / sqrt(nu)
+static unsigned g_conv = 0;
+template <class F>
+static inline double conv_sum(int count, F term) {  // sum_{k < count} term(k) under the selected GEMM convention
+  if (g_conv & 2u) {
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int k = 0;
+    for (; k + 4 <= count; k += 4) {
+      s0 += term(k);
+      s1 += term(k + 1);
+      s2 += term(k + 2);
+      s3 += term(k + 3);
+    }
+    double s = (s0 + s1) + (s2 + s3);
+    for (; k < count; k++) s += term(k);
+    return s;
+  }
+  if (g_conv & 1u) {
+    double s0 = 0, s1 = 0;
+    int k = 0;
+    for (; k + 2 <= count; k += 2) {
+      s0 += term(k);
+      s1 += term(k + 1);
+    }
+    double s = s0 + s1;
+    for (; k < count; k++) s += term(k);
+    return s;
+  }
+  double s = 0;
+  for (int k = 0; k < count; k++) s += term(k);
+  return s;
+}
 static inline bool computeCorrespondEpilineSinglePoint(const Cameras& cams, int view_from, int view_to,
                                                        const vec2& p, float epipolar_line[3]) {
   if (!cams.F_valid[(size_t)view_from * cams.n_views + view_to]) return false;  // "F.rows==3 && F.cols==3" fails
@@ -39,10 +77,17 @@ static inline bool computeCorrespondEpilineSinglePoint(const Cameras& cams, int 
   double b = (f[3] * t0 + f[4] * t1) + f[5];
   double c = (f[6] * t0 + f[7] * t1) + f[8];
   double nu = a * a + b * b;
-  nu = nu ? 1. / std::sqrt(nu) : 1.;
-  a *= nu;
-  b *= nu;
-  c *= nu;
+  if ((g_conv & 16u) && nu) {
+    const double sq = std::sqrt(nu);
+    a /= sq;
+    b /= sq;
+    c /= sq;
+  } else {
+    nu = nu ? 1. / std::sqrt(nu) : 1.;
+    a *= nu;
+    b *= nu;
+    c *= nu;
+  }
   epipolar_line[0] = (float)a;
   epipolar_line[1] = (float)b;
   epipolar_line[2] = (float)c;
@@ -93,15 +138,19 @@ static inline void jacobi_svd_last_v(const double At_in[4][6], int m, double out
   const int max_iter = 30;  // std::max(m, 30)
   for (int iter = 0; iter < max_iter; iter++) {
     bool changed = false;
-    for (int i = 0; i < n - 1; i++)
-      for (int j = i + 1; j < n; j++) {
+    // the pairs (i < j) of n = 4 rows in ascending order: i outer, j inner (test hook bit 8: the same pairs, last first)
+    static const int PAIR_I[6] = {0, 0, 0, 1, 1, 2}, PAIR_J[6] = {1, 2, 3, 2, 3, 3};
+    for (int pq = 0; pq < 6; pq++) {
+      {
+        const int pr = (g_conv & 8u) ? 5 - pq : pq;
+        const int i = PAIR_I[pr], j = PAIR_J[pr];
         double* Ai = At[i];
         double* Aj = At[j];
         double a = W[i], p = 0, b = W[j];
         for (int k = 0; k < m; k++) p += Ai[k] * Aj[k];
         if (std::fabs(p) <= eps * std::sqrt(a * b)) continue;
         p *= 2;
-        double beta = a - b, gamma = std::sqrt(p * p + beta * beta);
+        double beta = a - b, gamma = (g_conv & 4u) ? std::hypot(p, beta) : std::sqrt(p * p + beta * beta);
         double c, s;
         if (beta < 0) {
           double delta = (gamma - beta) * 0.5;
@@ -132,6 +181,7 @@ static inline void jacobi_svd_last_v(const double At_in[4][6], int m, double out
           Vj[k] = t1;
         }
       }
+    }
     if (!changed) break;
   }
   for (int i = 0; i < n; i++) {
@@ -192,7 +242,13 @@ struct GNObs {
 // multiplied by r summing over the 2n columns in order.
 static inline int em_GaussNewton(const std::vector<GNObs>& obs, const double init[3], double out[3]) {
   const int n = (int)obs.size();
-  std::vector<double> r(2 * n), J(6 * n);
+  // scratch of the solve, per thread and reused (the values are overwritten before they are read: same arithmetic; a
+  // std::vector pair per call was ~50 M malloc / free per C3' step, serialising the threads of an all-core run)
+  static thread_local std::vector<double> r_tl, J_tl;
+  if (r_tl.size() < (size_t)(2 * n)) r_tl.resize(2 * n);
+  if (J_tl.size() < (size_t)(6 * n)) J_tl.resize(6 * n);
+  double* const r = r_tl.data();
+  double* const J = J_tl.data();
   double X[3] = {init[0], init[1], init[2]};
   double last_mse = 0;
   for (int it = 0; it < 30; it++) {
@@ -228,9 +284,11 @@ static inline int em_GaussNewton(const std::vector<GNObs>& obs, const double ini
     double H[3][3];
     for (int i = 0; i < 3; i++)
       for (int j = 0; j < 3; j++) {
-        double s = 0;
-        for (int k = 0; k < 2 * n; k++) s += J[k * 3 + i] * J[k * 3 + j];
-        H[i][j] = s;
+        H[i][j] = g_conv & 3u ? conv_sum(2 * n, [&](int k) { return J[k * 3 + i] * J[k * 3 + j]; }) : [&]() {
+          double s = 0;
+          for (int k = 0; k < 2 * n; k++) s += J[k * 3 + i] * J[k * 3 + j];
+          return s;
+        }();
       }
     // cv::determinant 3x3 (det3 macro)
     double d = H[0][0] * (H[1][1] * H[2][2] - H[1][2] * H[2][1]) - H[0][1] * (H[1][0] * H[2][2] - H[1][2] * H[2][0]) +
@@ -252,11 +310,15 @@ static inline int em_GaussNewton(const std::vector<GNObs>& obs, const double ini
     }
     // X += (H^-1 * J^T) * r
     for (int i = 0; i < 3; i++) {
-      double s = 0;
-      for (int k = 0; k < 2 * n; k++) {
+      auto term = [&](int k) {
         double mik = (Hi[i][0] * J[k * 3 + 0] + Hi[i][1] * J[k * 3 + 1]) + Hi[i][2] * J[k * 3 + 2];
-        s += mik * r[k];
-      }
+        return mik * r[k];
+      };
+      double s = 0;
+      if (g_conv & 3u)
+        s = conv_sum(2 * n, term);
+      else
+        for (int k = 0; k < 2 * n; k++) s += term(k);
       X[i] += s;
     }
   }
@@ -300,7 +362,8 @@ static inline void em_estimate3Dpositions(const Cameras& cams, const std::vector
   double init[3], opt[3];
   dlt2_init(cams.P + (size_t)firstCamIdx * 16, coords[mm.first], cams.P + (size_t)lastCamIdx * 16,
             coords[mm.second], init);
-  std::vector<GNObs> obs(ids.size());
+  static thread_local std::vector<GNObs> obs;
+  obs.resize(ids.size());
   for (size_t i = 0; i < ids.size(); i++) {
     obs[i].P = cams.P + (size_t)ids[i] * 16;
     obs[i].x = coords[i].x;
@@ -323,7 +386,8 @@ static inline void em_add_new_observation_to_3Dpositions(const Cameras& cams, co
                                                          TriStats* st) {
   if (st) st->n_add++;
   double init[3] = {(double)cur_X.x, (double)cur_X.y, (double)cur_X.z}, opt[3];
-  std::vector<GNObs> obs(cur_ids.size() + 1);
+  static thread_local std::vector<GNObs> obs;
+  obs.resize(cur_ids.size() + 1);
   for (size_t i = 0; i < cur_ids.size(); i++) {
     obs[i].P = cams.P + (size_t)cur_ids[i] * 16;
     obs[i].x = cur_coords[i].x;

@@ -97,6 +97,40 @@ def test_scene_class_builds_of_the_expand_kernel_agree_with_the_general_one(have
         assert x["flags"] == y["flags"]
 
 
+@pytest.mark.parametrize("lanes", [0, 3])
+def test_lane_per_chain_engine_form_of_the_expand_stage_matches_oracle(have_gpu, monkeypatch, lanes):
+    """EG3D_K3B_ENGINE=1 runs the expand stage as the lane-per-chain engine (k3c_engine, eg3d_k3c_engine.h: one lane owns
+    a chain — the state machine of eg3d_chain_sm.h — and the wave serves all chains' Gauss-Newton solves and candidate
+    searches densely) instead of one wavefront per chain. Measured slower in round 5 and therefore not the default
+    (DESIGN_LOG.md), but it is a complete second implementation of rows a10-a16 and must stay bit-exact: C2-sized and
+    small scenes, a fuzz scene with mutated polylines, both with the default number of owning lanes per wave and with 3
+    (chains queue up behind each other on a lane)."""
+    monkeypatch.setenv("EG3D_K3B_ENGINE", "1")
+    if lanes:
+        monkeypatch.setenv("EG3D_K3C_LANES", str(lanes))
+    for cfg in (1, 2):
+        s = host.Synth(cfg)
+        ref = _oracle(s.scene).match(s.seeds, 0, s.n_seeds, nthreads=8)
+        ctx = api.Context(s.scene)
+        got = ctx.match_refpoints(s.seeds)
+        ctx.close()
+        rep = compare_edgepoints(ref, got)
+        assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], (cfg, rep["msgs"][:3])
+        assert got["flags"] == ref["flags"] and got["times"]["bytes_algorithmic"] == ref["stats"]["bytes_algorithmic"]
+    import ctypes as C
+    from fuzz_scenes import draw
+    for case in (3, 20):
+        _, sa, seeds = draw(case)
+        n = len(seeds.trk_off) - 1
+        from oracle import binding as ob
+        ref = ob.Oracle(C.byref(sa.c)).match(C.byref(seeds.c), 0, n, 8)
+        ctx = api.Context(C.byref(sa.c))
+        got = ctx.match_refpoints(C.byref(seeds.c))
+        ctx.close()
+        rep = compare_edgepoints(ref, got)
+        assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], (case, rep["msgs"][:3])
+
+
 @pytest.mark.parametrize("engine", [0, 1])
 def test_solve_longer_than_a_packed_round_is_redone_by_the_general_build(have_gpu, monkeypatch, engine):
     """A few-views build of the expand stage (k3b_expand small scenes / the engine without the solver's long-request
