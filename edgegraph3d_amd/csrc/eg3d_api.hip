@@ -578,7 +578,9 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
     // pool is sized for CUs / XCDs compute units, not for an eighth of whatever the device reports
     const uint32_t cus = (uint32_t)prop.multiProcessorCount;
     const uint32_t n_xcd = std::min(8u, std::max(1u, cus / 32u));
-    const uint32_t cus_per_xcd = (cus + n_xcd - 1u) / n_xcd;
+    // (at least 40: an XCD of 38 CUs on a part with fewer than 8 XCDs would be undersized by the estimate cus / 32 — the
+    // pools cost a few tens of MB more on gfx950, where an XCD has 32)
+    const uint32_t cus_per_xcd = std::max<uint32_t>((cus + n_xcd - 1u) / n_xcd, 40u);
     c->slots_per_xcd = ((uint32_t)per_cu + 1u) * cus_per_xcd + 16u;
     if (c->tune.slots_per_xcd) c->slots_per_xcd = c->tune.slots_per_xcd;  // tests / experiments
     c->k3c_per_cu = k3c_blocks_per_cu();

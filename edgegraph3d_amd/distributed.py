@@ -131,7 +131,7 @@ class RcclCloudGather:
         rc = self.G.eg3d_allgather_edgepoints(self.g, self.comm, self.world, self.rank, self.stream, C.byref(loc), C.byref(out),
                                               self.rank_points, self.rank_obs)
         if rc != 0:
-            return False
+            return rc, False
         parts = [cloud(r) for r in range(self.world)]
         want_X = np.concatenate([p[0] for p in parts])
         want_key = np.concatenate([p[2] for p in parts])
@@ -142,7 +142,7 @@ class RcclCloudGather:
         want_off = np.concatenate(want_off)
         want = [want_X, want_off, want_key] + [np.concatenate([p[i] for p in parts]) for i in (3, 4, 5, 6)]
         if int(out.n_points) != len(want_X) or int(out.n_obs) != obase:
-            return False
+            return 0, False
         try:
             hip = C.CDLL("libamdhip64.so.7")
         except OSError:
@@ -153,10 +153,10 @@ class RcclCloudGather:
             w = np.ascontiguousarray(w)
             got = np.empty_like(w)
             if w.nbytes and hip.hipMemcpy(got.ctypes.data, C.c_void_p(ptr), w.nbytes, 2) != 0:
-                return False
+                return 0, False
             if not np.array_equal(got.view(np.uint8), w.view(np.uint8)):
-                return False
-        return True
+                return 0, False
+        return 0, True
 
     def _choose_mode(self, dist, device_index):
         """The grouped send/recv exchange is the default; if the pre-flight cloud does not come out right on EVERY rank
@@ -166,15 +166,27 @@ class RcclCloudGather:
         tried = []
         for mode in ([self.mode] if self.mode == "bcast" else ["sendrecv", "bcast"]):
             self.G.eg3d_gather_set_mode(self.g, 1 if mode == "bcast" else 0)
-            ok = self._selftest_once(device_index)
-            t = _t.tensor([0 if ok else 1], dtype=_t.int32, device=dev)
+            rc, ok = self._selftest_once(device_index)
+            # [0] = ranks whose data came out wrong, [1] = ranks whose call FAILED (rc != 0: with EG3D_GATHER_ERR_FATAL the
+            # library has already aborted the communicator on that rank — it must not be used again, by anyone)
+            t = _t.tensor([0 if ok or rc != 0 else 1, 1 if rc != 0 else 0], dtype=_t.int32, device=dev)
             dist.all_reduce(t)
-            tried.append((mode, int(t.item()) == 0))
+            bad_data, failed = int(t[0].item()), int(t[1].item())
+            tried.append((mode, bad_data == 0 and failed == 0))
+            if failed:
+                # a failed call is not a reason to try the other mode on the same communicator: give it up on every rank
+                self.selftest = tried
+                if rc == -6:
+                    self.abandon_comm()
+                self.close()
+                raise RuntimeError("eg3d_allgather_edgepoints failed (rc %d on this rank, %d rank(s) failed) in its pre-flight "
+                                   "check, mode %s: the communicator is abandoned" % (rc, failed, mode))
             if tried[-1][1]:
                 self.mode = mode
                 self.selftest = tried
                 return
         self.selftest = tried
+        self.close()
         raise RuntimeError("eg3d_allgather_edgepoints failed its pre-flight check in every exchange mode: %s" % tried)
 
     def allgather(self, local_dev):

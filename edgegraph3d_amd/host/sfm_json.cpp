@@ -335,6 +335,17 @@ extern "C" int eg3d_sfm_set_camera(eg3d_sfm* s, int view, float focal, float ppx
   return 0;
 }
 
+extern "C" const char* eg3d_sfm_image_path(const eg3d_sfm* s, int view) {
+  if (!s || view < 0 || view >= (int)s->cams.size()) return nullptr;
+  return s->cams[view].path.c_str();
+}
+extern "C" int eg3d_sfm_image_size(const eg3d_sfm* s, int* width, int* height) {
+  if (!s) return -1;
+  if (width) *width = s->width;
+  if (height) *height = s->height;
+  return 0;
+}
+
 extern "C" int eg3d_sfm_seeds(const eg3d_sfm* s, eg3d_seeds* out) {
   if (!s || !out) return -1;
   out->n_seeds = (uint32_t)(s->trk_off.size() - 1);

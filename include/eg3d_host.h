@@ -169,6 +169,8 @@ void eg3d_sfm_destroy(eg3d_sfm* s);
 int eg3d_sfm_n_views(const eg3d_sfm* s);
 uint64_t eg3d_sfm_n_points(const eg3d_sfm* s);
 const float* eg3d_sfm_cam_P(const eg3d_sfm* s);           /* [V][16] */
+const char* eg3d_sfm_image_path(const eg3d_sfm* s, int view);   /* SfMData::camerasPaths_[view] (valid until the handle is destroyed) */
+int eg3d_sfm_image_size(const eg3d_sfm* s, int* width, int* height); /* SfMData::imageWidth_ / imageHeight_ */
 int eg3d_sfm_set_camera(eg3d_sfm* s, int view, float focal, float ppx, float ppy, const float* R9_rowmajor,
                         const float* center3, const char* image_path);
 /* seeds view of the points (pointers valid until the next mutation) */

@@ -533,18 +533,30 @@ class PLGPCM3ViewsPLGFollowing : public PLGPConsensusManager {
       cache_ = em_.match_refpoint_chains((unsigned long)refpoint);
       if (em_.last_status() != EG3D_OK) throw Eg3dError(em_.last_status(), std::string("eg3d: ") + eg3d_last_error());
       cached_point_ = refpoint;
+      served_.assign(cache_.size(), 0);
     }
+    // The track entry this call is about. The reference's loop (plg_matching_from_refpoints.cpp:68-73) calls once per
+    // track entry, in track order, so a view id that appears on several entries of the track is served entry by entry:
+    // the first entry of that view not handed out yet (all handed out: the round starts again — a caller that walks
+    // the track a second time). An entry whose starting intersections differ in number from the ones handed in is not
+    // the caller's entry and is skipped while another candidate remains.
     const std::vector<int>& track = em_.sfm_data().camViewingPointN_[refpoint];
-    int entry = -1;
-    for (size_t i = 0; i < track.size() && i < cache_.size(); i++) {
-      if (track[i] != starting_img_id) continue;
-      if (entry < 0) entry = (int)i;
-      // a repeated view id: the entry whose starting intersections are the ones handed in
-      if (cache_[i].size() == pair.first.size()) {
-        entry = (int)i;
-        break;
+    int entry = -1, fallback = -1;
+    for (int round = 0; round < 2 && entry < 0; round++) {
+      for (size_t i = 0; i < track.size() && i < cache_.size(); i++) {
+        if (track[i] != starting_img_id || served_[i]) continue;
+        if (fallback < 0) fallback = (int)i;
+        if (cache_[i].size() == pair.first.size()) {
+          entry = (int)i;
+          break;
+        }
       }
+      if (entry < 0 && fallback >= 0) entry = fallback;
+      if (entry < 0)  // every entry of this view was served: forget and look again
+        for (size_t i = 0; i < track.size() && i < served_.size(); i++)
+          if (track[i] == starting_img_id) served_[i] = 0;
     }
+    if (entry >= 0) served_[(size_t)entry] = 1;
     std::vector<points> res(pair.first.size());
     if (entry >= 0)
       for (size_t h = 0; h < res.size() && h < cache_[entry].size(); h++) res[h] = cache_[entry][h];
@@ -562,6 +574,7 @@ class PLGPCM3ViewsPLGFollowing : public PLGPConsensusManager {
   PLGEdgeManager& em_;
   int cached_point_ = -1;
   std::vector<std::vector<PLGEdgeManager::chain>> cache_;
+  std::vector<uint8_t> served_;  // per track entry of the cached point: its chains were handed out
 };
 
 namespace detail {
@@ -653,13 +666,21 @@ struct FilterContext {
   eg3d_ctx* ctx = nullptr;
   bool own = false;
   explicit FilterContext(const SfMData& s) {
-    PLGEdgeManager* d = PLGEdgeManager::default_manager();
-    if (d && d->ctx() && d->scene().n_views == s.numCameras_ &&
-        std::memcmp(d->scene().cam_P, &s.camerasList_[0].cameraMatrix[0][0], sizeof(float) * 16) == 0) {
-      ctx = d->ctx();
-      return;
-    }
     const int V = s.numCameras_;
+    if (V <= 0 || s.camerasList_.size() < (size_t)V)
+      throw Eg3dError(EG3D_ERR_ARG, "filter: the SfM data holds no cameras (numCameras_ / camerasList_)");
+    // the registered manager's context serves this rig only when EVERY camera matrix is the same (a different rig that
+    // shares camera 0 must not be filtered with the manager's cameras)
+    PLGEdgeManager* d = PLGEdgeManager::default_manager();
+    if (d && d->ctx() && d->scene().n_views == V) {
+      bool same = true;
+      for (int v = 0; v < V && same; v++)
+        same = std::memcmp(d->scene().cam_P + (size_t)v * 16, &s.camerasList_[(size_t)v].cameraMatrix[0][0], sizeof(float) * 16) == 0;
+      if (same) {
+        ctx = d->ctx();
+        return;
+      }
+    }
     std::vector<float> P;
     for (int v = 0; v < V; v++)
       for (int r = 0; r < 4; r++)

@@ -70,3 +70,21 @@ def read_png_edge_mask(path):
     if ctype in (0, 4):
         return (samples[:, :, 0] == maxv).astype(np.uint8)
     return (samples[:, :, :3] == maxv).all(axis=2).astype(np.uint8)
+
+
+def write_png_gray(path, mask):
+    """mask: [H, W] uint8 (0 / non-zero) -> an 8-bit grey PNG (0 / 255), no filtering; enough for the edge-image tests."""
+    import struct
+    import zlib
+
+    import numpy as np
+    m = (np.asarray(mask) != 0).astype(np.uint8) * 255
+    h, w = m.shape
+    raw = b"".join(b"\x00" + m[y].tobytes() for y in range(h))
+
+    def chunk(tag, data):
+        c = struct.pack(">I", len(data)) + tag + data
+        return c + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))

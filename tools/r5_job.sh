@@ -1,6 +1,10 @@
 #!/bin/bash
 mkdir -p gpurun_out
-export EG3D_K3B_ENGINE=1
-for l in 2 4 8 16; do echo "w2 lanes=$l"; EG3D_K3C_LANES=$l INFLIGHT=1 timeout 600 tools/quick_bench.sh 3 4; done
-echo "w2 lanes=8 in flight 4"; EG3D_K3C_LANES=8 INFLIGHT=4 timeout 600 tools/quick_bench.sh 3 8
-echo "c2 lanes=4"; EG3D_K3C_LANES=4 INFLIGHT=1 timeout 600 tools/quick_bench.sh 2 6
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -8
+timeout 900 python bench.py > gpurun_out/r5_bench_default.json 2> gpurun_out/r5_bench_default.err; tail -c 600 gpurun_out/r5_bench_default.err; python - <<'PY'
+import json
+d = json.loads(open("gpurun_out/r5_bench_default.json").read().strip().splitlines()[-1])
+print({k: d[k] for k in ("metric", "value", "ms_per_step", "n_gpus")})
+print("roofline", d.get("roofline")); print("cpu_baseline", d.get("cpu_baseline")); print("parity", d.get("parity"))
+print("speedup", d.get("speedup_vs_cpu_1thread"), "one at a time", d.get("ms_per_step_one_at_a_time"))
+PY
