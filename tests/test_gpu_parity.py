@@ -125,7 +125,7 @@ def test_lane_per_chain_engine_form_of_the_expand_stage_matches_oracle(have_gpu,
         from oracle import binding as ob
         ref = ob.Oracle(C.byref(sa.c)).match(C.byref(seeds.c), 0, n, 8)
         ctx = api.Context(C.byref(sa.c))
-        got = ctx.match_refpoints(C.byref(seeds.c))
+        got = ctx.match_refpoints(C.byref(seeds.c), 0, n)
         ctx.close()
         rep = compare_edgepoints(ref, got)
         assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], (case, rep["msgs"][:3])

@@ -1,6 +1,6 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/profile_r04.sh <workload: c3|c2|c4|c3real> [tag=r04]
-# rocprofv3 passes of bench.py for one workload (round 4):
+# usage (GPU box, repo root): tools/profile_round.sh <workload: c3|c2|c4|c3real> <tag, e.g. r05>
+# rocprofv3 passes of bench.py for one workload:
 #   kt      --kernel-trace --stats of the driver's command for that workload (steps in flight; the C4 / C5 sub-lines of the
 #           default line are left out with --no-sublines: they launch the same kernels on other workloads and would blur the
 #           per-kernel averages)
@@ -8,7 +8,7 @@
 #           that bench.py's roofline.kernel_ms_per_step (measured the same way, by HIP events) must agree with
 #   fetch / write / sq / sq2   SEPARATE --pmc passes of the serial command, as the profiling guide prescribes
 # Summaries -> gpurun_out/<tag>_<workload>_*; copy to profiles/ to commit.
-wl=${1:-c3}; tag=${2:-r04}_$wl
+wl=${1:-c3}; tag=${2:-r05}_$wl
 out=$PWD/gpurun_out; mkdir -p $out/tmp; export TMPDIR=$out/tmp
 [ -f $out/pmc_traffic.json ] || cp profiles/pmc_traffic.json $out/pmc_traffic.json  # the other workloads' entries are kept
 case $wl in
