@@ -319,6 +319,40 @@ class Leg:
         self.workers = []
 
 
+def _usable_cores():
+    """(cores this process can really use, how that was found). os.cpu_count() is what the box SHOWS; a container's CPU
+    quota (cgroup v2 cpu.max / v1 cfs quota) and the affinity mask are what it GETS — on the GPU boxes of this project 256
+    threads are visible and the quota is 16 cores: the oracle scales x15.5 up to 16 threads and gets slower beyond
+    (profiles/r05_cpu_scaling.json), so "all host cores" of the CPU comparator means the quota."""
+    import math
+    n = os.cpu_count() or 1
+    how = ["os.cpu_count() = %d" % n]
+    try:
+        a = len(os.sched_getaffinity(0))
+        if a < n:
+            n = a
+        how.append("affinity %d" % a)
+    except Exception:
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            c = max(1, int(math.ceil(float(q) / float(p))))
+            how.append("cgroup cpu.max %s/%s = %d cores" % (q, p, c))
+            n = min(n, c)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                c = max(1, int(math.ceil(q / p)))
+                how.append("cgroup cfs quota %d/%d = %d cores" % (q, p, c))
+                n = min(n, c)
+        except Exception:
+            pass
+    return n, "; ".join(how)
+
+
 def _pmc_entry(wkey):
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(pmc):
@@ -335,13 +369,25 @@ def _rooflines(wkey, bytes_alg, excl_ms, inflight_ms):
     steps in flight the launches of different steps share the GPU and the event duration is an overlapped wall time."""
     ent = _pmc_entry(wkey)
     dom = ent.get(DOM_NAME, {})
+    # the committed PMC figures belong to the device sources they were measured on: a changed kernel makes them stale
+    stale = None
+    try:
+        from edgegraph3d_amd import build as _build
+        fp_now, fp_prof = _build.device_source_fingerprint(), ent.get("source_fingerprint")
+        if fp_prof and fp_prof != fp_now:
+            stale = {"profiled_sources": fp_prof, "these_sources": fp_now, "last_measured_traffic": dom.get("hbm_bytes_per_step"),
+                     "what": "the committed PMC pass was made on other device sources / switches than this build: not reported as this run's traffic; re-run tools/profile_round.sh"}
+    except Exception:
+        pass
     primary_ms, basis = (excl_ms, "one step on the GPU at a time") if excl_ms else (inflight_ms, "steps in flight (no exclusive measurement in this run)")
     ach = (bytes_alg / (primary_ms * 1e-3)) / 1e9 if primary_ms and primary_ms > 0 else 0.0
     roof = {"bound": "hbm", "kernel": DOM_NAME, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS, "traffic": dom.get("hbm_bytes_per_step"), "traffic_source": ent.get("provenance"),
+            "frac": ach / HBM_PEAK_GBS, "traffic": None if stale else dom.get("hbm_bytes_per_step"), "traffic_source": ent.get("provenance"),
             "algorithmic_bytes_per_step": int(bytes_alg), "kernel_ms_per_step": primary_ms, "measured_with": basis,
             "note": "per step of rank 0: algorithmic bytes of the step (SURVEY 8d) / the kernel's HIP-event time in that step "
                     "(one launch per step)"}
+    if stale:
+        roof["traffic_stale"] = stale
     if excl_ms and inflight_ms:
         a2 = (bytes_alg / (inflight_ms * 1e-3)) / 1e9
         roof["in_flight"] = {"kernel_ms_per_step": inflight_ms, "achieved": a2, "frac": a2 / HBM_PEAK_GBS,
@@ -609,7 +655,7 @@ def main():
                 secs.append(r1["stats"]["seconds"])
                 pts = r1["n_points"]
             med = statistics.median(secs)
-            ncores = os.cpu_count() or 1
+            ncores, cores_how = _usable_cores()
             ae = e if wl != "c4" else min(e, b + 1024)  # (a whole C4 step is ~1000 core-seconds: the all-core run takes its first 1024 seeds)
             cpu_run(b, min(ae, b + max(1, (ae - b) // 8)), ncores)  # warm-up of the thread team
             r = cpu_run(b, ae, ncores)
@@ -620,7 +666,7 @@ def main():
                           "(%.2f s; runs: %s; spread %.1f %%); scene/grid construction excluded"
                           % ("all" if ce == e else "first %d %s" % (ce - b, unit), ce - b, unit, pts, len(secs), med,
                              ", ".join("%.2f" % s for s in secs), 100.0 * (max(secs) - min(secs)) / med),
-                "all_cores": {"value": all_value, "cores": ncores, "seconds": r["stats"]["seconds"],
+                "all_cores": {"value": all_value, "cores": ncores, "cores_found_by": cores_how, "seconds": r["stats"]["seconds"],
                               "parallel_efficiency": all_value / ((pts / med) * ncores),
                               "sample": "%s (%d %s, %d edge-points), one run after a warm-up of the thread team"
                                         % ("the whole step" if ae == e else "the step's first seeds", ae - b, unit, r["n_points"])},

@@ -150,6 +150,8 @@ def check_resources(lib, strict=True):
         sys.path.pop(0)
     res = {n: r for n, r in kr.kernel_resources(lib).items() if n.startswith("eg3d::")}
     out = os.path.join(ROOT, "profiles", "kernel_resources_%s.json" % os.path.splitext(os.path.basename(lib))[0])
+    if os.sep + "variants" + os.sep in os.path.abspath(lib):
+        out = os.devnull  # experimental variants are checked / printed, not recorded
     try:
         import json
         with open(out, "w") as f:
@@ -168,6 +170,20 @@ def check_resources(lib, strict=True):
         raise RuntimeError("build guard: kernel resources exceed the committed bounds (edgegraph3d_amd/build.py "
                            "RESOURCE_BOUNDS):\n  " + "\n  ".join(bad))
     return bad
+
+
+def device_source_fingerprint():
+    """sha256 over the device sources and the switches they are compiled with: what a PMC profile under profiles/ was
+    measured ON. tools/profile_summary.py records it beside the traffic figures; bench.py reports `roofline.traffic` only
+    while it still matches (a changed kernel makes the committed figure stale: it is then reported as such, not as
+    this run's traffic)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in _all_sources(CSRC_DIR, (".h", ".hpp", ".hip")):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    h.update(" ".join(HIP_FLAGS).encode())
+    return h.hexdigest()[:16]
 
 
 def build_oracle(force=False):

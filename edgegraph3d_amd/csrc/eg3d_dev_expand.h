@@ -818,7 +818,7 @@ EG3D_HD bool unique_polyline_4px(const DevScene& s, int view, float x, float y, 
 EG3D_HD bool lazy_presolve(const DevScene& s) { return s.n_views >= EG3D_LAZY_PRESOLVE_MIN_VIEWS; }
 #ifndef EG3D_PRESOLVE_WINDOW
 #define EG3D_PRESOLVE_WINDOW 16      /* chain points per window of speculative central solves, scenes of 16..63 views */
-#define EG3D_PRESOLVE_WINDOW_MANY 8  /*   ... of 64 views and more */
+#define EG3D_PRESOLVE_WINDOW_MANY 2  /*   ... of 64 views and more (round 5: 8 / 4 / 2 -> C4 step 1854 / 1792 / 1788 ms; 16 / 32 were +1.7 / +3.7 % on 8) */
 #endif
 EG3D_HD int presolve_window(const DevScene& s) { return s.n_views >= 64 ? EG3D_PRESOLVE_WINDOW_MANY : EG3D_PRESOLVE_WINDOW; }
 // speculative central ADD solve of the chain points [from, to) whose candidate is within 4 px

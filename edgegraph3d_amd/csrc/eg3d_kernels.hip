@@ -607,6 +607,12 @@ __global__ void k_compact_chains(uint32_t n_tasks, const ChainSeed* per_task, co
 #ifndef EG3D_LA_RESUME
 #define EG3D_LA_RESUME 0 /* look-ahead depth after a redone round (0 = off for the rest of the following call) */
 #endif
+#ifndef EG3D_SIDE_WALK_BATCH
+#define EG3D_SIDE_WALK_BATCH 0 /* side walks: the whole-segment tests of four consecutive walk steps in one pass over the lanes. Measured (round 5, profiles/r05_experiments/k3b_variants.txt): bit-exact, and SLOWER - C3' 44.7 against 43.4-43.5 ms: the sequential half of a step (partial segment, selection) is what a step costs, and most hits are on the partial segment; kept as a measured option */
+#endif
+#ifndef EG3D_PAR_APPEND
+#define EG3D_PAR_APPEND 1 /* a followed point's observations are stored by m lanes at once instead of m stores by every lane (C3' 43.7-43.9 -> 43.4-43.5 ms) */
+#endif
 #ifndef EG3D_SPEC_FOLLOW
 #define EG3D_SPEC_FOLLOW 1 /* chain following: walk up to 4 steps ahead, then triangulate them together */
 #endif
@@ -814,6 +820,132 @@ struct TeamWaveT {
       pls.n = pl.n;
       pls.start = pl.start;
       pls.end = pl.end;
+#if EG3D_SIDE_WALK_BATCH
+      // FOUR walk steps per pass over the lanes. A step = the next hit of chain point i's epipolar line from the
+      // current position: first the PARTIAL segment from the position to the next vertex (depends on the previous
+      // step's hit), then the WHOLE segments beyond it (which do not). Quarter q of the wave (16 lanes) tests line
+      // t + q against the 16 whole segments beyond the batch's starting position — all four lines at once, before any
+      // of the four hits is known; the steps are then resolved in order: partial segment (uniform), else the first lane
+      // of the step's quarter, among the segments still ahead of the position, whose test reported a hit or a
+      // quasi-parallel stop. Same tests on the same operands in the same order of precedence as one step at a time
+      // (the whole-segment tests of a line do not depend on where its walk starts); a step whose 16-segment window is
+      // exhausted on a longer polyline takes the one-step walk from the current position.
+      {
+        const bool to_start = direction == pls.start;
+        if (to_start || direction == pls.end) {
+          const int lane_i = lane(), q = lane_i >> 4, sl = lane_i & 15;
+          int cnt = 0, t = 0;
+          PlPt pos;
+          pos.seg = from.seg;
+          pos.x = from.x;
+          pos.y = from.y;
+          bool ended = false;
+          while (!ended && t < staged) {
+            const int nb = staged - t < 4 ? staged - t : 4;
+            const uint32_t seg0 = pos.seg;
+            // ---- the whole segments beyond seg0 against the lines of this batch
+            uint32_t r = 0, wseg = 0;
+            float hx = 0.f, hy = 0.f;
+            if (q < nb) {
+              const float la = epi[4 * (t + q) + 1], lb = epi[4 * (t + q) + 2], lc = epi[4 * (t + q) + 3];
+              bool valid;
+              uint32_t i;
+              if (to_start) {
+                valid = seg0 >= (uint32_t)sl + 1u;  // segment (v[i], v[i-1]), i = seg0 - sl >= 1
+                i = seg0 - (uint32_t)sl;
+                wseg = i - 1u;
+              } else {
+                i = seg0 + 1u + (uint32_t)sl;       // segment (v[i], v[i+1]), i <= n - 2
+                valid = i + 1u < pls.n;
+                wseg = i;
+              }
+              if (valid) {
+                const uint32_t i1 = to_start ? i - 1u : i + 1u;
+                r = seg_line_hit_guarded(pls.v[i].x, pls.v[i].y, pls.v[i1].x, pls.v[i1].y, la, lb, lc, line_dir(la, lb), hx, hy);
+              }
+            }
+            const unsigned long long any = __ballot(r != 0);
+            const uint32_t beyond0 = to_start ? seg0 : (pls.n - 2u - seg0);  // whole segments beyond the starting position
+            // ---- the steps of the batch, in order
+            int qq = 0;
+            for (; qq < nb; qq++) {
+              if (epi[4 * (t + qq)] == 0.0f) {
+                ended = true;
+                break;
+              }
+              const float la = epi[4 * (t + qq) + 1], lb = epi[4 * (t + qq) + 2], lc = epi[4 * (t + qq) + 3];
+              const uint32_t vi = to_start ? pos.seg : pos.seg + 1u;
+              float px = 0.f, py = 0.f;
+              const uint32_t rp = seg_line_hit_guarded(pos.x, pos.y, pls.v[vi].x, pls.v[vi].y, la, lb, lc, line_dir(la, lb), px, py);
+              if (rp & 2u) {
+                ended = true;
+                break;
+              }
+              PlPt nx;
+              if (rp & 1u) {
+                nx.seg = pos.seg;
+                nx.x = px;
+                nx.y = py;
+              } else {
+                const uint32_t adv = to_start ? seg0 - pos.seg : pos.seg - seg0;  // whole segments of the window already behind
+                const uint32_t m = adv < 16u ? ((uint32_t)(any >> (16 * qq)) & 0xffffu & (0xffffu << adv)) : 0u;
+                if (m) {
+                  const int f = 16 * qq + __ffs((int)m) - 1;
+                  const uint32_t rf = lane_bcast(r, f);
+                  if (rf & 2u) {
+                    ended = true;
+                    break;
+                  }
+                  nx.seg = lane_bcast(wseg, f);
+                  nx.x = lane_bcast(hx, f);
+                  nx.y = lane_bcast(hy, f);
+                } else if (beyond0 <= 16u) {
+                  ended = true;  // every segment up to the extreme was tested: the walk ends there
+                  break;
+                } else {
+                  // the window is exhausted on a long polyline: one step the plain way, then a new batch from there
+                  const uint32_t w = walk(pls, pos, direction, la, lb, lc, nx);
+                  if (!(w & WALK_FOUND)) {
+                    ended = true;
+                    break;
+                  }
+                  Pending& pd = out[cnt++];
+                  pd.o.view = view;
+                  pd.o.pl = from.pl;
+                  pd.o.seg = nx.seg;
+                  pd.o.x = nx.x;
+                  pd.o.y = nx.y;
+                  pd.ok = 0;
+                  pos = nx;
+                  qq++;
+                  break;
+                }
+              }
+              Pending& pd = out[cnt++];
+              pd.o.view = view;
+              pd.o.pl = from.pl;
+              pd.o.seg = nx.seg;
+              pd.o.x = nx.x;
+              pd.o.y = nx.y;
+              pd.ok = 0;
+              pos = nx;
+            }
+            t += qq;
+          }
+          if (ended || count <= staged) return cnt;
+          // more chain points than the staging area holds lines for (never on the bench's scenes): the rest one step at a
+          // time from the candidate array, continuing from the current position
+          {
+            Obs cur = from;
+            cur.seg = pos.seg;
+            cur.x = pos.x;
+            cur.y = pos.y;
+            const int ci2 = towards_start ? ci - staged : ci + staged;
+            return cnt + walk_side_candidates_core(s, c, pls, epi, 0, view, cur, direction, lo, ci2, hi, towards_start, out + cnt, walk);
+          }
+        }
+      }
+#endif
       return walk_side_candidates_core(s, c, pls, epi, staged, view, from, direction, lo, ci, hi, towards_start, out,
                                        walk);
     }
@@ -827,7 +959,20 @@ struct TeamWaveT {
       return false;
     }
     ChainPt np;
+#if EG3D_PAR_APPEND
+    // the new point's block is reserved for m + 1 observations (point_reserve: the smallest power of two >= 4 that holds
+    // them), so the m appends of new_point_from_list never relocate: lane i stores observation i (the sequential form has
+    // every lane store all m, one after the other)
+    np.X[0] = X[0];
+    np.X[1] = X[1];
+    np.X[2] = X[2];
+    point_init(np);
+    if (!point_reserve(c, np, (uint32_t)m + 1)) return false;
+    for (int i = lane(); i < m; i += 64) c.pool[np.off + (uint32_t)i] = list[i];
+    np.nobs = (uint32_t)m;
+#else
     if (!new_point_from_list(c, np, list, m, X)) return false;
+#endif
     if (front) {
       c.head--;
       c.pts[c.head] = np;
@@ -835,6 +980,9 @@ struct TeamWaveT {
       c.pts[c.head + c.len] = np;
     }
     c.len++;
+#if EG3D_PAR_APPEND
+    __syncthreads();  // the observations were stored by different lanes: visible to all before the next step reads them
+#endif
     return true;
   }
   // Chain following (follow_direction_vector_start/_end, plg_matching.cpp:771-795) with LOOK-AHEAD.

@@ -16,6 +16,7 @@ import json
 import os
 import re
 import sqlite3
+import sys
 from collections import defaultdict
 
 
@@ -126,6 +127,12 @@ def main():
             ent["provenance"] = ("profiles/%s_rocprof_summary.txt: separate rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE "
                                  "passes of `%s` (%d passes of the hot path each); bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> B), "
                                  "summed over the kernel's launches / passes" % (a.tag, a.pmc_cmd, a.pmc_steps))
+            try:
+                sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+                from edgegraph3d_amd import build as _build
+                ent["source_fingerprint"] = _build.device_source_fingerprint()
+            except Exception:
+                pass
             allw[a.workload] = ent
             json.dump(allw, open(path, "w"), indent=1)
         else:
