@@ -1629,7 +1629,10 @@ static_assert(2 * EG3D_SMALL_SCENE_VIEWS_HOST + 8 <= EG3D_COOP_ROWS && 2 * (EG3D
               "EG3D_SMALL_SCENE_VIEWS_HOST must be the last view count whose N-view step lists fit LDS");
 static constexpr auto k3b_expand_small = k3b_expand_t<EG3D_K3B_WAVES, 0, 0>;
 static constexpr auto k3b_expand = k3b_expand_t<EG3D_K3B_WAVES, 0, 1>;
-static constexpr auto k3b_expand_many = k3b_expand_t<EG3D_K3B_WAVES, 0, 2>;
+#ifndef EG3D_MANY_KEEP
+#define EG3D_MANY_KEEP 0 /* chunks of a long solve whose rows stay in registers between the passes of an iteration, many-views build (gn_round<KEEP>) */
+#endif
+static constexpr auto k3b_expand_many = k3b_expand_t<EG3D_K3B_WAVES, EG3D_MANY_KEEP, 2>;
 int k3b_blocks_per_cu() {  // the largest residency of the builds sizes the slot pools
   int best = 0;
   for (int k = 0; k < 3; k++) {

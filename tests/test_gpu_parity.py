@@ -117,6 +117,14 @@ def test_lane_per_chain_engine_form_of_the_expand_stage_matches_oracle(have_gpu,
         rep = compare_edgepoints(ref, got)
         assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], (cfg, rep["msgs"][:3])
         assert got["flags"] == ref["flags"] and got["times"]["bytes_algorithmic"] == ref["stats"]["bytes_algorithmic"]
+        if cfg == 1:  # the pipelines 1-2 extractor feeds the same stage (a sample = a virtual seed over all views)
+            n_sets, row_off, ids = s.polyline_sets(3)
+            ctx = api.Context(s.scene)
+            gs = ctx.match_polyline_sets(n_sets, row_off, ids)
+            ctx.close()
+            rs = _oracle(s.scene).match_polyline_sets(n_sets, row_off, ids, nthreads=8)
+            rep = compare_edgepoints(rs, gs)
+            assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], ("sets", rep["msgs"][:3])
     import ctypes as C
     from fuzz_scenes import draw
     for case in (3, 20):
