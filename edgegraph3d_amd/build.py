@@ -129,7 +129,7 @@ RESOURCE_BOUNDS = {
     # kernel (substring of the demangled name): {metadata field: largest accepted value}
     "k3b_expand_t<4, 0, 0>": {"vgpr_spill_count": 40, "private_segment_fixed_size": 192, "group_segment_fixed_size": 10240},
     "k3b_expand_t<4, 0, 1>": {"vgpr_spill_count": 180, "private_segment_fixed_size": 320, "group_segment_fixed_size": 10240},
-    "k3b_expand_t<4, 0, 2>": {"vgpr_spill_count": 40, "private_segment_fixed_size": 192, "group_segment_fixed_size": 10240},
+    "k3b_expand_t<4, 1, 2>": {"vgpr_spill_count": 80, "private_segment_fixed_size": 224, "group_segment_fixed_size": 10240},
     "k3a_orient": {"vgpr_spill_count": 0, "group_segment_fixed_size": 12800},
     "k3a_follow_spec": {"vgpr_spill_count": 0, "group_segment_fixed_size": 12800},
     "k3c_engine_t<false>": {"vgpr_spill_count": 256, "group_segment_fixed_size": 10240},

@@ -1630,7 +1630,7 @@ static_assert(2 * EG3D_SMALL_SCENE_VIEWS_HOST + 8 <= EG3D_COOP_ROWS && 2 * (EG3D
 static constexpr auto k3b_expand_small = k3b_expand_t<EG3D_K3B_WAVES, 0, 0>;
 static constexpr auto k3b_expand = k3b_expand_t<EG3D_K3B_WAVES, 0, 1>;
 #ifndef EG3D_MANY_KEEP
-#define EG3D_MANY_KEEP 0 /* chunks of a long solve whose rows stay in registers between the passes of an iteration, many-views build (gn_round<KEEP>) */
+#define EG3D_MANY_KEEP 1 /* chunks of a long solve whose rows stay in registers between the passes of an iteration, many-views build (gn_round<KEEP>): 0 / 1 / 2 -> C4 step 1810 / 1774 / 1823 ms at 27 / 60 / 263 spilled VGPRs (round 5; round 4 had only measured 4 chunks at 2 waves per SIMD: slower) */
 #endif
 static constexpr auto k3b_expand_many = k3b_expand_t<EG3D_K3B_WAVES, EG3D_MANY_KEEP, 2>;
 int k3b_blocks_per_cu() {  // the largest residency of the builds sizes the slot pools
