@@ -173,15 +173,20 @@ def check_resources(lib, strict=True):
 
 
 def device_source_fingerprint():
-    """sha256 over the device sources and the switches they are compiled with: what a PMC profile under profiles/ was
-    measured ON. tools/profile_summary.py records it beside the traffic figures; bench.py reports `roofline.traffic` only
-    while it still matches (a changed kernel makes the committed figure stale: it is then reported as such, not as
-    this run's traffic)."""
+    """sha256 over the device CODE (sources with comments and blank lines removed) and the switches it is compiled with:
+    what a PMC profile under profiles/ was measured ON. tools/profile_summary.py records it beside the traffic figures;
+    bench.py reports `roofline.traffic` only while it still matches (a changed kernel makes the committed figure stale:
+    it is then reported as such, not as this run's traffic). Editing a comment does not change it."""
     import hashlib
+    import re
     h = hashlib.sha256()
     for f in _all_sources(CSRC_DIR, (".h", ".hpp", ".hip")):
+        text = open(f, "r", errors="replace").read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)      # block comments
+        text = re.sub(r"//[^\n]*", "", text)                     # line comments (no string of these sources holds "//")
+        code = "\n".join(" ".join(l.split()) for l in text.splitlines() if l.strip())
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(code.encode())
     h.update(" ".join(HIP_FLAGS).encode())
     return h.hexdigest()[:16]
 
