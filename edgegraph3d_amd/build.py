@@ -181,6 +181,8 @@ def device_source_fingerprint():
     import re
     h = hashlib.sha256()
     for f in _all_sources(CSRC_DIR, (".h", ".hpp", ".hip")):
+        if os.path.basename(f) == "eg3d_api.hip":
+            continue  # host orchestration (no kernel lives there): buffer sizing and launch order do not change a kernel's traffic per launch
         text = open(f, "r", errors="replace").read()
         text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)      # block comments
         text = re.sub(r"//[^\n]*", "", text)                     # line comments (no string of these sources holds "//")

@@ -998,11 +998,12 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
     if (engine) {
       const uint32_t per_simd = (uint32_t)(c->tune.k3c_waves > 0 ? c->tune.k3c_waves : std::max(1, c->k3c_per_cu / 4));
       const uint32_t waves_max = c->n_simd * per_simd;
-      if (c->tune.k3c_lanes > 0)
-        eng_lanes = (uint32_t)std::min(64, c->tune.k3c_lanes);
-      else
-        while (eng_lanes > 8 && (uint64_t)waves_max * (eng_lanes / 2) >= nc) eng_lanes /= 2;
+      // owning lanes per wave: 8 by measurement (C3': 2 / 4 / 8 / 16 / 32 / 64 lanes -> 111 / 105 / 103 / 149 / 252 / 397 ms —
+      // more lanes buy no parallelism in the lane-private phases and add resident chains, DESIGN_LOG.md round 5)
+      eng_lanes = c->tune.k3c_lanes > 0 ? (uint32_t)std::min(64, c->tune.k3c_lanes) : 8u;
       eng_waves = std::max<uint32_t>(1, std::min<uint32_t>(waves_max, (nc + eng_lanes - 1) / eng_lanes));
+      // one working slice per owning lane: keep the arena within 16 GB (many-view scenes have slices of ~1 MB)
+      while (eng_waves > 64 && L.total * (size_t)eng_waves * eng_lanes > ((size_t)16 << 30)) eng_waves /= 2;
       BUF_TRY(c->b_cscratch.ensure(L.total * (size_t)eng_waves * eng_lanes));
       BUF_TRY(c->b_queue.ensure(4 * sizeof(uint32_t)));
       HIP_TRY(hipMemsetAsync(c->b_queue.p, 0, 4 * sizeof(uint32_t), st));
