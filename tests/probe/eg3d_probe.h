@@ -22,6 +22,10 @@ int eg3d_probe_gn_div(uint64_t n, const double* num, const double* den, double* 
 /* GnRow (j00 j01 j02 j10 j11 j12 r0 r1) of n rows with the plain divisions (out[0..8n)) and through the guarded fast
  * path (out[8n..16n)); P16 = one 4x4 camera matrix per row */
 int eg3d_probe_gn_rows(uint64_t n, const float* P16, const float* oxy, const double* X, double* out16n);
+/* the lane-group Gauss-Newton solver at full density (tools/gn_floor.py): n_blocks single-wave blocks x rounds windows of
+ * seven identical ADD requests of n <= 9 rows; *ms = kernel time; X_ok = {mean solution x of block 0, its accepted solves} */
+int eg3d_probe_gn_dense(const float* cam_P, int n_views, const int32_t* obs_view, const float* obs_xy, int n,
+                        const float* X0, int n_blocks, int rounds, float* ms, float* X_ok);
 /* 2-D geometry primitives on the GPU (tests/test_glm_pin.py): mode 0 project_f32 (in [n][19] = P16 + X -> [n][2]),
  * 1 seg_line_cos (in [n][7] = segment + line -> [n]), 2 seg_closest (in [n][6] = p, v, w -> [n][3] = d2, closest point) */
 int eg3d_probe_geom(uint64_t n, int mode, const float* in, float* out);

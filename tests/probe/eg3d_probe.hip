@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <vector>
 
 #include "eg3d_probe.h"
 #include "eg3d_dev_pipeline.h"
@@ -186,6 +187,77 @@ extern "C" int eg3d_probe_gn_rows(uint64_t n, const float* P16, const float* oxy
   (void)hipFree(dP);
   (void)hipFree(dxy);
   (void)hipFree(dX);
+  (void)hipFree(dout);
+  return 0;
+}
+
+// ---- the lane-group Gauss-Newton solver AT FULL DENSITY (tools/gn_floor.py): every single-wave block solves `rounds` windows
+// of SEVEN identical ADD requests of n rows each (7 x 9 = 63 of the 64 rows of a packed round; identical requests converge in
+// the same iteration, so no lane waits for another request) through coop_gn_groups — the product's solver, the product's
+// build switches, 4 waves per SIMD like the expand kernel. What comes out is the solver's speed of light on this chip under
+// the arithmetic contract (FP64, no FMA, ordered sums): row-iterations per second.
+__global__ void __launch_bounds__(64, 4) k_probe_gn_dense(const float* cam_P, const Obs* obs, int n, float x0, float y0, float z0,
+                                                          int rounds, float* out) {
+  __shared__ CoopLds L;
+  const int lane = (int)threadIdx.x;
+  if (lane == 0) {
+    L.cams_mid_range = 1;
+    L.long_refused = 0;
+  }
+  __syncthreads();
+  float acc = 0.0f;
+  int n_ok = 0;
+  for (int r = 0; r < rounds; r++) {
+    const float X0[3] = {x0, y0, z0};
+    float X[3] = {0.0f, 0.0f, 0.0f};
+    const Obs ex = obs[n - 1];
+    const bool ok = coop_gn_groups<0, false>(cam_P, L, lane < 7, obs, n - 1, true, (int32_t)ex.view, ex.x, ex.y, X0, X);
+    acc += X[0];
+    n_ok += ok ? 1 : 0;
+  }
+  if (lane == 0) {
+    out[4 * blockIdx.x] = acc / (float)rounds;
+    out[4 * blockIdx.x + 1] = (float)n_ok;
+  }
+}
+// obs_view / obs_xy: the n observations of the request (the last one is the ADD observation); returns the kernel time in ms
+// and, in X_ok[0..1], block 0's mean solution x and the number of accepted solves of its lane 0
+extern "C" int eg3d_probe_gn_dense(const float* cam_P, int n_views, const int32_t* obs_view, const float* obs_xy, int n,
+                                   const float* X0, int n_blocks, int rounds, float* ms, float* X_ok) {
+  if (n < 3 || n > 9 || n_blocks < 1 || rounds < 1) return -1;
+  float* dP;
+  Obs* dobs;
+  float* dout;
+  std::vector<Obs> h((size_t)n);
+  for (int i = 0; i < n; i++) {
+    h[i].view = (uint32_t)obs_view[i];
+    h[i].pl = 0;
+    h[i].seg = 0;
+    h[i].x = obs_xy[2 * i];
+    h[i].y = obs_xy[2 * i + 1];
+  }
+  PT(hipMalloc(&dP, (size_t)n_views * 64));
+  PT(hipMalloc(&dobs, sizeof(Obs) * (size_t)n));
+  PT(hipMalloc(&dout, sizeof(float) * 4 * (size_t)n_blocks));
+  PT(hipMemcpy(dP, cam_P, (size_t)n_views * 64, hipMemcpyHostToDevice));
+  PT(hipMemcpy(dobs, h.data(), sizeof(Obs) * (size_t)n, hipMemcpyHostToDevice));
+  hipEvent_t a, b;
+  PT(hipEventCreate(&a));
+  PT(hipEventCreate(&b));
+  hipLaunchKernelGGL(k_probe_gn_dense, dim3((unsigned)n_blocks), dim3(64), 0, 0, dP, dobs, n, X0[0], X0[1], X0[2], 2, dout);  // warm-up
+  PT(hipEventRecord(a, 0));
+  hipLaunchKernelGGL(k_probe_gn_dense, dim3((unsigned)n_blocks), dim3(64), 0, 0, dP, dobs, n, X0[0], X0[1], X0[2], rounds, dout);
+  PT(hipEventRecord(b, 0));
+  PT(hipDeviceSynchronize());
+  PT(hipEventElapsedTime(ms, a, b));
+  float r[4];
+  PT(hipMemcpy(r, dout, sizeof(r), hipMemcpyDeviceToHost));
+  X_ok[0] = r[0];
+  X_ok[1] = r[1];
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  (void)hipFree(dP);
+  (void)hipFree(dobs);
   (void)hipFree(dout);
   return 0;
 }
