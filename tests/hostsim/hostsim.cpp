@@ -67,7 +67,7 @@ static int build_dev_scene(const eg3d_scene* sc, HostScene& hs) {
 
 // The expand stage as the chain STATE MACHINE of eg3d_chain_sm.h (what the engine kernel k3c runs, one lane per
 // chain) with a sequential server: requests are answered one after the other by the plain solver / candidate code.
-static unsigned long long g_sm[16];  // advances, GN batches, GN requests, rows, closest batches, closest items, by batch kind [8..]
+static unsigned long long g_sm[16], g_smreq[8], g_smrows[8];  // g_smreq / g_smrows: solves / rows by batch kind  // advances, GN batches, GN requests, rows, closest batches, closest items, by batch kind [8..]
 template <class Env>
 static void run_chain_machine(const DevScene& ds, const StageAView& a, const TaskDesc& d, const ChainSeed& cs, uint32_t hyp_base,
                               const HypResult* res, const HPoint* arena, const int32_t* map_view, const uint32_t* map_entry,
@@ -87,6 +87,8 @@ static void run_chain_machine(const DevScene& ds, const StageAView& a, const Tas
         if (!sm_gn_request(q, j, r)) continue;
         g_sm[2]++;
         g_sm[3] += (unsigned long long)(r.nblock + (r.has_extra ? 1 : 0));
+        g_smreq[q.k.gn_kind & 7]++;
+        g_smrows[q.k.gn_kind & 7] += (unsigned long long)(r.nblock + (r.has_extra ? 1 : 0));
         Obs ex;
         ex.view = (uint32_t)r.ex_view;
         ex.pl = 0;
@@ -199,6 +201,7 @@ extern "C" int hostsim_match(const eg3d_scene* sc, const eg3d_seeds* seeds, uint
   const uint32_t n_hyp = hyp_off[nt];
   for (int i = 0; i < 8; i++) g_stat[i] = 0;
   for (int i = 0; i < 16; i++) g_sm[i] = 0;
+  for (int i = 0; i < 8; i++) g_smreq[i] = g_smrows[i] = 0;
   // K3a
   std::vector<HypResult> res(n_hyp ? n_hyp : 1);
   std::vector<HPoint> arena;
@@ -306,6 +309,14 @@ extern "C" int hostsim_match(const eg3d_scene* sc, const eg3d_seeds* seeds, uint
             g_sm[2] ? (double)g_sm[3] / (double)g_sm[2] : 0.0, g_sm[5] / nc, g_sm[8 + SMB_EPC] / nc, g_sm[8 + SMB_PRESOLVE] / nc,
             g_sm[8 + SMB_CENTRAL] / nc, g_sm[8 + SMB_SIDES] / nc, (g_sm[8 + SMB_LIST_A] + g_sm[8 + SMB_LIST_B]) / nc, g_sm[8 + SMB_LISTADD] / nc,
             (g_stat[5] - sm_walks0) / nc, (g_stat[5] - sm_walks0) ? (double)(g_stat[6] - sm_segs0) / (double)(g_stat[5] - sm_walks0) : 0.0);
+  }
+  if (slot_step >= 2 && getenv("HOSTSIM_SM_STATS")) {
+    const double nc = chains.size() ? (double)chains.size() : 1.0;
+    static const char* kn[8] = {"", "epc", "presolve", "central", "sides", "list", "listadd", "list3"};
+    fprintf(stderr, "  solves per chain by kind (rows each):");
+    for (int k = 1; k < 8; k++)
+      if (g_smreq[k]) fprintf(stderr, " %s %.1f (%.1f)", kn[k], g_smreq[k] / nc, (double)g_smrows[k] / (double)g_smreq[k]);
+    fprintf(stderr, "\n");
   }
   // K4
   out->n_points = np;
