@@ -12,6 +12,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 from edgegraph3d_amd import api, host  # noqa: E402
 from oracle import binding as ob  # noqa: E402
 from parity_util import compare_edgepoints  # noqa: E402
+from bench import _usable_cores  # noqa: E402
+
+NCORES = _usable_cores()[0]  # what the box grants (cgroup quota), not what it shows
 
 # usage: c4_batch_parity.py [seeds per batch = 8192] [first batch = 0] [batches = 1]   (13 batches of 8192 = all 100 000 seeds)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
@@ -30,14 +33,14 @@ for b in range(first, first + count):
     t0 = time.time()
     got = ctx.match_resident(lo, hi)
     t1 = time.time()
-    ref = orc.match(s.seeds, lo, hi, os.cpu_count())
+    ref = orc.match(s.seeds, lo, hi, NCORES)
     t2 = time.time()
     rep = compare_edgepoints(ref, got, rel_tol=1e-4)
     row = {"seeds": [lo, hi], "points": int(ref["n_points"]), "observations": int(ref["n_obs"]),
            "structure_exact": bool(rep["ok"]), "X_bit_exact": bool(rep.get("bitexact_X")),
            "obs_xy_bit_exact": bool(rep.get("bitexact_xy")), "max_rel_err_X": rep.get("max_rel_X"),
            "flags_device": int(got["flags"]), "flags_oracle": int(ref["flags"]),
-           "device_seconds_incl_copy": round(t1 - t0, 2), "oracle_seconds_all_cores": round(t2 - t1, 1), "cores": os.cpu_count()}
+           "device_seconds_incl_copy": round(t1 - t0, 2), "oracle_seconds_all_cores": round(t2 - t1, 1), "cores": NCORES}
     print(row, flush=True)
     rows.append(row)
     json.dump(rows, open("gpurun_out/c4_batch_parity_%d.json" % first, "w"), indent=1)
