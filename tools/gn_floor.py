@@ -6,7 +6,7 @@
   2. with a timing build (EG3D_LIB=edgegraph3d_amd/variants/libeg3d_timing.so, `tools/build_variant.sh timing
      -DEG3D_SECTION_TIMING`): the row-iterations one step of the workload really executes (k3b_expand's own counters);
   3. floor = (2) / (1), beside the kernel's measured time.
-usage: tools/gn_floor.py [cfg=3] [--json out]"""
+usage: tools/gn_floor.py [cfg=3] [n_seeds=all] [--json out]"""
 import ctypes as C, json, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,6 +14,7 @@ sys.path.insert(0, ROOT)
 from edgegraph3d_amd import _cdefs as D, api, build, host
 
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 3
+nseeds = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 0
 s = host.Synth(cfg)
 sc = s.scene_np()
 P = np.ascontiguousarray(sc["cam_P"], np.float32).reshape(-1, 16)
@@ -77,13 +78,14 @@ L = api.lib()
 if hasattr(L, "eg3d_probe_gn"):
     ctx = api.Context(s.scene); ctx.upload_seeds(s.seeds)
     buf = (C.c_ulonglong * 128)()
-    ctx.match_resident(0, s.n_seeds, device_only=True)
+    ns = nseeds or s.n_seeds
+    ctx.match_resident(0, ns, device_only=True)
     L.eg3d_probe_gn(buf, 1)
-    r = ctx.match_resident(0, s.n_seeds, device_only=True)
+    r = ctx.match_resident(0, ns, device_only=True)
     L.eg3d_probe_gn(buf, 1)
     b = list(buf)
     out["step"] = {"solves": b[64], "rows": b[66], "row_iterations": b[68], "lane_iterations_held": b[67], "rounds": b[69],
-                   "row_fill_of_64": 64.0 * b[68] / max(1, b[67]), "edge_points": int(r["n_points"])}
+                   "row_fill_of_64": 64.0 * b[68] / max(1, b[67]), "edge_points": int(r["n_points"]), "seeds": ns, "long_solves": b[102], "long_rounds": b[103]}
     out["floor_ms_at_dense_peak"] = 1e3 * b[68] / best
     print("one step of cfg %d: %d solves, %d row-iterations (fill %.1f of 64) -> %.2f ms at the dense peak"
           % (cfg, b[64], b[68], out["step"]["row_fill_of_64"], out["floor_ms_at_dense_peak"]))
