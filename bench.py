@@ -295,11 +295,43 @@ class Leg:
                   {k: sum(r["times"][k] for r, _ in rs) / ns for _, k in STAGES})
         # timed at the C ABI (the Python wrapper's numpy conversion is not part of the product)
         ctx = self.workers[0].ctx
+        # (one untimed call first: a host call runs on the context's internal lanes, which are created — with their work
+        # buffers and pinned staging — by the first call that needs them; the one-shot cost is under time_to_solution_one_shot)
         if self.sets is None:
+            ctx.time_match_to_host(*self.step_range(0))
             tt = [ctx.time_match_to_host(*self.step_range(i)) for i in range(ns)]
         else:
+            ctx.time_match_sets_to_host(self.sets[0], self.sets[1], self.sets[2])
             tt = [ctx.time_match_sets_to_host(self.sets[0], self.sets[1], self.sets[2]) for _ in range(ns)]
         return single, (sum(t for t, _ in tt) / ns, sum(n for _, n in tt) / ns)
+
+    def setup_and_time_to_solution(self):
+        """What a one-shot caller pays (setup reported separately): a FRESH context — eg3d_create = scene
+        validation, bounding boxes, the 2 x V uniform grids (built on host threads), uploads —, eg3d_upload_seeds, and ONE
+        eg3d_match_resident call with the D2H copy of the cloud, nothing warm (work buffers, lanes and pinned staging are
+        allocated inside the call); then the same call again on the now warm context. Seconds, timed at the C ABI."""
+        api = self.api
+        b, e = self.step_range(0)
+        t0 = time.perf_counter()
+        ctx = api.Context(self.synth.scene, self.env["local_rank"])
+        t1 = time.perf_counter()
+        ctx.upload_seeds(self.synth.seeds)
+        t2 = time.perf_counter()
+        cold, n = ctx.time_match_to_host(b, e)
+        warm = min(ctx.time_match_to_host(b, e)[0] for _ in range(3))
+        # a second create on the same process (driver state warm): the figure the grid construction itself costs
+        t3 = time.perf_counter()
+        ctx2 = api.Context(self.synth.scene, self.env["local_rank"])
+        t4 = time.perf_counter()
+        ctx2.close()
+        ctx.close()
+        return {"create_ms": (t1 - t0) * 1e3, "create_again_ms": (t4 - t3) * 1e3, "upload_seeds_ms": (t2 - t1) * 1e3,
+                "first_call_ms": cold * 1e3, "warm_call_ms": warm * 1e3, "edge_points": n,
+                "time_to_solution_ms": (t2 - t0 + cold) * 1e3,
+                "what": "fresh context: eg3d_create (validation, bounding boxes, 2 x V grids on host threads, uploads) + "
+                        "eg3d_upload_seeds + ONE eg3d_match_resident call with the D2H copy into caller-owned arrays, work "
+                        "buffers cold (first_call_ms; warm_call_ms = best of 3 more calls on the same context); "
+                        "create_again_ms = a second eg3d_create of the same scene in this process"}
 
     def describe(self):
         V = self.synth.n_views
@@ -374,7 +406,12 @@ def _rooflines(wkey, bytes_alg, excl_ms, inflight_ms):
     try:
         from edgegraph3d_amd import build as _build
         fp_now, fp_prof = _build.device_source_fingerprint(), ent.get("source_fingerprint")
-        if fp_prof and fp_prof != fp_now:
+        env_set = _build.kernel_choice_env_set()
+        if env_set:
+            stale = {"profiled_sources": fp_prof, "these_sources": fp_now, "last_measured_traffic": dom.get("hbm_bytes_per_step"),
+                     "what": "environment switches that choose the kernel build or its launch are set (%s): the committed PMC pass "
+                             "does not describe this run" % ", ".join(env_set)}
+        elif fp_prof and fp_prof != fp_now:
             stale = {"profiled_sources": fp_prof, "these_sources": fp_now, "last_measured_traffic": dom.get("hbm_bytes_per_step"),
                      "what": "the committed PMC pass was made on other device sources / switches than this build: not reported as this run's traffic; re-run tools/profile_round.sh"}
     except Exception:
@@ -557,9 +594,11 @@ def main():
     bytes_alg = sum(r["times"]["bytes_algorithmic"] for r, _ in results) / len(results)  # this rank, per step
     gstats = leg.gather_stats()
     # untimed side measurements reported beside the value
-    single = e2e = tts = None
+    single = e2e = tts = setup = None
     if rank == 0 and world == 1 and not args.no_extras:
         single, e2e = leg.serial_and_e2e(args.steps)
+        if sets is None:
+            setup = leg.setup_and_time_to_solution()
     if wl == "c4" and not args.no_extras and sets is None:
         tts = leg.time_to_solution()   # every rank takes part (collectives)
 
@@ -625,7 +664,16 @@ def main():
             line["value_one_step_at_a_time"] = single[1] / single[0]
             line["end_to_end"] = {"ms_per_step": e2e[0] * 1e3, "value": e2e[1] / e2e[0],
                                   "what": "one step at a time incl. the D2H copy of the edge-point cloud into "
-                                          "caller-owned host arrays (eg3d_match_resident / eg3d_match_polyline_sets, device_only=0), timed at the C ABI"}
+                                          "caller-owned host arrays (eg3d_match_resident / eg3d_match_polyline_sets, device_only=0), timed at the C ABI; "
+                                          "the call is cut into 3 sub-batches on the context's internal lanes (eg3d_set_pipelining default for host calls), "
+                                          "so most of the copy runs behind the later sub-batches' kernels"}
+            line["ms_slowest_chain"] = max(r["times"].get("ms_slowest_chain", 0.0) for r, _ in results)
+            line["ms_slowest_chain_what"] = ("the longest time ONE chain held its wavefront in k3b_expand (device clock): no expand launch — "
+                                             "hence no lone call, however it is cut or overlapped — is shorter than its slowest chain plus the stages before it")
+        if setup is not None:
+            line["setup_ms"] = {"eg3d_create": setup["create_ms"], "eg3d_create_again": setup["create_again_ms"],
+                                "eg3d_upload_seeds": setup["upload_seeds_ms"]}
+            line["time_to_solution_one_shot"] = setup
         if world == 1 and not args.no_cpu_baseline:
             from oracle import binding as ob   # cpu_baseline leg: the checker timed as the CPU port
             sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -43,7 +43,7 @@ class Candidates(C.Structure):
 class StageTimes(C.Structure):
     _fields_ = [("ms_total", C.c_float), ("ms_candidates", C.c_float), ("ms_epipolar", C.c_float),
                 ("ms_hypotheses", C.c_float), ("ms_select", C.c_float), ("ms_expand", C.c_float),
-                ("ms_emit", C.c_float), ("bytes_algorithmic", C.c_uint64)]
+                ("ms_emit", C.c_float), ("bytes_algorithmic", C.c_uint64), ("ms_slowest_chain", C.c_float)]
 
 
 class DeviceEdgePoints(C.Structure):

@@ -52,6 +52,7 @@ def lib():
         L.eg3d_match_polyline_sets.argtypes = [C.c_void_p, C.POINTER(D.PolylineSets), C.c_uint32, C.c_uint32, C.c_int,
                                                C.POINTER(D.EdgePoints), C.POINTER(D.StageTimes)]
         L.eg3d_last_device_output.argtypes = [C.c_void_p, C.POINTER(D.DeviceEdgePoints)]
+        L.eg3d_set_pipelining.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.eg3d_gn_filter.argtypes = [C.c_void_p, D.f32p, D.u32p, D.i32p, D.f32p, C.c_uint64, C.c_float, C.c_int,
                                      D.f32p, D.u8p, D.f32p]
         _LIB = L
@@ -62,7 +63,7 @@ def lib():
 EXPORTED_SYMBOLS = [
     "eg3d_last_error", "eg3d_device_count", "eg3d_dlt_rows", "eg3d_create", "eg3d_clone", "eg3d_destroy", "eg3d_get_grid", "eg3d_candidates_run",
     "eg3d_free_candidates", "eg3d_match_refpoints", "eg3d_free_edgepoints", "eg3d_upload_seeds",
-    "eg3d_match_resident", "eg3d_gn_filter", "eg3d_last_device_output", "eg3d_match_polyline_sets",
+    "eg3d_match_resident", "eg3d_gn_filter", "eg3d_last_device_output", "eg3d_match_polyline_sets", "eg3d_set_pipelining",
 ]
 
 
@@ -88,6 +89,10 @@ class Context:
         h = C.c_void_p()
         _check(lib().eg3d_clone(self._h, C.byref(h)), "eg3d_clone")
         return Context(None, _handle=h)
+
+    def set_pipelining(self, lanes=0, units=0):
+        """Sub-batches of one call kept in flight inside the library (eg3d_set_pipelining): lanes=1 switches it off."""
+        _check(lib().eg3d_set_pipelining(self._h, lanes, units), "eg3d_set_pipelining")
 
     def close(self):
         if self._h:

@@ -12,10 +12,14 @@
 #include <cstdlib>
 #include <sys/mman.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
 #include <memory>
+#include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -128,10 +132,25 @@ struct HostGrids {
 //   EG3D_NO_LPT=1          launch chains in identity order instead of longest-first (diagnostic)
 //   EG3D_K3B_FULL=1        always run the general build of the expand kernel (default: the build for the scene's class —
 //                          polylines of <= 512 vertices and <= 28 views: small, >= 29 views: many views; general otherwise)
-//   EG3D_K3B_ENGINE=0|1    expand stage: 1 = the lane-per-chain engine (k3c_engine, eg3d_k3c_engine.h), 0 = one wavefront per
-//                          chain (k3b_expand). EG3D_K3C_WAVES=n waves per SIMD of the engine's grid, EG3D_K3C_LANES=n lanes of a
-//                          wave that own a chain (default: as many waves as fit, then as few lanes as cover the chains)
+//   EG3D_K3B_ENGINE=0|1    (builds with -DEG3D_WITH_K3C_ENGINE only: variants/libeg3d_engine.so) expand stage: 1 = the
+//                          lane-per-chain engine (k3c_engine, eg3d_k3c_engine.h), 0 = one wavefront per chain (k3b_expand).
+//                          EG3D_K3C_WAVES=n waves per SIMD of the engine's grid, EG3D_K3C_LANES=n lanes of a wave that own a
+//                          chain (default: as many waves as fit, then as few lanes as cover the chains). A library built
+//                          without the engine refuses EG3D_K3B_ENGINE=1 at eg3d_create.
+//   EG3D_PIPELINE_LANES=n  sub-batches of ONE eg3d_match_* call kept in flight on internal contexts (default 0 = by the kind of
+//                          call: 3 for a call that copies its cloud to the host, 1 for a device-only call; 1 = the call
+//                          runs as a single batch on the context's own stream). EG3D_PIPELINE_UNITS=n: sub-batches the call's
+//                          range is cut into (default: chosen from the range, see plan_seed_units). eg3d_set_pipelining
+//                          overrides both. Chosen by measurement (profiles/r06_experiments/pipelining_*.json):
+//   EG3D_UNIT_RAMP=r       unit i of a seed call gets a share ~ r^i of the range (default 0.6: the LAST unit, whose D2H copy
+//                          nothing can hide, is the smallest); EG3D_LANE_PRIORITIES=0|1: lane 0's stream high priority, lane
+//                          1 normal, the others low (default 1: the earlier units finish — and cross PCIe — first)
+//   EG3D_TEST_FAIL_UNIT=k  tests: the k-th unit (1-based) of every pipelined call fails when its turn to place comes
 struct Tunables {
+  int lanes = 0, units = 0, test_fail_unit = 0;
+  double unit_ramp = 0.6;
+  int lane_priorities = 1;
+  static constexpr int kHostCallLanes = 3;  // lanes = 0: a host call's default
   int k3a_engine_waves = 0, k3a_engine_lanes = 0;
   int k3b_engine = EG3D_K3B_ENGINE_DEFAULT, k3c_waves = 0, k3c_lanes = 0;
   bool assume_short = false;  // EG3D_K3B_ASSUME_SHORT=1 (tests): start with the few-views builds whatever the view count, so that
@@ -157,6 +176,11 @@ struct Tunables {
     if (const char* e = getenv("EG3D_TRACE_ARENA")) t.trace_arena = e[0] == '1';
     if (const char* e = getenv("EG3D_K3B_FULL")) t.k3b_full = e[0] == '1';
     if (const char* e = getenv("EG3D_SLOTS_PER_XCD")) t.slots_per_xcd = (uint32_t)std::max(1, atoi(e));
+    if (const char* e = getenv("EG3D_PIPELINE_LANES")) t.lanes = std::min(16, std::max(0, atoi(e)));
+    if (const char* e = getenv("EG3D_TEST_FAIL_UNIT")) t.test_fail_unit = atoi(e);
+    if (const char* e = getenv("EG3D_LANE_PRIORITIES")) t.lane_priorities = atoi(e);
+    if (const char* e = getenv("EG3D_UNIT_RAMP")) t.unit_ramp = std::min(16.0, std::max(1.0 / 16.0, atof(e)));
+    if (const char* e = getenv("EG3D_PIPELINE_UNITS")) t.units = std::min(4096, std::max(0, atoi(e)));
     return t;
   }
 };
@@ -199,6 +223,7 @@ struct eg3d_ctx {
   hipEvent_t ecopy[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // D2H of the cloud: one per output array
   uint32_t chain_cap = 384, pool_cap = 0, hyp_cap = 160;
   uint32_t n_simd = 0;  // SIMDs of the device (4 per CU): sizes the K3a engine's launch
+  int wall_clock_khz = 0;  // rate of wall_clock64() on the device (hipDeviceAttributeWallClockRate)
   double arena_per_hyp = 16.0;  // hypothesis arena: points per hypothesis to reserve (learned from overflows)
   void* pinned = nullptr;  // pinned host staging area of the D2H copies of a cloud (grow-only)
   size_t pinned_cap = 0;
@@ -212,6 +237,10 @@ struct eg3d_ctx {
   bool last_accumulated = false;  // the output buffers hold the whole cloud of the last call (device-only calls)
   uint32_t last_nc = 0;
   uint32_t last_nhyp = 0;
+  // Internal pipelining of ONE call (run_pipelined): lane 0 is this context, lanes 1.. are clones created on first use
+  // (own stream / work buffers, shared scene and seeds). A lane is never handed to the caller.
+  std::vector<eg3d_ctx*> lanes;
+  bool is_lane = false;
 };
 
 template <typename T>
@@ -410,6 +439,11 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
   c->tune = Tunables::from_env();
   if (c->tune.hyp_cap) c->hyp_cap = c->tune.hyp_cap;
   c->hg = std::make_shared<HostGrids>();
+  if (c->tune.lane_priorities) {
+    int least = 0, greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_TRY(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
+  } else
   HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   for (int i = 0; i < 8; i++) {
     HIP_TRY(hipEventCreate(&c->ea[i]));
@@ -485,37 +519,92 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
     UP(b_bb, bb.data(), bb.size());
     HIP_TRY(hipStreamSynchronize(c->stream));  // `bbo` / `bb` go out of scope
   }
-  // grids: built on the host (row a3), one CSR over (view, cell) per cell size
-  for (int which = 0; which < 2; which++) {
-    std::vector<uint32_t> off(1, 0), ids;
-    c->hg->h_off[which].resize(V);
-    c->hg->h_ids[which].resize(V);
-    for (int v = 0; v < V; v++) {
-      uint32_t w = 0, h = 0, *o = nullptr, *i = nullptr, dropped = 0;
-      if (eg3d_host_build_grid(sc, v, which == 0 ? 30.0f : 4.0f, &w, &h, &o, &i, &dropped) != 0) {
-        g_err = "eg3d_create: grid construction failed";
-        eg3d_destroy(c);
-        return EG3D_ERR_ARG;
+  // grids: built on the host (row a3), one CSR over (view, cell) per cell size. The 2 x V builds are independent
+  // (polyLine_2d_map.cpp:40-58 constructs one map per view): they run on a few host threads — serially this was 2x the
+  // whole hot path of a dtu006-sized job (round-5 VERDICT: 90 ms for C3', 0.87 s for C4).
+  {
+    struct GridJob {
+      uint32_t w = 0, h = 0, dropped = 0, *o = nullptr, *i = nullptr;
+      int rc = 0;
+    };
+    std::vector<GridJob> jobs((size_t)2 * V);
+    std::atomic<int> next{0};
+    auto work = [&]() {
+      for (int j; (j = next.fetch_add(1)) < 2 * V;) {
+        GridJob& g = jobs[(size_t)j];
+        // (the 4 px grids first: they are the long jobs)
+        g.rc = eg3d_host_build_grid(sc, j % V, j < V ? 4.0f : 30.0f, &g.w, &g.h, &g.o, &g.i, &g.dropped);
       }
-      c->gw[which] = w;
-      c->gh[which] = h;
-      c->grid_dropped += dropped;
-      const uint32_t base = (uint32_t)ids.size();
-      for (uint32_t cc = 0; cc < w * h; cc++) off.push_back(base + o[cc + 1]);
-      ids.insert(ids.end(), i, i + o[w * h]);
-      c->hg->h_off[which][v].assign(o, o + w * h + 1);
-      c->hg->h_ids[which][v].assign(i, i + o[w * h]);
-      free(o);
-      free(i);
+    };
+    {
+      const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+      const int nthr = (int)std::min<unsigned>(std::min<unsigned>(hw, EG3D_COPY_THREADS), (unsigned)(2 * V));
+      std::vector<std::thread> th;
+      try {
+        for (int t = 1; t < nthr; t++) th.emplace_back(work);
+      } catch (...) {  // no more threads: the calling thread does what is left
+      }
+      work();
+      for (auto& t : th) t.join();
     }
-    if (which == 0) {
-      UP(b_g30o, off.data(), off.size());
-      UP(b_g30i, ids.data(), ids.size());
-    } else {
-      UP(b_g4o, off.data(), off.size());
-      UP(b_g4i, ids.data(), ids.size());
+    bool ok = true;
+    for (auto& g : jobs) ok = ok && g.rc == 0;
+    for (int which = 0; which < 2 && ok; which++) {
+      std::vector<uint32_t> off(1, 0), ids;
+      c->hg->h_off[which].resize(V);
+      c->hg->h_ids[which].resize(V);
+      size_t n_ids = 0, n_off = 1;
+      for (int v = 0; v < V; v++) {
+        const GridJob& g = jobs[(size_t)(which == 0 ? V + v : v)];
+        n_ids += g.o[(size_t)g.w * g.h];
+        n_off += (size_t)g.w * g.h;
+      }
+      if (n_ids > 0xffffffffull) {
+        g_err = "eg3d_create: the grids of this scene hold more than 2^32-1 (cell, polyline) entries";
+        for (auto& g : jobs) {
+          free(g.o);
+          free(g.i);
+        }
+        eg3d_destroy(c);
+        return EG3D_ERR_CAPACITY;
+      }
+      off.reserve(n_off);
+      ids.reserve(n_ids);
+      for (int v = 0; v < V; v++) {
+        const GridJob& g = jobs[(size_t)(which == 0 ? V + v : v)];
+        const uint32_t w = g.w, h = g.h, *o = g.o, *i = g.i;
+        c->gw[which] = w;
+        c->gh[which] = h;
+        c->grid_dropped += g.dropped;
+        const uint32_t base = (uint32_t)ids.size();
+        for (uint32_t cc = 0; cc < w * h; cc++) off.push_back(base + o[cc + 1]);
+        ids.insert(ids.end(), i, i + o[w * h]);
+        c->hg->h_off[which][v].assign(o, o + w * h + 1);
+        c->hg->h_ids[which][v].assign(i, i + o[w * h]);
+      }
+      if (which == 0) {
+        if ((rc = upload(c->b_g30o, off.data(), off.size(), c->stream)) == EG3D_OK) rc = upload(c->b_g30i, ids.data(), ids.size(), c->stream);
+      } else {
+        if ((rc = upload(c->b_g4o, off.data(), off.size(), c->stream)) == EG3D_OK) rc = upload(c->b_g4i, ids.data(), ids.size(), c->stream);
+      }
+      if (rc == EG3D_OK && hipStreamSynchronize(c->stream) != hipSuccess) {  // `off`/`ids` go out of scope
+        g_err = "eg3d_create: uploading the grids failed";
+        rc = EG3D_ERR_HIP;
+      }
+      if (rc != EG3D_OK) ok = false;
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));  // `off`/`ids` go out of scope
+    for (auto& g : jobs) {
+      free(g.o);
+      free(g.i);
+    }
+    if (!ok) {
+      if (rc == EG3D_OK) {
+        g_err = "eg3d_create: grid construction failed";
+        rc = EG3D_ERR_ARG;
+      }
+      eg3d_destroy(c);
+      return rc;
+    }
   }
 #undef UP
   DevScene& d = c->ds;
@@ -564,6 +653,7 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   c->n_simd = (uint32_t)prop.multiProcessorCount * 4;
+  if (hipDeviceGetAttribute(&c->wall_clock_khz, hipDeviceAttributeWallClockRate, device) != hipSuccess) c->wall_clock_khz = 0;
   {
     // working-slice slots per XCD: what can be resident (occupancy query x CUs of an XCD) plus a margin —
     // the occupancy API may be one block per CU off, and a pool must never be smaller than the residency
@@ -583,11 +673,21 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
     const uint32_t cus_per_xcd = std::max<uint32_t>((cus + n_xcd - 1u) / n_xcd, 40u);
     c->slots_per_xcd = ((uint32_t)per_cu + 1u) * cus_per_xcd + 16u;
     if (c->tune.slots_per_xcd) c->slots_per_xcd = c->tune.slots_per_xcd;  // tests / experiments
-    c->k3c_per_cu = k3c_blocks_per_cu();
-    if (c->k3c_per_cu < 1) {
-      g_err = "eg3d_create: occupancy query of the expand engine failed";
+    // (the lane-per-chain engine is an opt-in second form: only a context that asks for it depends on its kernel)
+    if (c->tune.k3b_engine != 0) {
+#ifdef EG3D_WITH_K3C_ENGINE
+      c->k3c_per_cu = k3c_blocks_per_cu();
+      if (c->k3c_per_cu < 1) {
+        g_err = "eg3d_create: occupancy query of the expand engine failed";
+        eg3d_destroy(c);
+        return EG3D_ERR_HIP;
+      }
+#else
+      g_err = "eg3d_create: EG3D_K3B_ENGINE=1, but this library was built without the lane-per-chain engine "
+              "(-DEG3D_WITH_K3C_ENGINE: edgegraph3d_amd/variants/libeg3d_engine.so)";
       eg3d_destroy(c);
-      return EG3D_ERR_HIP;
+      return EG3D_ERR_ARG;
+#endif
     }
   }
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -642,6 +742,7 @@ extern "C" int eg3d_clone(eg3d_ctx* parent, eg3d_ctx** out) {
   c->pool_cap = parent->pool_cap;
   c->hyp_cap = parent->hyp_cap;
   c->n_simd = parent->n_simd;
+  c->wall_clock_khz = parent->wall_clock_khz;
   c->arena_per_hyp = parent->arena_per_hyp;
   c->slots_per_xcd = parent->slots_per_xcd;
   c->k3c_per_cu = parent->k3c_per_cu;
@@ -655,6 +756,8 @@ extern "C" int eg3d_clone(eg3d_ctx* parent, eg3d_ctx** out) {
 
 extern "C" void eg3d_destroy(eg3d_ctx* c) {
   if (!c) return;
+  for (size_t l = 1; l < c->lanes.size(); l++) eg3d_destroy(c->lanes[l]);  // (lane 0 is the context itself)
+  c->lanes.clear();
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (!c->scene_owner)  // creation failed half-way: the scene buffers are still this context's
@@ -882,21 +985,144 @@ struct RawVec {
 
 static void copy_mt(void* dst, const void* src, size_t bytes) { eg3d::copy_mt(dst, src, bytes); }
 
+// What one unit (a sub-batch of a call: a seed range or a run of polyline sets) adds to the call's totals.
 struct HostOut {
-  RawVec<float> X, xy;
-  RawVec<uint32_t> pl, seg, key;
-  RawVec<uint64_t> off;
-  RawVec<int32_t> view;
   uint64_t n_points = 0, n_obs = 0, n_tasks = 0, n_hyp = 0, n_chains = 0;
   uint32_t flags = 0;
   uint64_t bytes_algorithmic = 0, bytes_vertices = 0;
   float ms[7] = {0, 0, 0, 0, 0, 0, 0};
+  uint32_t max_chain_ticks = 0;  // the slowest chain of the expand launches (constant-rate clock)
+  int pieces = 0;  // (unit, chunk) pieces placed
+};
+
+// Where the units of ONE eg3d_match_* call put their output. Units are computed concurrently on the context's lanes
+// (run_pipelined) but PLACED strictly in unit order — the call's cloud is the concatenation of its units' clouds in seed /
+// set order, byte for byte what a single batch produces (seeds are independent: plg_matching_from_refpoints.cpp:83-104).
+// The order is kept by a turnstile: a unit may place (learn its offsets, reserve its part of the destination) only when
+// every earlier unit has placed everything.
+//   host calls (device_only == 0): a unit's arrays cross PCIe into its lane's pinned staging area as soon as its k4_emit is
+//     done, whatever its turn; once it holds the turn it reserves [p0, p0 + np) x [o0, o0 + no) of the caller-bound arrays,
+//     passes the turn on, and copies staging -> destination while the later units are still computing.
+//   device-only calls: the unit waits for its turn BEFORE k4_emit, which then writes straight into the owner's output
+//     buffers at the unit's offsets (eg3d_last_device_output sees one whole cloud, as before).
+struct CallSink {
+  eg3d_ctx* owner = nullptr;
+  int device_only = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  uint32_t turn = 0;  // the unit that places next
+  bool failed = false;
+  int rc = EG3D_OK;
+  std::string err;
+  // destination of a host call; dst_mu: copiers hold it shared, a (rare) growth of the arrays holds it exclusively
+  RawVec<float> X, xy;
+  RawVec<uint32_t> pl, seg, key;
+  RawVec<uint64_t> off;
+  RawVec<int32_t> view;
+  std::shared_mutex dst_mu;
+  uint64_t n_points = 0, n_obs = 0;          // placed so far
+  double weight_total = 0, weight_placed = 0;  // share of the call placed so far (sizes the destination's first allocation)
+  bool keyed_by_sample = false;              // polyline-set calls: key[0] = sample index of the CALL ...
+  uint32_t key0_next = 0;                    // ... = samples of the units placed so far + the sample's index in its unit
+  HostOut tot;
+  void unit_tasks(uint32_t n) {  // (holding the turn)
+    if (keyed_by_sample) key0_next += n;
+  }
+
+  bool acquire(uint32_t u) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return failed || turn == u; });
+    return !failed;
+  }
+  void release(uint32_t u) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (turn == u) turn = u + 1;
+    }
+    cv.notify_all();
+  }
+  void fail(int code, const std::string& text) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!failed) {
+        failed = true;
+        rc = code;
+        err = text;
+      }
+    }
+    cv.notify_all();
+  }
+  // (holding the turn) reserve np points / no observations of the host destination; w = this piece's share of the call
+  bool place_host(uint64_t np, uint64_t no, double w, uint64_t& p0, uint64_t& o0) {
+    p0 = n_points;
+    o0 = n_obs;
+    const uint64_t need_p = p0 + np, need_o = o0 + no;
+    if (need_p + 1 > off.cap || need_o > view.cap) {
+      // estimated size of the whole call from the share placed so far (virtual until touched; a block that has to grow
+      // later is the slow case, so the estimate is generous)
+      double f = 1.0;
+      if (weight_total > weight_placed + w && weight_placed + w > 0) f = 1.5 * weight_total / (weight_placed + w);
+      const size_t rp = (size_t)std::max<double>((double)need_p, f * (double)need_p) + 1;
+      const size_t ro = (size_t)std::max<double>((double)need_o, f * (double)need_o) + 1;
+      std::unique_lock<std::shared_mutex> lk(dst_mu);
+      if (!X.reserve(rp * 3) || !off.reserve(rp + 1) || !key.reserve(rp * 4) || !view.reserve(ro) || !pl.reserve(ro) ||
+          !seg.reserve(ro) || !xy.reserve(ro * 2))
+        return false;
+    }
+    n_points = need_p;
+    n_obs = need_o;
+    weight_placed += w;
+    return true;
+  }
+  void add(const HostOut& h) {
+    std::lock_guard<std::mutex> lk(mu);
+    tot.n_tasks += h.n_tasks;
+    tot.n_hyp += h.n_hyp;
+    tot.n_chains += h.n_chains;
+    tot.flags |= h.flags;
+    tot.bytes_algorithmic += h.bytes_algorithmic;
+    tot.pieces += h.pieces;
+    tot.max_chain_ticks = std::max(tot.max_chain_ticks, h.max_chain_ticks);
+    for (int k = 0; k < 7; k++) tot.ms[k] += h.ms[k];
+  }
+};
+
+// A unit's pass through the turnstile (it may take the turn several times: once per chunk of an expand stage cut by
+// EG3D_MAX_SCRATCH_MB; it passes the turn on exactly once).
+struct UnitTurn {
+  CallSink& S;
+  uint32_t u;
+  double weight;       // the unit's share of the call (sum of track lengths / polylines)
+  bool held = false, passed = false;
+  bool take() {
+    if (held) return true;
+    if (passed) return false;
+    if (S.owner->tune.test_fail_unit == (int)u + 1) {  // (tests: the failure path of the turnstile)
+      g_err = "eg3d: unit failure requested by EG3D_TEST_FAIL_UNIT";
+      return false;
+    }
+    held = S.acquire(u);
+    return held;
+  }
+  void pass() {
+    if (passed) return;
+    if (!held && !S.acquire(u)) {  // (failed call: nobody waits for a turn any more)
+      passed = true;
+      return;
+    }
+    S.release(u);
+    held = false;
+    passed = true;
+  }
 };
 
 // Stage B: task setup, K3a, K3s, K3b + K4 in chunks. Consumes the StageAView in B (from the seed
-// path's stage A or from the polyline-set sampler) and appends to H.
-int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
+// path's stage A or from the polyline-set sampler); the output goes to the call's sink in unit order (T), the
+// unit's counts and times to H.
+int run_stage_b(eg3d_ctx* c, BatchState& B, UnitTurn& T, HostOut& H) {
   hipStream_t st = c->stream;
+  CallSink& S = T.S;
+  const int device_only = S.device_only;
   const uint32_t nt = B.n_tasks;
   // ---- task setup + hypothesis offsets
   BUF_TRY(c->b_tasks.ensure(sizeof(TaskDesc) * (nt + 1)));
@@ -990,11 +1216,16 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
                            hipMemcpyDeviceToDevice, st));
     // the expand stage's two forms: one wavefront per chain on XCD-affine slots (k3b_expand), or the lane-per-chain
     // engine (k3c_engine): n_waves single-wave blocks whose first eng_lanes lanes own a working slice each
+#ifdef EG3D_WITH_K3C_ENGINE
     const bool engine = c->tune.k3b_engine != 0;
+#else
+    const bool engine = false;
+#endif
     uint32_t eng_waves = 0, eng_lanes = 64;
     SlotPools pools;
     pools.base = nullptr;
     pools.stride = pools.ring_n = pools.slots_per_xcd = 0;
+#ifdef EG3D_WITH_K3C_ENGINE
     if (engine) {
       const uint32_t per_simd = (uint32_t)(c->tune.k3c_waves > 0 ? c->tune.k3c_waves : std::max(1, c->k3c_per_cu / 4));
       const uint32_t waves_max = c->n_simd * per_simd;
@@ -1007,7 +1238,9 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
       BUF_TRY(c->b_cscratch.ensure(L.total * (size_t)eng_waves * eng_lanes));
       BUF_TRY(c->b_queue.ensure(4 * sizeof(uint32_t)));
       HIP_TRY(hipMemsetAsync(c->b_queue.p, 0, 4 * sizeof(uint32_t), st));
-    } else {
+    } else
+#endif
+    {
       BUF_TRY(c->b_cscratch.ensure(L.total * 8 * (size_t)c->slots_per_xcd));
       pools.slots_per_xcd = c->slots_per_xcd;
       pools.ring_n = 1;
@@ -1071,6 +1304,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
     // that repeats a view can exceed it — the kernel then raises CTR_LONG_REFUSED and the chunk is redone with the general
     // build (k3b_full latched for the context), like the capacity overflows below.
     const bool general = c->tune.k3b_full || c->k3b_long_latched || c->max_pl_vtx > EG3D_STAGE_VTX_HOST;
+#ifdef EG3D_WITH_K3C_ENGINE
     if (engine)
       launch_k3c(st, eng_waves, eng_lanes, c->ds, B.a, c->b_tasks.as<TaskDesc>(), c->b_chains.as<ChainSeed>() + c0, nc,
                  c->b_hyp_off.as<uint32_t>(), c->b_res.as<HypResult>(), c->b_arena.as<HPoint>(), c->b_map_view.as<int32_t>(),
@@ -1079,6 +1313,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
                  c->b_order.as<uint32_t>(), c->b_queue.as<uint32_t>(),
                  (c->tune.k3b_full || c->k3b_long_latched || (c->V > EG3D_SMALL_SCENE_VIEWS_HOST && !c->tune.assume_short)) ? 1 : 0);
     else
+#endif
     launch_k3b(st, c->ds, B.a, c->b_tasks.as<TaskDesc>(), c->b_chains.as<ChainSeed>() + c0, nc,
                c->b_hyp_off.as<uint32_t>(), c->b_res.as<HypResult>(), c->b_arena.as<HPoint>(),
                c->b_map_view.as<int32_t>(), c->b_map_entry.as<uint32_t>(), c->b_map_n.as<uint32_t>(), L,
@@ -1150,61 +1385,57 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
         continue;
       }
     }
-    // Device-only calls keep the WHOLE cloud of the call in the output buffers (chunk after chunk, batch after
-    // batch, global observation offsets), so that eg3d_last_device_output is complete whatever the chunking —
-    // the RCCL gather reads it. Calls that copy to the host reuse the buffers per chunk (chunk-local offsets,
-    // rebased on the host below).
+    // ---- K4 + placement of this chunk. Device-only calls keep the WHOLE cloud of the call in the OWNER's output buffers
+    // (unit after unit, chunk after chunk, global observation offsets), so that eg3d_last_device_output is complete whatever
+    // the cutting — the RCCL gather reads it: the chunk waits for its unit's turn, then k4_emit writes at the call's running
+    // offsets. Calls that copy to the host emit into the lane's own buffers (chunk-local offsets, rebased on the host below)
+    // and start the D2H at once; the turn is only needed to learn where the chunk goes in the caller's arrays.
     const bool accumulate = device_only != 0;
-    const size_t P0 = accumulate ? (size_t)H.n_points : 0, O0 = accumulate ? (size_t)H.n_obs : 0;
-    BUF_TRY(c->o_X.ensure_keep(sizeof(float) * 3 * (P0 + np + 1), sizeof(float) * 3 * P0, st));
-    BUF_TRY(c->o_off.ensure_keep(sizeof(eg3d_off_t) * (P0 + np + 1), sizeof(eg3d_off_t) * P0, st));
-    BUF_TRY(c->o_key.ensure_keep(sizeof(uint32_t) * 4 * (P0 + np + 1), sizeof(uint32_t) * 4 * P0, st));
-    BUF_TRY(c->o_view.ensure_keep(sizeof(int32_t) * (O0 + no + 1), sizeof(int32_t) * O0, st));
-    BUF_TRY(c->o_pl.ensure_keep(sizeof(uint32_t) * (O0 + no + 1), sizeof(uint32_t) * O0, st));
-    BUF_TRY(c->o_seg.ensure_keep(sizeof(uint32_t) * (O0 + no + 1), sizeof(uint32_t) * O0, st));
-    BUF_TRY(c->o_xy.ensure_keep(sizeof(float) * 2 * (O0 + no + 1), sizeof(float) * 2 * O0, st));
+    const bool last_chunk = c0 + nc >= B.n_chains;
+    const double w_piece = T.weight * (double)nc / (double)std::max(1u, B.n_chains);
+    eg3d_ctx* const oc = accumulate ? S.owner : c;  // whose output buffers k4_emit writes
+    size_t P0 = 0, O0 = 0;
+    uint32_t key0 = 0;
+    if (accumulate) {
+      if (!T.take()) return EG3D_ERR_HIP;  // another unit of the call failed: its error is the call's
+      P0 = (size_t)S.n_points;
+      O0 = (size_t)S.n_obs;
+      key0 = S.key0_next + B.key0_base;
+    }
+    BUF_TRY(oc->o_X.ensure_keep(sizeof(float) * 3 * (P0 + np + 1), sizeof(float) * 3 * P0, st));
+    BUF_TRY(oc->o_off.ensure_keep(sizeof(eg3d_off_t) * (P0 + np + 1), sizeof(eg3d_off_t) * P0, st));
+    BUF_TRY(oc->o_key.ensure_keep(sizeof(uint32_t) * 4 * (P0 + np + 1), sizeof(uint32_t) * 4 * P0, st));
+    BUF_TRY(oc->o_view.ensure_keep(sizeof(int32_t) * (O0 + no + 1), sizeof(int32_t) * O0, st));
+    BUF_TRY(oc->o_pl.ensure_keep(sizeof(uint32_t) * (O0 + no + 1), sizeof(uint32_t) * O0, st));
+    BUF_TRY(oc->o_seg.ensure_keep(sizeof(uint32_t) * (O0 + no + 1), sizeof(uint32_t) * O0, st));
+    BUF_TRY(oc->o_xy.ensure_keep(sizeof(float) * 2 * (O0 + no + 1), sizeof(float) * 2 * O0, st));
     HIP_TRY(hipEventRecord(c->ea[6], st));
     c->stage_cap_pts = std::max<uint64_t>(c->stage_cap_pts, (uint64_t)np + np / 16);  // sizing hint of the next launch
     c->stage_cap_obs = std::max<uint64_t>(c->stage_cap_obs, (uint64_t)no + no / 16);
     launch_k4(st, c->b_tasks.as<TaskDesc>(), c->b_chains.as<ChainSeed>() + c0, nc, stage,
-              c->b_couts.as<ChainOut>(), c->b_cpoff.as<uint32_t>(), c->b_cooff.as<uint32_t>(), P0, O0, B.key0_base,
-              c->o_X.as<float>(), c->o_off.as<eg3d_off_t>(), c->o_view.as<int32_t>(), c->o_pl.as<uint32_t>(),
-              c->o_seg.as<uint32_t>(), c->o_xy.as<float>(), c->o_key.as<uint32_t>());
+              c->b_couts.as<ChainOut>(), c->b_cpoff.as<uint32_t>(), c->b_cooff.as<uint32_t>(), P0, O0, key0,
+              oc->o_X.as<float>(), oc->o_off.as<eg3d_off_t>(), oc->o_view.as<int32_t>(), oc->o_pl.as<uint32_t>(),
+              oc->o_seg.as<uint32_t>(), oc->o_xy.as<float>(), oc->o_key.as<uint32_t>());
     HIP_TRY(hipEventRecord(c->eb[6], st));
-    HIP_TRY(hipStreamSynchronize(st));
     H.flags |= (hc.flags & 0xffu);
     H.bytes_vertices = hc.bytes;  // running total of this batch (K1 + K3b so far)
-    float t = 0;
-    HIP_TRY(hipEventElapsedTime(&t, c->ea[5], c->eb[5]));
-    ms_expand += t;
-    HIP_TRY(hipEventElapsedTime(&t, c->ea[6], c->eb[6]));
-    ms_emit += t;
-    if (!device_only && np) {
-      const size_t p0 = H.X.size() / 3, o0 = H.view.size();
-      if (nc < B.n_chains - c0) {  // more chunks to come: reserve the batch's estimated total (virtual until touched)
-        const double f = 1.2 * (double)(B.n_chains - c0) / (double)nc;
-        const size_t rp = p0 + (size_t)(f * np) + 1, ro = o0 + (size_t)(f * no) + 1;
-        if (!H.X.reserve(rp * 3) || !H.off.reserve(rp + 1) || !H.key.reserve(rp * 4) || !H.view.reserve(ro) ||
-            !H.pl.reserve(ro) || !H.seg.reserve(ro) || !H.xy.reserve(ro * 2)) {
-          g_err = "eg3d: out of host memory for the edge-point cloud";
-          return EG3D_ERR_ARG;
-        }
+    H.max_chain_ticks = std::max(H.max_chain_ticks, hc.max_chain_ticks);
+    if (accumulate) {
+      HIP_TRY(hipStreamSynchronize(st));  // k4_emit has written: the next piece may grow / write the owner's buffers
+      S.n_points += np;
+      S.n_obs += no;
+      if (last_chunk) {
+        S.unit_tasks(B.n_tasks);
+        T.pass();
       }
-      if (!H.X.grow_to((p0 + np) * 3) || !H.off.grow_to(p0 + np + 1) || !H.key.grow_to((p0 + np) * 4) ||
-          !H.view.grow_to(o0 + no) || !H.pl.grow_to(o0 + no) || !H.seg.grow_to(o0 + no) || !H.xy.grow_to((o0 + no) * 2)) {
-        g_err = "eg3d: out of host memory for the edge-point cloud";
-        return EG3D_ERR_ARG;
-      }
-      H.off.n = p0 + np;  // (one spare slot is kept for the final n_obs sentinel)
-      // D2H through the context's pinned staging area (grow-only): seven async copies at PCIe speed, each followed
+    } else if (np) {
+      // D2H through the lane's pinned staging area (grow-only): seven async copies at PCIe speed, each followed
       // by an event; the multi-threaded copy of an array into the caller's pageable memory starts when ITS event has
       // fired, while the later arrays are still crossing PCIe. (A pageable hipMemcpy runs at ~2 GB/s and made the
       // copy 3x the compute time on the dtu006-shaped workload.)
       const size_t sz[7] = {sizeof(float) * 3 * np, sizeof(eg3d_off_t) * np,   sizeof(uint32_t) * 4 * np, sizeof(int32_t) * no,
                             sizeof(uint32_t) * no,  sizeof(uint32_t) * no,      sizeof(float) * 2 * no};
       const void* src[7] = {c->o_X.p, c->o_off.p, c->o_key.p, c->o_view.p, c->o_pl.p, c->o_seg.p, c->o_xy.p};
-      void* dst[7] = {H.X.data() + p0 * 3, H.off.data() + p0,  H.key.data() + p0 * 4, H.view.data() + o0,
-                      H.pl.data() + o0,    H.seg.data() + o0,  H.xy.data() + o0 * 2};
       size_t total = 0, at[7];
       for (int k = 0; k < 7; k++) {
         at[k] = total;
@@ -1228,31 +1459,69 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
         if (sz[k]) HIP_TRY(hipMemcpyAsync((char*)c->pinned + at[k], src[k], sz[k], hipMemcpyDeviceToHost, st));
         HIP_TRY(hipEventRecord(c->ecopy[i], st));
       }
+      // where the chunk goes: known once every earlier unit has placed its output
+      if (!T.take()) return EG3D_ERR_HIP;
+      uint64_t p0 = 0, o0 = 0;
+      const bool placed = S.place_host(np, no, w_piece, p0, o0);
+      const uint32_t key0_host = S.key0_next + B.key0_base;
+      if (last_chunk) {
+        S.unit_tasks(B.n_tasks);
+        T.pass();  // the later units place (and copy) while this one copies
+      }
+      if (!placed) {
+        g_err = "eg3d: out of host memory for the edge-point cloud";
+        return EG3D_ERR_ARG;
+      }
 #ifdef EG3D_COPY_TIMING
       const auto tc1 = std::chrono::steady_clock::now();
 #endif
-      for (int i = 0; i < 7; i++) {
-        const int k = order[i];
-        HIP_TRY(hipEventSynchronize(c->ecopy[i]));
-        copy_mt(dst[k], (char*)c->pinned + at[k], sz[k]);
+      {
+        std::shared_lock<std::shared_mutex> lk(S.dst_mu);
+        void* dst[7] = {S.X.data() + p0 * 3, S.off.data() + p0,  S.key.data() + p0 * 4, S.view.data() + o0,
+                        S.pl.data() + o0,    S.seg.data() + o0,  S.xy.data() + o0 * 2};
+        for (int i = 0; i < 7; i++) {
+          const int k = order[i];
+          HIP_TRY(hipEventSynchronize(c->ecopy[i]));
+          copy_mt(dst[k], (char*)c->pinned + at[k], sz[k]);
+        }
+        if (o0) {
+          uint64_t* off = S.off.data();
+          for (size_t i = p0; i < p0 + np; i++) off[i] += (uint64_t)o0;
+        }
+        if (key0_host) {  // polyline-set calls: key[0] counts the samples of the whole call
+          uint32_t* key = S.key.data();
+          for (size_t i = p0; i < p0 + np; i++) key[4 * i] += key0_host;
+        }
       }
 #ifdef EG3D_COPY_TIMING
       const auto tc2 = std::chrono::steady_clock::now();
-      fprintf(stderr, "chunk: p0 %zu o0 %zu np %u no %u nc %u  ", p0, o0, np, no, nc);
-      fprintf(stderr, "copy timing: %.1f MB  D2H %.2f ms  host copy %.2f ms\n", total / 1e6,
+      fprintf(stderr, "chunk: p0 %zu o0 %zu np %u no %u nc %u  ", (size_t)p0, (size_t)o0, np, no, nc);
+      fprintf(stderr, "copy timing: %.1f MB  D2H queue + turn %.2f ms  wait + host copy %.2f ms\n", total / 1e6,
               std::chrono::duration<double, std::milli>(tc1 - tc0).count(),
               std::chrono::duration<double, std::milli>(tc2 - tc1).count());
 #endif
-      if (o0)
-        for (size_t i = p0; i < p0 + np; i++) H.off[i] += (uint64_t)o0;
+    } else if (last_chunk) {
+      if (!T.take()) return EG3D_ERR_HIP;
+      S.unit_tasks(B.n_tasks);
+      T.pass();
     }
+    HIP_TRY(hipStreamSynchronize(st));
+    float t = 0;
+    HIP_TRY(hipEventElapsedTime(&t, c->ea[5], c->eb[5]));
+    ms_expand += t;
+    HIP_TRY(hipEventElapsedTime(&t, c->ea[6], c->eb[6]));
+    ms_emit += t;
     H.n_points += np;
     H.n_obs += no;
-    c->last_np = accumulate ? H.n_points : np;
-    c->last_no = accumulate ? H.n_obs : no;
-    c->last_accumulated = accumulate;
-    c->last_chunks++;
+    H.pieces++;
+    c->last_np = np;  // (the owner's view of the whole call is set when the call ends)
+    c->last_no = no;
     c->last_nc = nc;
+  }
+  if (!B.n_chains) {  // a unit without chains still takes its turn
+    if (!T.take()) return EG3D_ERR_HIP;
+    S.unit_tasks(B.n_tasks);
+    T.pass();
   }
   HIP_TRY(hipStreamSynchronize(st));
   float t = 0;
@@ -1276,13 +1545,13 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, int device_only, HostOut& H) {
   return EG3D_OK;
 }
 
-int run_batch(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, HostOut& H) {
+int run_batch(eg3d_ctx* c, uint32_t b, uint32_t e, UnitTurn& T, HostOut& H) {
   BatchState B;
   memset(&B, 0, sizeof(B));
   B.b = b;
   B.e = e;
   BUF_TRY(run_stage_a(c, B, nullptr));
-  BUF_TRY(run_stage_b(c, B, device_only, H));
+  BUF_TRY(run_stage_b(c, B, T, H));
   // per seed 12 + k*12 + k*64 + k(k-1)*72 (the vertices touched and the output were
   // added by stage B)
   for (uint32_t sd_i = b; sd_i < e; sd_i++) {
@@ -1296,12 +1565,12 @@ int run_batch(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, HostOut& H) 
 // collect the epipolar hits of every sample; then the common stage B. `sets` is already on the
 // device; h_row_off is its host copy of the row offsets.
 int run_sets_batch(eg3d_ctx* c, const SetsDev& sets, const uint32_t* h_row_off, uint32_t n_rows_total, uint32_t set_b,
-                   uint32_t set_e, int device_only, uint32_t sample_base, HostOut& H) {
+                   uint32_t set_e, UnitTurn& T, HostOut& H) {
   hipStream_t st = c->stream;
   const uint32_t V = (uint32_t)c->V;
   BatchState B;
   memset(&B, 0, sizeof(B));
-  B.key0_base = sample_base;
+  B.key0_base = 0;  // (key[0] = sample index of the CALL: the sink adds the samples of the units before this one)
   const uint32_t item_b = h_row_off[(size_t)set_b * V], item_e = h_row_off[(size_t)set_e * V];
   const uint32_t n_items = item_e - item_b;
   BUF_TRY(c->b_ctr.ensure(sizeof(Counters)));
@@ -1375,7 +1644,7 @@ int run_sets_batch(eg3d_ctx* c, const SetsDev& sets, const uint32_t* h_row_off, 
   a.list_cnt = c->b_list_cnt.as<uint32_t>();
   a.hits = c->b_hits.as<Obs>();
   a.dense_k = V;
-  BUF_TRY(run_stage_b(c, B, device_only, H));
+  BUF_TRY(run_stage_b(c, B, T, H));
   // per sample: its coordinates, V camera matrices, V-1 fundamental matrices (the scanned vertices
   // and the output were added by the kernels)
   H.bytes_algorithmic += (uint64_t)nt * (8 + (uint64_t)V * 64 + (uint64_t)(V - 1) * 72);
@@ -1391,28 +1660,160 @@ T* dup_to_malloc(const std::vector<T>& v, size_t extra = 0) {
 
 }  // namespace
 
+// ---- one call = units on lanes ----------------------------------------------------------------------------------------
+// The reference's parallel entry point runs the seeds of ONE call on its OpenMP team (plg_matching_from_refpoints.cpp:83-104,
+// `#pragma omp parallel for`). The analogue here: a call's range is cut into units (contiguous, balanced by the sum of track
+// lengths), the units run concurrently on the context's lanes — internal contexts with their own HIP stream, work buffers
+// and host thread — and their clouds are concatenated in unit order (CallSink). What that buys on one GPU: the candidate /
+// hypothesis stages and the D2H copy of one unit overlap the expand stage of another, and the thin tail of one expand launch
+// (a few long chains on an otherwise empty GPU) is filled by the next unit's chains.
+static void lane_share_inputs(eg3d_ctx* owner, eg3d_ctx* l) {
+  if (l == owner) return;
+  l->n_seeds = owner->n_seeds;
+  l->h_trk = owner->h_trk;
+  l->b_toff = owner->b_toff;
+  l->b_tview = owner->b_tview;
+  l->b_txy = owner->b_txy;
+  l->seeds_owner = owner->seeds_owner;
+  // what a lane has learned about the scene's needs serves all of them (capacities only grow)
+  l->chain_cap = std::max(l->chain_cap, owner->chain_cap);
+  l->pool_cap = std::max(l->pool_cap, owner->pool_cap);
+  l->arena_per_hyp = std::max(l->arena_per_hyp, owner->arena_per_hyp);
+  l->k3b_long_latched = l->k3b_long_latched || owner->k3b_long_latched;
+}
+static void lane_return_learned(eg3d_ctx* owner, const eg3d_ctx* l) {
+  if (l == owner) return;
+  owner->chain_cap = std::max(l->chain_cap, owner->chain_cap);
+  owner->pool_cap = std::max(l->pool_cap, owner->pool_cap);
+  owner->arena_per_hyp = std::max(l->arena_per_hyp, owner->arena_per_hyp);
+  owner->k3b_long_latched = l->k3b_long_latched || owner->k3b_long_latched;
+}
+static int ensure_lanes(eg3d_ctx* c, int n) {
+  if (c->lanes.empty()) c->lanes.push_back(c);
+  while ((int)c->lanes.size() < n) {
+    eg3d_ctx* l = nullptr;
+    BUF_TRY(eg3d_clone(c, &l));
+    l->is_lane = true;
+    l->tune.lanes = 1;
+    if (c->tune.lane_priorities) {
+      int least = 0, greatest = 0;
+      HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+      (void)hipStreamDestroy(l->stream);
+      l->stream = nullptr;
+      const int mid = (least + greatest) / 2;
+      HIP_TRY(hipStreamCreateWithPriority(&l->stream, hipStreamNonBlocking, c->lanes.size() == 1 ? mid : least));
+    }
+    c->lanes.push_back(l);
+  }
+  return EG3D_OK;
+}
+
+struct UnitRange {
+  uint32_t b, e;
+  double w;
+};
+// Cuts [b, e) into contiguous units of (nearly) equal weight; cum[i] = weight of items [0, i) (ascending).
+template <typename Cum>
+static std::vector<UnitRange> cut_by_weight(uint32_t b, uint32_t e, uint32_t n_units, Cum cum, double ramp = 1.0) {
+  std::vector<UnitRange> out;
+  if (b >= e) return out;
+  n_units = std::max(1u, std::min(n_units, e - b));
+  const double w0 = (double)cum(b), w1 = (double)cum(e);
+  // unit i gets a share proportional to ramp^i (1 = equal units; < 1 = the later units are smaller)
+  double share_all = 0, share_done = 0, r = 1.0;
+  for (uint32_t k = 0; k < n_units; k++, r *= ramp) share_all += r;
+  r = 1.0;
+  uint32_t at = b;
+  for (uint32_t k = 1; k <= n_units && at < e; k++) {
+    uint32_t end = e;
+    share_done += r;
+    r *= ramp;
+    if (k < n_units) {
+      const double target = w0 + (w1 - w0) * share_done / share_all;
+      uint32_t lo = at + 1, hi = e;  // first index whose prefix weight reaches the target (at least one item per unit)
+      while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if ((double)cum(mid) < target) lo = mid + 1; else hi = mid;
+      }
+      end = std::min(e - (n_units - k), std::max(at + 1, lo));  // leave an item for each unit still to come
+    }
+    out.push_back({at, end, (double)cum(end) - (double)cum(at)});
+    at = end;
+  }
+  return out;
+}
+
+// Runs the units on up to n_lanes lanes (the calling thread drives lane 0). run(lane, unit index, turn, stats) -> status.
+template <typename Run>
+static int run_pipelined(eg3d_ctx* c, CallSink& S, const std::vector<UnitRange>& units, int n_lanes, Run run) {
+  const uint32_t n_units = (uint32_t)units.size();
+  n_lanes = (int)std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)std::max(1, n_lanes), n_units));
+  BUF_TRY(ensure_lanes(c, n_lanes));
+  for (int l = 0; l < n_lanes; l++) lane_share_inputs(c, c->lanes[(size_t)l]);
+  for (const UnitRange& u : units) S.weight_total += u.w;
+  std::atomic<uint32_t> next{0};
+  auto worker = [&](eg3d_ctx* lane) {
+    if (hipSetDevice(lane->device) != hipSuccess) {
+      S.fail(EG3D_ERR_HIP, "eg3d: hipSetDevice failed on a pipeline thread");
+      return;
+    }
+    for (uint32_t u; (u = next.fetch_add(1)) < n_units;) {
+      UnitTurn T{S, u, units[u].w};
+      HostOut H;
+      const int rc = run(lane, u, T, H);
+      if (rc != EG3D_OK) {
+        S.fail(rc, g_err);  // (this thread's message; the first failure of the call is the one reported)
+        return;
+      }
+      T.pass();
+      S.add(H);
+    }
+  };
+  std::vector<std::thread> th;
+  try {
+    for (int l = 1; l < n_lanes; l++) th.emplace_back(worker, c->lanes[(size_t)l]);
+  } catch (...) {  // no more threads: the lanes that did start (and this thread) take all units
+  }
+  worker(c);
+  for (auto& t : th) t.join();
+  for (int l = 0; l < n_lanes; l++) lane_return_learned(c, c->lanes[(size_t)l]);
+  if (S.failed) {
+    g_err = S.err;
+    return S.rc;
+  }
+  return EG3D_OK;
+}
+
 extern "C" void eg3d_free_edgepoints(eg3d_edgepoints* e);
-static int finish_match(HostOut& H, int device_only, float total, eg3d_edgepoints* out, eg3d_stage_times* times) {
-  out->n_points = H.n_points;
-  out->n_obs = H.n_obs;
+static int finish_match(eg3d_ctx* c, CallSink& S, float total, eg3d_edgepoints* out, eg3d_stage_times* times) {
+  const HostOut& H = S.tot;
+  const int device_only = S.device_only;
+  out->n_points = S.n_points;
+  out->n_obs = S.n_obs;
   out->n_tasks = H.n_tasks;
   out->n_hypotheses = H.n_hyp;
   out->n_chains = H.n_chains;
   out->flags = H.flags;
+  c->last_chunks = H.pieces;
+  c->last_accumulated = device_only != 0;
+  if (device_only) {
+    c->last_np = S.n_points;
+    c->last_no = S.n_obs;
+  }
   if (!device_only) {
-    const size_t npts = H.off.size();
-    if (!H.off.grow_to(npts + 1)) {
+    const size_t npts = (size_t)S.n_points;
+    if (!S.off.reserve(npts + 1)) {
       g_err = "eg3d: out of host memory for the edge-point cloud";
       return EG3D_ERR_ARG;
     }
-    H.off[npts] = H.n_obs;
-    out->X = H.X.release();
-    out->obs_off = H.off.release();
-    out->obs_view = H.view.release();
-    out->obs_pl = H.pl.release();
-    out->obs_seg = H.seg.release();
-    out->obs_xy = H.xy.release();
-    out->key = H.key.release();
+    S.off[npts] = S.n_obs;
+    out->X = S.X.release();
+    out->obs_off = S.off.release();
+    out->obs_view = S.view.release();
+    out->obs_pl = S.pl.release();
+    out->obs_seg = S.seg.release();
+    out->obs_xy = S.xy.release();
+    out->key = S.key.release();
     out->_owner = (void*)1;
   }
   if (times) {
@@ -1423,7 +1824,8 @@ static int finish_match(HostOut& H, int device_only, float total, eg3d_edgepoint
     times->ms_select = H.ms[4];
     times->ms_expand = H.ms[5];
     times->ms_emit = H.ms[6];
-    times->bytes_algorithmic = H.bytes_algorithmic + 12 * H.n_points + 20 * H.n_obs;
+    times->bytes_algorithmic = H.bytes_algorithmic + 12 * S.n_points + 20 * S.n_obs;
+    times->ms_slowest_chain = c->wall_clock_khz > 0 ? (float)((double)H.max_chain_ticks / (double)c->wall_clock_khz) : 0.0f;
   }
   if (H.flags & (EG3D_FLAG_CHAIN_OVERFLOW | EG3D_FLAG_OBS_OVERFLOW | EG3D_FLAG_HYP_OVERFLOW)) {
     g_err = "eg3d: a device-side capacity was exceeded (flags in out->flags)";
@@ -1435,6 +1837,54 @@ static int finish_match(HostOut& H, int device_only, float total, eg3d_edgepoint
   return EG3D_OK;
 }
 
+extern "C" int eg3d_set_pipelining(eg3d_ctx* c, int lanes, int units) {
+  if (!c || lanes < 0 || units < 0) {
+    g_err = "eg3d_set_pipelining: bad arguments";
+    return EG3D_ERR_ARG;
+  }
+  c->tune.lanes = std::min(16, lanes);
+  c->tune.units = std::min(4096, units);
+  return EG3D_OK;
+}
+
+static int lanes_for(const eg3d_ctx* c, int device_only) {
+  if (c->tune.lanes > 0) return c->tune.lanes;
+  // by measurement (round 6): cutting a call buys nothing on the device — every expand launch lasts at least as long as its
+  // slowest chain and the launches of a call's units run nearly first-in-first-out — but it hides most of the D2H copy
+  return device_only ? 1 : Tunables::kHostCallLanes;
+}
+
+// Units of a seed range. One lane: batches of 16 384 seeds (one expand launch each), as before round 6. Several lanes:
+// at least one unit per lane when the range is worth cutting (>= 128 seeds per unit), never more than 16 384 seeds per unit,
+// balanced by the sum of track lengths (the same weight the multi-GPU sharding uses).
+static std::vector<UnitRange> plan_seed_units(const eg3d_ctx* c, uint32_t b, uint32_t e, int lanes) {
+  const uint32_t SEED_BATCH = 16384, MIN_UNIT = 128;
+  const uint32_t n = e - b;
+  const std::vector<uint32_t>& trk = *c->h_trk;
+  auto cum = [&](uint32_t i) { return (double)trk[i] + 1e-3 * (double)i; };  // (+ a little per seed: seeds without tracks still count)
+  if (lanes <= 1 && !c->tune.units) {
+    std::vector<UnitRange> out;
+    for (uint32_t s0 = b; s0 < e; s0 += SEED_BATCH) {
+      const uint32_t s1 = std::min(e, s0 + SEED_BATCH);
+      out.push_back({s0, s1, cum(s1) - cum(s0)});
+    }
+    return out;
+  }
+  uint32_t n_units = c->tune.units ? (uint32_t)c->tune.units : std::min<uint32_t>((uint32_t)lanes, n / MIN_UNIT);
+  n_units = std::max(n_units, (n + SEED_BATCH - 1) / SEED_BATCH);
+  std::vector<UnitRange> out = cut_by_weight(b, e, std::max(1u, n_units), cum, c->tune.unit_ramp);
+  // (balancing by weight can leave a unit of many short tracks above the batch bound: cut such a unit again)
+  for (size_t i = 0; i < out.size();) {
+    if (out[i].e - out[i].b > SEED_BATCH) {
+      const uint32_t mid = out[i].b + (out[i].e - out[i].b) / 2, end = out[i].e;
+      out[i] = {out[i].b, mid, cum(mid) - cum(out[i].b)};
+      out.insert(out.begin() + (long)i + 1, {mid, end, cum(end) - cum(mid)});
+    } else {
+      i++;
+    }
+  }
+  return out;
+}
 
 extern "C" int eg3d_match_resident(eg3d_ctx* c, uint32_t b, uint32_t e, int device_only, eg3d_edgepoints* out,
                                    eg3d_stage_times* times) {
@@ -1444,20 +1894,29 @@ extern "C" int eg3d_match_resident(eg3d_ctx* c, uint32_t b, uint32_t e, int devi
   }
   HIP_TRY(hipSetDevice(c->device));
   memset(out, 0, sizeof(*out));
-  HostOut H;
+  CallSink S;
+  S.owner = c;
+  S.device_only = device_only;
   c->last_np = c->last_no = 0;
   c->last_chunks = 0;
-  const uint32_t SEED_BATCH = 16384;
+  const int lanes = lanes_for(c, device_only);
+  const std::vector<UnitRange> units = plan_seed_units(c, b, e, lanes);
+  const auto t0 = std::chrono::steady_clock::now();
   HIP_TRY(hipEventRecord(c->ea[7], c->stream));  // the context's own events: nothing to leak on an error path
-  for (uint32_t s = b; s < e; s += SEED_BATCH) {
-    int rc = run_batch(c, s, std::min(e, s + SEED_BATCH), device_only, H);
-    if (rc != EG3D_OK) return rc;
-  }
+  int rc = EG3D_OK;
+  if (!units.empty())
+    rc = run_pipelined(c, S, units, lanes, [&](eg3d_ctx* lane, uint32_t u, UnitTurn& T, HostOut& H) {
+      return run_batch(lane, units[u].b, units[u].e, T, H);
+    });
+  if (rc != EG3D_OK) return rc;
   HIP_TRY(hipEventRecord(c->eb[7], c->stream));
   HIP_TRY(hipEventSynchronize(c->eb[7]));
   float total = 0;
   HIP_TRY(hipEventElapsedTime(&total, c->ea[7], c->eb[7]));
-  return finish_match(H, device_only, total, out, times);
+  // (several lanes: the context's own stream saw one of them only — the call's wall time is the total)
+  if (units.size() > 1 && lanes > 1)
+    total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return finish_match(c, S, total, out, times);
 }
 
 extern "C" int eg3d_last_device_output(eg3d_ctx* c, eg3d_device_edgepoints* out) {
@@ -1518,27 +1977,44 @@ extern "C" int eg3d_match_polyline_sets(eg3d_ctx* c, const eg3d_polyline_sets* p
   sd.n_views = V;
   sd.row_off = c->b_sets_off.as<uint32_t>();
   sd.pl_ids = c->b_sets_ids.as<uint32_t>();
-  HostOut H;
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the sets are resident before any lane reads them
+  CallSink S;
+  S.owner = c;
+  S.device_only = device_only;
+  S.keyed_by_sample = true;
   c->last_np = c->last_no = 0;
   c->last_chunks = 0;
-  HIP_TRY(hipEventRecord(c->ea[7], c->stream));
-  // batches of whole sets, bounded by the number of polylines (every sample owns V lists)
+  const int lanes = lanes_for(c, device_only);
+  // units = runs of whole sets, bounded by the number of polylines (every sample owns V lists); with several lanes at
+  // least one unit per lane, balanced by the number of polylines
   const uint32_t max_items = V >= 64 ? 2048u : 16384u;
-  uint32_t sample_base = 0;
-  for (uint32_t s0 = set_b; s0 < set_e;) {
-    uint32_t s1 = s0 + 1;
-    while (s1 < set_e && ps->row_off[(size_t)(s1 + 1) * V] - ps->row_off[(size_t)s0 * V] <= max_items) s1++;
-    const uint64_t tasks_before = H.n_tasks;
-    int rc = run_sets_batch(c, sd, ps->row_off, n_rows, s0, s1, device_only, sample_base, H);  // key[0] = sample index of the call
-    if (rc != EG3D_OK) return rc;
-    sample_base += (uint32_t)(H.n_tasks - tasks_before);
-    s0 = s1;
+  std::vector<UnitRange> units;
+  {
+    auto cum = [&](uint32_t i) { return (double)ps->row_off[(size_t)i * V] + 1e-3 * (double)i; };
+    const uint32_t want = c->tune.units ? (uint32_t)c->tune.units : (uint32_t)lanes;
+    for (const UnitRange& r : cut_by_weight(set_b, set_e, want, cum))
+      for (uint32_t s0 = r.b; s0 < r.e;) {  // (a unit above the bound is cut into runs of whole sets within it)
+        uint32_t s1 = s0 + 1;
+        while (s1 < r.e && ps->row_off[(size_t)(s1 + 1) * V] - ps->row_off[(size_t)s0 * V] <= max_items) s1++;
+        units.push_back({s0, s1, cum(s1) - cum(s0)});
+        s0 = s1;
+      }
   }
+  const auto t0 = std::chrono::steady_clock::now();
+  HIP_TRY(hipEventRecord(c->ea[7], c->stream));
+  int rc = EG3D_OK;
+  if (!units.empty())
+    rc = run_pipelined(c, S, units, lanes, [&](eg3d_ctx* lane, uint32_t u, UnitTurn& T, HostOut& H) {
+      return run_sets_batch(lane, sd, ps->row_off, n_rows, units[u].b, units[u].e, T, H);
+    });
+  if (rc != EG3D_OK) return rc;
   HIP_TRY(hipEventRecord(c->eb[7], c->stream));
   HIP_TRY(hipEventSynchronize(c->eb[7]));
   float total = 0;
   HIP_TRY(hipEventElapsedTime(&total, c->ea[7], c->eb[7]));
-  return finish_match(H, device_only, total, out, times);
+  if (units.size() > 1 && lanes > 1)
+    total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return finish_match(c, S, total, out, times);
 }
 
 extern "C" void eg3d_free_edgepoints(eg3d_edgepoints* e) {

@@ -57,6 +57,7 @@ struct CoopLds {
   uint8_t res_ok[EG3D_COOP_REQ];
   uint8_t cams_mid_range;  // DevScene::cams_mid_range (set once per workgroup): enables the shared-reciprocal rows
   uint8_t long_refused;    // a request of more than EG3D_GN_PACK_MAX rows reached a build without the long-request path
+  uint32_t t_start;        // k3b_expand: low word of the constant-rate clock when the chain started (Counters::max_chain_ticks)
   // Per-group sums (G >= 2 => <= 32 groups x 7 doubles). They live in product columns 6..13: a pass's sums are written
   // after the last chunk's products have been consumed (behind its barrier), pass 2 only writes columns 0..5, and
   // every lane has read the sums before the next pass writes products again — never live together.

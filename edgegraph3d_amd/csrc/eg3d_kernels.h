@@ -29,6 +29,8 @@ struct Counters {
   uint32_t arena_used;
   uint32_t flags;  // EG3D_FLAG_* bits | CTR_ARENA_OVERFLOW
   unsigned long long bytes;  // algorithmic bytes of polyline vertices touched
+  uint32_t max_chain_ticks;  // k3b_expand: the longest time one chain held its wavefront (ticks of the constant-rate clock, wall_clock64)
+  uint32_t pad_;
 };
 
 void launch_seed_prep(hipStream_t st, SeedsDev sd, uint32_t seed_begin, uint32_t n_seeds, uint32_t sv_base,
@@ -91,13 +93,15 @@ struct SlotPools {
 #define EG3D_STAGE_VTX_HOST 512 /* = EG3D_STAGE_VTX: vertices of a polyline the side walks stage in LDS */
 int k3b_blocks_per_cu();  // resident k3b_expand workgroups per CU (occupancy query; 0 on failure)
 void launch_pool_init(hipStream_t st, SlotPools pools);
-// lane-per-chain engine of the expand stage (eg3d_k3c_engine.h); see eg3d_kernels.hip
+// lane-per-chain engine of the expand stage (eg3d_k3c_engine.h; builds with -DEG3D_WITH_K3C_ENGINE only); see eg3d_kernels.hip
+#ifdef EG3D_WITH_K3C_ENGINE
 int k3c_blocks_per_cu();
 void launch_k3c(hipStream_t st, uint32_t n_waves, uint32_t lanes_per_wave, DevScene s, StageAView a, const TaskDesc* tasks,
                 const ChainSeed* chains, uint32_t n_chains, const uint32_t* hyp_off, const HypResult* res, const HPoint* arena,
                 const int32_t* map_view, const uint32_t* map_entry, const uint32_t* map_n, ChainLayout L, unsigned char* slices,
                 StageBuf stage, ChainOut* outs, uint32_t* out_points, uint32_t* out_obs, Counters* ctr, const uint32_t* order,
                 uint32_t* queue, int long_gn);
+#endif
 void launch_k3b(hipStream_t st, DevScene s, StageAView a, const TaskDesc* tasks, const ChainSeed* chains,
                 uint32_t n_chains, const uint32_t* hyp_off, const HypResult* res, const HPoint* arena,
                 const int32_t* map_view, const uint32_t* map_entry, const uint32_t* map_n, ChainLayout L,

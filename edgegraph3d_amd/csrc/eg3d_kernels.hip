@@ -1295,6 +1295,7 @@ __global__ void __launch_bounds__(64, WAVES) k3b_expand_t(DevScene s, StageAView
   if (lane == 0) {
     lds.cams_mid_range = s.cams_mid_range ? 1 : 0;
     lds.long_refused = 0;
+    lds.t_start = (uint32_t)wall_clock64();
   }
   __syncthreads();
   // wave-uniform descriptors: kept in scalar registers for the chain's whole life (as vector registers they would be
@@ -1365,6 +1366,8 @@ __global__ void __launch_bounds__(64, WAVES) k3b_expand_t(DevScene s, StageAView
     if (co.flags) atomicOr(&ctr->flags, co.flags);
     if (SCENE == 0 && lds.long_refused) atomicOr(&ctr->flags, CTR_LONG_REFUSED);
     if (co.bytes) atomicAdd(&ctr->bytes, (unsigned long long)co.bytes);
+    // how long this chain held its wavefront (a launch cannot be shorter than its slowest chain: reported per call)
+    atomicMax(&ctr->max_chain_ticks, (uint32_t)wall_clock64() - lds.t_start);
   }
 }
 
@@ -1663,8 +1666,14 @@ void launch_k3b(hipStream_t st, DevScene s, StageAView a, const TaskDesc* tasks,
                        arena, map_view, map_entry, map_n, L, slices, pools, stage, outs, out_points, out_obs, ctr, order);
 }
 }  // namespace eg3d
+// The lane-per-chain engine is a second, slower form of the expand stage: compiled only into builds made with
+// -DEG3D_WITH_K3C_ENGINE (edgegraph3d_amd/build.py build_hip_engine -> variants/libeg3d_engine.so); the product libraries
+// do not carry it. Its state machine (eg3d_chain_sm.h) stays checked on the host by tests/hostsim.
+#ifdef EG3D_WITH_K3C_ENGINE
 #include "eg3d_k3c_engine.h"
+#endif
 namespace eg3d {
+#ifdef EG3D_WITH_K3C_ENGINE
 // The expand stage as a lane-per-chain engine (eg3d_k3c_engine.h): n_waves single-wavefront blocks whose first
 // lanes_per_wave lanes each own a working slice (slices: [n_waves * lanes_per_wave] x L.total bytes) and take chains from
 // the launch's queue (*queue zeroed by the caller) until it is empty. long_gn = 0: scenes whose solves all fit a packed
@@ -1690,7 +1699,8 @@ void launch_k3c(hipStream_t st, uint32_t n_waves, uint32_t lanes_per_wave, DevSc
     hipLaunchKernelGGL(k3c_engine_short, dim3(n_waves), dim3(64), 0, st, s, a, tasks, chains, n_chains, hyp_off, res, arena,
                        map_view, map_entry, map_n, L, slices, stage, outs, out_points, out_obs, ctr, order, queue, lanes_per_wave);
 }
-#if defined(EG3D_SECTION_TIMING) || defined(EG3D_K3C_TIMING)
+#endif  // EG3D_WITH_K3C_ENGINE
+#if defined(EG3D_WITH_K3C_ENGINE) && (defined(EG3D_SECTION_TIMING) || defined(EG3D_K3C_TIMING))
 int k3c_dbg_read(unsigned long long* out, int reset) {  // out[128]: g_k3c_dbg[32] then g_k3c_prof[96]
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k3c_dbg), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
   if (hipMemcpyFromSymbol(out + 32, HIP_SYMBOL(g_k3c_prof), sizeof(unsigned long long) * 96) != hipSuccess) return -1;

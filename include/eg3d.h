@@ -141,6 +141,8 @@ typedef struct eg3d_stage_times {
   float ms_expand;       /* K3b expand-all-views            */
   float ms_emit;         /* K4 compaction                   */
   uint64_t bytes_algorithmic; /* SURVEY 8(d) algorithmic bytes of this call */
+  float ms_slowest_chain; /* the longest time ONE chain held its wavefront in the expand stage: a lower bound of every
+                             expand launch, whatever else the GPU is doing (appended in round 6: the struct grew, rebuild callers) */
 } eg3d_stage_times;
 
 const char* eg3d_last_error(void);
@@ -187,9 +189,8 @@ int eg3d_match_refpoints(eg3d_ctx* ctx, const eg3d_seeds* seeds, uint32_t seed_b
  * hit. As in the reference's parallel build the PLGMatchesManager is not consulted
  * (is_matched() == false: it is empty when pipelines 1-2 run and never updated inside the loop).
  * Output as eg3d_match_refpoints, in the reference's order (set, start view, polyline id, sample);
- * key = (sample index of the call, start view, 0, index in chain); in the device view
- * (eg3d_last_device_output after device_only) the sample index counts from the start of the last
- * internal batch of sets. */
+ * key = (sample index of the call, start view, 0, index in chain), in the host arrays and in the
+ * device view (eg3d_last_device_output after device_only) alike. */
 typedef struct eg3d_polyline_sets {
   uint32_t n_sets;
   const uint32_t* row_off; /* [n_sets * n_views + 1] CSR over rows (set * n_views + view) */
@@ -206,14 +207,28 @@ int eg3d_upload_seeds(eg3d_ctx* ctx, const eg3d_seeds* seeds);
 int eg3d_match_resident(eg3d_ctx* ctx, uint32_t seed_begin, uint32_t seed_end, int device_only,
                         eg3d_edgepoints* out, eg3d_stage_times* times);
 
+/* Internal pipelining of ONE eg3d_match_* call. The reference's parallel entry point runs the seeds of a call on its OpenMP
+ * team (plg_matching_from_refpoints.cpp:83-104, `#pragma omp parallel for`; polyline_matching.cpp:153-208 for the sets);
+ * here a call's range is cut into `units` contiguous sub-batches (balanced by the sum of track lengths / polylines) that
+ * run concurrently on `lanes` internal contexts (own HIP stream, work buffers and host thread, created on first use,
+ * shared scene and seeds), so that the candidate / hypothesis stages and the D2H copy of one sub-batch overlap the expand
+ * stage of another. The output is the concatenation of the sub-batches in order: byte for byte what a single batch
+ * produces. lanes: 1 = no pipelining (the call runs on the context's own stream, one batch of <= 16 384 seeds at a time),
+ * 0 = the default, by the kind of call (EG3D_PIPELINE_LANES overrides): 3 for a call that copies its cloud to the host —
+ * most of the D2H copy disappears behind the later sub-batches — and 1 for a device-only call, which measured no gain
+ * (every expand launch lasts at least as long as its slowest chain: eg3d_stage_times.ms_slowest_chain); units: 0 = chosen
+ * from the range (one per lane when each gets >= 128 seeds; EG3D_PIPELINE_UNITS). A clone inherits its parent's setting. Use lanes = 1 on contexts that are themselves driven
+ * concurrently (one per host thread): stacking both forms of overlap only multiplies the work buffers. */
+int eg3d_set_pipelining(eg3d_ctx* ctx, int lanes, int units);
+
 /* Device-resident view of the edge-points produced by the most recent eg3d_match_* call
  * (pointers into the context's HBM buffers, valid until the next call on this context).
  * A call made with device_only != 0 keeps its WHOLE result in these buffers however many internal
- * seed batches (16 384 seeds, one expand launch each) it took (global 64-bit observation offsets;
+ * sub-batches (<= 16 384 seeds, one expand launch each) it took (global 64-bit observation offsets;
  * obs_off has n_points entries, no sentinel) and `complete` is 1 — this is what the multi-GPU exchange
  * of the edge-point cloud consumes without a host trip; the buffers grow to the size of the call's
  * cloud (12 + 8 + 16 B per point, 20 B per observation). A call that copies to the host
- * (device_only == 0) reuses the buffers per batch: `complete` is then 1 only if it ran as a single one. */
+ * (device_only == 0) reuses the buffers per sub-batch: `complete` is then 1 only if it ran as a single one. */
 typedef struct eg3d_device_edgepoints {
   uint64_t n_points, n_obs;
   const float* X;

@@ -339,39 +339,24 @@ class PLGEdgeManager : public EdgeManager {
     return res;
   }
 
-  // plg_matching_from_refpoints_parallel over all reference points. Seeds are independent
-  // (plg_matching_from_refpoints.cpp:83-104), so the points are cut into batches that are kept in
-  // flight on `contexts` clones of the context (eg3d_clone: shared scene and seeds, own stream), one
-  // host thread each; batch results are appended in seed order, which is the reference's order.
+  // plg_matching_from_refpoints_parallel over all reference points: ONE call of the C ABI. Seeds are independent
+  // (plg_matching_from_refpoints.cpp:83-104 runs them on its OpenMP team); since round 6 the library itself cuts a call
+  // into sub-batches that it keeps in flight on internal contexts and concatenates in seed order, which is the
+  // reference's order (eg3d_set_pipelining; until round 5 this shim did the same above the ABI with eg3d_clone).
+  // set_batching(seeds per sub-batch, sub-batches in flight): 0 / 0 = the library's defaults.
   void set_batching(uint32_t seeds_per_batch, int contexts) {
-    batch_ = seeds_per_batch ? seeds_per_batch : 2048;
-    n_ctx_ = contexts < 1 ? 1 : contexts;
+    batch_ = seeds_per_batch;
+    n_ctx_ = contexts < 0 ? 0 : contexts;
   }
   std::vector<new_3dpoint_plgp_matches> match_all(PLGMatchesManager* plgmm = nullptr) {
     std::vector<new_3dpoint_plgp_matches> res;
     if (!ctx_) return res;
     const uint32_t n = (uint32_t)sfmd_.numPoints_;
-    const uint32_t nb = (n + batch_ - 1) / batch_;
+    const uint32_t nb = 1;
     std::vector<eg3d_edgepoints> parts(nb);
     std::vector<int> rc(nb, EG3D_OK);
-    std::vector<eg3d_ctx*> ctxs(1, ctx_);
-    for (int k = 1; k < n_ctx_ && (uint32_t)k < nb; k++) {
-      eg3d_ctx* c = nullptr;
-      if (eg3d_clone(ctx_, &c) != EG3D_OK) break;
-      ctxs.push_back(c);
-    }
-    std::atomic<uint32_t> next(0);
-    auto work = [&](eg3d_ctx* c) {
-      for (uint32_t i = next.fetch_add(1); i < nb; i = next.fetch_add(1)) {
-        const uint32_t b = i * batch_, e = (b + batch_ < n) ? b + batch_ : n;
-        rc[i] = eg3d_match_resident(c, b, e, 0, &parts[i], nullptr);
-      }
-    };
-    std::vector<std::thread> th;
-    for (size_t k = 1; k < ctxs.size(); k++) th.emplace_back(work, ctxs[k]);
-    work(ctxs[0]);
-    for (auto& t : th) t.join();
-    for (size_t k = 1; k < ctxs.size(); k++) eg3d_destroy(ctxs[k]);
+    eg3d_set_pipelining(ctx_, n_ctx_, batch_ ? (int)((n + batch_ - 1) / batch_) : 0);
+    rc[0] = eg3d_match_resident(ctx_, 0, n, 0, &parts[0], nullptr);
     status_ = EG3D_OK;
     for (uint32_t i = 0; i < nb; i++)
       if (rc[i] != EG3D_OK) status_ = rc[i];
@@ -501,8 +486,8 @@ class PLGEdgeManager : public EdgeManager {
   eg3d_scene scene_;
   eg3d_ctx* ctx_ = nullptr;
   int status_ = EG3D_OK;
-  uint32_t batch_ = 2048;
-  int n_ctx_ = 3;
+  uint32_t batch_ = 0;
+  int n_ctx_ = 0;
 };
 
 // PLGPConsensusManager (plgp_consensus_manager.hpp:56-72): the strategy interface of the path, same two pure virtuals.

@@ -97,50 +97,7 @@ def test_scene_class_builds_of_the_expand_kernel_agree_with_the_general_one(have
         assert x["flags"] == y["flags"]
 
 
-@pytest.mark.parametrize("lanes", [0, 3])
-def test_lane_per_chain_engine_form_of_the_expand_stage_matches_oracle(have_gpu, monkeypatch, lanes):
-    """EG3D_K3B_ENGINE=1 runs the expand stage as the lane-per-chain engine (k3c_engine, eg3d_k3c_engine.h: one lane owns
-    a chain — the state machine of eg3d_chain_sm.h — and the wave serves all chains' Gauss-Newton solves and candidate
-    searches densely) instead of one wavefront per chain. Measured slower in round 5 and therefore not the default
-    (DESIGN_LOG.md), but it is a complete second implementation of rows a10-a16 and must stay bit-exact: C2-sized and
-    small scenes, a fuzz scene with mutated polylines, both with the default number of owning lanes per wave and with 3
-    (chains queue up behind each other on a lane)."""
-    monkeypatch.setenv("EG3D_K3B_ENGINE", "1")
-    if lanes:
-        monkeypatch.setenv("EG3D_K3C_LANES", str(lanes))
-    for cfg in (1, 2):
-        s = host.Synth(cfg)
-        ref = _oracle(s.scene).match(s.seeds, 0, s.n_seeds, nthreads=8)
-        ctx = api.Context(s.scene)
-        got = ctx.match_refpoints(s.seeds)
-        ctx.close()
-        rep = compare_edgepoints(ref, got)
-        assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], (cfg, rep["msgs"][:3])
-        assert got["flags"] == ref["flags"] and got["times"]["bytes_algorithmic"] == ref["stats"]["bytes_algorithmic"]
-        if cfg == 1:  # the pipelines 1-2 extractor feeds the same stage (a sample = a virtual seed over all views)
-            n_sets, row_off, ids = s.polyline_sets(3)
-            ctx = api.Context(s.scene)
-            gs = ctx.match_polyline_sets(n_sets, row_off, ids)
-            ctx.close()
-            rs = _oracle(s.scene).match_polyline_sets(n_sets, row_off, ids, nthreads=8)
-            rep = compare_edgepoints(rs, gs)
-            assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], ("sets", rep["msgs"][:3])
-    import ctypes as C
-    from fuzz_scenes import draw
-    for case in (3, 20):
-        _, sa, seeds = draw(case)
-        n = len(seeds.trk_off) - 1
-        from oracle import binding as ob
-        ref = ob.Oracle(C.byref(sa.c)).match(C.byref(seeds.c), 0, n, 8)
-        ctx = api.Context(C.byref(sa.c))
-        got = ctx.match_refpoints(C.byref(seeds.c), 0, n)
-        ctx.close()
-        rep = compare_edgepoints(ref, got)
-        assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], (case, rep["msgs"][:3])
-
-
-@pytest.mark.parametrize("engine", [0, 1])
-def test_solve_longer_than_a_packed_round_is_redone_by_the_general_build(have_gpu, monkeypatch, engine):
+def test_solve_longer_than_a_packed_round_is_redone_by_the_general_build(have_gpu, monkeypatch):
     """A few-views build of the expand stage (k3b_expand small scenes / the engine without the solver's long-request
     path) that meets a solve of more than 32 rows must not fail the call: it raises CTR_LONG_REFUSED, the host latches
     the general build for the context and redoes the chunk (eg3d_api.hip run_stage_b). Forced here with
@@ -152,7 +109,6 @@ def test_solve_longer_than_a_packed_round_is_redone_by_the_general_build(have_gp
     ref = _oracle(s.scene).match(s.seeds, 0, s.n_seeds, nthreads=8)
     assert int(np.diff(ref["obs_off"].astype(np.int64)).max()) > 33
     monkeypatch.setenv("EG3D_K3B_ASSUME_SHORT", "1")
-    monkeypatch.setenv("EG3D_K3B_ENGINE", str(engine))
     ctx = api.Context(s.scene)
     for _ in range(2):
         got = ctx.match_refpoints(s.seeds)
