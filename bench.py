@@ -118,9 +118,8 @@ class Leg:
     def __init__(self, env, wl, path="refpoints", seeds=0, batch_seeds=0, inflight=4):
         import numpy as np  # noqa: F401
         from edgegraph3d_amd import api, host
-        from edgegraph3d_amd.distributed import shard_ranges_balanced
+        from edgegraph3d_amd.distributed import StepPlan
         self.env, self.wl, self.api = env, wl, api
-        self._shard = shard_ranges_balanced
         world = env["world"]
         if wl == "c3real":
             self.synth = _RealEdges(seeds)
@@ -132,8 +131,8 @@ class Leg:
         self.n_total = self.synth.n_seeds
         self.trk_off = self.synth.seeds_np()[0]
         batch = batch_seeds or ((C4_BATCH if world == 1 else C4_RANK_SHARE * world) if wl == "c4" else self.n_total)
-        self.batch = min(batch, self.n_total)
-        self.n_batches = max(1, self.n_total // self.batch)
+        self.plan = StepPlan(self.trk_off, self.n_total, batch, world, env["rank"])   # the per-step sharding (also what tests/test_multirank_gloo.py runs)
+        self.batch, self.n_batches = self.plan.batch, self.plan.n_batches
         if path == "sets" and wl == "c3real":
             raise SystemExit("bench.py --path sets needs a synthetic workload (the sets come from its 3-D curves)")
         self.sets = self.synth.polyline_sets() if path == "sets" else None
@@ -180,16 +179,14 @@ class Leg:
     def step_range(self, i):
         """Seed range of step i on this rank: batch i (cyclic over the WHOLE batches) split into `world` contiguous,
         sum-of-track-length balanced ranges (rank order = seed order)."""
-        b0 = (i % self.n_batches) * self.batch
-        return self._shard(self.trk_off, b0, b0 + self.batch, self.env["world"])[self.env["rank"]]
+        return self.plan.step_range(i)
 
     def pass_range(self, i):
         """The same for ONE pass over all seeds: ceil(n / batch) steps, the last one partial."""
-        b0 = i * self.batch
-        return self._shard(self.trk_off, b0, min(b0 + self.batch, self.n_total), self.env["world"])[self.env["rank"]]
+        return self.plan.pass_range(i)
 
     def n_pass_steps(self):
-        return (self.n_total + self.batch - 1) // self.batch
+        return self.plan.n_pass_steps()
 
     def run_steps(self, first, n, pool, device_only=True, ranges=None):
         """Steps first..first+n-1, at most len(pool) in flight; results (and the collectives, which
@@ -458,20 +455,40 @@ def _c5_subline(device):
     s = host.Synth(5)   # 16-view rig: k really spans 3..10
     X, off, view, xy = s.points(n)
     ctx = api.Context(s.scene, device)
-    ms = []
-    for _ in range(4):
+    ms, wall = [], []
+    for _ in range(5):
+        t0 = time.perf_counter()
         Xo, inl, m = ctx.gn_filter(X, off, view, xy, 2.25)
+        wall.append(time.perf_counter() - t0)
         ms.append(m)
     k_ms = float(statistics.median(ms[1:]))
+    e2e_ms = 1e3 * float(statistics.median(wall[1:]))
     n_obs = int(off[-1])
     alg = n * (12 + 12 + 1 + 4) + n_obs * 12  # X in/out, inlier, obs_off; per observation view id + xy
     out = {"workload": "C5 (BASELINE configs[4]): %d points, %d observations (k~U[3,10], mean %.2f), 16-view rig, gn_max_mse 2.25"
                        % (n, n_obs, n_obs / n),
            "kernel": "k5_gn_filter", "kernel_ms": k_ms, "value": n / (k_ms * 1e-3), "unit": "points/s", "dtype": "f32",
            "inlier_frac": float(inl.mean()),
+           "end_to_end": {"ms": e2e_ms, "value": n / (e2e_ms * 1e-3), "unit": "points/s",
+                          "what": "one eg3d_gn_filter call from caller-owned host arrays to caller-owned host arrays: input checks, H2D of "
+                                  "the points and observations (%.0f MB, pageable), k5_gn_filter, D2H of X and the inlier flags (%.0f MB); "
+                                  "wrapper's numpy conversions included" % ((n * 16 + n_obs * 12) / 1e6, n * 13 / 1e6)},
            "roofline": {"bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg,
-                        "note": "FP32-VALU-bound (profiles/r02_c5_rocprof_summary.txt: VALU ~90 % busy, traffic = algorithmic)"}}
+                        "note": "FP32/FP64-VALU-bound, not HBM-bound: see roofline_valu (profiles/r06_c5_rocprof_summary.txt; "
+                                "iteration statistics profiles/r06_c5_iterations.json)"}}
+    try:
+        v = json.load(open(os.path.join(ROOT, "profiles", "r06_c5_valu.json")))
+        prof_ms = v.get("kernel_ms") or k_ms
+        peak = N_SIMD * 64.0 * (prof_ms * 1e-3 * CLOCK_HZ / 4.0)
+        out["roofline_valu"] = {"bound": "valu", "kernel": "k5_gn_filter", "unit": "lane-slots (quad-cycle units) per launch",
+                                "achieved": v.get("SQ_THREAD_CYCLES_VALU"), "peak": peak,
+                                "frac": (v.get("SQ_THREAD_CYCLES_VALU") or 0.0) / peak,
+                                "valu_busy_frac": (v.get("SQ_ACTIVE_INST_VALU") or 0.0) / (N_SIMD * (prof_ms * 1e-3 * CLOCK_HZ / 4.0)),
+                                "active_lane_frac": v.get("active_lane_frac"), "kernel_ms_in_profile": prof_ms,
+                                "source": "profiles/r06_c5_rocprof_summary.txt (committed PMC pass of tools/profile_c5.sh)"}
+    except Exception:
+        pass
     from oracle import binding as ob   # checker + cpu_baseline leg
     o = ob.Oracle(s.scene)
     m = 200000

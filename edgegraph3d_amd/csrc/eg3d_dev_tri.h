@@ -720,12 +720,22 @@ EG3D_HD bool triangulate_combinations(const float* cam_P, const Obs* a, int n, O
 // Pointer types are template parameters so that the filter kernel can run it on operands staged in
 // LDS (address_space(3) pointers => ds_read) as well as on HBM arrays; pstride = floats per camera
 // matrix in cam_P (16 in HBM, 12 in the kernel's LDS copy: the last row is never read).
+// The iteration is RESUMABLE: gauss_newton_f32_span runs passes [it0, it1) on a state (X, last_mse) and says whether the point
+// is finished — the filter kernel runs the first passes of all its points, packs the ones still running into dense
+// wavefronts and continues them; the arithmetic of a point does not depend on where its passes were cut.
+struct GnF32State {
+  float X[3];
+  float last_mse;
+};
+enum { GN_F32_RUNNING = 0, GN_F32_DONE = 1, GN_F32_FAILED = -1 };
 template <class PP, class VP, class XYP>
-EG3D_HD bool gauss_newton_f32_t(PP cam_P, int pstride, VP views, XYP xy, int n, const float X0[3], float gn_max_mse,
-                                bool legacy_abs, float Xout[3]) {
-  float X[3] = {X0[0], X0[1], X0[2]};
-  float last_mse = 0;
-  for (int it = 0; it < 30; it++) {
+EG3D_HD int gauss_newton_f32_span(PP cam_P, int pstride, VP views, XYP xy, int n, GnF32State& st, bool legacy_abs, int it0,
+                                  int it1, int* n_iter = nullptr /* diagnostics: residual passes run */) {
+  float X[3] = {st.X[0], st.X[1], st.X[2]};
+  float last_mse = st.last_mse;
+  int result = GN_F32_RUNNING;
+  for (int it = it0; it < it1; it++) {
+    if (n_iter) *n_iter = it + 1;
     float mse = 0;
     double H00 = 0, H01 = 0, H02 = 0, H11 = 0, H12 = 0, H22 = 0;
     for (int m = 0; m < n; m++) {
@@ -768,14 +778,17 @@ EG3D_HD bool gauss_newton_f32_t(PP cam_P, int pstride, VP views, XYP xy, int n, 
     } else {
       conv = (double)EG3D_FABSF(diff) < 0.0000000005;
     }
-    if (conv) break;
+    if (conv) {
+      result = GN_F32_DONE;
+      break;
+    }
     last_mse = mse / (float)(n * 2);
     float h00 = (float)H00, h01 = (float)H01, h02 = (float)H02, h11 = (float)H11, h12 = (float)H12, h22 = (float)H22;
     float h10 = h01, h20 = h02, h21 = h12;
     double dd = h00 * ((double)h11 * h22 - (double)h12 * h21) - h01 * ((double)h10 * h22 - (double)h12 * h20) +
                 h02 * ((double)h10 * h21 - (double)h11 * h20);
     float d = (float)dd;
-    if ((double)d < 0.0000000001) return false;
+    if ((double)d < 0.0000000001) return GN_F32_FAILED;
     float I00 = 0, I01 = 0, I02 = 0, I10 = 0, I11 = 0, I12 = 0, I20 = 0, I21 = 0, I22 = 0;
     if (dd != 0.) {
       double id = 1. / dd;
@@ -821,18 +834,33 @@ EG3D_HD bool gauss_newton_f32_t(PP cam_P, int pstride, VP views, XYP xy, int n, 
     X[1] += (float)d1;
     X[2] += (float)d2;
   }
-  if (last_mse < gn_max_mse) {
-    Xout[0] = X[0];
-    Xout[1] = X[1];
-    Xout[2] = X[2];
+  st.X[0] = X[0];
+  st.X[1] = X[1];
+  st.X[2] = X[2];
+  st.last_mse = last_mse;
+  return result;
+}
+template <class PP, class VP, class XYP>
+EG3D_HD bool gauss_newton_f32_t(PP cam_P, int pstride, VP views, XYP xy, int n, const float X0[3], float gn_max_mse,
+                                bool legacy_abs, float Xout[3], int* n_iter = nullptr) {
+  GnF32State st;
+  st.X[0] = X0[0];
+  st.X[1] = X0[1];
+  st.X[2] = X0[2];
+  st.last_mse = 0;
+  if (gauss_newton_f32_span(cam_P, pstride, views, xy, n, st, legacy_abs, 0, 30, n_iter) == GN_F32_FAILED) return false;
+  if (st.last_mse < gn_max_mse) {  // (converged or all 30 passes run: gauss_newton.cpp:130-133 accepts on the last mse either way)
+    Xout[0] = st.X[0];
+    Xout[1] = st.X[1];
+    Xout[2] = st.X[2];
     return true;
   }
   return false;
 }
 
 EG3D_HD bool gauss_newton_f32(const float* cam_P, const int32_t* views, const float* xy, int n, const float X0[3],
-                              float gn_max_mse, bool legacy_abs, float Xout[3]) {
-  return gauss_newton_f32_t(cam_P, 16, views, xy, n, X0, gn_max_mse, legacy_abs, Xout);
+                              float gn_max_mse, bool legacy_abs, float Xout[3], int* n_iter = nullptr) {
+  return gauss_newton_f32_t(cam_P, 16, views, xy, n, X0, gn_max_mse, legacy_abs, Xout, n_iter);
 }
 
 }  // namespace eg3d

@@ -1449,9 +1449,21 @@ __global__ void __launch_bounds__(64) k4_emit(const TaskDesc* tasks, const Chain
 // conversions). Measured alternatives (same bits, slower): persistent lanes with a flattened
 // per-row state machine and a global work counter — the end-of-pass step then diverges on almost every
 // trip (4.4 ms vs 3.2 ms per 1 M points).
+// Round 6 — lane occupancy (tools/c5_iterations.py: on the 1 M-point workload 62 % of the points run all 30 passes, the
+// others stop after 4-10, and k spans 3..10; with points taken in input order a wavefront keeps 0.71 of its lanes busy by
+// passes and only 0.41 by residual rows, because every pass runs as long as the longest list among its 64 lanes). The
+// block's points are therefore SORTED BY k in LDS (counting sort) before lanes take them: a wavefront's lists have (nearly)
+// the same length. 2.83 -> 2.17 ms per 1 M points, vector instructions 1.78e9 -> 1.03e9, measured active-lane fraction
+// 0.69 (profiles/r06_c5_rocprof_summary.txt). A point's arithmetic does not depend on the lane that runs it, so the output
+// is bit for bit what one lane per point in input order produces.
+// Measured and dropped: packing the points still running after 6 / 10 passes into the block's first wavefronts (state
+// through LDS, order kept; gauss_newton_f32_span makes the iteration resumable): 2.37 / 2.21 ms against 2.17 without —
+// a block of 4 wavefronts rarely empties a whole one (0.62 x 256 points = 2.5 wavefronts), and the freed lanes of a
+// partly empty wavefront cost nothing extra.
 #define K5_BLOCK 256
 #define K5_OBS_CAP 2816
 #define K5_VIEW_CAP 256
+#define K5_KBUCKETS 65 /* list lengths 0..63 and "64 or more" */
 __global__ void __launch_bounds__(K5_BLOCK) k5_gn_filter(const float* cam_P, int n_views, const float* X,
                                                         const uint32_t* obs_off, const int32_t* obs_view,
                                                         const float* obs_xy, uint64_t n, float gn_max_mse,
@@ -1461,31 +1473,67 @@ __global__ void __launch_bounds__(K5_BLOCK) k5_gn_filter(const float* cam_P, int
   __shared__ float sP[K5_VIEW_CAP * 12];
   __shared__ int32_t sV[K5_OBS_CAP];
   __shared__ float sXY[2 * K5_OBS_CAP];
+  __shared__ uint32_t s_cnt[K5_KBUCKETS], s_base[K5_KBUCKETS];
+  __shared__ uint16_t s_perm[K5_BLOCK];
   const uint64_t p0 = (uint64_t)blockIdx.x * K5_BLOCK;
   const uint64_t p1 = p0 + K5_BLOCK < n ? p0 + K5_BLOCK : n;
+  const uint32_t np = (uint32_t)(p1 - p0);
   const uint32_t o0 = obs_off[p0], o1 = obs_off[p1];
   const uint32_t m = o1 - o0;
+  const uint32_t t = threadIdx.x;
   const bool staged = n_views <= K5_VIEW_CAP && m <= K5_OBS_CAP;  // block-uniform
   if (staged) {
-    for (uint32_t t = threadIdx.x; t < (uint32_t)n_views * 12u; t += K5_BLOCK) sP[t] = cam_P[(t / 12u) * 16u + t % 12u];
-    for (uint32_t t = threadIdx.x; t < m; t += K5_BLOCK) sV[t] = obs_view[o0 + t];
-    for (uint32_t t = threadIdx.x; t < 2u * m; t += K5_BLOCK) sXY[t] = obs_xy[2 * (size_t)o0 + t];
+    for (uint32_t q = t; q < (uint32_t)n_views * 12u; q += K5_BLOCK) sP[q] = cam_P[(q / 12u) * 16u + q % 12u];
+    for (uint32_t q = t; q < m; q += K5_BLOCK) sV[q] = obs_view[o0 + q];
+    for (uint32_t q = t; q < 2u * m; q += K5_BLOCK) sXY[q] = obs_xy[2 * (size_t)o0 + q];
+  }
+  if (t < K5_KBUCKETS) s_cnt[t] = 0;
+  __syncthreads();
+  // ---- (1) counting sort of the block's points by list length (the order inside a bucket is whatever the LDS atomics
+  // give: it decides which lane runs a point, not what the point computes)
+  uint32_t kb = 0, rank = 0;
+  if (t < np) {
+    const uint32_t k = obs_off[p0 + t + 1] - obs_off[p0 + t];
+    kb = k < K5_KBUCKETS - 1 ? k : K5_KBUCKETS - 1;
+    rank = atomicAdd(&s_cnt[kb], 1u);
   }
   __syncthreads();
-  const uint64_t i = p0 + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t a = obs_off[i], b = obs_off[i + 1];
-  float x0[3] = {X[3 * i], X[3 * i + 1], X[3 * i + 2]}, o[3];
-  bool ok;
-  if (staged)
-    ok = gauss_newton_f32_t((lds_fp)&sP[0], 12, (lds_ip)&sV[0] + (a - o0), (lds_fp)&sXY[0] + 2 * (a - o0), (int)(b - a), x0,
-                            gn_max_mse, legacy_abs != 0, o);
-  else
-    ok = gauss_newton_f32(cam_P, obs_view + a, obs_xy + 2 * (size_t)a, (int)(b - a), x0, gn_max_mse, legacy_abs != 0, o);
-  inlier[i] = ok ? 1 : 0;
-  X_out[3 * i] = ok ? o[0] : x0[0];
-  X_out[3 * i + 1] = ok ? o[1] : x0[1];
-  X_out[3 * i + 2] = ok ? o[2] : x0[2];
+  if (t < K5_KBUCKETS) {
+    uint32_t base = 0;
+    for (uint32_t q = 0; q < t; q++) base += s_cnt[q];
+    s_base[t] = base;
+  }
+  __syncthreads();
+  if (t < np) s_perm[s_base[kb] + rank] = (uint16_t)t;
+  __syncthreads();
+  // ---- lane t takes the t-th point of the sorted order
+  auto run_span = [&](uint32_t j, GnF32State& st, int it0, int it1) -> int {
+    const uint64_t i = p0 + j;
+    const uint32_t a = obs_off[i], b = obs_off[i + 1];
+    if (staged)
+      return gauss_newton_f32_span((lds_fp)&sP[0], 12, (lds_ip)&sV[0] + (a - o0), (lds_fp)&sXY[0] + 2 * (a - o0), (int)(b - a),
+                                   st, legacy_abs != 0, it0, it1);
+    return gauss_newton_f32_span(cam_P, 16, obs_view + a, obs_xy + 2 * (size_t)a, (int)(b - a), st, legacy_abs != 0, it0, it1);
+  };
+  auto finish = [&](uint32_t j, const GnF32State& st, int r) {  // gauss_newton.cpp:130-133: accepted on the last mse, converged or not
+    const uint64_t i = p0 + j;
+    const bool ok = r != GN_F32_FAILED && st.last_mse < gn_max_mse;
+    const float x0 = X[3 * i], x1 = X[3 * i + 1], x2 = X[3 * i + 2];
+    inlier[i] = ok ? 1 : 0;
+    X_out[3 * i] = ok ? st.X[0] : x0;
+    X_out[3 * i + 1] = ok ? st.X[1] : x1;
+    X_out[3 * i + 2] = ok ? st.X[2] : x2;
+  };
+  if (t < np) {
+    const uint32_t j = s_perm[t];
+    const uint64_t i = p0 + j;
+    GnF32State st;
+    st.X[0] = X[3 * i];
+    st.X[1] = X[3 * i + 1];
+    st.X[2] = X[3 * i + 2];
+    st.last_mse = 0;
+    finish(j, st, run_span(j, st, 0, 30));
+  }
 }
 
 // Exclusive scans of 32-bit counts wrap silently when the total passes 2^32. The counts are

@@ -45,6 +45,35 @@ def shard_ranges_balanced(trk_off, begin, end, world):
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
+class StepPlan:
+    """Which seeds a rank takes in step i of the multi-GPU workload — the ONE statement of it: bench.py's Leg uses this
+    object, and tests/test_multirank_gloo.py runs the same object on CPU ranks. A step = one batch of `batch` seeds
+    (bench.py --gpus N: 4096 x N), split over the ranks into contiguous ranges balanced by the sum of track lengths;
+    rank order = seed order, so the concatenation of the ranks' clouds is the batch's cloud."""
+
+    def __init__(self, trk_off, n_total, batch, world, rank):
+        self.trk_off, self.n_total, self.world, self.rank = trk_off, int(n_total), int(world), int(rank)
+        self.batch = max(1, min(int(batch), self.n_total)) if self.n_total else 1
+        self.n_batches = max(1, self.n_total // self.batch)   # whole batches: the timed steps cycle through them
+
+    def batch_bounds(self, i, cyclic=True):
+        b0 = ((i % self.n_batches) if cyclic else i) * self.batch
+        return b0, min(b0 + self.batch, self.n_total)
+
+    def step_range(self, i):
+        """Timed step i: batch i (cyclic over the WHOLE batches), this rank's share."""
+        b0, b1 = self.batch_bounds(i, True)
+        return shard_ranges_balanced(self.trk_off, b0, b1, self.world)[self.rank]
+
+    def pass_range(self, i):
+        """Step i of ONE pass over all seeds: ceil(n / batch) steps, the last one partial."""
+        b0, b1 = self.batch_bounds(i, False)
+        return shard_ranges_balanced(self.trk_off, b0, b1, self.world)[self.rank]
+
+    def n_pass_steps(self):
+        return (self.n_total + self.batch - 1) // self.batch
+
+
 class RcclCloudGather:
     """The C-ABI exchange step (include/eg3d_rccl.h: eg3d_allgather_edgepoints in libeg3d_rccl.so) on an
     RCCL communicator created by the same library (eg3d_comm_init: hipSetDevice + ncclCommInitRank); the
@@ -78,6 +107,18 @@ class RcclCloudGather:
         rc = self.G.eg3d_comm_init(uid, world, rank, device_index, C.byref(self.comm))
         if rc != 0:
             raise RuntimeError("eg3d_comm_init (hipSetDevice + ncclCommInitRank) failed (%d) on rank %d" % (rc, rank))
+        # pre-flight, part 1: what RCCL itself reports about the communicator must be what the launcher started
+        self.G.eg3d_comm_query.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        n_, r_, d_ = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        rc = self.G.eg3d_comm_query(self.comm, C.byref(n_), C.byref(r_), C.byref(d_))
+        self.comm_info = {"ncclCommCount": n_.value, "ncclCommUserRank": r_.value, "ncclCommCuDevice": d_.value}
+        import sys as _sys
+        print("RCCL-PREFLIGHT rank %d/%d: ncclCommCount=%d ncclCommUserRank=%d device=%d (rc %d)"
+              % (rank, world, n_.value, r_.value, d_.value, rc), file=_sys.stderr, flush=True)
+        if rc != 0 or n_.value != world or r_.value != rank or d_.value != device_index:
+            self.close()
+            raise RuntimeError("RCCL pre-flight: the communicator reports %s, expected %d ranks / rank %d / device %d"
+                               % (self.comm_info, world, rank, device_index))
         self.G.eg3d_gather_create.restype = C.c_void_p
         self.G.eg3d_gather_create.argtypes = [C.c_int]
         self.G.eg3d_gather_destroy.argtypes = [C.c_void_p]

@@ -119,6 +119,19 @@ extern "C" int eg3d_comm_init(const void* id128, int n_ranks, int rank, int devi
   *comm = (void*)c;
   return 0;
 }
+// What RCCL itself says about the communicator: ranks it spans, this process's rank in it, the HIP device it is bound to.
+// bench.py prints these per rank before the first step ("did RCCL see N ranks, one per GPU"), and refuses to run otherwise.
+extern "C" int eg3d_comm_query(void* comm, int* n_ranks, int* rank, int* device) {
+  if (!comm) return EG3D_GATHER_ERR_ARG;
+  int n = -1, r = -1, d = -1;
+  if (ncclCommCount((ncclComm_t)comm, &n) != ncclSuccess) return EG3D_GATHER_ERR_NCCL;
+  if (ncclCommUserRank((ncclComm_t)comm, &r) != ncclSuccess) return EG3D_GATHER_ERR_NCCL;
+  if (ncclCommCuDevice((ncclComm_t)comm, &d) != ncclSuccess) return EG3D_GATHER_ERR_NCCL;
+  if (n_ranks) *n_ranks = n;
+  if (rank) *rank = r;
+  if (device) *device = d;
+  return 0;
+}
 extern "C" void eg3d_comm_destroy(void* comm) {
   if (comm) (void)ncclCommDestroy((ncclComm_t)comm);
 }

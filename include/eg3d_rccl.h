@@ -32,6 +32,9 @@ typedef struct eg3d_gather eg3d_gather; /* staging + result buffers of one rank 
 #define EG3D_COMM_ID_BYTES 128
 int eg3d_comm_unique_id(void* id128);
 int eg3d_comm_init(const void* id128, int n_ranks, int rank, int device, void** comm);
+/* ncclCommCount / ncclCommUserRank / ncclCommCuDevice of the communicator (any of the pointers may be NULL): the
+ * pre-flight line a launcher reads to see that RCCL spans the N ranks it started, one per GPU. */
+int eg3d_comm_query(void* comm, int* n_ranks, int* rank, int* device);
 void eg3d_comm_destroy(void* comm);
 
 eg3d_gather* eg3d_gather_create(int device);

@@ -470,6 +470,21 @@ extern "C" int hostsim_triangulate(const float* cam_P, const int32_t* views, con
   uint32_t flags = 0;
   return triangulate_array(cam_P, a.data(), n, X, flags) ? 1 : 0;
 }
+// diagnostics (tools/c5_iterations.py): residual passes each point of the config-5 filter runs (1..30; the device code
+// of k5_gn_filter compiled for the host, so the counts are the kernel's)
+extern "C" int hostsim_gn_filter_iters(const float* cam_P, const float* X, const uint32_t* obs_off, const int32_t* obs_view,
+                                       const float* obs_xy, uint64_t n, float gn_max_mse, int legacy_abs, uint8_t* iters) {
+#pragma omp parallel for schedule(static, 4096)
+  for (int64_t i = 0; i < (int64_t)n; i++) {
+    uint32_t a = obs_off[i], b = obs_off[i + 1];
+    float o[3];
+    int it = 0;
+    (void)gauss_newton_f32(cam_P, obs_view + a, obs_xy + 2 * a, (int)(b - a), X + 3 * i, gn_max_mse, legacy_abs != 0, o, &it);
+    iters[i] = (uint8_t)it;
+  }
+  return 0;
+}
+
 extern "C" int hostsim_gn_filter(const float* cam_P, const float* X, const uint32_t* obs_off, const int32_t* obs_view,
                                  const float* obs_xy, uint64_t n, float gn_max_mse, int legacy_abs, float* Xo,
                                  uint8_t* inl) {

@@ -87,7 +87,7 @@ def test_abi_library_exports_every_declared_symbol():
                           capture_output=True, text=True, check=True).stdout
     rhdr = open(os.path.join(root, "include", "eg3d_rccl.h")).read()
     rsyms = set(re.findall(r"\b(eg3d_(?:gather|allgather|comm|concat)_[a-z_0-9]+)\s*\(", rhdr))
-    assert len(rsyms) == 9  # gather create / destroy / set_mode / set_chunk_bytes, allgather, concat, comm unique_id / init / destroy
+    assert len(rsyms) == 10  # gather create / destroy / set_mode / set_chunk_bytes, allgather, concat, comm unique_id / init / query / destroy
     for name in rsyms:
         assert re.search(r"\b%s\b" % name, syms), name
 

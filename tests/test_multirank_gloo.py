@@ -122,3 +122,85 @@ def test_gloo_allgather_reproduces_single_process_output(world, empty_rank, fail
         assert np.array_equal(c["obs_pl"].astype(np.uint32), ref["obs_pl"])
         assert np.array_equal(c["obs_seg"].astype(np.uint32), ref["obs_seg"])
         assert np.array_equal(c["obs_xy"].view(np.uint32), ref["obs_xy"].view(np.uint32))
+
+
+def _worker_steps(rank, world, port, n_seeds, batch, q):
+    """bench.py --gpus N on CPU ranks: the SAME StepPlan object Leg uses decides which seeds this rank takes in each
+    step; the device code of stage B runs as its host simulation; HostCloudGather stands in for the RCCL exchange."""
+    import hashlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from oracle import binding as ob
+    import hostsim_binding as hs
+    from edgegraph3d_amd.distributed import StepPlan
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = host.default_config(4)        # BASELINE configs[3] shape: 200 views, ~20k segments per view
+    cfg.n_seeds = n_seeds
+    s = host.Synth(cfg)
+    o = ob.Oracle(s.scene)
+    plan = StepPlan(s.seeds_np()[0], s.n_seeds, batch, world, rank)
+    g = HostCloudGather(dist, world, rank)
+    digests = []
+    for i in range(plan.n_pass_steps()):
+        b, e = plan.pass_range(i)
+        assert (b, e) == plan.step_range(i) or i >= plan.n_batches   # whole batches: the timed steps take the same ranges
+        r = (hs.match(s.scene, s.seeds, b, e, o.candidates_raw(s.seeds, b, e), chain_cap=8192, pool_cap=1 << 18)
+             if e > b else _empty_cloud())
+        cloud, rc = g.allgather(r)
+        assert rc == 0
+        h = hashlib.sha256()
+        for k in ("X", "obs_off", "key", "obs_view", "obs_pl", "obs_seg", "obs_xy"):
+            dt = {"obs_off": np.uint64, "key": np.uint32, "obs_pl": np.uint32, "obs_seg": np.uint32}.get(k)
+            a = np.ascontiguousarray(cloud[k] if dt is None else np.asarray(cloud[k]).astype(dt))
+            h.update(a.view(np.uint8).tobytes())
+        digests.append((int(cloud["n_points"]), int(cloud["n_obs"]), (b, e), h.hexdigest()))
+    q.put((rank, digests))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_world_8_steps_of_a_c4_shaped_scene_with_the_bench_sharding():
+    """8 ranks, a 200-view scene, 96 seeds in steps of 40 (two whole batches + a partial one: 5 seeds per rank and step,
+    fewer in the last): every step's gathered cloud must be, on every rank, the oracle's cloud of that batch."""
+    import hashlib
+    from oracle import binding as ob
+    from edgegraph3d_amd.distributed import StepPlan
+    world, n_seeds, batch = 8, 96, 40
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_steps, args=(r, world, port, n_seeds, batch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=540) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cfg = host.default_config(4)
+    cfg.n_seeds = n_seeds
+    s = host.Synth(cfg)
+    o = ob.Oracle(s.scene)
+    plan0 = StepPlan(s.seeds_np()[0], s.n_seeds, batch, world, 0)
+    assert plan0.n_pass_steps() == 3 and plan0.n_batches == 2
+    covered = []
+    for i in range(plan0.n_pass_steps()):
+        b0, b1 = plan0.batch_bounds(i, cyclic=False)
+        ref = o.match(s.seeds, b0, b1, 8)
+        h = hashlib.sha256()
+        for k in ("X", "obs_off", "key", "obs_view", "obs_pl", "obs_seg", "obs_xy"):
+            dt = {"obs_off": np.uint64, "key": np.uint32, "obs_pl": np.uint32, "obs_seg": np.uint32}.get(k)
+            a = np.ascontiguousarray(ref[k] if dt is None else np.asarray(ref[k]).astype(dt))
+            h.update(a.view(np.uint8).tobytes())
+        ranges = [got[r][i][2] for r in range(world)]
+        assert ranges[0][0] == b0 and ranges[-1][1] == b1 and all(ranges[r][1] == ranges[r + 1][0] for r in range(world - 1))
+        covered.append((b0, b1))
+        for r in range(world):
+            assert got[r][i][:2] == (ref["n_points"], ref["n_obs"]), (r, i)
+            assert got[r][i][3] == h.hexdigest(), (r, i)
+    assert covered[0][0] == 0 and covered[-1][1] == n_seeds

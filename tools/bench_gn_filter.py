@@ -15,8 +15,9 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from edgegraph3d_amd import api, host  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
-runs = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+_pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+n = int(_pos[0]) if len(_pos) > 0 else 1000000
+runs = int(_pos[1]) if len(_pos) > 1 else 5
 s = host.Synth(5)   # 16-view rig: k really spans 3..10
 X, off, view, xy = s.points(n)
 ctx = api.Context(s.scene)
