@@ -147,8 +147,13 @@ class Leg:
             def __init__(self, parent=None):
                 super().__init__(daemon=True)
                 if parent is None:
+                    t0 = time.perf_counter()
                     self.ctx = api.Context(leg.synth.scene, env["local_rank"])
+                    t1 = time.perf_counter()
                     self.ctx.upload_seeds(leg.synth.seeds)   # inputs resident in HBM before the timed region
+                    leg.setup_ms = {"eg3d_create": (t1 - t0) * 1e3, "eg3d_upload_seeds": (time.perf_counter() - t1) * 1e3,
+                                    "what": "this leg's first context (the first eg3d_create of a process also pays the HIP "
+                                            "runtime's start-up, ~0.1 s: see time_to_solution_one_shot for a warm one)"}
                 else:
                     self.ctx = parent.ctx.clone()        # shares the resident scene and seeds (eg3d_clone)
                 self.todo, self.done = queue.Queue(), queue.Queue()
@@ -296,11 +301,15 @@ class Leg:
         # buffers and pinned staging — by the first call that needs them; the one-shot cost is under time_to_solution_one_shot)
         if self.sets is None:
             ctx.time_match_to_host(*self.step_range(0))
+            ctx.time_match_to_host(*self.step_range(0))   # (the second host call of a context is the one that creates its lanes)
             tt = [ctx.time_match_to_host(*self.step_range(i)) for i in range(ns)]
         else:
             ctx.time_match_sets_to_host(self.sets[0], self.sets[1], self.sets[2])
+            ctx.time_match_sets_to_host(self.sets[0], self.sets[1], self.sets[2])
             tt = [ctx.time_match_sets_to_host(self.sets[0], self.sets[1], self.sets[2]) for _ in range(ns)]
-        return single, (sum(t for t, _ in tt) / ns, sum(n for _, n in tt) / ns)
+        ts = sorted(t for t, _ in tt)
+        self.e2e_spread = {"min_ms": ts[0] * 1e3, "max_ms": ts[-1] * 1e3, "mean_ms": sum(ts) / ns * 1e3, "calls": ns}
+        return single, (statistics.median(ts), sum(n for _, n in tt) / ns)
 
     def setup_and_time_to_solution(self):
         """What a one-shot caller pays (setup reported separately): a FRESH context — eg3d_create = scene
@@ -679,17 +688,21 @@ def main():
             line["ms_per_step_one_at_a_time"] = single[0] * 1e3
             line["stage_ms_one_at_a_time"] = {n: round(single[2][k], 4) for n, k in STAGES}
             line["value_one_step_at_a_time"] = single[1] / single[0]
-            line["end_to_end"] = {"ms_per_step": e2e[0] * 1e3, "value": e2e[1] / e2e[0],
-                                  "what": "one step at a time incl. the D2H copy of the edge-point cloud into "
+            line["end_to_end"] = {"ms_per_step": e2e[0] * 1e3, "value": e2e[1] / e2e[0], "spread": getattr(leg, "e2e_spread", None),
+                                  "what": "MEDIAN of the calls (each allocates and first-touches fresh caller-owned arrays: the host side of the copy varies "
+                                          "with the OS; spread beside it); one step at a time incl. the D2H copy of the edge-point cloud into "
                                           "caller-owned host arrays (eg3d_match_resident / eg3d_match_polyline_sets, device_only=0), timed at the C ABI; "
-                                          "the call is cut into 3 sub-batches on the context's internal lanes (eg3d_set_pipelining default for host calls), "
-                                          "so most of the copy runs behind the later sub-batches' kernels"}
+                                          "a context that has served a host call before cuts the next ones into 3 sub-batches on its internal lanes "
+                                          "(eg3d_set_pipelining default), so most of the copy runs behind the later sub-batches' kernels; a context's FIRST "
+                                          "host call runs uncut (time_to_solution_one_shot.first_call_ms)"}
             line["ms_slowest_chain"] = max(r["times"].get("ms_slowest_chain", 0.0) for r, _ in results)
             line["ms_slowest_chain_what"] = ("the longest time ONE chain held its wavefront in k3b_expand (device clock): no expand launch — "
                                              "hence no lone call, however it is cut or overlapped — is shorter than its slowest chain plus the stages before it")
-        if setup is not None:
+        if setup is None:
+            line["setup_ms"] = leg.setup_ms
+        else:
             line["setup_ms"] = {"eg3d_create": setup["create_ms"], "eg3d_create_again": setup["create_again_ms"],
-                                "eg3d_upload_seeds": setup["upload_seeds_ms"]}
+                                "eg3d_upload_seeds": setup["upload_seeds_ms"], "first_context_of_the_process": leg.setup_ms}
             line["time_to_solution_one_shot"] = setup
         if world == 1 and not args.no_cpu_baseline:
             from oracle import binding as ob   # cpu_baseline leg: the checker timed as the CPU port
@@ -763,6 +776,7 @@ def main():
             tts4 = l4.time_to_solution()
             k3b4 = sum(r["times"][DOM_KEY] for r, _ in rs4) / len(rs4)
             line["scaling_base"] = {
+                "setup_ms": l4.setup_ms,
                 "workload": l4.describe(), "workload_key": "c4", "n_gpus": 1, "steps": 3, "steps_in_flight": l4.inflight,
                 "value": sum(t for _, t in rs4) / el4, "unit": "edge-points/s", "ms_per_step": el4 * 1e3 / 3,
                 "edge_points_per_step": sum(t for _, t in rs4) / 3, "k3b_expand_ms_in_flight": k3b4,

@@ -111,8 +111,14 @@ struct DevOwner {
       if (p) (void)hipFree(p);
   }
 };
-struct HostGrids {
-  std::vector<std::vector<uint32_t>> h_off[2], h_ids[2];
+struct HostGrids {  // per view: the arrays eg3d_host_build_grid returned (malloc'ed; owned here)
+  std::vector<uint32_t*> h_off[2], h_ids[2];
+  ~HostGrids() {
+    for (int w = 0; w < 2; w++) {
+      for (uint32_t* p : h_off[w]) free(p);
+      for (uint32_t* p : h_ids[w]) free(p);
+    }
+  }
 };
 
 // Test / tuning knobs, read from the environment ONCE when a context is created (eg3d_create; clones
@@ -148,6 +154,8 @@ struct HostGrids {
 //   EG3D_TEST_FAIL_UNIT=k  tests: the k-th unit (1-based) of every pipelined call fails when its turn to place comes
 struct Tunables {
   int lanes = 0, units = 0, test_fail_unit = 0;
+  int copy_threads = 0;  // EG3D_COPY_THREADS_PER_LANE: host threads that copy one piece of a cloud from the ring to the caller's
+                         // arrays (0 = EG3D_COPY_THREADS shared by the lanes of the call: 16 on one lane, 5 each on three)
   double unit_ramp = 0.6;
   int lane_priorities = 1;
   static constexpr int kHostCallLanes = 3;  // lanes = 0: a host call's default
@@ -158,6 +166,8 @@ struct Tunables {
   bool trace_arena = false;
   bool k3b_full = false;  // EG3D_K3B_FULL=1: always the full expand kernel (diagnostic)
   uint32_t arena_cap0 = 0, hyp_cap = 0;
+  uint32_t chain_cap0 = 0, pool_cap0 = 0;  // EG3D_CHAIN_CAP0 / EG3D_POOL_CAP0 (tests): initial points / observation slots per chain,
+                                           // small enough to force the relaunch-what-overflowed path several times
   size_t max_scratch = 0;  // 0 = no limit
   uint32_t slots_per_xcd = 0;  // 0 = sized from the occupancy query
   bool use_lpt = true;
@@ -171,6 +181,8 @@ struct Tunables {
     if (const char* e = getenv("EG3D_K3B_ASSUME_SHORT")) t.assume_short = e[0] == '1';
     if (const char* e = getenv("EG3D_HYP_CAP")) t.hyp_cap = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("EG3D_ARENA_CAP0")) t.arena_cap0 = (uint32_t)std::max(16, atoi(e));
+    if (const char* e = getenv("EG3D_CHAIN_CAP0")) t.chain_cap0 = (uint32_t)std::max(8, atoi(e));
+    if (const char* e = getenv("EG3D_POOL_CAP0")) t.pool_cap0 = (uint32_t)std::max(64, atoi(e));
     if (const char* e = getenv("EG3D_MAX_SCRATCH_MB")) t.max_scratch = (size_t)std::max(1, atoi(e)) << 20;
     if (const char* e = getenv("EG3D_NO_LPT")) t.use_lpt = !(e[0] == '1');
     if (const char* e = getenv("EG3D_TRACE_ARENA")) t.trace_arena = e[0] == '1';
@@ -178,6 +190,7 @@ struct Tunables {
     if (const char* e = getenv("EG3D_SLOTS_PER_XCD")) t.slots_per_xcd = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("EG3D_PIPELINE_LANES")) t.lanes = std::min(16, std::max(0, atoi(e)));
     if (const char* e = getenv("EG3D_TEST_FAIL_UNIT")) t.test_fail_unit = atoi(e);
+    if (const char* e = getenv("EG3D_COPY_THREADS_PER_LANE")) t.copy_threads = std::min(32, std::max(1, atoi(e)));
     if (const char* e = getenv("EG3D_LANE_PRIORITIES")) t.lane_priorities = atoi(e);
     if (const char* e = getenv("EG3D_UNIT_RAMP")) t.unit_ramp = std::min(16.0, std::max(1.0 / 16.0, atof(e)));
     if (const char* e = getenv("EG3D_PIPELINE_UNITS")) t.units = std::min(4096, std::max(0, atoi(e)));
@@ -206,7 +219,7 @@ struct eg3d_ctx {
   DevBuf b_sv_seed, b_map_view, b_map_entry, b_map_n, b_raw_cnt, b_raw_off, b_cand_pl, b_start_hits, b_cand_cnt,
       b_start_cnt, b_task_off, b_task_seed, b_task_entry, b_task_hit, b_task_k, b_task_list_off, b_list_cnt, b_list_ptr,
       b_hits, b_tasks, b_nhyp, b_hyp_off, b_res, b_arena, b_ctr, b_cs_task, b_valid, b_chain_off, b_chains,
-      b_cscratch, b_couts, b_cpts, b_cobs, b_cpoff, b_cooff, b_scan_tmp, b_scanchk, b_cost, b_cidx, b_cost2, b_order;
+      b_cscratch, b_couts, b_cpts, b_cobs, b_cpoff, b_cooff, b_scan_tmp, b_scanchk, b_cost, b_cidx, b_cost2, b_order, b_redo[2];
   DevBuf o_X, o_off, o_view, o_pl, o_seg, o_xy, o_key;
   DevBuf f_X, f_off, f_view, f_xy, f_Xo, f_inl;
   DevBuf b_sets_off, b_sets_ids;  // polyline sets of the current eg3d_match_polyline_sets call
@@ -220,13 +233,13 @@ struct eg3d_ctx {
   uint32_t max_pl_vtx = 0;  // vertices of the scene's longest valid polyline
   uint64_t stage_cap_pts = 0, stage_cap_obs = 0;
   hipEvent_t ea[8], eb[8];  // begin/end events per stage: 1 K1, 2 K2, 3 K3a, 4 K3s, 5 K3b, 6 K4, 0 misc, 7 whole call
-  hipEvent_t ecopy[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // D2H of the cloud: one per output array
+  hipEvent_t ecopy[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // D2H of the cloud: one per ring buffer (EG3D_D2H_RING <= 7)
   uint32_t chain_cap = 384, pool_cap = 0, hyp_cap = 160;
   uint32_t n_simd = 0;  // SIMDs of the device (4 per CU): sizes the K3a engine's launch
   int wall_clock_khz = 0;  // rate of wall_clock64() on the device (hipDeviceAttributeWallClockRate)
   double arena_per_hyp = 16.0;  // hypothesis arena: points per hypothesis to reserve (learned from overflows)
-  void* pinned = nullptr;  // pinned host staging area of the D2H copies of a cloud (grow-only)
-  size_t pinned_cap = 0;
+  void* pinned = nullptr;  // the ring of pinned host buffers the D2H copies of a cloud go through (ensure_d2h_ring)
+  size_t pinned_cap = 0, ring_chunk = 0;
   // mailbox for the small read-backs of a step (scan totals, counters): pinned host memory mapped into the
   // GPU's address space, written by k_publish, polled by the calling thread (no driver round trip)
   uint32_t* mbox = nullptr;
@@ -241,7 +254,33 @@ struct eg3d_ctx {
   // (own stream / work buffers, shared scene and seeds). A lane is never handed to the caller.
   std::vector<eg3d_ctx*> lanes;
   bool is_lane = false;
+  uint32_t host_calls = 0;  // eg3d_match_* calls with device_only == 0 this context has completed (lanes_for)
 };
+
+// D2H ring of a context: EG3D_D2H_RING pinned buffers of `ring_chunk` bytes (run_stage_b) — 16 MB each for a cloud worth it,
+// 2 MB each for small ones (pinning memory costs ~0.2 ms per MB: the big ring is a fifth of a small scene's whole call).
+// Allocated by the thread that drives the context, normally right after the expand launch, whose run time hides the pinning
+// (the cloud's size is then an estimate from the number of chains; a ring that turns out too small for a big cloud is
+// replaced once, at copy time).
+#ifndef EG3D_D2H_CHUNK
+#define EG3D_D2H_CHUNK ((size_t)16 << 20)
+#endif
+#define EG3D_D2H_CHUNK_SMALL ((size_t)2 << 20)
+#define EG3D_D2H_BIG_CLOUD ((size_t)96 << 20) /* bytes of a unit's cloud from which the 16 MB buffers pay */
+#ifndef EG3D_D2H_RING
+#define EG3D_D2H_RING 4
+#endif
+static int ensure_d2h_ring(eg3d_ctx* c, size_t cloud_bytes) {
+  const size_t want = cloud_bytes >= EG3D_D2H_BIG_CLOUD ? EG3D_D2H_CHUNK : EG3D_D2H_CHUNK_SMALL;
+  if (c->pinned && c->ring_chunk >= want) return EG3D_OK;
+  if (c->pinned) (void)hipHostFree(c->pinned);
+  c->pinned = nullptr;
+  c->ring_chunk = c->pinned_cap = 0;
+  HIP_TRY(hipHostMalloc(&c->pinned, want * EG3D_D2H_RING, hipHostMallocDefault));
+  c->ring_chunk = want;
+  c->pinned_cap = want * EG3D_D2H_RING;
+  return EG3D_OK;
+}
 
 template <typename T>
 static int upload(DevBuf& b, const T* src, size_t n, hipStream_t st) {
@@ -549,38 +588,55 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
     }
     bool ok = true;
     for (auto& g : jobs) ok = ok && g.rc == 0;
+    // the per-view arrays become the context's host copies (eg3d_get_grid) as they are; the device CSR over (view, cell)
+    // is assembled from them on the same threads
+    for (int which = 0; which < 2; which++) {
+      c->hg->h_off[which].assign((size_t)V, nullptr);
+      c->hg->h_ids[which].assign((size_t)V, nullptr);
+      for (int v = 0; v < V; v++) {
+        GridJob& g = jobs[(size_t)(which == 0 ? V + v : v)];
+        c->hg->h_off[which][(size_t)v] = g.o;
+        c->hg->h_ids[which][(size_t)v] = g.i;
+      }
+    }
     for (int which = 0; which < 2 && ok; which++) {
-      std::vector<uint32_t> off(1, 0), ids;
-      c->hg->h_off[which].resize(V);
-      c->hg->h_ids[which].resize(V);
-      size_t n_ids = 0, n_off = 1;
+      std::vector<size_t> id_base((size_t)V + 1, 0), off_base((size_t)V + 1, 0);
       for (int v = 0; v < V; v++) {
         const GridJob& g = jobs[(size_t)(which == 0 ? V + v : v)];
-        n_ids += g.o[(size_t)g.w * g.h];
-        n_off += (size_t)g.w * g.h;
+        c->gw[which] = g.w;
+        c->gh[which] = g.h;
+        c->grid_dropped += g.dropped;
+        id_base[(size_t)v + 1] = id_base[(size_t)v] + g.o[(size_t)g.w * g.h];
+        off_base[(size_t)v + 1] = off_base[(size_t)v] + (size_t)g.w * g.h;
       }
-      if (n_ids > 0xffffffffull) {
+      if (id_base[(size_t)V] > 0xffffffffull) {
         g_err = "eg3d_create: the grids of this scene hold more than 2^32-1 (cell, polyline) entries";
-        for (auto& g : jobs) {
-          free(g.o);
-          free(g.i);
-        }
         eg3d_destroy(c);
         return EG3D_ERR_CAPACITY;
       }
-      off.reserve(n_off);
-      ids.reserve(n_ids);
-      for (int v = 0; v < V; v++) {
-        const GridJob& g = jobs[(size_t)(which == 0 ? V + v : v)];
-        const uint32_t w = g.w, h = g.h, *o = g.o, *i = g.i;
-        c->gw[which] = w;
-        c->gh[which] = h;
-        c->grid_dropped += g.dropped;
-        const uint32_t base = (uint32_t)ids.size();
-        for (uint32_t cc = 0; cc < w * h; cc++) off.push_back(base + o[cc + 1]);
-        ids.insert(ids.end(), i, i + o[w * h]);
-        c->hg->h_off[which][v].assign(o, o + w * h + 1);
-        c->hg->h_ids[which][v].assign(i, i + o[w * h]);
+      std::vector<uint32_t> off(off_base[(size_t)V] + 1), ids(std::max<size_t>(id_base[(size_t)V], 1));
+      off[0] = 0;
+      std::atomic<int> nextv{0};
+      auto fill = [&]() {
+        for (int v; (v = nextv.fetch_add(1)) < V;) {
+          const GridJob& g = jobs[(size_t)(which == 0 ? V + v : v)];
+          const size_t nc = (size_t)g.w * g.h;
+          const uint32_t base = (uint32_t)id_base[(size_t)v];
+          uint32_t* dst = off.data() + off_base[(size_t)v] + 1;
+          for (size_t cc = 0; cc < nc; cc++) dst[cc] = base + g.o[cc + 1];
+          if (g.o[nc]) memcpy(ids.data() + id_base[(size_t)v], g.i, sizeof(uint32_t) * g.o[nc]);
+        }
+      };
+      {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const int nthr = (int)std::min<unsigned>(std::min<unsigned>(hw, EG3D_COPY_THREADS), (unsigned)V);
+        std::vector<std::thread> th;
+        try {
+          for (int t = 1; t < nthr; t++) th.emplace_back(fill);
+        } catch (...) {
+        }
+        fill();
+        for (auto& t : th) t.join();
       }
       if (which == 0) {
         if ((rc = upload(c->b_g30o, off.data(), off.size(), c->stream)) == EG3D_OK) rc = upload(c->b_g30i, ids.data(), ids.size(), c->stream);
@@ -592,10 +648,6 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
         rc = EG3D_ERR_HIP;
       }
       if (rc != EG3D_OK) ok = false;
-    }
-    for (auto& g : jobs) {
-      free(g.o);
-      free(g.i);
     }
     if (!ok) {
       if (rc == EG3D_OK) {
@@ -648,8 +700,12 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
     if (sc->pl_valid[p]) c->max_pl_vtx = std::max(c->max_pl_vtx, sc->pl_vtx_off[p + 1] - sc->pl_vtx_off[p]);
   // observation slots per chain (blocks double when they fill, so budget ~3x the live count);
   // grown automatically when a chain overflows
-  c->pool_cap = std::min<uint32_t>(32768, 768u * (uint32_t)std::min(V, 32));
+  // (many-view scenes: points carry ~V/3 observations and blocks are relocated as they double — C4 settles at 196 608; starting
+  // at 24 576 as until round 6 cost the first call three extra rounds of the expand stage)
+  c->pool_cap = std::min<uint32_t>(131072, 768u * (uint32_t)std::min(V, 128));
   if (c->pool_cap < 6144) c->pool_cap = 6144;
+  if (c->tune.pool_cap0) c->pool_cap = c->tune.pool_cap0;
+  if (c->tune.chain_cap0) c->chain_cap = c->tune.chain_cap0;
   hipDeviceProp_t prop;
   HIP_TRY(hipGetDeviceProperties(&prop, device));
   c->n_simd = (uint32_t)prop.multiProcessorCount * 4;
@@ -770,7 +826,7 @@ extern "C" void eg3d_destroy(eg3d_ctx* c) {
                    &c->b_task_k, &c->b_task_list_off, &c->b_list_cnt, &c->b_list_ptr, &c->b_hits, &c->b_tasks,
                    &c->b_nhyp, &c->b_hyp_off, &c->b_res, &c->b_arena, &c->b_ctr, &c->b_cs_task,
                    &c->b_valid, &c->b_chain_off, &c->b_chains, &c->b_cscratch, &c->b_couts, &c->b_cpts, &c->b_cobs,
-                   &c->b_cpoff, &c->b_cooff, &c->b_scan_tmp, &c->b_scanchk, &c->b_cost, &c->b_cidx, &c->b_cost2, &c->b_order, &c->o_X, &c->o_off, &c->o_view, &c->o_pl, &c->o_seg,
+                   &c->b_cpoff, &c->b_cooff, &c->b_scan_tmp, &c->b_scanchk, &c->b_cost, &c->b_cidx, &c->b_cost2, &c->b_order, &c->b_redo[0], &c->b_redo[1], &c->o_X, &c->o_off, &c->o_view, &c->o_pl, &c->o_seg,
                    &c->o_xy, &c->o_key, &c->f_X, &c->f_off, &c->f_view, &c->f_xy, &c->f_Xo, &c->f_inl, &c->b_sets_off, &c->b_sets_ids, &c->b_fscratch, &c->b_queue, &c->b_items,
                    &c->b_pools, &c->b_stage_pts, &c->b_stage_obs, &c->b_stage_used};
   for (DevBuf* b : all) b->release();
@@ -794,8 +850,8 @@ extern "C" int eg3d_get_grid(eg3d_ctx* c, int view, int which, uint32_t* ncols, 
   }
   *ncols = c->gw[which];
   *nrows = c->gh[which];
-  *cell_off = c->hg->h_off[which][view].data();
-  *ids = c->hg->h_ids[which][view].data();
+  *cell_off = c->hg->h_off[which][(size_t)view];
+  *ids = c->hg->h_ids[which][(size_t)view];
   return EG3D_OK;
 }
 
@@ -1022,6 +1078,7 @@ struct CallSink {
   std::shared_mutex dst_mu;
   uint64_t n_points = 0, n_obs = 0;          // placed so far
   double weight_total = 0, weight_placed = 0;  // share of the call placed so far (sizes the destination's first allocation)
+  int lanes_active = 1;                      // lanes working on the call (shares the host copy threads among them)
   bool keyed_by_sample = false;              // polyline-set calls: key[0] = sample index of the CALL ...
   uint32_t key0_next = 0;                    // ... = samples of the units placed so far + the sample's index in its unit
   HostOut tot;
@@ -1204,16 +1261,24 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, UnitTurn& T, HostOut& H) {
   const size_t max_scratch = c->tune.max_scratch;
   float ms_expand = 0, ms_emit = 0;
   uint32_t chunk = 0;
+  // A launch in which some chains outgrew their working slices is followed by a RELAUNCH OF THOSE CHAINS ONLY with larger
+  // slices (redo_n of the chunk's redo_nc chains, listed in b_redo[redo_buf]); the others keep their packed results.
+  // (Until round 6 the whole chunk was launched again: the first call on a many-view scene ran its expand stage four times —
+  // C4: 6.8 s against 1.75 s warm.)
+  uint32_t redo_n = 0, redo_nc = 0;
+  int redo_buf = 0;
   for (uint32_t c0 = 0; c0 < B.n_chains; c0 += chunk) {
     // capacities can grow between chunks (overflow -> retry below), so the layout is per chunk
     const ChainLayout L = chain_layout(c->chain_cap, c->pool_cap, (uint32_t)c->V);
-    chunk = (uint32_t)std::max<size_t>(1, max_scratch ? std::min<size_t>(B.n_chains - c0, max_scratch / L.total)
-                                                      : (size_t)(B.n_chains - c0));
+    chunk = redo_n ? redo_nc
+                   : (uint32_t)std::max<size_t>(1, max_scratch ? std::min<size_t>(B.n_chains - c0, max_scratch / L.total)
+                                                               : (size_t)(B.n_chains - c0));
     const uint32_t nc = std::min(chunk, B.n_chains - c0);
     BUF_TRY(ensure_mailbox(c));
     uint32_t* const saved_bytes = c->b_scanchk.as<uint32_t>() + 4;  // device copy of the byte counter before this chunk
-    HIP_TRY(hipMemcpyAsync(saved_bytes, &c->b_ctr.as<Counters>()->bytes, sizeof(unsigned long long),
-                           hipMemcpyDeviceToDevice, st));
+    if (!redo_n)
+      HIP_TRY(hipMemcpyAsync(saved_bytes, &c->b_ctr.as<Counters>()->bytes, sizeof(unsigned long long),
+                             hipMemcpyDeviceToDevice, st));
     // the expand stage's two forms: one wavefront per chain on XCD-affine slots (k3b_expand), or the lane-per-chain
     // engine (k3c_engine): n_waves single-wave blocks whose first eng_lanes lanes own a working slice each
 #ifdef EG3D_WITH_K3C_ENGINE
@@ -1251,8 +1316,8 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, UnitTurn& T, HostOut& H) {
       launch_pool_init(st, pools);
     }
     // staging area: what the previous launches needed, or a first guess (an overflowing launch is repeated once
-    // with the exact need, which the output scans report)
-    {
+    // with the exact need, which the output scans report). A relaunch of some chains appends to the area as it is.
+    if (!redo_n) {
       const uint64_t guess_pts = 96ull * nc;
       const uint64_t per_pt = (uint64_t)std::min(100, std::max(8, c->V / 2));
       const uint64_t want_pts = std::max<uint64_t>(c->stage_cap_pts, guess_pts);
@@ -1284,6 +1349,9 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, UnitTurn& T, HostOut& H) {
     BUF_TRY(c->b_cost2.ensure(sizeof(uint32_t) * (nc + 1)));
     BUF_TRY(c->b_order.ensure(sizeof(uint32_t) * (nc + 1)));
     const bool use_lpt = c->tune.use_lpt;
+    const uint32_t n_launch = redo_n ? redo_n : nc;
+    const uint32_t* const launch_order = redo_n ? c->b_redo[redo_buf].as<uint32_t>() : c->b_order.as<uint32_t>();
+    if (!redo_n) {
     launch_chain_cost(st, B.a, c->b_tasks.as<TaskDesc>(), c->b_chains.as<ChainSeed>() + c0, nc, c->b_cost.as<uint32_t>(),
                       c->b_cidx.as<uint32_t>());
     {
@@ -1298,6 +1366,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, UnitTurn& T, HostOut& H) {
     }
     if (!use_lpt)  // identity order (diagnostic): chain j runs in block j
       HIP_TRY(hipMemcpyAsync(c->b_order.p, c->b_cidx.p, sizeof(uint32_t) * nc, hipMemcpyDeviceToDevice, st));
+    }
     HIP_TRY(hipEventRecord(c->ea[5], st));
     // scene class of the launch: solves of more than 32 rows (EG3D_GN_PACK_MAX) need the builds with the solver's
     // long-request path. Few views normally means none (one observation per view), and the smaller builds run; a point
@@ -1314,13 +1383,15 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, UnitTurn& T, HostOut& H) {
                  (c->tune.k3b_full || c->k3b_long_latched || (c->V > EG3D_SMALL_SCENE_VIEWS_HOST && !c->tune.assume_short)) ? 1 : 0);
     else
 #endif
-    launch_k3b(st, c->ds, B.a, c->b_tasks.as<TaskDesc>(), c->b_chains.as<ChainSeed>() + c0, nc,
+    launch_k3b(st, c->ds, B.a, c->b_tasks.as<TaskDesc>(), c->b_chains.as<ChainSeed>() + c0, n_launch,
                c->b_hyp_off.as<uint32_t>(), c->b_res.as<HypResult>(), c->b_arena.as<HPoint>(),
                c->b_map_view.as<int32_t>(), c->b_map_entry.as<uint32_t>(), c->b_map_n.as<uint32_t>(), L,
                c->b_cscratch.as<unsigned char>(), pools, stage, c->b_couts.as<ChainOut>(), c->b_cpts.as<uint32_t>(),
-               c->b_cobs.as<uint32_t>(), c->b_ctr.as<Counters>(), c->b_order.as<uint32_t>(),
+               c->b_cobs.as<uint32_t>(), c->b_ctr.as<Counters>(), launch_order,
                general ? 1 : (c->V > EG3D_SMALL_SCENE_VIEWS_HOST && !c->tune.assume_short) ? 2 : 0);
     HIP_TRY(hipEventRecord(c->eb[5], st));
+    if (!device_only)  // (first host call of this lane: pinned while the expand kernel runs; ~50 points of ~12 observations per chain)
+      BUF_TRY(ensure_d2h_ring(c, (size_t)nc * 50u * (36u + 20u * (size_t)std::min(c->V, 12))));
     // the two output scans are queued right behind K3b; its counters (capacity overflow?) and both totals
     // come back in ONE read-back
     BUF_TRY(scan_queue_u32(c, c->b_cpts.as<uint32_t>(), c->b_cpoff.as<uint32_t>(), nc + 1, 0));
@@ -1350,10 +1421,12 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, UnitTurn& T, HostOut& H) {
         return EG3D_ERR_HIP;
       }
       c->k3b_long_latched = true;
+      if (c->tune.trace_arena) fprintf(stderr, "eg3d: expand launch of %u chains redone: a solve of more than 32 rows -> general build\n", nc);
       HIP_TRY(hipMemcpyAsync(&c->b_ctr.as<Counters>()->bytes, saved_bytes, sizeof(unsigned long long),
                              hipMemcpyDeviceToDevice, st));
       HIP_TRY(hipStreamSynchronize(st));
       chunk = 0;  // do not advance
+      redo_n = 0;  // (every chain of the chunk again)
       continue;
     }
     if (hc.flags & CTR_SLOT_STARVED) {
@@ -1363,12 +1436,16 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, UnitTurn& T, HostOut& H) {
     if (!(hc.flags & (EG3D_FLAG_CHAIN_OVERFLOW | EG3D_FLAG_OBS_OVERFLOW)) && (np > stage.cap_pts || no > stage.cap_obs)) {
       // the staging area was too small for this launch: its chains were counted but not all packed. Size it
       // for what they need (kept for later calls) and repeat the launch.
+      if (c->tune.trace_arena)
+        fprintf(stderr, "eg3d: expand launch of %u chains redone: staging area %zu points / %zu observations, needed %u / %u\n", nc,
+                (size_t)stage.cap_pts, (size_t)stage.cap_obs, np, no);
       c->stage_cap_pts = std::max<uint64_t>(c->stage_cap_pts, (uint64_t)np + np / 16 + 64);
       c->stage_cap_obs = std::max<uint64_t>(c->stage_cap_obs, (uint64_t)no + no / 16 + 64);
       HIP_TRY(hipMemcpyAsync(&c->b_ctr.as<Counters>()->bytes, saved_bytes, sizeof(unsigned long long),
                              hipMemcpyDeviceToDevice, st));
       HIP_TRY(hipStreamSynchronize(st));
       chunk = 0;  // do not advance
+      redo_n = 0;  // (every chain of the chunk again: what was packed does not fit the area as it is)
       continue;
     }
     if (hc.flags & (EG3D_FLAG_CHAIN_OVERFLOW | EG3D_FLAG_OBS_OVERFLOW)) {
@@ -1379,12 +1456,43 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, UnitTurn& T, HostOut& H) {
       if (can_grow) {
         if (hc.flags & EG3D_FLAG_CHAIN_OVERFLOW) c->chain_cap *= 2;
         if (hc.flags & EG3D_FLAG_OBS_OVERFLOW) c->pool_cap *= 2;
-        HIP_TRY(hipMemcpyAsync(&c->b_ctr.as<Counters>()->bytes, saved_bytes, sizeof(unsigned long long),
-                               hipMemcpyDeviceToDevice, st));
+        H.flags |= hc.flags & 0xffu & ~(uint32_t)(EG3D_FLAG_CHAIN_OVERFLOW | EG3D_FLAG_OBS_OVERFLOW);  // what the chains that keep their results raised
+        {
+          float t_launch = 0;  // (the launch is over: its counters have been read back)
+          HIP_TRY(hipEventElapsedTime(&t_launch, c->ea[5], c->eb[5]));
+          ms_expand += t_launch;
+        }
+        uint32_t n_again = 0;
+        if (!engine) {
+          // list the chains of this launch that overflowed (and take their share of the byte counter back)
+          const int nb = redo_n ? 1 - redo_buf : 0;
+          BUF_TRY(c->b_redo[nb].ensure(sizeof(uint32_t) * (nc + 1)));
+          BUF_TRY(c->b_queue.ensure(4 * sizeof(uint32_t)));
+          HIP_TRY(hipMemsetAsync(c->b_queue.p, 0, 4 * sizeof(uint32_t), st));
+          launch_collect_overflow(st, c->b_couts.as<ChainOut>(), launch_order, n_launch, c->b_redo[nb].as<uint32_t>(),
+                                  c->b_queue.as<uint32_t>(), c->b_ctr.as<Counters>());
+          Readback rb(c);
+          const int in = rb.add(c->b_queue.p, 1);
+          BUF_TRY(rb.run());
+          n_again = *rb.item(in);
+          redo_buf = nb;
+        }
+        if (c->tune.trace_arena)
+          fprintf(stderr, "eg3d: expand launch of %u chains: %u outgrew their slices (flags %u); relaunching %s with %u points / %u "
+                          "observation slots per chain\n", n_launch, n_again, hc.flags & 3u, n_again ? "those" : "the chunk", c->chain_cap, c->pool_cap);
+        if (n_again) {
+          redo_n = n_again;
+          redo_nc = nc;
+        } else {  // (the engine form, or nothing listed: the whole chunk again)
+          redo_n = 0;
+          HIP_TRY(hipMemcpyAsync(&c->b_ctr.as<Counters>()->bytes, saved_bytes, sizeof(unsigned long long),
+                                 hipMemcpyDeviceToDevice, st));
+        }
         chunk = 0;  // do not advance
         continue;
       }
     }
+    redo_n = 0;
     // ---- K4 + placement of this chunk. Device-only calls keep the WHOLE cloud of the call in the OWNER's output buffers
     // (unit after unit, chunk after chunk, global observation offsets), so that eg3d_last_device_output is complete whatever
     // the cutting — the RCCL gather reads it: the chunk waits for its unit's turn, then k4_emit writes at the call's running
@@ -1429,37 +1537,46 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, UnitTurn& T, HostOut& H) {
         T.pass();
       }
     } else if (np) {
-      // D2H through the lane's pinned staging area (grow-only): seven async copies at PCIe speed, each followed
-      // by an event; the multi-threaded copy of an array into the caller's pageable memory starts when ITS event has
-      // fired, while the later arrays are still crossing PCIe. (A pageable hipMemcpy runs at ~2 GB/s and made the
-      // copy 3x the compute time on the dtu006-shaped workload.)
+      // D2H through the lane's RING of pinned buffers (EG3D_D2H_RING of EG3D_D2H_CHUNK bytes, allocated once — behind the
+      // first expand launch, see ensure_d2h_ring): the seven arrays are cut into pieces of at most one buffer; a piece
+      // crosses PCIe into a free buffer (async, an event behind it) and is copied on by a few host threads into the
+      // caller's pageable memory while the next pieces are crossing. (A pageable hipMemcpy runs at ~2 GB/s and made the
+      // copy 3x the compute time on the dtu006-shaped workload. Until round 6 a whole unit was staged at once: pinning
+      // that much memory — 0.57 GB for C3' — cost the FIRST call of a context 110-160 ms, twice its kernels.)
       const size_t sz[7] = {sizeof(float) * 3 * np, sizeof(eg3d_off_t) * np,   sizeof(uint32_t) * 4 * np, sizeof(int32_t) * no,
                             sizeof(uint32_t) * no,  sizeof(uint32_t) * no,      sizeof(float) * 2 * no};
-      const void* src[7] = {c->o_X.p, c->o_off.p, c->o_key.p, c->o_view.p, c->o_pl.p, c->o_seg.p, c->o_xy.p};
-      size_t total = 0, at[7];
-      for (int k = 0; k < 7; k++) {
-        at[k] = total;
-        total += (sz[k] + 255) & ~(size_t)255;
-      }
-      if (total > c->pinned_cap) {
-        if (c->pinned) (void)hipHostFree(c->pinned);
-        c->pinned = nullptr;
-        c->pinned_cap = 0;
-        const size_t want = total + total / 4;
-        HIP_TRY(hipHostMalloc(&c->pinned, want, hipHostMallocDefault));
-        c->pinned_cap = want;
+      const char* src[7] = {(const char*)c->o_X.p,  (const char*)c->o_off.p, (const char*)c->o_key.p, (const char*)c->o_view.p,
+                            (const char*)c->o_pl.p, (const char*)c->o_seg.p, (const char*)c->o_xy.p};
+      struct Piece {
+        int k;
+        size_t at, bytes;
+      };
+      std::vector<Piece> pieces;
+      size_t total = 0;
+      // (the big observation arrays first)
+      static const int order[7] = {6, 3, 4, 5, 2, 1, 0};
+      for (int i = 0; i < 7; i++) total += sz[i];
+      BUF_TRY(ensure_d2h_ring(c, total));
+      const size_t CH = c->ring_chunk;
+      for (int i = 0; i < 7; i++) {
+        const int k = order[i];
+        for (size_t at = 0; at < sz[k]; at += CH) pieces.push_back({k, at, std::min<size_t>(CH, sz[k] - at)});
       }
 #ifdef EG3D_COPY_TIMING
       const auto tc0 = std::chrono::steady_clock::now();
 #endif
-      // (the big observation arrays first: their host copies overlap with the transfers behind them)
-      static const int order[7] = {6, 3, 4, 5, 2, 1, 0};
-      for (int i = 0; i < 7; i++) {
-        const int k = order[i];
-        if (sz[k]) HIP_TRY(hipMemcpyAsync((char*)c->pinned + at[k], src[k], sz[k], hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipEventRecord(c->ecopy[i], st));
-      }
-      // where the chunk goes: known once every earlier unit has placed its output
+      size_t issued = 0, done = 0;
+      auto issue = [&]() -> int {  // the next piece into its ring buffer
+        const Piece& q = pieces[issued];
+        const int slot = (int)(issued % EG3D_D2H_RING);
+        HIP_TRY(hipMemcpyAsync((char*)c->pinned + (size_t)slot * CH, src[q.k] + q.at, q.bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(c->ecopy[slot], st));
+        issued++;
+        return EG3D_OK;
+      };
+      // the first pieces cross PCIe whatever the unit's turn ...
+      while (issued < pieces.size() && issued < EG3D_D2H_RING) BUF_TRY(issue());
+      // ... where they go is known once every earlier unit has placed its output
       if (!T.take()) return EG3D_ERR_HIP;
       uint64_t p0 = 0, o0 = 0;
       const bool placed = S.place_host(np, no, w_piece, p0, o0);
@@ -1477,12 +1594,18 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, UnitTurn& T, HostOut& H) {
 #endif
       {
         std::shared_lock<std::shared_mutex> lk(S.dst_mu);
-        void* dst[7] = {S.X.data() + p0 * 3, S.off.data() + p0,  S.key.data() + p0 * 4, S.view.data() + o0,
-                        S.pl.data() + o0,    S.seg.data() + o0,  S.xy.data() + o0 * 2};
-        for (int i = 0; i < 7; i++) {
-          const int k = order[i];
-          HIP_TRY(hipEventSynchronize(c->ecopy[i]));
-          copy_mt(dst[k], (char*)c->pinned + at[k], sz[k]);
+        char* dst[7] = {(char*)(S.X.data() + p0 * 3), (char*)(S.off.data() + p0), (char*)(S.key.data() + p0 * 4),
+                        (char*)(S.view.data() + o0),  (char*)(S.pl.data() + o0),  (char*)(S.seg.data() + o0),
+                        (char*)(S.xy.data() + o0 * 2)};
+        while (done < pieces.size()) {
+          const Piece& q = pieces[done];
+          const int slot = (int)(done % EG3D_D2H_RING);
+          HIP_TRY(hipEventSynchronize(c->ecopy[slot]));
+          eg3d::copy_mt(dst[q.k] + q.at, (char*)c->pinned + (size_t)slot * CH, q.bytes,
+                        c->tune.copy_threads > 0 ? c->tune.copy_threads : std::max(2, EG3D_COPY_THREADS / std::max(1, S.lanes_active)),
+                        (size_t)1 << 20);
+          done++;
+          if (issued < pieces.size()) BUF_TRY(issue());  // the buffer just emptied takes the next piece
         }
         if (o0) {
           uint64_t* off = S.off.data();
@@ -1496,7 +1619,7 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, UnitTurn& T, HostOut& H) {
 #ifdef EG3D_COPY_TIMING
       const auto tc2 = std::chrono::steady_clock::now();
       fprintf(stderr, "chunk: p0 %zu o0 %zu np %u no %u nc %u  ", (size_t)p0, (size_t)o0, np, no, nc);
-      fprintf(stderr, "copy timing: %.1f MB  D2H queue + turn %.2f ms  wait + host copy %.2f ms\n", total / 1e6,
+      fprintf(stderr, "copy timing: %.1f MB in %zu pieces  first pieces + turn %.2f ms  D2H + host copy %.2f ms\n", total / 1e6, pieces.size(),
               std::chrono::duration<double, std::milli>(tc1 - tc0).count(),
               std::chrono::duration<double, std::milli>(tc2 - tc1).count());
 #endif
@@ -1749,6 +1872,7 @@ static int run_pipelined(eg3d_ctx* c, CallSink& S, const std::vector<UnitRange>&
   const uint32_t n_units = (uint32_t)units.size();
   n_lanes = (int)std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)std::max(1, n_lanes), n_units));
   BUF_TRY(ensure_lanes(c, n_lanes));
+  S.lanes_active = n_lanes;
   for (int l = 0; l < n_lanes; l++) lane_share_inputs(c, c->lanes[(size_t)l]);
   for (const UnitRange& u : units) S.weight_total += u.w;
   std::atomic<uint32_t> next{0};
@@ -1796,6 +1920,7 @@ static int finish_match(eg3d_ctx* c, CallSink& S, float total, eg3d_edgepoints* 
   out->flags = H.flags;
   c->last_chunks = H.pieces;
   c->last_accumulated = device_only != 0;
+  if (!device_only) c->host_calls++;
   if (device_only) {
     c->last_np = S.n_points;
     c->last_no = S.n_obs;
@@ -1849,9 +1974,13 @@ extern "C" int eg3d_set_pipelining(eg3d_ctx* c, int lanes, int units) {
 
 static int lanes_for(const eg3d_ctx* c, int device_only) {
   if (c->tune.lanes > 0) return c->tune.lanes;
-  // by measurement (round 6): cutting a call buys nothing on the device — every expand launch lasts at least as long as its
-  // slowest chain and the launches of a call's units run nearly first-in-first-out — but it hides most of the D2H copy
-  return device_only ? 1 : Tunables::kHostCallLanes;
+  // by measurement (round 6): cutting a call buys nothing on the device — every expand launch lasts at least as
+  // long as its slowest chain and the launches of a call's units run nearly first-in-first-out — but it hides most of the
+  // D2H copy of a host call (C3' 64 -> 54 ms). Lanes have a price when they are created (streams, work buffers, pinned
+  // rings: +50-90 ms on the call that creates them, seconds on a 200-view scene), so the FIRST host call of a context — a
+  // one-shot caller's only call — runs on the context alone; a context that is called again is worth the lanes.
+  if (device_only) return 1;
+  return c->host_calls > 0 ? Tunables::kHostCallLanes : 1;
 }
 
 // Units of a seed range. One lane: batches of 16 384 seeds (one expand launch each), as before round 6. Several lanes:
@@ -2235,7 +2364,7 @@ extern "C" int eg3d_probe_hyp_sections(eg3d_ctx* c, double* sum, double* slowest
 }
 
 #endif
-#if defined(EG3D_SECTION_TIMING) || defined(EG3D_K3C_TIMING)
+#if defined(EG3D_WITH_K3C_ENGINE) && (defined(EG3D_SECTION_TIMING) || defined(EG3D_K3C_TIMING))
 // ... and of the lane-per-chain engine (eg3d_k3c_engine.h g_k3c_dbg)
 namespace eg3d { int k3c_dbg_read(unsigned long long* out, int reset); }
 extern "C" int eg3d_probe_k3c(unsigned long long* out128, int reset) { return eg3d::k3c_dbg_read(out128, reset); }

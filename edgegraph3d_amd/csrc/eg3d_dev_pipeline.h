@@ -331,7 +331,9 @@ EG3D_HD_FLAT void expand_chain(const Team& tm, const DevScene& s, const StageAVi
   const uint32_t* me = map_entry + base;
   const uint32_t lo = tm.uni(a.task_list_off[cs.task]);
   uint32_t j = 0;
-  for (int v = 0; v < s.n_views; v++) {
+  // (an initial chain that did not fit its slice is incomplete — its central point may be missing: nothing is expanded, the
+  // capacity flag makes the host relaunch the chain with a larger slice)
+  for (int v = 0; v < s.n_views && !(c.flags & 3u); v++) {
     if (v == d.sel_view[0] || v == d.sel_view[1] || v == d.sel_view[2]) continue;
     while (j < n && mv[j] < v) j++;
     const Obs* epc = nullptr;

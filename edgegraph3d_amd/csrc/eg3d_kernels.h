@@ -107,6 +107,8 @@ void launch_k3b(hipStream_t st, DevScene s, StageAView a, const TaskDesc* tasks,
                 const int32_t* map_view, const uint32_t* map_entry, const uint32_t* map_n, ChainLayout L,
                 unsigned char* slices, SlotPools pools, StageBuf stage, ChainOut* outs, uint32_t* out_points,
                 uint32_t* out_obs, Counters* ctr, const uint32_t* order, int scene_class /* polylines of <= 512 vertices: 0 small (<= 28 views) or 2 many views (>= 29); 1 general: the build of the kernel without the paths such a scene cannot reach */);
+void launch_collect_overflow(hipStream_t st, const ChainOut* outs, const uint32_t* order, uint32_t n, uint32_t* redo,
+                             uint32_t* n_redo, Counters* ctr);
 void launch_chain_cost(hipStream_t st, StageAView a, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains,
                        uint32_t* cost, uint32_t* idx);
 void launch_k4(hipStream_t st, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains, StageBuf stage,

@@ -1371,6 +1371,21 @@ __global__ void __launch_bounds__(64, WAVES) k3b_expand_t(DevScene s, StageAView
   }
 }
 
+// After an expand launch in which chains outgrew their working slices: the chains of THAT launch (order[0..n)) whose result
+// carries a capacity flag are listed for a relaunch with larger slices — the others keep their packed results — and what
+// the listed chains added to the launch's byte counter is taken back (they will add it again).
+__global__ void k_collect_overflow(const ChainOut* outs, const uint32_t* order, uint32_t n, uint32_t* redo, uint32_t* n_redo,
+                                   Counters* ctr) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n) return;
+  const uint32_t j = order[b];
+  const ChainOut co = outs[j];
+  if (co.flags & 3u) {  // EG3D_FLAG_CHAIN_OVERFLOW | EG3D_FLAG_OBS_OVERFLOW (include/eg3d.h)
+    redo[atomicAdd(n_redo, 1u)] = j;
+    if (co.bytes) atomicAdd(&ctr->bytes, 0ull - (unsigned long long)co.bytes);
+  }
+}
+
 // Cost estimate of a chain for the longest-processing-time-first launch order of K3b:
 // initial length x track size of its seed (every track view may attach to every point).
 __global__ void k_chain_cost(StageAView a, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains,
@@ -1760,6 +1775,11 @@ int k3c_dbg_read(unsigned long long* out, int reset) {  // out[128]: g_k3c_dbg[3
   return 0;
 }
 #endif
+void launch_collect_overflow(hipStream_t st, const ChainOut* outs, const uint32_t* order, uint32_t n, uint32_t* redo,
+                             uint32_t* n_redo, Counters* ctr) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_collect_overflow, blocks_for(n, 256), dim3(256), 0, st, outs, order, n, redo, n_redo, ctr);
+}
 void launch_chain_cost(hipStream_t st, StageAView a, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains,
                        uint32_t* cost, uint32_t* idx) {
   if (!n_chains) return;

@@ -215,8 +215,10 @@ int eg3d_match_resident(eg3d_ctx* ctx, uint32_t seed_begin, uint32_t seed_end, i
  * stage of another. The output is the concatenation of the sub-batches in order: byte for byte what a single batch
  * produces. lanes: 1 = no pipelining (the call runs on the context's own stream, one batch of <= 16 384 seeds at a time),
  * 0 = the default, by the kind of call (EG3D_PIPELINE_LANES overrides): 3 for a call that copies its cloud to the host —
- * most of the D2H copy disappears behind the later sub-batches — and 1 for a device-only call, which measured no gain
- * (every expand launch lasts at least as long as its slowest chain: eg3d_stage_times.ms_slowest_chain); units: 0 = chosen
+ * most of the D2H copy disappears behind the later sub-batches — on a context that has ALREADY completed a host call (lanes
+ * cost 50-90 ms, on many-view scenes seconds, when they are created: a one-shot caller's only call runs on the context
+ * alone), and 1 for a device-only call, which measured no gain (every expand launch lasts at least as long as its slowest
+ * chain: eg3d_stage_times.ms_slowest_chain); units: 0 = chosen
  * from the range (one per lane when each gets >= 128 seeds; EG3D_PIPELINE_UNITS). A clone inherits its parent's setting. Use lanes = 1 on contexts that are themselves driven
  * concurrently (one per host thread): stacking both forms of overlap only multiplies the work buffers. */
 int eg3d_set_pipelining(eg3d_ctx* ctx, int lanes, int units);

@@ -58,6 +58,13 @@ struct EdgeMatchingOptions {
   bool estimate_F = false;  // fundamental matrices estimated from the tracks (own LMedS) instead of analytic from the cameras
   bool require_images = true;  // the photographs named by the SfM data must exist in images_folder (as parse_images fails without them)
   int device = 0;
+  // edge_reconstruction_pipeline (pipelines.cpp:201-246) runs three pipelines; this build runs pipeline 3 (reference points)
+  // only: pipelines 1-2 consume polyline matches of the similarity-graph / Louvain matchers, which are out of scope (their
+  // extractor, eg3d_match_polyline_sets, is built; examples/edge_matcher_refpoints.cpp feeds it from a file). The output can
+  // therefore hold fewer edge-points than the reference's. quiet = false prints one line to stderr saying so per call;
+  // after a call skipped_pipelines says which were left out.
+  bool quiet = false;
+  int skipped_pipelines = 0;  // bit 0: pipeline 1 (similarity graph), bit 1: pipeline 2 (closeness to refpoints) [out]
 };
 inline EdgeMatchingOptions& edge_matching_options() {
   static EdgeMatchingOptions o;
@@ -305,6 +312,11 @@ inline int edge_matching(edge_matcher_input_params& emip, SfMData& sfm_data) {
 
   // edge_reconstruction_pipeline (pipelines.cpp:201-246): pipelines 1-2 have no polyline matches here (their matchers are
   // out of scope); pipeline 3
+  edge_matching_options().skipped_pipelines = 3;
+  if (!edge_matching_options().quiet)
+    std::fprintf(stderr, "eg3d edge_matching: pipelines 1-2 (polyline matches of the similarity-graph / Louvain matchers) are not "
+                         "part of this build; running pipeline 3 (reference points) only: the output may hold fewer edge-points "
+                         "than the reference's (INTEGRATION.md)\n");
   std::vector<new_3dpoint_plgp_matches> p3ds = plg_matching_from_refpoints_parallel(sfm_data, em.get(), cm.get(), plgmm);
   const std::vector<new_3dpoint_plgp_matches> filtered_p3ds =
       filter_3d_points_close_2d_array(sfm_data.numCameras_, sfm_data.imageWidth_, sfm_data.imageHeight_, p3ds);

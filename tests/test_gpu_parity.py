@@ -204,20 +204,53 @@ def test_c4_far_end_window_parity(have_gpu):
     ctx.close()
 
 
-def test_c4_shaped_subset_parity_and_capacity_growth(have_gpu):
+def test_c4_shaped_subset_parity_and_capacity_growth(have_gpu, monkeypatch, capfd):
     """200 views / ~20k segments per view (BASELINE configs[3] shape), first 40 seeds: points carry
     dozens of observations, which outgrows the default per-chain pool -> the library must enlarge
-    it and still match the oracle exactly."""
+    it and still match the oracle exactly. Since round 6 only the chains that overflowed are launched again
+    (the others keep their packed results): the trace says so, and the byte counter — of which the relaunched
+    chains' first attempt is taken back — still equals the oracle's."""
     cfg = host.default_config(4)
     cfg.n_seeds = 40
     s = host.Synth(cfg)
+    monkeypatch.setenv("EG3D_TRACE_ARENA", "1")
     ctx = api.Context(s.scene)
     got = ctx.match_refpoints(s.seeds)
+    err = capfd.readouterr().err
     ref = _oracle(s.scene).match(s.seeds, 0, s.n_seeds, nthreads=16)
     rep = compare_edgepoints(ref, got, rel_tol=1e-4)
     assert rep["ok"], rep["msgs"]
-    assert (got["flags"] & 7) == 0
+    assert (got["flags"] & 7) == 0 and got["flags"] == ref["flags"]
     assert got["n_obs"] > 20 * got["n_points"]
+    assert "outgrew their slices" in err and "relaunching those" in err, err[-400:]
+    assert got["times"]["bytes_algorithmic"] == ref["stats"]["bytes_algorithmic"]
+    again = ctx.match_refpoints(s.seeds)   # the grown capacities are kept: no relaunch the second time
+    assert "outgrew" not in capfd.readouterr().err
+    assert np.array_equal(again["X"].view(np.uint32), got["X"].view(np.uint32))
+    ctx.close()
+
+
+@pytest.mark.parametrize("lanes", [1, 3])
+def test_relaunch_of_overflowed_chains_round_after_round(have_gpu, monkeypatch, capfd, lanes):
+    """Tiny initial capacities (EG3D_CHAIN_CAP0 / EG3D_POOL_CAP0, test knobs) make most chains of a C2-sized scene outgrow
+    their slices several times over: every round relaunches only what overflowed in the round before, with doubled
+    capacities, until nothing does. Cloud, flags and byte counter == oracle; also with the call cut into units on lanes."""
+    s = host.Synth(1)
+    ref = _oracle(s.scene).match(s.seeds, 0, s.n_seeds, nthreads=8)
+    monkeypatch.setenv("EG3D_CHAIN_CAP0", "8")
+    monkeypatch.setenv("EG3D_POOL_CAP0", "64")
+    monkeypatch.setenv("EG3D_TRACE_ARENA", "1")
+    ctx = api.Context(s.scene)
+    ctx.upload_seeds(s.seeds)
+    ctx.set_pipelining(lanes, 0)
+    got = ctx.match_resident(0, s.n_seeds)
+    err = capfd.readouterr().err
+    rep = compare_edgepoints(ref, got)
+    assert rep["ok"] and rep["bitexact_X"] and rep["bitexact_xy"], rep["msgs"][:3]
+    assert got["flags"] == ref["flags"] and got["times"]["bytes_algorithmic"] == ref["stats"]["bytes_algorithmic"]
+    assert err.count("relaunching those") >= 3, err[-600:]
+    dev = ctx.match_resident(0, s.n_seeds, device_only=True)
+    assert dev["n_points"] == ref["n_points"]
     ctx.close()
 
 

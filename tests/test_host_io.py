@@ -261,3 +261,44 @@ def test_multithreaded_host_copy_covers_every_byte(tmp_path):
                            os.path.join(root, "tests", "hostcopy", "hostcopy_check.cpp"), "-o", exe])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "HOSTCOPY-OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_compare_sfm_json_measures_structural_agreement_of_two_runs(tmp_path):
+    """tools/compare_sfm_json.py (the recipe for a user who holds a real reference run: README): two
+    before_filtering.json files are compared point by point through their observation lists. Built here from one
+    document and a hand-made variant: one edge-point moved by 1e-6 relative, one moved by 1e-3, one with an extra
+    observation (same start, grew differently), one missing, one new."""
+    import copy
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import compare_sfm_json as cmp
+    base = _openmvg_doc(0)
+
+    def pt(key, X, obs):
+        return {"key": key, "value": {"X": X, "observations": [{"key": v, "value": {"id_feat": 0, "x": xy}} for v, xy in obs]}}
+    edge = [pt(100 + i, [10.0 + i, 20.0, 500.0 + i], [(0, [100.5 + i, 200.25]), (1, [300.0 + i, 210.0]), (2, [50.0, 60.0 + i])])
+            for i in range(6)]
+    a = copy.deepcopy(base)
+    a["structure"] += copy.deepcopy(edge)
+    b = copy.deepcopy(base)
+    eb = copy.deepcopy(edge)
+    eb[1]["value"]["X"][2] *= 1.0 + 1e-6          # within tolerance
+    eb[2]["value"]["X"][2] *= 1.0 + 1e-3          # structurally identical, outside tolerance
+    eb[3]["value"]["observations"].append({"key": 1, "value": {"id_feat": 0, "x": [7.0, 8.0]}})   # grew differently
+    del eb[4]                                     # only in the reference
+    eb.append(pt(300, [1.0, 2.0, 3.0], [(2, [9.0, 9.5]), (0, [1.0, 1.5])]))                        # only in ours
+    b["structure"] += eb
+    pa, pb, pin = str(tmp_path / "a.json"), str(tmp_path / "b.json"), str(tmp_path / "in.json")
+    json.dump(a, open(pa, "w"))
+    json.dump(b, open(pb, "w"))
+    json.dump(base, open(pin, "w"))
+    rep = cmp.compare(cmp.read_cloud(pa), cmp.read_cloud(pb), len(cmp.read_cloud(pin)[0]))
+    assert rep["input_points"] == 1 and rep["edge_points_ref"] == 6 and rep["edge_points_got"] == 6
+    assert rep["structurally_identical"] == 4 and rep["X_bit_equal"] == 2 and rep["X_within_tol"] == 3
+    assert 5e-4 < rep["max_rel_dX"] < 2e-3
+    assert rep["same_first_observation_different_list"] == 1 and rep["only_in_ref"] == 1 and rep["only_in_got"] == 2
+    # without the input file the SfM points are taken to be the common prefix: leading edge-points that agree count as input
+    auto = cmp.compare(cmp.read_cloud(pa), cmp.read_cloud(pb))
+    assert auto["input_points"] == 2 and auto["structurally_identical"] == 3
+    same = cmp.compare(cmp.read_cloud(pa), cmp.read_cloud(pa))
+    assert same["input_points"] == 7  # identical files: everything is common prefix
