@@ -1397,18 +1397,21 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, UnitTurn& T, HostOut& H) {
     BUF_TRY(scan_queue_u32(c, c->b_cpts.as<uint32_t>(), c->b_cpoff.as<uint32_t>(), nc + 1, 0));
     BUF_TRY(scan_queue_u32(c, c->b_cobs.as<uint32_t>(), c->b_cooff.as<uint32_t>(), nc + 1, 1));
     uint32_t np = 0, no = 0;
+    unsigned long long stage_used[2] = {0, 0};
     {
       Readback rb(c);
       const int ic = rb.add(c->b_ctr.p, sizeof(Counters) / 4);
       const int ip = rb.add(c->b_cpoff.as<uint32_t>() + nc, 1);
       const int io = rb.add(c->b_cooff.as<uint32_t>() + nc, 1);
       const int iw = rb.add(c->b_scanchk.as<uint32_t>(), 2);
+      const int iu = rb.add(c->b_stage_used.p, 4);  // what the launches of this chunk have packed (two 64-bit counters)
       rb.clear_after(c->b_scanchk.as<uint32_t>());
       rb.clear_after(c->b_scanchk.as<uint32_t>() + 1);
       BUF_TRY(rb.run());
       memcpy(&hc, rb.item(ic), sizeof(Counters));
       np = *rb.item(ip);
       no = *rb.item(io);
+      memcpy(stage_used, rb.item(iu), sizeof(stage_used));
       const bool overflow = hc.flags & (EG3D_FLAG_CHAIN_OVERFLOW | EG3D_FLAG_OBS_OVERFLOW);
       if (!overflow && rb.item(iw)[0]) return wrapped_error("edge-points of one chunk");
       if (!overflow && rb.item(iw)[1]) return wrapped_error("observations of one chunk");
@@ -1433,14 +1436,17 @@ int run_stage_b(eg3d_ctx* c, BatchState& B, UnitTurn& T, HostOut& H) {
       g_err = "eg3d: internal: the expand kernel found no free working slice (slot pool smaller than the residency)";
       return EG3D_ERR_HIP;
     }
-    if (!(hc.flags & (EG3D_FLAG_CHAIN_OVERFLOW | EG3D_FLAG_OBS_OVERFLOW)) && (np > stage.cap_pts || no > stage.cap_obs)) {
+    // (the area holds what every launch of the chunk packed — after a relaunch of some chains also their discarded first
+    // attempts — so it is the packed totals, not the cloud's, that must fit)
+    if (!(hc.flags & (EG3D_FLAG_CHAIN_OVERFLOW | EG3D_FLAG_OBS_OVERFLOW)) &&
+        (np > stage.cap_pts || no > stage.cap_obs || stage_used[0] > stage.cap_pts || stage_used[1] > stage.cap_obs)) {
       // the staging area was too small for this launch: its chains were counted but not all packed. Size it
       // for what they need (kept for later calls) and repeat the launch.
       if (c->tune.trace_arena)
         fprintf(stderr, "eg3d: expand launch of %u chains redone: staging area %zu points / %zu observations, needed %u / %u\n", nc,
                 (size_t)stage.cap_pts, (size_t)stage.cap_obs, np, no);
-      c->stage_cap_pts = std::max<uint64_t>(c->stage_cap_pts, (uint64_t)np + np / 16 + 64);
-      c->stage_cap_obs = std::max<uint64_t>(c->stage_cap_obs, (uint64_t)no + no / 16 + 64);
+      c->stage_cap_pts = std::max<uint64_t>(c->stage_cap_pts, std::max<uint64_t>(np, stage_used[0]) + np / 16 + 64);
+      c->stage_cap_obs = std::max<uint64_t>(c->stage_cap_obs, std::max<uint64_t>(no, stage_used[1]) + no / 16 + 64);
       HIP_TRY(hipMemcpyAsync(&c->b_ctr.as<Counters>()->bytes, saved_bytes, sizeof(unsigned long long),
                              hipMemcpyDeviceToDevice, st));
       HIP_TRY(hipStreamSynchronize(st));
@@ -1980,6 +1986,10 @@ static int lanes_for(const eg3d_ctx* c, int device_only) {
   // rings: +50-90 ms on the call that creates them, seconds on a 200-view scene), so the FIRST host call of a context — a
   // one-shot caller's only call — runs on the context alone; a context that is called again is worth the lanes.
   if (device_only) return 1;
+  // every lane owns a full slot arena (the residency of the expand kernel x the slice size): on many-view scenes that is
+  // 17 GB per lane (C4) for a 3 % gain with the copy and a loss without — such scenes stay on the context alone
+  const size_t arena = chain_layout(c->chain_cap, c->pool_cap, (uint32_t)c->V).total * 8 * (size_t)c->slots_per_xcd;
+  if (arena > ((size_t)4 << 30)) return 1;
   return c->host_calls > 0 ? Tunables::kHostCallLanes : 1;
 }
 

@@ -1468,8 +1468,8 @@ __global__ void __launch_bounds__(64) k4_emit(const TaskDesc* tasks, const Chain
 // others stop after 4-10, and k spans 3..10; with points taken in input order a wavefront keeps 0.71 of its lanes busy by
 // passes and only 0.41 by residual rows, because every pass runs as long as the longest list among its 64 lanes). The
 // block's points are therefore SORTED BY k in LDS (counting sort) before lanes take them: a wavefront's lists have (nearly)
-// the same length. 2.83 -> 2.17 ms per 1 M points, vector instructions 1.78e9 -> 1.03e9, measured active-lane fraction
-// 0.69 (profiles/r06_c5_rocprof_summary.txt). A point's arithmetic does not depend on the lane that runs it, so the output
+// the same length. 2.83 -> 2.17 ms per 1 M points, vector instructions 1.78e9 -> 1.18e9, measured active-lane fraction
+// 0.61 (profiles/r06_c5_rocprof_summary.txt). A point's arithmetic does not depend on the lane that runs it, so the output
 // is bit for bit what one lane per point in input order produces.
 // Measured and dropped: packing the points still running after 6 / 10 passes into the block's first wavefronts (state
 // through LDS, order kept; gauss_newton_f32_span makes the iteration resumable): 2.37 / 2.21 ms against 2.17 without —

@@ -1,8 +1,8 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/final_numbers.sh <tag, e.g. r05> [workloads to profile, default "c3 c2 c4"]
+# usage (GPU box, repo root): tools/final_numbers.sh <tag, e.g. r06> [workloads to profile, default "c3 c2 c4"]
 # The profile sets of a round's final build (tools/profile_round.sh per workload) + the bench lines DESIGN_LOG.md quotes,
 # all under gpurun_out/<tag>_*; copy what is to be judged into profiles/.
-tag=${1:-r05}; wls=${2:-"c3 c2 c4"}
+tag=${1:-r06}; wls=${2:-"c3 c2 c4"}
 mkdir -p gpurun_out
 for wl in $wls; do bash tools/profile_round.sh $wl $tag > gpurun_out/profile_${tag}_$wl.log 2>&1; tail -n 25 gpurun_out/profile_${tag}_$wl.log; done
 run() { name=$1; shift; ( "$@" > gpurun_out/${tag}_final_$name.json 2> gpurun_out/${tag}_final_$name.err ); python - gpurun_out/${tag}_final_$name.json <<'P'

@@ -45,7 +45,7 @@ th, act = last("SQ_THREAD_CYCLES_VALU"), last("SQ_ACTIVE_INST_VALU")
 if th and act:
     open(sys.argv[1], "a").write("\n# active-lane fraction of k5_gn_filter = SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) = %.4f\n" % (th / (64.0 * act)))
 import json
-m = re.search(r"k5_gn_filter\S*\s+calls\s+\d+\s+total [0-9.]+ us\s+avg ([0-9.]+) us", t)
+m = re.search(r"k5_gn_filter.*?calls\s+\d+\s+total [0-9.]+ us\s+avg ([0-9.]+) us", t)
 json.dump({"kernel": "k5_gn_filter", "kernel_ms": float(m.group(1)) / 1e3 if m else None, "SQ_THREAD_CYCLES_VALU": th,
            "SQ_ACTIVE_INST_VALU": act, "SQ_INSTS_VALU": last("SQ_INSTS_VALU"), "SQ_WAVES": last("SQ_WAVES"), "SQ_WAIT_ANY": last("SQ_WAIT_ANY"),
            "SQ_WAVE_CYCLES": last("SQ_WAVE_CYCLES"), "FETCH_SIZE": last("FETCH_SIZE"), "WRITE_SIZE": last("WRITE_SIZE"),

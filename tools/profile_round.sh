@@ -8,9 +8,13 @@
 #           that bench.py's roofline.kernel_ms_per_step (measured the same way, by HIP events) must agree with
 #   fetch / write / sq / sq2   SEPARATE --pmc passes of the serial command, as the profiling guide prescribes
 # Summaries -> gpurun_out/<tag>_<workload>_*; copy to profiles/ to commit.
-wl=${1:-c3}; tag=${2:-r05}_$wl
+wl=${1:-c3}; tag=${2:-r06}_$wl
 out=$PWD/gpurun_out; mkdir -p $out/tmp; export TMPDIR=$out/tmp
 [ -f $out/pmc_traffic.json ] || cp profiles/pmc_traffic.json $out/pmc_traffic.json  # the other workloads' entries are kept
+# c4: a context's FIRST launch on a many-view scene is followed by a relaunch of the chains that outgrew their slices (round 6:
+# only those); the per-launch means below are meant to describe the steady-state launch, so the profiled contexts start with
+# the capacities every C4 context settles at (test knobs; the kernel and its launch are the steady-state ones)
+[ "$wl" = c4 ] && export EG3D_CHAIN_CAP0=768 EG3D_POOL_CAP0=196608
 case $wl in
   c4) kt_args="--workload c4 --steps 3 --warmup 1 --no-cpu-baseline --no-extras"; pmc_args="--workload c4 --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline --no-extras"; pmc_steps=3;;
   *)  kt_args="--workload $wl --steps 20 --warmup 5 --no-cpu-baseline --no-sublines"; pmc_args="--workload $wl --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --no-extras"; pmc_steps=4;;
