@@ -417,6 +417,9 @@ def _rooflines(wkey, bytes_alg, excl_ms, inflight_ms):
             stale = {"profiled_sources": fp_prof, "these_sources": fp_now, "last_measured_traffic": dom.get("hbm_bytes_per_step"),
                      "what": "environment switches that choose the kernel build or its launch are set (%s): the committed PMC pass "
                              "does not describe this run" % ", ".join(env_set)}
+        elif dom and not fp_prof:
+            stale = {"profiled_sources": None, "these_sources": fp_now, "last_measured_traffic": dom.get("hbm_bytes_per_step"),
+                     "what": "the committed PMC pass of this workload predates the source fingerprint (rounds 2-4): not reported as this run's traffic"}
         elif fp_prof and fp_prof != fp_now:
             stale = {"profiled_sources": fp_prof, "these_sources": fp_now, "last_measured_traffic": dom.get("hbm_bytes_per_step"),
                      "what": "the committed PMC pass was made on other device sources / switches than this build: not reported as this run's traffic; re-run tools/profile_round.sh"}

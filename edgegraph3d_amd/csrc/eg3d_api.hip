@@ -111,14 +111,17 @@ struct DevOwner {
       if (p) (void)hipFree(p);
   }
 };
-struct HostGrids {  // per view: the arrays eg3d_host_build_grid returned (malloc'ed; owned here)
-  std::vector<uint32_t*> h_off[2], h_ids[2];
-  ~HostGrids() {
-    for (int w = 0; w < 2; w++) {
-      for (uint32_t* p : h_off[w]) free(p);
-      for (uint32_t* p : h_ids[w]) free(p);
-    }
-  }
+// Host copies of the grids for eg3d_get_grid (per view CSR with view-local offsets). The grids live on the device (K0 builds
+// them there); the copies are made by the first eg3d_get_grid call that asks for a cell size — tests do, the hot path never.
+struct HostGrids {
+  std::mutex mu;
+  bool have[2] = {false, false};
+  std::vector<std::vector<uint32_t>> h_off[2], h_ids[2];
+  // where to fetch them from (device arrays of the shared, immutable scene)
+  int device = 0, n_views = 0;
+  const uint32_t* d_off[2] = {nullptr, nullptr};
+  const uint32_t* d_ids[2] = {nullptr, nullptr};
+  uint32_t cells_per_view[2] = {0, 0};
 };
 
 // Test / tuning knobs, read from the environment ONCE when a context is created (eg3d_create; clones
@@ -153,6 +156,8 @@ struct HostGrids {  // per view: the arrays eg3d_host_build_grid returned (mallo
 //                          1 normal, the others low (default 1: the earlier units finish — and cross PCIe — first)
 //   EG3D_TEST_FAIL_UNIT=k  tests: the k-th unit (1-based) of every pipelined call fails when its turn to place comes
 struct Tunables {
+  bool grid_on_host = false;  // EG3D_GRID_ON_HOST=1 (diagnostic / A-B): build the uniform grids with the host builder on threads
+                              // (rounds 1-5, and round 6 before K0) instead of on the device
   int lanes = 0, units = 0, test_fail_unit = 0;
   int copy_threads = 0;  // EG3D_COPY_THREADS_PER_LANE: host threads that copy one piece of a cloud from the ring to the caller's
                          // arrays (0 = EG3D_COPY_THREADS shared by the lanes of the call: 16 on one lane, 5 each on three)
@@ -190,6 +195,7 @@ struct Tunables {
     if (const char* e = getenv("EG3D_SLOTS_PER_XCD")) t.slots_per_xcd = (uint32_t)std::max(1, atoi(e));
     if (const char* e = getenv("EG3D_PIPELINE_LANES")) t.lanes = std::min(16, std::max(0, atoi(e)));
     if (const char* e = getenv("EG3D_TEST_FAIL_UNIT")) t.test_fail_unit = atoi(e);
+    if (const char* e = getenv("EG3D_GRID_ON_HOST")) t.grid_on_host = e[0] == '1';
     if (const char* e = getenv("EG3D_COPY_THREADS_PER_LANE")) t.copy_threads = std::min(32, std::max(1, atoi(e)));
     if (const char* e = getenv("EG3D_LANE_PRIORITIES")) t.lane_priorities = atoi(e);
     if (const char* e = getenv("EG3D_UNIT_RAMP")) t.unit_ramp = std::min(16.0, std::max(1.0 / 16.0, atof(e)));
@@ -389,6 +395,78 @@ static int scan_total_u32(eg3d_ctx* c, const uint32_t* in, uint32_t* out, size_t
   return EG3D_OK;
 }
 
+// K0: both uniform grids of the scene on the device (the scene's polylines are already resident: c->ds). Per cell size:
+// count the (cell, polyline) pairs of every polyline, exclusive scan, write them as 64-bit keys, radix sort, unique, CSR.
+// Temporaries (24 B per pair) are freed before the function returns.
+static int build_grids_device(eg3d_ctx* c, uint32_t NP) {
+  hipStream_t st = c->stream;
+  const int V = c->V;
+  DevBuf t_cnt, t_off, t_keys, t_keys2, t_n;
+  struct Release {
+    DevBuf* b[5];
+    ~Release() {
+      for (DevBuf* x : b) x->release();
+    }
+  } rel{{&t_cnt, &t_off, &t_keys, &t_keys2, &t_n}};
+  BUF_TRY(t_n.ensure(2 * sizeof(uint32_t)));  // [0] unique keys, [1] samples outside the image
+  HIP_TRY(hipMemsetAsync(t_n.p, 0, 2 * sizeof(uint32_t), st));
+  for (int which = 0; which < 2; which++) {
+    const float cell = which == 0 ? 30.0f : 4.0f;
+    const int map_w = (int)std::ceil(c->W / cell), map_h = (int)std::ceil(c->H / cell);  // (as host/grid_build.cpp: float division)
+    c->gw[which] = (uint32_t)map_w;
+    c->gh[which] = (uint32_t)map_h;
+    const unsigned long long total_cells = (unsigned long long)V * (unsigned long long)map_w * (unsigned long long)map_h;
+    if (total_cells >= 0xffffffffull) {
+      g_err = "eg3d_create: the scene's grids have more than 2^32-2 cells";
+      return EG3D_ERR_CAPACITY;
+    }
+    DevBuf& g_off = which == 0 ? c->b_g30o : c->b_g4o;
+    DevBuf& g_ids = which == 0 ? c->b_g30i : c->b_g4i;
+    BUF_TRY(t_cnt.ensure(sizeof(uint32_t) * ((size_t)NP + 1)));
+    BUF_TRY(t_off.ensure(sizeof(uint32_t) * ((size_t)NP + 1)));
+    HIP_TRY(hipMemsetAsync(t_cnt.as<uint32_t>() + NP, 0, sizeof(uint32_t), st));
+    launch_k0_pairs(st, false, c->ds, NP, cell, map_w, map_h, t_cnt.as<uint32_t>(), nullptr, nullptr, t_n.as<uint32_t>() + 1);
+    uint32_t n_pairs = 0;
+    BUF_TRY(scan_total_u32(c, t_cnt.as<uint32_t>(), t_off.as<uint32_t>(), (size_t)NP + 1, n_pairs, "(cell, polyline) entries of the grids"));
+    BUF_TRY(g_off.ensure(sizeof(uint32_t) * ((size_t)total_cells + 1)));
+    uint32_t n_unique = 0;
+    if (n_pairs) {
+      BUF_TRY(t_keys.ensure(sizeof(unsigned long long) * (size_t)n_pairs));
+      BUF_TRY(t_keys2.ensure(sizeof(unsigned long long) * (size_t)n_pairs));
+      launch_k0_pairs(st, true, c->ds, NP, cell, map_w, map_h, nullptr, t_off.as<uint32_t>(), t_keys.as<unsigned long long>(), nullptr);
+      int end_bit = EG3D_K0_PL_BITS_HOST;
+      while (end_bit < 64 && (total_cells >> (end_bit - EG3D_K0_PL_BITS_HOST)) != 0) end_bit++;
+      size_t tmp = 0;
+      HIP_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, t_keys.as<unsigned long long>(), t_keys2.as<unsigned long long>(),
+                                                (int)n_pairs, 0, end_bit, st));
+      BUF_TRY(c->b_scan_tmp.ensure(tmp));
+      HIP_TRY(hipcub::DeviceRadixSort::SortKeys(c->b_scan_tmp.p, tmp, t_keys.as<unsigned long long>(), t_keys2.as<unsigned long long>(),
+                                                (int)n_pairs, 0, end_bit, st));
+      tmp = 0;
+      HIP_TRY(hipcub::DeviceSelect::Unique(nullptr, tmp, t_keys2.as<unsigned long long>(), t_keys.as<unsigned long long>(),
+                                           t_n.as<uint32_t>(), (int)n_pairs, st));
+      BUF_TRY(c->b_scan_tmp.ensure(tmp));
+      HIP_TRY(hipcub::DeviceSelect::Unique(c->b_scan_tmp.p, tmp, t_keys2.as<unsigned long long>(), t_keys.as<unsigned long long>(),
+                                           t_n.as<uint32_t>(), (int)n_pairs, st));
+      Readback rb(c);
+      const int in = rb.add(t_n.p, 2);
+      BUF_TRY(rb.run());
+      n_unique = rb.item(in)[0];
+      if (which == 1) c->grid_dropped = rb.item(in)[1];  // (both cell sizes have been counted by now)
+    }
+    BUF_TRY(g_ids.ensure(sizeof(uint32_t) * std::max<size_t>(n_unique, 1)));
+    if (n_unique)
+      launch_k0_csr(st, t_keys.as<unsigned long long>(), n_unique, (uint32_t)total_cells, g_off.as<uint32_t>(), g_ids.as<uint32_t>());
+    else
+      HIP_TRY(hipMemsetAsync(g_off.p, 0, sizeof(uint32_t) * ((size_t)total_cells + 1), st));
+    c->hg->d_off[which] = g_off.as<uint32_t>();
+    c->hg->d_ids[which] = g_ids.as<uint32_t>();
+    c->hg->cells_per_view[which] = (uint32_t)(map_w * map_h);
+  }
+  HIP_TRY(hipStreamSynchronize(st));  // the temporaries go away
+  return EG3D_OK;
+}
+
 extern "C" int eg3d_dlt_rows(void) { return EG3D_DLT_ROWS; }
 
 extern "C" int eg3d_device_count(void) {
@@ -558,10 +636,33 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
     UP(b_bb, bb.data(), bb.size());
     HIP_TRY(hipStreamSynchronize(c->stream));  // `bbo` / `bb` go out of scope
   }
-  // grids: built on the host (row a3), one CSR over (view, cell) per cell size. The 2 x V builds are independent
-  // (polyLine_2d_map.cpp:40-58 constructs one map per view): they run on a few host threads — serially this was 2x the
-  // whole hot path of a dtu006-sized job (round-5 VERDICT: 90 ms for C3', 0.87 s for C4).
-  {
+#undef UP
+  DevScene& d = c->ds;
+  d.n_views = V;
+  d.width = sc->width;
+  d.height = sc->height;
+  d.cam_P = c->b_camP.as<float>();
+  d.F = c->b_F.as<double>();
+  d.F_valid = c->b_Fv.as<uint8_t>();
+  d.view_pl_off = c->b_vpo.as<uint32_t>();
+  d.pl_vtx_off = c->b_pvo.as<uint32_t>();
+  d.vtx = c->b_vtx.as<f2>();
+  d.pl_start = c->b_pls.as<uint32_t>();
+  d.pl_end = c->b_ple.as<uint32_t>();
+  d.pl_bb_off = c->b_bbo.as<uint32_t>();
+  d.pl_bb = c->b_bb.as<float>();
+  // grids (row a3), one CSR over (view, cell) per cell size: built on the DEVICE (K0, build_grids_device) from the polylines
+  // just uploaded. EG3D_GRID_ON_HOST=1 (diagnostic) runs the host builder instead — the 2 x V builds are independent
+  // (polyLine_2d_map.cpp:40-58 constructs one map per view), so they run on a few host threads; serially, as until round 5,
+  // this was 2x the whole hot path of a dtu006-sized job (90 ms for C3', 0.87 s for C4).
+  c->hg->device = device;
+  c->hg->n_views = V;
+  if (!c->tune.grid_on_host) {
+    if ((rc = build_grids_device(c, NP)) != EG3D_OK) {
+      eg3d_destroy(c);
+      return rc;
+    }
+  } else {
     struct GridJob {
       uint32_t w = 0, h = 0, dropped = 0, *o = nullptr, *i = nullptr;
       int rc = 0;
@@ -588,16 +689,25 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
     }
     bool ok = true;
     for (auto& g : jobs) ok = ok && g.rc == 0;
-    // the per-view arrays become the context's host copies (eg3d_get_grid) as they are; the device CSR over (view, cell)
-    // is assembled from them on the same threads
-    for (int which = 0; which < 2; which++) {
-      c->hg->h_off[which].assign((size_t)V, nullptr);
-      c->hg->h_ids[which].assign((size_t)V, nullptr);
-      for (int v = 0; v < V; v++) {
-        GridJob& g = jobs[(size_t)(which == 0 ? V + v : v)];
-        c->hg->h_off[which][(size_t)v] = g.o;
-        c->hg->h_ids[which][(size_t)v] = g.i;
+    // the per-view arrays are copied for eg3d_get_grid; the device CSR over (view, cell) is assembled on the same threads
+    struct FreeJobs {
+      std::vector<GridJob>& j;
+      ~FreeJobs() {
+        for (auto& g : j) {
+          free(g.o);
+          free(g.i);
+        }
       }
+    } free_jobs{jobs};
+    for (int which = 0; which < 2 && ok; which++) {
+      c->hg->h_off[which].resize((size_t)V);
+      c->hg->h_ids[which].resize((size_t)V);
+      for (int v = 0; v < V; v++) {
+        const GridJob& g = jobs[(size_t)(which == 0 ? V + v : v)];
+        c->hg->h_off[which][(size_t)v].assign(g.o, g.o + (size_t)g.w * g.h + 1);
+        c->hg->h_ids[which][(size_t)v].assign(g.i, g.i + g.o[(size_t)g.w * g.h]);
+      }
+      c->hg->have[which] = true;
     }
     for (int which = 0; which < 2 && ok; which++) {
       std::vector<size_t> id_base((size_t)V + 1, 0), off_base((size_t)V + 1, 0);
@@ -658,19 +768,6 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
       return rc;
     }
   }
-#undef UP
-  DevScene& d = c->ds;
-  d.n_views = V;
-  d.width = sc->width;
-  d.height = sc->height;
-  d.cam_P = c->b_camP.as<float>();
-  d.F = c->b_F.as<double>();
-  d.F_valid = c->b_Fv.as<uint8_t>();
-  d.view_pl_off = c->b_vpo.as<uint32_t>();
-  d.pl_vtx_off = c->b_pvo.as<uint32_t>();
-  d.vtx = c->b_vtx.as<f2>();
-  d.pl_start = c->b_pls.as<uint32_t>();
-  d.pl_end = c->b_ple.as<uint32_t>();
   d.g30_w = (int)c->gw[0];
   d.g30_h = (int)c->gh[0];
   d.g4_w = (int)c->gw[1];
@@ -679,8 +776,6 @@ extern "C" int eg3d_create(const eg3d_scene* sc, int device, eg3d_ctx** out) {
   d.g30_ids = c->b_g30i.as<uint32_t>();
   d.g4_off = c->b_g4o.as<uint32_t>();
   d.g4_ids = c->b_g4i.as<uint32_t>();
-  d.pl_bb_off = c->b_bbo.as<uint32_t>();
-  d.pl_bb = c->b_bb.as<float>();
   {
     bool mid = true;
     for (size_t v = 0; v < (size_t)V && mid; v++)
@@ -848,10 +943,31 @@ extern "C" int eg3d_get_grid(eg3d_ctx* c, int view, int which, uint32_t* ncols, 
     g_err = "eg3d_get_grid: bad arguments";
     return EG3D_ERR_ARG;
   }
+  HostGrids& hg = *c->hg;
+  {
+    std::lock_guard<std::mutex> lk(hg.mu);
+    if (!hg.have[which]) {  // first request for this cell size: fetch the device CSR and cut it into per-view CSRs
+      HIP_TRY(hipSetDevice(hg.device));
+      const size_t cpv = hg.cells_per_view[which], V = (size_t)hg.n_views;
+      std::vector<uint32_t> off(V * cpv + 1);
+      HIP_TRY(hipMemcpy(off.data(), hg.d_off[which], sizeof(uint32_t) * off.size(), hipMemcpyDeviceToHost));
+      std::vector<uint32_t> all(std::max<size_t>(off.back(), 1));
+      if (off.back()) HIP_TRY(hipMemcpy(all.data(), hg.d_ids[which], sizeof(uint32_t) * off.back(), hipMemcpyDeviceToHost));
+      hg.h_off[which].resize(V);
+      hg.h_ids[which].resize(V);
+      for (size_t v = 0; v < V; v++) {
+        const uint32_t base = off[v * cpv];
+        hg.h_off[which][v].resize(cpv + 1);
+        for (size_t cc = 0; cc <= cpv; cc++) hg.h_off[which][v][cc] = off[v * cpv + cc] - base;
+        hg.h_ids[which][v].assign(all.begin() + base, all.begin() + off[(v + 1) * cpv]);
+      }
+      hg.have[which] = true;
+    }
+  }
   *ncols = c->gw[which];
   *nrows = c->gh[which];
-  *cell_off = c->hg->h_off[which][(size_t)view];
-  *ids = c->hg->h_ids[which][(size_t)view];
+  *cell_off = hg.h_off[which][(size_t)view].data();
+  *ids = hg.h_ids[which][(size_t)view].data();
   return EG3D_OK;
 }
 

@@ -107,6 +107,12 @@ void launch_k3b(hipStream_t st, DevScene s, StageAView a, const TaskDesc* tasks,
                 const int32_t* map_view, const uint32_t* map_entry, const uint32_t* map_n, ChainLayout L,
                 unsigned char* slices, SlotPools pools, StageBuf stage, ChainOut* outs, uint32_t* out_points,
                 uint32_t* out_obs, Counters* ctr, const uint32_t* order, int scene_class /* polylines of <= 512 vertices: 0 small (<= 28 views) or 2 many views (>= 29); 1 general: the build of the kernel without the paths such a scene cannot reach */);
+#define EG3D_K0_PL_BITS_HOST 19 /* = EG3D_K0_PL_BITS (static_assert in eg3d_kernels.hip) */
+// K0: the uniform grids on the device (eg3d_kernels.hip). fill = false counts the (cell, polyline) pairs of every polyline
+// into cnt[g]; fill = true writes them as 64-bit keys (view * cells + cell) << 19 | polyline behind off[g].
+void launch_k0_pairs(hipStream_t st, bool fill, DevScene s, uint32_t n_pl, float cell_dim, int map_w, int map_h, uint32_t* cnt,
+                     const uint32_t* off, unsigned long long* keys, uint32_t* dropped);
+void launch_k0_csr(hipStream_t st, const unsigned long long* keys, uint32_t n, uint32_t total_cells, uint32_t* off, uint32_t* ids);
 void launch_collect_overflow(hipStream_t st, const ChainOut* outs, const uint32_t* order, uint32_t n, uint32_t* redo,
                              uint32_t* n_redo, Counters* ctr);
 void launch_chain_cost(hipStream_t st, StageAView a, const TaskDesc* tasks, const ChainSeed* chains, uint32_t n_chains,

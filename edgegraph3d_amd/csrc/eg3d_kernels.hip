@@ -100,6 +100,87 @@ __global__ void k1_count_raw(DevScene s, SeedsDev sd, uint32_t sv_base, uint32_t
   raw_cnt[sv] = n;
 }
 
+// ------------------------------------------------------------------ K0 ---------
+// Uniform-grid construction on the device (round 6). Behaviour reproduced: PolyLine2DMap ctor +
+// polyline::get_intersectedcells_2dmap_set (matching/plg_matching/polyLine_2d_map.cpp:40-58, plgs/polyline_graph_2d.cpp:
+// 555-577,819-835): every polyline is sampled from its start every cell / (1.414 + 0.1) px (Euclidean stepping: the walk of
+// eg3d_dev_geom.h, the one the kernels use everywhere), samples on a cell boundary are dropped, and each remaining sample's
+// cell lists the polyline once. Own design: one lane walks one polyline and emits 64-bit keys (view, cell, polyline) — first
+// counted, then written behind an exclusive scan —, a radix sort + unique of the keys IS the per-cell ascending id list,
+// and one pass over the unique keys writes the CSR offsets. (host/grid_build.cpp is the same statement for one view on the
+// host: the tests compare the two, and both with the oracle.)
+#define EG3D_K0_PL_BITS 19 /* a view holds <= 524 288 polylines (eg3d_create refuses more) */
+static_assert(EG3D_K0_PL_BITS == EG3D_K0_PL_BITS_HOST, "key layout of the grid builder");
+template <bool FILL>
+__global__ void k0_grid_pairs(DevScene s, uint32_t n_pl, float cell_dim, int map_w, int map_h, uint32_t* cnt, const uint32_t* off,
+                              unsigned long long* keys, uint32_t* dropped) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_pl) return;
+  const uint32_t a = s.pl_vtx_off[g], b = s.pl_vtx_off[g + 1];
+  uint32_t count = 0;
+  if (b - a >= 2) {  // (an invalidated polyline has no vertices on the device)
+    uint32_t lo = 0, hi = (uint32_t)s.n_views;  // view of polyline g: last v with view_pl_off[v] <= g
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (s.view_pl_off[mid] <= g) lo = mid; else hi = mid;
+    }
+    const unsigned long long cell_base = (unsigned long long)lo * (unsigned long long)((uint32_t)map_w * (uint32_t)map_h);
+    const unsigned long long pl_local = g - s.view_pl_off[lo];
+    PlRef pl;
+    pl.v = s.vtx + a;
+    pl.n = b - a;
+    pl.start = s.pl_start[g];
+    pl.end = s.pl_end[g];
+    const float step = (float)(cell_dim / (1.414 + 0.1));
+    const uint32_t direction = pl.end;  // get_other_end(start): end, which equals start for loops (the walk stops at once: Q8)
+    const uint32_t base = FILL ? off[g] : 0u;
+    bool have_prev = false, pushed = false;
+    int32_t prev_c = 0, prev_r = 0;
+    uint32_t n_dropped = 0;
+    auto visit = [&](const PlPt& p) {
+      const CellCoord cc = cell_of(cell_dim, p.x, p.y);
+      if (cc.bx || cc.by) return;
+      if (have_prev && pushed && cc.col == prev_c && cc.row == prev_r) return;
+      if (cc.col < 0 || cc.col >= map_w || cc.row < 0 || cc.row >= map_h) {
+        n_dropped++;  // the reference indexes out of bounds here; inputs must keep vertices inside the image
+      } else {
+        if (FILL) keys[base + count] = ((cell_base + (unsigned long long)(cc.row * map_w + cc.col)) << EG3D_K0_PL_BITS) | pl_local;
+        count++;
+        pushed = true;
+      }
+      prev_c = cc.col;
+      prev_r = cc.row;
+      have_prev = true;
+    };
+    PlPt cur;
+    cur.seg = 0;
+    cur.x = pl.v[0].x;
+    cur.y = pl.v[0].y;
+    visit(cur);
+    for (;;) {
+      PlPt nx;
+      const uint32_t w = walk_by_distance(pl, cur, direction, step, nx);
+      visit(nx);
+      cur = nx;
+      if (w & WALK_EXTREME) break;
+    }
+    if (!FILL && n_dropped) atomicAdd(dropped, n_dropped);
+  }
+  if (!FILL) cnt[g] = count;
+}
+// unique sorted keys -> CSR over (view, cell): off[c] = first key whose cell is >= c, ids = the polyline ids
+__global__ void k0_grid_csr(const unsigned long long* keys, uint32_t n, uint32_t total_cells, uint32_t* off, uint32_t* ids) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long k = keys[i];
+  const uint32_t cell = (uint32_t)(k >> EG3D_K0_PL_BITS);
+  ids[i] = (uint32_t)(k & ((1ull << EG3D_K0_PL_BITS) - 1ull));
+  const uint32_t first = i ? (uint32_t)(keys[i - 1] >> EG3D_K0_PL_BITS) + 1u : 0u;
+  for (uint32_t c = first; c <= cell; c++) off[c] = i;
+  if (i == n - 1)
+    for (uint32_t c = cell + 1; c <= total_cells; c++) off[c] = n;
+}
+
 // ------------------------------------------------------------------ K1 ---------
 // One wavefront per (seed, track entry). Lanes 0..8 each own one grid cell of the (shrunk)
 // 3x3 window and k-way-merge the ascending id lists (wave-min of the heads) so candidates
@@ -1775,6 +1856,18 @@ int k3c_dbg_read(unsigned long long* out, int reset) {  // out[128]: g_k3c_dbg[3
   return 0;
 }
 #endif
+void launch_k0_pairs(hipStream_t st, bool fill, DevScene s, uint32_t n_pl, float cell_dim, int map_w, int map_h, uint32_t* cnt,
+                     const uint32_t* off, unsigned long long* keys, uint32_t* dropped) {
+  if (!n_pl) return;
+  if (fill)
+    hipLaunchKernelGGL(k0_grid_pairs<true>, blocks_for(n_pl, 64), dim3(64), 0, st, s, n_pl, cell_dim, map_w, map_h, cnt, off, keys, dropped);
+  else
+    hipLaunchKernelGGL(k0_grid_pairs<false>, blocks_for(n_pl, 64), dim3(64), 0, st, s, n_pl, cell_dim, map_w, map_h, cnt, off, keys, dropped);
+}
+void launch_k0_csr(hipStream_t st, const unsigned long long* keys, uint32_t n, uint32_t total_cells, uint32_t* off, uint32_t* ids) {
+  if (!n) return;
+  hipLaunchKernelGGL(k0_grid_csr, blocks_for(n, 256), dim3(256), 0, st, keys, n, total_cells, off, ids);
+}
 void launch_collect_overflow(hipStream_t st, const ChainOut* outs, const uint32_t* order, uint32_t n, uint32_t* redo,
                              uint32_t* n_redo, Counters* ctr) {
   if (!n) return;

@@ -165,7 +165,8 @@ void eg3d_destroy(eg3d_ctx* ctx);
 int eg3d_clone(eg3d_ctx* parent, eg3d_ctx** out);
 
 /* which: 0 = 30 px candidate grid, 1 = 4 px expand-all-views grid. Pointers stay
- * valid until eg3d_destroy. cell index = row*ncols + col. */
+ * valid until eg3d_destroy. cell index = row*ncols + col. (The grids are built and kept on the device; the first call for a
+ * cell size copies that grid to the host.) */
 int eg3d_get_grid(eg3d_ctx* ctx, int view, int which, uint32_t* ncols, uint32_t* nrows,
                   const uint32_t** cell_off, const uint32_t** ids);
 

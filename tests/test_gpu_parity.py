@@ -475,3 +475,44 @@ def test_scenes_built_from_edge_images_parity():
         assert got["n_points"] > 1000, name
         assert (got["flags"] & 7) == 0
         ctx.close()
+
+
+def test_device_grids_equal_the_host_builder(have_gpu, monkeypatch):
+    """K0 (round 6): eg3d_create builds both uniform grids on the device — one lane walks one polyline and emits
+    (view, cell, polyline) keys; sort + unique + one CSR pass. The host builder (eg3d_host_build_grid: the same walk, one
+    view at a time; what rounds 1-5 shipped) and the oracle are the statement it must reproduce exactly: the C2 scene, a
+    quarter of C3', and mutated fuzz scenes (loops, invalidated polylines that keep their vertices, small images), every
+    view, both cell sizes; EG3D_GRID_ON_HOST=1 (the diagnostic host path) gives the same context."""
+    import ctypes as C
+    from fuzz_scenes import draw
+    scenes = [(host.Synth(2).scene, "C2", None)]
+    s3 = host.Synth(3)
+    scenes.append((s3.scene, "C3'", range(0, s3.n_views, 4)))
+    keep = [s3]
+    for case in (1, 3, 6, 9, 20, 33):
+        _, sa, _ = draw(case)
+        keep.append(sa)
+        scenes.append((C.byref(sa.c), "fuzz %d" % case, None))
+    for scene, name, views in scenes:
+        ctx = api.Context(scene)
+        sc = scene.contents if hasattr(scene, "contents") else scene._obj
+        for v in (views if views is not None else range(int(sc.n_views))):
+            for which, cell in ((0, 30.0), (1, 4.0)):
+                a = ctx.grid(v, which)
+                ncols, nrows, off, ids, _ = host.build_grid(scene, v, cell)
+                assert a[0] == ncols and a[1] == nrows, (name, v, which)
+                assert np.array_equal(a[2], off) and np.array_equal(a[3], ids), (name, v, which)
+        ctx.close()
+    monkeypatch.setenv("EG3D_GRID_ON_HOST", "1")
+    s = host.Synth(1)
+    ch = api.Context(s.scene)
+    monkeypatch.delenv("EG3D_GRID_ON_HOST")
+    cd = api.Context(s.scene)
+    for v in range(s.n_views):
+        for which in (0, 1):
+            a, b = ch.grid(v, which), cd.grid(v, which)
+            assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    ref = _oracle(s.scene).match(s.seeds, 0, s.n_seeds, nthreads=8)
+    assert compare_edgepoints(ref, ch.match_refpoints(s.seeds))["ok"]
+    ch.close()
+    cd.close()
