@@ -261,6 +261,7 @@ struct eg3d_ctx {
   std::vector<eg3d_ctx*> lanes;
   bool is_lane = false;
   uint32_t host_calls = 0;  // eg3d_match_* calls with device_only == 0 this context has completed (lanes_for)
+  uint64_t last_host_cloud_bytes = 0;  // ... and the size of the last one's cloud
 };
 
 // D2H ring of a context: EG3D_D2H_RING pinned buffers of `ring_chunk` bytes (run_stage_b) — 16 MB each for a cloud worth it,
@@ -2042,7 +2043,10 @@ static int finish_match(eg3d_ctx* c, CallSink& S, float total, eg3d_edgepoints* 
   out->flags = H.flags;
   c->last_chunks = H.pieces;
   c->last_accumulated = device_only != 0;
-  if (!device_only) c->host_calls++;
+  if (!device_only) {
+    c->host_calls++;
+    c->last_host_cloud_bytes = 36 * S.n_points + 20 * S.n_obs;
+  }
   if (device_only) {
     c->last_np = S.n_points;
     c->last_no = S.n_obs;
@@ -2106,7 +2110,8 @@ static int lanes_for(const eg3d_ctx* c, int device_only) {
   // 17 GB per lane (C4) for a 3 % gain with the copy and a loss without — such scenes stay on the context alone
   const size_t arena = chain_layout(c->chain_cap, c->pool_cap, (uint32_t)c->V).total * 8 * (size_t)c->slots_per_xcd;
   if (arena > ((size_t)4 << 30)) return 1;
-  return c->host_calls > 0 ? Tunables::kHostCallLanes : 1;
+  // ... and a small cloud has no copy worth hiding (C3-real, 0.3 MB: 3.3 ms uncut, 5.1 ms on three lanes)
+  return c->host_calls > 0 && c->last_host_cloud_bytes >= ((uint64_t)4 << 20) ? Tunables::kHostCallLanes : 1;
 }
 
 // Units of a seed range. One lane: batches of 16 384 seeds (one expand launch each), as before round 6. Several lanes:

@@ -10,6 +10,7 @@
 // PrettyWriter produces for the same document (json_text.hpp): floats through Grisu2 + its notation rule,
 // numbers copied from the input re-printed from the reader's verdict on them, strings decoded and re-escaped —
 // checked byte for byte against the reference tree's vendored rapidjson (tests/test_json_rapidjson.py).
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -20,6 +21,10 @@
 #include <sstream>
 #include <string>
 #include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "../../include/eg3d_host.h"
 #include "camera_model.hpp"
@@ -621,6 +626,63 @@ extern "C" eg3d_sfm* eg3d_sfm_read_json(const char* path) {
 }
 
 static int sfm_write_json_impl(const eg3d_sfm* s, const char* in_path, const char* out_path);
+// The text write_val prints for points [i0, i1) of the "structure" array (elements at indent level 2, 4 spaces per level),
+// without building the document: "key" = the point's index, "X" = its coordinates, one observation object per track entry
+// ("key" = view, "value": {"id_feat": 0, "x": [x, y]}). Numbers are the writer's text of the float widened to double (the
+// document path prints normalize_number(double_text(d)), which is the identity on double_text's output: Grisu text reads
+// back to the same double — tests/test_host_io.py checks it on random floats).
+static void structure_text(const eg3d_sfm* s, size_t i0, size_t i1, size_t n_total, std::string& out, bool& nonfinite) {
+  out.clear();
+  out.reserve((i1 - i0) * 2048);
+  auto ind = [&](int n) { out.append((size_t)n * 4, ' '); };
+  auto num = [&](float v) {
+    const double d = (double)v;
+    if (!(d == d) || d > 1.7e308 || d < -1.7e308) {
+      nonfinite = true;
+      out += "null";
+    } else {
+      out += eg3d_json::double_text(d);
+    }
+  };
+  auto integer = [&](long long v) {
+    char buf[24];
+    const int k = snprintf(buf, sizeof(buf), "%lld", v);
+    out.append(buf, (size_t)k);
+  };
+  for (size_t i = i0; i < i1; i++) {
+    ind(2); out += "{\n";
+    ind(3); out += "\"key\": "; integer((long long)i); out += ",\n";
+    ind(3); out += "\"value\": {\n";
+    ind(4); out += "\"X\": [\n";
+    for (int k = 0; k < 3; k++) {
+      ind(5); num(s->X[3 * i + k]); out += k < 2 ? ",\n" : "\n";
+    }
+    ind(4); out += "],\n";
+    ind(4); out += "\"observations\": ";
+    const uint32_t a = s->trk_off[i], b = s->trk_off[i + 1];
+    if (a == b) {
+      out += "[]\n";
+    } else {
+      out += "[\n";
+      for (uint32_t j = a; j < b; j++) {
+        ind(5); out += "{\n";
+        ind(6); out += "\"key\": "; integer(s->trk_view[j]); out += ",\n";
+        ind(6); out += "\"value\": {\n";
+        ind(7); out += "\"id_feat\": 0,\n";
+        ind(7); out += "\"x\": [\n";
+        ind(8); num(s->trk_xy[2 * j]); out += ",\n";
+        ind(8); num(s->trk_xy[2 * j + 1]); out += "\n";
+        ind(7); out += "]\n";
+        ind(6); out += "}\n";
+        ind(5); out += j + 1 < b ? "},\n" : "}\n";
+      }
+      ind(4); out += "]\n";
+    }
+    ind(3); out += "}\n";
+    ind(2); out += i + 1 < n_total ? "},\n" : "}\n";
+  }
+}
+
 extern "C" int eg3d_sfm_write_json(const eg3d_sfm* s, const char* in_path, const char* out_path) {
   try {
     return sfm_write_json_impl(s, in_path, out_path);
@@ -720,37 +782,63 @@ static int sfm_write_json_impl(const eg3d_sfm* s, const char* in_path, const cha
     ex.a.push_back(e);
   }
   root.o.emplace_back("extrinsics", ex);
-  JVal st;
-  st.t = JVal::ARR;
-  const size_t n = s->X.size() / 3;
-  for (size_t i = 0; i < n; i++) {
-    JVal p, val, X, obs;
-    p.t = val.t = JVal::OBJ;
-    X.t = obs.t = JVal::ARR;
-    for (int k = 0; k < 3; k++) X.a.push_back(jnum(s->X[3 * i + k]));
-    for (uint32_t j = s->trk_off[i]; j < s->trk_off[i + 1]; j++) {
-      JVal o, ov, x;
-      o.t = ov.t = JVal::OBJ;
-      x.t = JVal::ARR;
-      x.a.push_back(jnum(s->trk_xy[2 * j]));
-      x.a.push_back(jnum(s->trk_xy[2 * j + 1]));
-      ov.o.emplace_back("id_feat", jint(0));
-      ov.o.emplace_back("x", x);
-      o.o.emplace_back("key", jint(s->trk_view[j]));
-      o.o.emplace_back("value", ov);
-      obs.a.push_back(o);
-    }
-    val.o.emplace_back("X", X);
-    val.o.emplace_back("observations", obs);
-    p.o.emplace_back("key", jint((long long)i));
-    p.o.emplace_back("value", val);
-    st.a.push_back(p);
-  }
-  root.o.emplace_back("structure", st);
   copy_or("control_points", empty_arr);
+  // ---- the file. Everything but "structure" is small and goes through the document writer; the structure — one entry per
+  // point, 5 KB of text each with its observations: 1.7 GB for a dtu006-sized cloud — is STREAMED: the text write_val
+  // would print for it is generated straight from the arrays, chunk by chunk on the host's cores, and written in order.
+  // (Until round 6 the structure was built as a document tree first — a std::string per number, a deep copy per
+  // push_back — and every number went text -> strtod -> text again on its way out: 15 s for that file, 160x the GPU's
+  // share of the run. Same bytes: tests/test_json_rapidjson.py, tests/test_host_io.py.)
   std::ofstream f(out_path, std::ios::binary);
   if (!f) return -1;
-  write_val(f, root, 0);
-  if (g_nonfinite_written) return -2;  // a NaN / infinite coordinate was written as null: not a valid SfM file
+  f << "{\n";
+  const JVal control_points = root.o.back().second;
+  root.o.pop_back();
+  for (auto& kv : root.o) {
+    indent(f, 1);
+    f << '"' << eg3d_json::escape_string(kv.first) << "\": ";
+    write_val(f, kv.second, 1);
+    f << ",\n";
+  }
+  indent(f, 1);
+  f << "\"structure\": ";
+  const size_t n = s->X.size() / 3;
+  bool nonfinite = false;
+  if (!n) {
+    f << "[]";
+  } else {
+    f << "[\n";
+    const size_t CH = 256;  // points per chunk
+    const size_t n_chunks = (n + CH - 1) / CH;
+    int threads = 1;
+#ifdef _OPENMP
+    threads = std::max(1, std::min(omp_get_max_threads(), 32));
+#endif
+    const size_t wave = (size_t)threads * 2;
+    std::vector<std::string> text(wave);
+    std::vector<char> bad(wave, 0);
+    for (size_t c0 = 0; c0 < n_chunks; c0 += wave) {
+      const size_t c1 = std::min(n_chunks, c0 + wave);
+#pragma omp parallel for schedule(dynamic, 1)
+      for (long long c = (long long)c0; c < (long long)c1; c++) {
+        bool nf = false;
+        structure_text(s, (size_t)c * CH, std::min(n, ((size_t)c + 1) * CH), n, text[(size_t)c - c0], nf);
+        bad[(size_t)c - c0] = nf ? 1 : 0;
+      }
+      for (size_t c = c0; c < c1; c++) {
+        f.write(text[c - c0].data(), (std::streamsize)text[c - c0].size());
+        nonfinite = nonfinite || bad[c - c0];
+      }
+      if (!f.good()) return -1;
+    }
+    indent(f, 1);
+    f << "]";
+  }
+  f << ",\n";
+  indent(f, 1);
+  f << "\"control_points\": ";
+  write_val(f, control_points, 1);
+  f << "\n}";
+  if (g_nonfinite_written || nonfinite) return -2;  // a NaN / infinite coordinate was written as null: not a valid SfM file
   return f.good() ? 0 : -1;
 }

@@ -38,6 +38,7 @@
 // The polyline graphs travel in a container file so that the expensive one-off construction from the
 // edge images (--make-plgs) is separate from the matching run. Build (see tests/test_gpu_edge_cases.py):
 //   g++ -std=c++17 -I include examples/edge_matcher_refpoints.cpp -Ledgegraph3d_amd -leg3d -leg3d_host ...
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -176,18 +177,12 @@ static int make_synthetic(int cfg_index, const std::string& dir) {
 static int make_plgs(const char* out_path, int n, char** images) {
   std::vector<eg3d_plg_view> views((size_t)n);
   int W = 0, H = 0;
-  for (int i = 0; i < n; i++) {
-    int w = 0, h = 0;
-    if (eg3d_plg_build_from_png(images[i], &w, &h, &views[(size_t)i]) != 0) {
-      std::fprintf(stderr, "edge_matcher_refpoints: cannot build the polyline graph of %s\n", images[i]);
-      return 1;
-    }
-    if (i && (w != W || h != H)) {
-      std::fprintf(stderr, "edge_matcher_refpoints: %s is %dx%d, the first image %dx%d\n", images[i], w, h, W, H);
-      return 1;
-    }
-    W = w;
-    H = h;
+  // all views at once, on the host's cores (the views are independent)
+  const int bad = eg3d_plg_build_views_from_png(images, n, &W, &H, views.data());
+  if (bad != 0) {
+    std::fprintf(stderr, "edge_matcher_refpoints: cannot build the polyline graph of %s (unreadable, or not the size of the first image)\n",
+                 bad < 0 && -bad - 1 < n ? images[-bad - 1] : "?");
+    return 1;
   }
   eg3d_plg* g = eg3d_plg_from_views(n, W, H, views.data());
   uint64_t n_pl = 0;
@@ -218,11 +213,24 @@ int main(int argc, char** argv) {
     else if (std::strcmp(argv[a], "--sets2") == 0 && a + 1 < argc) sets_path[1] = argv[++a];
   }
 
+  // wall time of every stage of the run, host stages included (--times prints them; stderr)
+  bool print_times = false;
+  for (int a = 4; a < argc; a++) print_times |= std::strcmp(argv[a], "--times") == 0;
+  auto t_last = std::chrono::steady_clock::now();
+  const auto t_begin = t_last;
+  auto lap = [&](const char* what) {
+    const auto now = std::chrono::steady_clock::now();
+    if (print_times)
+      std::fprintf(stderr, "[time] %-44s %9.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   // ---- inputs (edge_matcher.cpp:64-95)
   eg3d_sfm* sfm = eg3d_sfm_read_json(argv[1]);
+  lap("read the OpenMVG JSON");
   if (!sfm) return fail("reading the OpenMVG file");
   eg3d_plg* plg = eg3d_plg_read(argv[2]);
   if (!plg) return fail("reading the polyline graphs");
+  lap("read the polyline graphs");
   const int V = eg3d_sfm_n_views(sfm);
   eg3d_scene sc = *eg3d_plg_scene(plg);
   if (sc.n_views != V) return fail("views of the SfM file and of the polyline graphs differ");
@@ -249,8 +257,10 @@ int main(int argc, char** argv) {
   sc.F_valid = Fv.data();
   const uint64_t first_edgepoint = eg3d_sfm_n_points(sfm);
 
+  lap("fundamental matrices");
   eg3d_ctx* ctx = nullptr;
   if (eg3d_create(&sc, 0, &ctx) != EG3D_OK) return fail("eg3d_create");
+  lap("eg3d_create (incl. HIP runtime start-up)");
   Cloud all_stages;
   eg3d_stage_times tm;
   // ---- pipelines 1 and 2 (pipelines.cpp:219-223): the extractor over the polyline matches of each stage, in
@@ -278,17 +288,21 @@ int main(int argc, char** argv) {
     if (eg3d_match_refpoints(ctx, &seeds, 0, seeds.n_seeds, 0, &e, &tm) != EG3D_OK) return fail("eg3d_match_refpoints");
     std::printf("matched %u reference points -> %llu edge-points (%llu observations) in %.2f ms on the GPU\n", seeds.n_seeds,
                 (unsigned long long)e.n_points, (unsigned long long)e.n_obs, tm.ms_total);
+    lap("eg3d_match_refpoints (first call, with the copy)");
     all_stages.append(e);
     eg3d_free_edgepoints(&e);
+    lap("append to the run's cloud");
   }
   eg3d_edgepoints pts = all_stages.view_as_edgepoints();
 
   // ---- filter_3d_points_close_2d_array + add_3dpoints_to_sfmd (pipelines.cpp:236-239; edge_matcher.cpp:150-158)
   std::vector<uint8_t> keep(pts.n_points ? pts.n_points : 1);
   if (eg3d_host_filter_close_2d(V, sc.width, sc.height, &pts, keep.data()) != 0) return fail("dedup");
+  lap("3 px de-duplication (filter_3d_points_close_2d_array)");
   uint64_t kept = 0;
   for (uint64_t i = 0; i < pts.n_points; i++) kept += keep[i];
   if (eg3d_sfm_add_edgepoints(sfm, &pts, keep.data()) != 0) return fail("adding the edge-points");
+  lap("add_3dpoints_to_sfmd");
   std::printf("kept %llu edge-points after the 3 px de-duplication; SfM data now holds %llu points\n",
               (unsigned long long)kept, (unsigned long long)eg3d_sfm_n_points(sfm));
 
@@ -309,11 +323,15 @@ int main(int argc, char** argv) {
     eg3d_sfm_remove_outliers(sfm, inl.data());
     std::printf("filter: %llu of %llu points kept (Gauss-Newton mse < 2.25, more than %d observations)\n",
                 (unsigned long long)n_in, (unsigned long long)n, thr);
+    lap("filter (Gauss-Newton on the GPU + observation count)");
   }
 
   // ---- output_sfm_data (edge_matcher.cpp:169)
   if (eg3d_sfm_write_json(sfm, argv[1], argv[3]) != 0) return fail("writing the output");
+  lap("write the OpenMVG JSON");
   std::printf("wrote %s (%llu points)\n", argv[3], (unsigned long long)eg3d_sfm_n_points(sfm));
+  if (print_times)
+    std::fprintf(stderr, "[time] %-44s %9.2f ms\n", "whole run", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
   eg3d_destroy(ctx);
   eg3d_plg_destroy(plg);
   eg3d_sfm_destroy(sfm);

@@ -157,16 +157,16 @@ inline bool convert_edge_images_to_optimized_polyline_graphs(const char* input_e
   plgs.clear();
   plgs.resize((size_t)sfmd.numCameras_);
   width = height = 0;
+  // the views are independent: all of them are built at once on the host's cores (eg3d_plg_build_views_from_png; one after
+  // the other — the reference's loop — 25 dtu006-sized edge maps take 3 s, sixty times the GPU's share of the whole call)
+  std::vector<std::string> paths;
+  std::vector<const char*> cpaths;
+  for (int v = 0; v < sfmd.numCameras_; v++) paths.push_back(detail::join_path(input_edges_folder, sfmd.camerasPaths_[v]));
+  for (const std::string& p : paths) cpaths.push_back(p.c_str());
+  std::vector<eg3d_plg_view> views((size_t)sfmd.numCameras_);
+  if (eg3d_plg_build_views_from_png(cpaths.data(), sfmd.numCameras_, &width, &height, views.data()) != 0) return false;
   for (int v = 0; v < sfmd.numCameras_; v++) {
-    eg3d_plg_view g;
-    int w = 0, h = 0;
-    if (eg3d_plg_build_from_png(detail::join_path(input_edges_folder, sfmd.camerasPaths_[v]).c_str(), &w, &h, &g) != 0) return false;
-    if (v && (w != width || h != height)) {
-      eg3d_plg_view_free(&g);
-      return false;
-    }
-    width = w;
-    height = h;
+    eg3d_plg_view& g = views[(size_t)v];
     PolyLineGraph2D& out = plgs[(size_t)v];
     out.polylines.resize(g.n_polylines);
     for (uint32_t p = 0; p < g.n_polylines; p++) {

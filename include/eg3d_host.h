@@ -90,6 +90,10 @@ int eg3d_plg_build_from_mask(const uint8_t* mask, int width, int height, eg3d_pl
 int eg3d_png_read_edge_mask(const char* path, int* width, int* height, uint8_t** mask);
 int eg3d_plg_build_from_png(const char* path, int* width, int* height, eg3d_plg_view* out);
 void eg3d_plg_view_free(eg3d_plg_view* v);
+/* All views of a scene, built concurrently on the host's cores (the reference builds them one after the other:
+ * convert_edge_images_pixel_to_segment.cpp:868-892). out[n_views]; 0, or -(v + 1) for the first view whose image cannot be
+ * read or differs in size from view 0's (nothing is left allocated then). */
+int eg3d_plg_build_views_from_png(const char* const* paths, int n_views, int* width, int* height, eg3d_plg_view* out);
 /* assembles per-view graphs into the container the path consumes (eg3d_plg_scene) */
 eg3d_plg* eg3d_plg_from_views(int n_views, int width, int height, const eg3d_plg_view* views);
 

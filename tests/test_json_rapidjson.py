@@ -236,7 +236,7 @@ def test_written_file_is_byte_identical_to_the_reference_writers_and_reader_inde
     extra = []
     tricky = np.array([1e-7, 1e21, 1e22, 3.4e38, 1.17549435e-38, 1e-45, 123456792.0, 0.1, 1 / 3, 2.5e-7, -0.0, 16777216.0],
                       np.float32)
-    for i in range(40):
+    for i in range(2600):   # (ten of the writer's 256-point chunks: their seams are part of the comparison)
         Xp = np.concatenate([tricky, rng.standard_normal(200).astype(np.float32) * np.float32(10) ** rng.uniform(-20, 20, 200).astype(np.float32)])
         Xp = Xp[rng.integers(0, len(Xp), 3)].astype(np.float32)
         k = int(rng.integers(2, 4))

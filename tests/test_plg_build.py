@@ -280,3 +280,51 @@ def test_random_masks_product_equals_oracle(case):
     a = host.plg_from_mask(m)
     b = ob.plg_from_mask(m)
     _same(a, b)
+
+
+def test_all_views_at_once_equals_one_view_at_a_time(tmp_path):
+    """eg3d_plg_build_views_from_png builds the views of a scene concurrently on the host's cores (the reference's loop,
+    convert_edge_images_pixel_to_segment.cpp:868-892, takes them one after the other: 3 s for 25 dtu006-sized maps). Every
+    view must be what eg3d_plg_build_from_png gives alone; a missing image or one of another size is reported by its
+    index and leaves nothing allocated."""
+    import ctypes as C
+    from edgegraph3d_amd import _cdefs as D
+    L = host.lib()
+    L.eg3d_plg_build_views_from_png.argtypes = [C.POINTER(C.c_char_p), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                                C.POINTER(D.PlgView)]
+    L.eg3d_plg_build_from_png.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(D.PlgView)]
+    L.eg3d_plg_view_free.argtypes = [C.POINTER(D.PlgView)]
+    files = sorted(glob.glob(os.path.join(EDGES, "*.png")))[:9]
+    arr = (C.c_char_p * len(files))(*[f.encode() for f in files])
+    views = (D.PlgView * len(files))()
+    w, h = C.c_int(), C.c_int()
+    assert L.eg3d_plg_build_views_from_png(arr, len(files), C.byref(w), C.byref(h), views) == 0
+    assert (w.value, h.value) == (1600, 1200)
+    for i in (0, 4, 8):
+        one, ww, hh = D.PlgView(), C.c_int(), C.c_int()
+        assert L.eg3d_plg_build_from_png(files[i].encode(), C.byref(ww), C.byref(hh), C.byref(one)) == 0
+        a, b = D.plg_view_to_dict(one), D.plg_view_to_dict(views[i])
+        assert all(np.array_equal(a[k], b[k]) for k in a), i
+        L.eg3d_plg_view_free(C.byref(one))
+    for v in views:
+        L.eg3d_plg_view_free(C.byref(v))
+    # view 2 missing -> -3; an image of another size as view 1 -> -2
+    bad = list(files[:4])
+    bad[2] = str(tmp_path / "missing.png")
+    arr = (C.c_char_p * 4)(*[f.encode() for f in bad])
+    views = (D.PlgView * 4)()
+    assert L.eg3d_plg_build_views_from_png(arr, 4, C.byref(w), C.byref(h), views) == -3
+    assert all(not v.pl_vtx_off for v in views)
+    small = str(tmp_path / "small.png")
+    raw = b"".join(b"\x00" + bytes([255 if (x + y) % 7 == 0 else 0 for x in range(40)]) for y in range(30))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+    open(small, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 40, 30, 8, 0, 0, 0, 0)) +
+                            chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+    one, ww, hh = D.PlgView(), C.c_int(), C.c_int()
+    assert L.eg3d_plg_build_from_png(small.encode(), C.byref(ww), C.byref(hh), C.byref(one)) == 0 and (ww.value, hh.value) == (40, 30)
+    L.eg3d_plg_view_free(C.byref(one))
+    arr = (C.c_char_p * 2)(files[0].encode(), small.encode())
+    views = (D.PlgView * 2)()
+    assert L.eg3d_plg_build_views_from_png(arr, 2, C.byref(w), C.byref(h), views) == -2
