@@ -2466,9 +2466,24 @@ extern "C" int eg3d_probe_sections(eg3d_ctx* c, double* sum, double* slowest, ui
   return EG3D_OK;
 }
 
+// the raw per-section sums (16 doubles: Chain::tsec) of the most recent k3b_expand launch — what the LIGHT timing builds
+// (-DEG3D_ONE_SECTION=k: section k and the whole chain only) are read through; tools/section_light.py
+extern "C" int eg3d_probe_sections_raw(eg3d_ctx* c, double* sum16, uint32_t* n_chains) {
+  if (!c || !sum16) return EG3D_ERR_ARG;
+  std::vector<ChainOut> co(c->last_nc ? c->last_nc : 1);
+  if (c->last_nc) HIP_TRY(hipMemcpy(co.data(), c->b_couts.p, sizeof(ChainOut) * c->last_nc, hipMemcpyDeviceToHost));
+  for (int k = 0; k < 16; k++) sum16[k] = 0;
+  for (uint32_t j = 0; j < c->last_nc; j++)
+    for (int k = 0; k < 16; k++) sum16[k] += (double)co[j].tsec[k];
+  if (n_chains) *n_chains = c->last_nc;
+  return EG3D_OK;
+}
+
+#ifndef EG3D_ONE_SECTION
 // Gauss-Newton diagnostics of the expand kernel since the last reset (eg3d_dev_coopgn.h g_gn_dbg)
 namespace eg3d { int gn_dbg_read(unsigned long long* out, int reset); }
 extern "C" int eg3d_probe_gn(unsigned long long* out128, int reset) { return eg3d::gn_dbg_read(out128, reset); }
+#endif
 
 extern "C" int eg3d_probe_hyp_sections(eg3d_ctx* c, double* sum, double* slowest, uint32_t* counts) {
   if (!c || !sum || !slowest || !counts) return EG3D_ERR_ARG;

@@ -963,7 +963,7 @@ EG3D_HD void sm_finish(const SmChain& q, ChainOut& out) {
   out.head = (uint32_t)c.head;
   out.bytes = c.bytes;
   out.spt = out.sobs = 0;
-  for (int k = 0; k < 12; k++) out.tsec[k] = 0;
+  for (int k = 0; k < 16; k++) out.tsec[k] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -28,8 +28,198 @@ namespace eg3d {
 #ifndef EG3D_COOP_REQ
 #define EG3D_COOP_REQ 32
 #endif
+// First iteration (0-based) of a Gauss-Newton solve that checks convergence on the residuals alone before it computes the
+// Jacobian and the normal equations (gn_round's PRE_IT; 30 = never, the round 1-5 form). Measured (round 6,
+// profiles/r06_experiments/gn_precheck_ab.txt): the many-views build gains (C4 step 1773 -> 1706 ms: its solves of ~75
+// rows are bound by row arithmetic), the small / general builds do not (C3' 43.6-43.9 -> 43.8-44.2 ms, C2 6.67 -> 6.66:
+// their rounds are bound by the dependent chain load -> row -> LDS -> ordered sum, which the shorter row does not
+// shorten, and the extra code costs 7-18 spilled registers) — so it is on for SCENE 2 only (TeamWaveT::kPreIt).
+#ifndef EG3D_GN_PRECHECK_IT
+#define EG3D_GN_PRECHECK_IT 2
+#endif
+#ifndef EG3D_GN_PRECHECK_ALL
+#define EG3D_GN_PRECHECK_ALL 0 /* 1 = every build of the expand kernel, not only the many-views one (A/B switch) */
+#endif
 #define EG3D_STAGE_VTX 512
 #define EG3D_STAGE_EPI 192
+// ---- the 2-view DLT on a GROUP OF 8 LANES (round 6) ---------------------------------------------------------------
+// The one-lane decomposition (svd4_smallest_v_mem) is a stream of ~8 000 vector instructions — ~230 per Jacobi
+// rotation, ~36 rotations — that a wavefront executes for ONE useful lane (a uniform section) or for the few
+// lanes of a look-ahead round: measured with the light timing build it was 19.5 % of k3b_expand's chain clocks on
+// C3' (profiles/r06_experiments/sections_light_c3.txt). Here lane k of the group holds ROW k of A (the four entries
+// At[0..3][k]) and, for k < 4, row k of V, in registers: a rotation's update of both columns is then ONE pass over
+// the lanes (6 instructions instead of 84 with their LDS loads and stores), and only what the arithmetic contract
+// orders — the sums over k of the dot product p and of the new squared norms a, b, which every sequential
+// implementation adds k = 0, 1, ... — goes through LDS: the lanes store their products, every lane of the group
+// reads them back and adds them in that order, starting from +0.0 as the sequential loop does. Every lane of the
+// group thus holds the same p, a, b, W[] and takes the same decisions (skip test, rotation angle, convergence):
+// same operations on the same operands in the same order as svd4_smallest_v => the same bits
+// (tests/test_gpu_arith.py compares the two forms on the seeds' triples, degenerate pairs included).
+// Eight groups per wavefront: the look-ahead rounds of chain following run their <= 8 DLTs side by side.
+struct alignas(16) DltGrpLds {
+  double s[8][4][8];  // [group][staging row][lane of the group]
+};
+// `on` = this lane's group has a DLT to do (uniform within a group of 8 lanes; the operands are too). Must be called by
+// all 64 lanes of the single-wave block. Every lane of an `on` group returns the start point.
+__device__ __forceinline__ void dlt2_grp8(DltGrpLds& S, bool on, const float* P1, float x1, float y1, const float* P2,
+                                          float x2, float y2, double X0[3]) {
+  constexpr int M = EG3D_DLT_M, R = EG3D_DLT_ROWS;
+  const int lane = (int)(threadIdx.x & 63u), g = lane >> 3, l = lane & 7;
+  double(*sg)[8] = S.s[g];
+  double ar[4] = {0, 0, 0, 0}, vr[4] = {0, 0, 0, 0};
+  if (on && l < M) {
+    const bool second = l >= R;
+    const int r = second ? l - R : l;
+    const float* P = second ? P2 : P1;
+    const double x = second ? x2 : x1, y = second ? y2 : y1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (r == 0)
+        ar[k] = x * (double)P[8 + k] - (double)P[k];
+      else if (r == 1)
+        ar[k] = y * (double)P[8 + k] - (double)P[4 + k];
+      else
+        ar[k] = x * (double)P[4 + k] - y * (double)P[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) vr[k] = (k == l) ? 1.0 : 0.0;
+  const double eps = 2.2204460492503131e-16 * 10;
+  double W[4];
+  // W[i] = sum over k of At[i][k]^2, k ascending from +0.0
+  {
+    __syncthreads();
+    if (l < M) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) sg[i][l] = ar[i] * ar[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      double sd = 0;
+#pragma unroll
+      for (int k = 0; k < M; k++) sd += sg[i][k];
+      W[i] = sd;
+    }
+  }
+  bool live = on;
+  // one rotation of columns (i, j): static indices (the columns live in registers)
+  auto rotate = [&](double& ai, double& aj, double& vi, double& vj, double& Wi, double& Wj, bool& changed) {
+    __syncthreads();
+    if (l < M) sg[0][l] = ai * aj;
+    __syncthreads();
+    double a = Wi, p = 0, b = Wj;
+#pragma unroll
+    for (int k = 0; k < M; k++) p += sg[0][k];
+    bool skip;
+    {
+      const double ab = a * b, p2 = p * p, t = (eps * eps) * ab;
+      if (t > 1e-250 && p2 > t * 1.0000001)
+        skip = false;
+      else if (t > 1e-250 && p2 < t * 0.9999999)
+        skip = true;
+      else
+        skip = absd(p) <= eps * EG3D_SQRT(ab);
+    }
+    const bool act = live && !skip;
+    if (!__any(act)) return;  // wave-uniform
+    double c = 1, sn = 0;
+    if (act) {
+      p *= 2;
+      double beta = a - b, gamma = EG3D_SQRT(p * p + beta * beta);
+      if (beta < 0) {
+        double delta = (gamma - beta) * 0.5;
+        sn = EG3D_SQRT(delta / gamma);
+        c = p / (gamma * sn * 2);
+      } else {
+        c = EG3D_SQRT((gamma + beta) / (gamma * 2));
+        sn = p / (gamma * c * 2);
+      }
+    }
+    const double t0 = c * ai + sn * aj;
+    const double t1 = c * aj - sn * ai;
+    if (l < M) {
+      sg[1][l] = t0 * t0;
+      sg[2][l] = t1 * t1;
+    }
+    __syncthreads();
+    if (act) {
+      a = 0;
+      b = 0;
+#pragma unroll
+      for (int k = 0; k < M; k++) {
+        a += sg[1][k];
+        b += sg[2][k];
+      }
+      ai = t0;
+      aj = t1;
+      Wi = a;
+      Wj = b;
+      changed = true;
+      const double u0 = c * vi + sn * vj;
+      const double u1 = c * vj - sn * vi;
+      vi = u0;
+      vj = u1;
+    }
+  };
+#pragma unroll 1
+  for (int iter = 0; iter < 30; iter++) {
+    if (!__any(live)) break;
+    bool changed = false;
+    rotate(ar[0], ar[1], vr[0], vr[1], W[0], W[1], changed);
+    rotate(ar[0], ar[2], vr[0], vr[2], W[0], W[2], changed);
+    rotate(ar[0], ar[3], vr[0], vr[3], W[0], W[3], changed);
+    rotate(ar[1], ar[2], vr[1], vr[2], W[1], W[2], changed);
+    rotate(ar[1], ar[3], vr[1], vr[3], W[1], W[3], changed);
+    rotate(ar[2], ar[3], vr[2], vr[3], W[2], W[3], changed);
+    if (!changed) live = false;
+  }
+  // singular values (descending selection sort; which column ends up last)
+  double Ws[4];
+  {
+    __syncthreads();
+    if (l < M) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) sg[i][l] = ar[i] * ar[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      double sd = 0;
+#pragma unroll
+      for (int k = 0; k < M; k++) sd += sg[i][k];
+      Ws[i] = EG3D_SQRT(sd);
+    }
+  }
+  int order[4] = {0, 1, 2, 3};
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    int j = i;
+#pragma unroll
+    for (int k = i + 1; k < 4; k++)
+      if (Ws[j] < Ws[k]) j = k;
+    if (i != j) {
+      double tw = Ws[i];
+      Ws[i] = Ws[j];
+      Ws[j] = tw;
+      int to = order[i];
+      order[i] = order[j];
+      order[j] = to;
+    }
+  }
+  const int last = order[3];
+  // out[k] = Vt[last][k]: lane k's entry `last` of its row of V
+  const double mine = last == 0 ? vr[0] : last == 1 ? vr[1] : last == 2 ? vr[2] : vr[3];
+  __syncthreads();
+  if (l < 4) sg[0][l] = mine;
+  __syncthreads();
+  const float h0 = (float)sg[0][0], h1 = (float)sg[0][1], h2 = (float)sg[0][2], h3 = (float)sg[0][3];
+  X0[0] = (double)(h0 / h3);
+  X0[1] = (double)(h1 / h3);
+  X0[2] = (double)(h2 / h3);
+  __syncthreads();
+}
+
 // 9 920 bytes: gfx950 allocates LDS in 1 280-byte units, 8 units per wave = 16 single-wave
 // workgroups per CU (4 per SIMD) in 160 KiB. (Rounds 1-3: 12 784 bytes, 3 per SIMD.)
 struct CoopLds {
@@ -43,9 +233,12 @@ struct CoopLds {
     } walk;
     // the matrices of up to 8 concurrent 2-view DLTs (look-ahead following: one per lane; a uniform section: slot 0)
     double dlt_work[8][EG3D_DLT_WORK_DOUBLES];
+    // ... or, lane-group form (dlt2_grp8 below): per group of 8 lanes four staging rows for the in-order sums
+    DltGrpLds dltg;
   };
   int32_t la_m[8];               // look-ahead following: observations kept by step j
   uint32_t la_fl[8];             //   and the diagnostic flags its walks raised
+  int32_t la_st[8];              //   and the starting observation that produced it (the redo of a failed step goes on from there)
   Obs tmp_a[EG3D_COOP_ROWS];     // the N-view step's candidate observations (Chain::tmp_a) when they fit
   float x0[EG3D_COOP_REQ][3];    // in: start point of request j; out: its result
   const Obs* gbase[EG3D_COOP_REQ];   // observation array of request j
@@ -120,7 +313,10 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 struct GnRow {
   double j00, j01, j02, j10, j11, j12, r0, r1;
 };
-#if defined(EG3D_SECTION_TIMING)
+#if defined(EG3D_SECTION_TIMING) && !defined(EG3D_ONE_SECTION)
+#define EG3D_GN_COUNTERS 1
+#endif
+#if defined(EG3D_GN_COUNTERS)
 // diagnostic (timing builds): [0..31] requests by iterations run, [32..63] rounds by iterations run,
 // [64] requests, [65] accepted, [66] rows of all requests, [67] row-iterations a round's lanes were held
 // (64 x iterations x chunks), [68] row-iterations of live groups (rows x iterations), [69] rounds,
@@ -203,6 +399,27 @@ __device__ __forceinline__ void gn_row(const float* __restrict__ P, float ox, fl
   w.j12 = (p12 * zH - p22 * yH) / zz;
 }
 
+// The residuals of a row alone — exactly the r0 / r1 gn_row computes (same operations on the same operands), without the
+// six Jacobian entries (one shared reciprocal and 6 x (2 products, a difference, a division) less: ~45 % of a full row).
+// For the convergence pre-check of gn_round.
+__device__ __forceinline__ void gn_row_res(const float* __restrict__ P, float ox, float oy, const double X[3], double& r0,
+                                           double& r1, bool cams_mid_range) {
+  const double p00 = P[0], p01 = P[1], p02 = P[2], p03 = P[3];
+  const double p10 = P[4], p11 = P[5], p12 = P[6], p13 = P[7];
+  const double p20 = P[8], p21 = P[9], p22 = P[10], p23 = P[11];
+  const double xH = ((p00 * X[0] + p01 * X[1]) + p02 * X[2]) + p03 * 1.0;
+  const double yH = ((p10 * X[0] + p11 * X[1]) + p12 * X[2]) + p13 * 1.0;
+  const double zH = ((p20 * X[0] + p21 * X[1]) + p22 * X[2]) + p23 * 1.0;
+  if (cams_mid_range && gn_mid_range(xH) && gn_mid_range(yH) && gn_mid_range(zH)) {
+    const GnRecip rz = gn_recip(zH);
+    r0 = (double)ox - gn_div(xH, rz);
+    r1 = (double)oy - gn_div(yH, rz);
+    return;
+  }
+  r0 = (double)ox - xH / zH;
+  r1 = (double)oy - yH / zH;
+}
+
 // s + A[0] + B[0] + A[1] + B[1] + ... in exactly that order (the order contract of the normal equations), with the
 // LDS reads of up to 8 rows in flight before the first addition needs one: the plain loop waited out the full LDS
 // latency once per row (ds_read2_b64 -> s_waitcnt lgkmcnt(0) -> two dependent adds: ~130 cycles per row, a third of
@@ -263,7 +480,7 @@ __device__ __forceinline__ double ordered_sum2(double s, const double* __restric
 // HOIST: a one-chunk round requests the lane's observation ONCE, before the iterations (the engine kernel: its rows come
 // from the slices of many chains and miss the caches — a trip per iteration was most of a round there; k3b_expand, whose
 // chain is cache-resident, measured the three extra live registers as a loss and keeps the load per iteration).
-template <int KEEP, bool HOIST = false>
+template <int KEEP, bool HOIST = false, int PRE_IT = 30>
 __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool act, int l, int G, int gb, int n, int nb,
                                          const Obs* a, int32_t xv, float xx, float xy, int cmax, double X[3]) {
   const int lane = (int)(threadIdx.x & 63u);
@@ -282,7 +499,7 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
   double last_mse = 0;
   const double two_n = (double)(n * 2);
   int dbg_it = 0, dbg_round = 0;
-#if defined(EG3D_SECTION_TIMING)
+#if defined(EG3D_GN_COUNTERS)
   unsigned long long gts_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long gt_begin_ = __builtin_readcyclecounter();
 #endif
@@ -291,6 +508,59 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
     dbg_round++;
     if (!done) dbg_it++;
     EG3D_GN_T0();
+    // ---- convergence pre-check (round 6): from its third iteration on a solve almost always stops (C3': 92 % of the requests
+    // run exactly three), and the iteration that stops needs only the mean squared residual — not the Jacobian, the twelve
+    // products of the normal equations or their sums. So: residuals alone first, summed in observation order into the very
+    // accumulator of pass 1 (same additions, same order => the same mse, bit for bit), the same test; a group that passes
+    // it is done exactly as pass 1 would have found it, one that does not runs the full iteration below, which computes
+    // the same mse again and takes the same decision (last_mse is untouched here).
+    if (PRE_IT < 30 && it >= PRE_IT) {
+      double macc = 0;
+      const bool sums_mse = !done && l == 6 % G;
+      for (int c = 0; c < cmax; c++) {
+        const int r = c * G + l;
+        if (!done && r < n) {
+          int32_t view;
+          float ox, oy;
+          if (HOIST && cmax == 1) {
+            view = hview;
+            ox = hox;
+            oy = hoy;
+          } else if (r < nb) {
+            view = a[r].view;
+            ox = a[r].x;
+            oy = a[r].y;
+          } else {
+            view = xv;
+            ox = xx;
+            oy = xy;
+          }
+          double r0, r1;
+          gn_row_res(cam_P + (size_t)view * 16, ox, oy, X, r0, r1, L.cams_mid_range != 0);
+          L.prod[12][lane] = r0 * r0;
+          L.prod[13][lane] = r1 * r1;
+        }
+        __syncthreads();
+        if (sums_mse) {
+          int rows = n - c * G;
+          rows = rows > G ? G : rows;
+          if (rows > 0) macc = ordered_sum2(macc, &L.prod[12][gb], &L.prod[13][gb], rows);
+        }
+        __syncthreads();
+      }
+      if (sums_mse) L.gsum(gs, 6) = macc;
+      __syncthreads();
+      if (!done) {
+        const double mse = L.gsum(gs, 6);
+        if (absd(mse / two_n - last_mse) < 0.0000005) {
+          done = true;
+          ok = last_mse < 9;
+        }
+      }
+      __syncthreads();
+      EG3D_GN_T(0);
+      if (!__any(!done)) break;
+    }
     // ---- pass 1: H (6) and mse; accumulator e lives in group lane e % G, slot e / G
     double acc[4] = {0, 0, 0, 0};
     constexpr int NK = KEEP > 0 ? KEEP : 1;
@@ -472,7 +742,7 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
     EG3D_GN_T(6);
   }
   if (act && !done) ok = last_mse < 9;
-#if defined(__HIP_DEVICE_COMPILE__) && defined(EG3D_SECTION_TIMING)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(EG3D_GN_COUNTERS)
   if (act && l == 0) {
     EG3D_GN_DBG(dbg_it < 31 ? dbg_it : 31, 1);
     EG3D_GN_DBG(64, 1);
@@ -501,7 +771,7 @@ __device__ __forceinline__ bool gn_round(const float* cam_P, CoopLds& L, bool ac
 // lanes own the requests) and made visible by a barrier. Lane j < EG3D_COOP_REQ passes want / n_req of entry j. Must be
 // called by all 64 lanes; every request must have >= 2 rows. On return the table holds verdict and solution of every
 // entry (L.res_ok[j], L.x0[j]) until the next call; lane j also gets its own as the return value / Xout.
-template <int KEEP = 0, bool LONG_GN = true, bool HOIST = false>
+template <int KEEP = 0, bool LONG_GN = true, bool HOIST = false, int PRE_IT = 30>
 __device__ __forceinline__ bool coop_gn_run(const float* cam_P, CoopLds& L, bool want, int n_req, float Xout[3]) {
   const int lane = (int)(threadIdx.x & 63u);
   const bool is_short = want && n_req <= EG3D_GN_PACK_MAX;
@@ -549,7 +819,7 @@ __device__ __forceinline__ bool coop_gn_run(const float* cam_P, CoopLds& L, bool
         X[1] = (double)L.x0[rq][1];
         X[2] = (double)L.x0[rq][2];
       }
-      const bool ok = gn_round<0, HOIST>(cam_P, L, act, l, n, lane - l, n, nb, a, xv, xx, xy, 1, X);
+      const bool ok = gn_round<0, HOIST, PRE_IT>(cam_P, L, act, l, n, lane - l, n, nb, a, xv, xx, xy, 1, X);
       if (act && l == 0) {
         L.res_ok[rq] = ok ? 1 : 0;
         L.x0[rq][0] = (float)X[0];
@@ -627,7 +897,7 @@ __device__ __forceinline__ bool coop_gn_run(const float* cam_P, CoopLds& L, bool
         X[1] = (double)L.x0[rq][1];
         X[2] = (double)L.x0[rq][2];
       }
-      const bool ok = gn_round<KEEP>(cam_P, L, act, l, G, lane - l, n, nb, a, xv, xx, xy, (mxn + G - 1) >> lg, X);
+      const bool ok = gn_round<KEEP, false, PRE_IT>(cam_P, L, act, l, G, lane - l, n, nb, a, xv, xx, xy, (mxn + G - 1) >> lg, X);
       if (act && l == 0) {
         L.res_ok[rq] = ok ? 1 : 0;
         L.x0[rq][0] = (float)X[0];
@@ -650,12 +920,12 @@ __device__ __forceinline__ bool coop_gn_run(const float* cam_P, CoopLds& L, bool
 // Must be called by all 64 lanes of the (single-wave) block; every request must have >= 2 rows. On
 // return lane j holds the verdict and solution of ITS request (false when !want); the request
 // table keeps them too (L.res_ok[j], L.x0[j]) until the next call.
-template <int KEEP = 0, bool LONG_GN = true>
+template <int KEEP = 0, bool LONG_GN = true, int PRE_IT = 30>
 __device__ __forceinline__ bool coop_gn_groups(const float* cam_P, CoopLds& L, bool want_in, const Obs* base, int nblock,
                                                bool has_extra, int32_t ex_view, float ex_x, float ex_y,
                                                const float X0[3], float Xout[3]) {
   const int lane = (int)(threadIdx.x & 63u);
-#if defined(EG3D_SECTION_TIMING)
+#if defined(EG3D_GN_COUNTERS)
   const unsigned long long gg_begin_ = __builtin_readcyclecounter();
 #endif
   const bool want = want_in && lane < EG3D_COOP_REQ;  // the request table has EG3D_COOP_REQ entries (callers keep to it)
@@ -673,8 +943,8 @@ __device__ __forceinline__ bool coop_gn_groups(const float* cam_P, CoopLds& L, b
     L.res_ok[lane] = 0;
   }
   __syncthreads();
-  const bool res = coop_gn_run<KEEP, LONG_GN>(cam_P, L, want, n_req, Xout);
-#if defined(EG3D_SECTION_TIMING)
+  const bool res = coop_gn_run<KEEP, LONG_GN, false, PRE_IT>(cam_P, L, want, n_req, Xout);
+#if defined(EG3D_GN_COUNTERS)
   if (lane == 0) EG3D_GN_DBG(112, __builtin_readcyclecounter() - gg_begin_);
 #endif
   return res;

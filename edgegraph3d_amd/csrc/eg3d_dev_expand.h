@@ -33,7 +33,7 @@ struct Pending {
 };
 // Per chain point, for the view being offered: unique 4 px-grid polyline and closest point.
 struct ViewCand {
-  uint32_t valid;  // exactly one polyline in the window
+  uint32_t valid;  // exactly one polyline in the window: 0x80000000 | its vertex count (0 = no candidate)
   uint32_t pl, seg;
   float x, y, d2;
   uint32_t cok;    // speculative central ADD solve of (point + this observation) succeeded
@@ -80,13 +80,25 @@ struct Chain {
   int32_t tmp_cap;
   uint32_t flags;
   uint64_t bytes;  // vertices of 4 px-grid polylines tested (algorithmic bytes)
-  uint64_t tsec[12];  // diagnostic: shader-clock ticks per section (0 cand, 1 step walks, 2 side walks, 3 batch GN, 4 follow, 5 step DLT, 6 step GN, 7 whole, 8 commit, 9 chain init, 10 epc pre-solves, 11 new point)
+  uint64_t tsec[16];  // diagnostic: shader-clock ticks per section (0 cand, 1 step walks, 2 side walks, 3 batch GN, 4 follow, 5 step DLT, 6 step GN, 7 whole, 8 commit, 9 chain init, 10 epc pre-solves, 11 new point, 12 expand_to_view, 13 attach_view, 14 3-subset fallback, 15 sequential N-view steps of the following)
 };
 #if defined(__HIP_DEVICE_COMPILE__) && defined(EG3D_SECTION_TIMING)
 #define EG3D_TICK() ((uint64_t)__builtin_readcyclecounter())
 #else
 #define EG3D_TICK() ((uint64_t)0)
 #endif
+// -DEG3D_ONE_SECTION=k (with -DEG3D_SECTION_TIMING): the LIGHT timing build — only section k and the whole chain (7) are
+// accumulated, and the Gauss-Newton counters are off: two live counters instead of sixteen, so the kernel keeps its
+// registers and its speed (the full timing build runs ~10x slower and distorts the shares). tools/section_light.sh.
+#ifdef EG3D_ONE_SECTION
+#define EG3D_SEC_ON(i) ((i) == EG3D_ONE_SECTION || (i) == 7)
+#else
+#define EG3D_SEC_ON(i) true
+#endif
+#define EG3D_SEC_ADD(arr, i, v)            \
+  do {                                     \
+    if (EG3D_SEC_ON(i)) (arr)[i] += (v);   \
+  } while (0)
 
 EG3D_HD ChainPt& chain_at(Chain& c, int i) { return c.pts[c.head + i]; }
 
@@ -202,6 +214,14 @@ struct TeamSeq {
     int k = 0;
     while (k < m && pred(k)) k++;
     return k;
+  }
+  // which of the candidate slots [base, base + 64) below `end` hold a candidate (bit k = slot base + k): the visit of a
+  // view jumps from candidate to candidate instead of loading every point's entry to find most of them empty
+  EG3D_HD uint64_t valid_mask(const Chain& c, int base, int end) const {
+    uint64_t m = 0;
+    for (int k = 0; k < 64 && base + k < end; k++)
+      if (c.cand[base + k].valid) m |= 1ull << k;
+    return m;
   }
   EG3D_HD int group_size(int) const { return 1; }
   EG3D_HD void group_best(int, float&, PlPt&) const {}
@@ -347,8 +367,8 @@ EG3D_HD bool triangulate_array_team(const Team& tm, const DevScene& s, const Obs
   const uint64_t t1 = EG3D_TICK();
   const bool ok = tm.gn_array(s, a, n, X0, Xout);
   if (tsec) {
-    tsec[5] += t1 - t0;
-    tsec[6] += EG3D_TICK() - t1;
+    EG3D_SEC_ADD(tsec, 5, t1 - t0);
+    EG3D_SEC_ADD(tsec, 6, EG3D_TICK() - t1);
   }
   return ok;
 }
@@ -412,18 +432,22 @@ EG3D_HD int stepn_fallback(const Team& tm, const DevScene& s, Obs* sel, int m, O
 // runs the (rare, expensive) 3-subset fallback only when the sequential order actually reaches
 // it. Flags of candidates past the winner are dropped, as the sequential order never ran them.
 // The new point is returned in tmp_a[0..m) with its X.
+// st0 = first starting observation to try (the sequential semantics start at 0; a team that has already evaluated the
+// candidates before st0 itself — the look-ahead rounds of the wavefront team, redoing a step — passes where to go on).
 template <class Team>
 EG3D_HD_FLAT int stepn_chain(const Team& tm, const DevScene& s, Chain& c, const ChainPt& cur, const uint32_t* dirs,
-                        float Xout[3]) {
+                        float Xout[3], int st0 = 0) {
   const int n = (int)cur.nobs;
   if (n > EG3D_STEP_OBS || !Team::kSlotStep) {
-    for (int st = 0; st < n; st++) {
+    for (int st = st0; st < n; st++) {
       const uint64_t tw0 = EG3D_TICK();
       int m = stepn_walks(tm, s, c.pool + cur.off, n, st, dirs, c.tmp_a, c.tmp_cap, c.flags);
-      c.tsec[1] += EG3D_TICK() - tw0;
+      EG3D_SEC_ADD(c.tsec, 1, EG3D_TICK() - tw0);
       if (!m) continue;
       if (triangulate_array_team(tm, s, c.tmp_a, m, Xout, c.flags, c.tsec)) return m;
+      const uint64_t tfb0 = EG3D_TICK();
       m = stepn_fallback(tm, s, c.tmp_a, m, c.tmp_b, c.tmp_mask, Xout, c.flags);
+      EG3D_SEC_ADD(c.tsec, 14, EG3D_TICK() - tfb0);
       if (m) return m;
     }
     return 0;
@@ -461,7 +485,9 @@ EG3D_HD_FLAT int stepn_chain(const Team& tm, const DevScene& s, Chain& c, const 
       Xout[2] = sl.X[2];
     } else {
       for (int i = 0; i < m; i++) c.tmp_a[i] = sl.sel[i];
+      const uint64_t tfb0 = EG3D_TICK();
       m = stepn_fallback(tm, s, c.tmp_a, m, c.tmp_b, c.tmp_mask, Xout, c.flags);
+      EG3D_SEC_ADD(c.tsec, 14, EG3D_TICK() - tfb0);
       if (!m) continue;
       return m;
     }
@@ -515,7 +541,7 @@ EG3D_HD_FLAT int follow_end(const Team& tm, const DevScene& s, Chain& c, bool fr
     } else {
       c.pts[c.head + c.len] = np;
     }
-    c.tsec[11] += EG3D_TICK() - tn0;
+    EG3D_SEC_ADD(c.tsec, 11, EG3D_TICK() - tn0);
     c.len++;
     added++;
   }
@@ -632,7 +658,7 @@ EG3D_HD_FLAT int walk_sides_both(const Team& tm, const DevScene& s, Chain& c, in
     tm.sync();
     n1 = tm.leading_true(m1, [&](int j) { return p1[j].ok != 0; });
     n2 = n1 > 0 ? tm.leading_true(m2, [&](int j) { return p2[j].ok != 0; }) : 0;
-    c.tsec[3] += EG3D_TICK() - t1;
+    EG3D_SEC_ADD(c.tsec, 3, EG3D_TICK() - t1);
   };
   n1 = n2 = 0;
   uint64_t t0 = EG3D_TICK();
@@ -644,7 +670,7 @@ EG3D_HD_FLAT int walk_sides_both(const Team& tm, const DevScene& s, Chain& c, in
     which = 2;
     walks(pl.end, pl.start, m1, m2);
   }
-  c.tsec[2] += EG3D_TICK() - t0;
+  EG3D_SEC_ADD(c.tsec, 2, EG3D_TICK() - t0);
   if (m1 == 0) return 0;
   solves(m1, m2);
   if (n1 > 0) return which;
@@ -653,7 +679,7 @@ EG3D_HD_FLAT int walk_sides_both(const Team& tm, const DevScene& s, Chain& c, in
   t0 = EG3D_TICK();
   tm.walk_stage(s, c, view, pl, lo, ci, hi);
   walks(pl.end, pl.start, m1, m2);
-  c.tsec[2] += EG3D_TICK() - t0;
+  EG3D_SEC_ADD(c.tsec, 2, EG3D_TICK() - t0);
   if (m1 == 0) return 0;
   solves(m1, m2);
   return n1 > 0 ? 2 : 0;
@@ -677,7 +703,7 @@ EG3D_HD_FLAT bool attach_view(const Team& tm, const DevScene& s, Chain& c, const
   } else {
     uint64_t t0 = EG3D_TICK();
     bool okc = tm.add_one(s, c, chain_at(c, ci), o, Xc);
-    c.tsec[1] += EG3D_TICK() - t0;
+    EG3D_SEC_ADD(c.tsec, 1, EG3D_TICK() - t0);
     if (!okc) return false;
   }
   const int view = o.view;
@@ -760,7 +786,7 @@ EG3D_HD_FLAT bool attach_view(const Team& tm, const DevScene& s, Chain& c, const
   to_start = n1;
   to_end = n2;
   uint64_t tf0 = EG3D_TICK();
-  c.tsec[8] += tf0 - tcm0;
+  EG3D_SEC_ADD(c.tsec, 8, tf0 - tcm0);
   // grow the chain at the front, then at the back (one call site: the following code is large)
   for (int side = 0; side < 2; side++) {
     const bool front = side == 0;
@@ -777,7 +803,7 @@ EG3D_HD_FLAT bool attach_view(const Team& tm, const DevScene& s, Chain& c, const
       to_end += g;
     }
   }
-  c.tsec[4] += EG3D_TICK() - tf0;
+  EG3D_SEC_ADD(c.tsec, 4, EG3D_TICK() - tf0);
   tm.sync();
   return true;
 }
@@ -875,6 +901,7 @@ EG3D_HD_FLAT void view_candidates(const Team& tm, const DevScene& s, Chain& c, i
     cp.seg = 0xffffffffu;
     cp.x = cp.y = 0.0f;
     bool have = false;
+    uint32_t nvtx = 0;
     if (act) {
       const ChainPt& pt = chain_at(c, i);
       if (part == 0) {
@@ -892,13 +919,14 @@ EG3D_HD_FLAT void view_candidates(const Team& tm, const DevScene& s, Chain& c, i
         const uint32_t s1 = s0 + chunk < nseg ? s0 + chunk : nseg;
         if (s0 < s1 || part == 0) d2 = polyline_closest_pruned(pl, u, w, s0 < nseg ? s0 : nseg, s1, cp);
         have = true;
+        nvtx = pl.n;
         vc.pl = pl_id;
       }
     }
     tm.group_best(G, d2, cp);
     if (act && part == 0) {
       if (have) {
-        vc.valid = 1;
+        vc.valid = 0x80000000u | nvtx;
         vc.d2 = d2;
         vc.seg = cp.seg;
         vc.x = cp.x;
@@ -908,11 +936,11 @@ EG3D_HD_FLAT void view_candidates(const Team& tm, const DevScene& s, Chain& c, i
     }
   }
   tm.sync();
-  c.tsec[0] += EG3D_TICK() - tc0;
+  EG3D_SEC_ADD(c.tsec, 0, EG3D_TICK() - tc0);
   if (!tm.lazy_presolve(s)) {
     const uint64_t tp0 = EG3D_TICK();
     central_presolves(tm, s, c, v, from, c.len);
-    c.tsec[10] += EG3D_TICK() - tp0;  // (diagnostic: all speculative central solves are booked with the epc pre-solves)
+    EG3D_SEC_ADD(c.tsec, 10, EG3D_TICK() - tp0);  // (diagnostic: all speculative central solves are booked with the epc pre-solves)
   }
 }
 
@@ -950,12 +978,15 @@ EG3D_HD_FLAT void expand_to_view(const Team& tm, const DevScene& s, Chain& c, in
         });
     tm.sync();
   }
-  c.tsec[10] += EG3D_TICK() - te0;
+  EG3D_SEC_ADD(c.tsec, 10, EG3D_TICK() - te0);
   for (int e = 0; e < n_epc; e++) {
     int a, b;
     const bool pre = e < n_pre;
-    if (attach_view(tm, s, c, epc[e], 0, centre, c.len, a, b, pre ? &c.epcres[e].ok : nullptr,
-                    pre ? c.epcres[e].X : nullptr)) {
+    const uint64_t ta0 = EG3D_TICK();
+    const bool att = attach_view(tm, s, c, epc[e], 0, centre, c.len, a, b, pre ? &c.epcres[e].ok : nullptr,
+                                 pre ? c.epcres[e].X : nullptr);
+    EG3D_SEC_ADD(c.tsec, 13, EG3D_TICK() - ta0);
+    if (att) {
       epc_matched = true;
       if (a > centre) {
         centre = a;
@@ -971,7 +1002,35 @@ EG3D_HD_FLAT void expand_to_view(const Team& tm, const DevScene& s, Chain& c, in
   int last_matched = -1;
   view_candidates(tm, s, c, v, 0);
   int spec_slot_hi = 0;  // lazy mode: pre-solves exist for the visited slots below this one
+  // The visit goes from candidate to candidate (round 6): a point without one is a no-op of the loop, and most points of
+  // most views have none — loading each point's entry to find that out was a dependent trip to memory per point and
+  // view. The candidate array is indexed by absolute slot and was filled for the slots [head, head + len) of this
+  // moment; `valid` never changes afterwards, and the points a following appends are never visited in this view.
+  const int slot_hi0 = c.head + c.len;
+  int mask_base = 0;
+  uint64_t vmask = 0;
+  bool have_mask = false;
   for (int cur = 0; cur < c.len; cur++) {
+    {
+      int slot = c.head + cur;
+      while (slot < slot_hi0) {
+        if (!have_mask || slot < mask_base || slot >= mask_base + 64) {
+          mask_base = slot;
+          vmask = tm.valid_mask(c, mask_base, slot_hi0);
+          have_mask = true;
+        }
+        const uint64_t m = vmask >> (slot - mask_base);
+        if (m) {
+          slot += __builtin_ctzll(m);
+          break;
+        }
+        slot = mask_base + 64;
+      }
+      int nxt = slot < slot_hi0 ? slot - c.head : c.len;  // the next point with a candidate (c.len: none)
+      if (epc_matched && cur <= idx_first && idx_first < nxt) nxt = idx_first;  // ... or where the epipolar attachment's points start
+      if (nxt >= c.len) break;
+      cur = nxt;
+    }
     if (epc_matched && cur == idx_first) {
       cur = idx_second;
       last_matched = idx_second;
@@ -979,14 +1038,14 @@ EG3D_HD_FLAT void expand_to_view(const Team& tm, const DevScene& s, Chain& c, in
     }
     const ViewCand vc = tm.uni(c.cand[c.head + cur]);
     if (!vc.valid) continue;
-    c.bytes += 8ull * (s.pl_vtx_off[s.view_pl_off[v] + vc.pl + 1] - s.pl_vtx_off[s.view_pl_off[v] + vc.pl]);
+    c.bytes += 8ull * (vc.valid & 0x7fffffffu);  // the polyline's vertex count (view_candidates)
     if (vc.d2 > 16.0f) return;  // abandons this view (Q4)
     if (tm.lazy_presolve(s) && c.head + cur >= spec_slot_hi) {
       int to = cur + presolve_window(s);
       if (to > c.len) to = c.len;
       const uint64_t tp0 = EG3D_TICK();
       central_presolves(tm, s, c, v, cur, to);
-      c.tsec[10] += EG3D_TICK() - tp0;
+      EG3D_SEC_ADD(c.tsec, 10, EG3D_TICK() - tp0);
       spec_slot_hi = c.head + to;
     }
     Obs o;
@@ -997,7 +1056,10 @@ EG3D_HD_FLAT void expand_to_view(const Team& tm, const DevScene& s, Chain& c, in
     o.y = vc.y;
     int hi = epc_matched ? (cur <= idx_first ? idx_first : c.len) : c.len;
     int a, b;
-    if (attach_view(tm, s, c, o, last_matched + 1, cur, hi, a, b, &c.cand[c.head + cur].cok, c.cand[c.head + cur].cX)) {
+    const uint64_t ta0 = EG3D_TICK();
+    const bool att = attach_view(tm, s, c, o, last_matched + 1, cur, hi, a, b, &c.cand[c.head + cur].cok, c.cand[c.head + cur].cX);
+    EG3D_SEC_ADD(c.tsec, 13, EG3D_TICK() - ta0);
+    if (att) {
       if (a > cur) {
         centre = a;
         cur = a + b;

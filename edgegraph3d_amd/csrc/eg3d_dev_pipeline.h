@@ -244,7 +244,7 @@ struct ChainOut {
   uint32_t n_points, n_obs, flags, head;
   uint64_t bytes;
   uint64_t spt, sobs;  // where the finished chain was packed in the launch's staging area (k3b_expand)
-  uint64_t tsec[12];  // diagnostic section ticks (zero unless built with EG3D_SECTION_TIMING)
+  uint64_t tsec[16];  // diagnostic section ticks (zero unless built with EG3D_SECTION_TIMING)
 };
 
 // Build the chain reverse(pts1) + central + pts2, then offer it to every view except the
@@ -260,7 +260,7 @@ EG3D_HD_FLAT void expand_chain(const Team& tm, const DevScene& s, const StageAVi
   tm.bind(c);
   c.flags = 0;
   c.bytes = 0;
-  for (int k = 0; k < 12; k++) c.tsec[k] = 0;
+  for (int k = 0; k < 16; k++) c.tsec[k] = 0;
   const uint64_t t_begin = EG3D_TICK();
   c.pool_used = 0;
   const HypResult& w = res[cs.winner];
@@ -323,7 +323,7 @@ EG3D_HD_FLAT void expand_chain(const Team& tm, const DevScene& s, const StageAVi
   }
   int centre = centre0;  // index of the central point; moves when the chain grows at the front
   tm.sync();
-  c.tsec[9] = EG3D_TICK() - t_begin;
+  EG3D_SEC_ADD(c.tsec, 9, EG3D_TICK() - t_begin);
   // every view except the three selected, ascending; epc = the task's hits in that view
   const uint32_t base = tm.uni(track_base(a, d.seed));
   const uint32_t n = tm.uni(track_n_views(a, map_n, d.seed));
@@ -342,7 +342,9 @@ EG3D_HD_FLAT void expand_chain(const Team& tm, const DevScene& s, const StageAVi
       epc = a.hits + tm.uni(a.list_ptr[lo + me[j]]);
       n_epc = (int)tm.uni(a.list_cnt[lo + me[j]]);
     }
+    const uint64_t tv0 = EG3D_TICK();
     expand_to_view(tm, s, c, v, epc, n_epc, centre);
+    EG3D_SEC_ADD(c.tsec, 12, EG3D_TICK() - tv0);
   }
   uint32_t nobs = 0;
   for (int i = 0; i < c.len; i++) nobs += chain_at(c, i).nobs;
@@ -352,7 +354,7 @@ EG3D_HD_FLAT void expand_chain(const Team& tm, const DevScene& s, const StageAVi
   out.head = (uint32_t)c.head;
   out.bytes = c.bytes;
   c.tsec[7] = EG3D_TICK() - t_begin;
-  for (int k = 0; k < 12; k++) out.tsec[k] = c.tsec[k];
+  for (int k = 0; k < 16; k++) out.tsec[k] = c.tsec[k];
 }
 
 // A finished chain leaves its working slice as a packed record in the launch's STAGING area: n_points

@@ -35,7 +35,7 @@ namespace eg3d {
 
 // timing build: shader clocks of a wave's phases, summed over the launch (g_gn_dbg[113 + 7*kernel ..]: advance, serve,
 // read answers; iterations, requests served, working lanes) — tools/k3a_stats.py
-#ifdef EG3D_SECTION_TIMING
+#ifdef EG3D_GN_COUNTERS
 #define K3A_T0() unsigned long long kt_[3] = {0, 0, 0}, kc_[4] = {0, 0, 0, 0}, kt0_ = __builtin_readcyclecounter(), kt1_
 #define K3A_T(i) (kt1_ = __builtin_readcyclecounter(), kt_[i] += kt1_ - kt0_, kt0_ = kt1_)
 #define K3A_C(i, v) (kc_[i] += (v))

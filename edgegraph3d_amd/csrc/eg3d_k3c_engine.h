@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(64, EG3D_K3C_WAVES) k3c_engine_t(DevScene s, S
       co.flags = q.c.flags;
       co.head = (uint32_t)q.c.head;
       co.bytes = q.c.bytes;
-      for (int k = 0; k < 12; k++) co.tsec[k] = 0;
+      for (int k = 0; k < 16; k++) co.tsec[k] = 0;
       const unsigned long long pb = atomicAdd(&stage.used[0], (unsigned long long)co.n_points);
       const unsigned long long ob = atomicAdd(&stage.used[1], (unsigned long long)co.n_obs);
       co.spt = pb;

@@ -682,11 +682,17 @@ __global__ void k_compact_chains(uint32_t n_tasks, const ChainSeed* per_task, co
 #ifndef EG3D_DLT_HOT_IN_LDS
 #define EG3D_DLT_HOT_IN_LDS 1 /* the DLTs of chain following keep their matrices in LDS (1) or in registers (0); the rare 3-subset fallback's always in LDS */
 #endif
+#ifndef EG3D_DLT_GRP
+#define EG3D_DLT_GRP 1 /* the 2-view DLTs of the expand stage on groups of 8 lanes (dlt2_grp8, eg3d_dev_coopgn.h: rows of A and V in registers, only the ordered sums through LDS) instead of one lane per DLT with its matrices in LDS (0: rounds 3-5) */
+#endif
+#ifndef EG3D_REDO_SKIP
+#define EG3D_REDO_SKIP 1 /* the redo of a look-ahead step whose triangulation failed does not walk and triangulate that candidate a second time (same walks, same DLT, same solve, same failure): it starts at the 3-subset fallback on the list the round already holds and goes on with the later starting observations (0: the whole sequential N-view step, rounds 3-5) */
+#endif
 #ifndef EG3D_LOOKAHEAD
 #define EG3D_LOOKAHEAD 8 /* steps walked ahead per round (<= 8, and <= 64 / observations of the end point) */
 #endif
 #ifndef EG3D_LA_RESUME
-#define EG3D_LA_RESUME 0 /* look-ahead depth after a redone round (0 = off for the rest of the following call) */
+#define EG3D_LA_RESUME 8 /* look-ahead depth after a redone round (0 = off for the rest of the following call: rounds 3-5). Round 6, light timing build: the sequential N-view steps were 17 % of the chain clocks for 215 k steps against 21 % for the 1.2 M steps of the look-ahead rounds (a step on its own pays a whole DLT stream and a solver batch); A/B 0 / 2 / 4 / 8: C3' 43.7 / 42.5 / 42.3 / 42.4 ms, C2 6.22 / 5.50 / 5.42 / 5.15 ms */
 #endif
 #ifndef EG3D_SIDE_WALK_BATCH
 #define EG3D_SIDE_WALK_BATCH 0 /* side walks: the whole-segment tests of four consecutive walk steps in one pass over the lanes. Measured (round 5, profiles/r05_experiments/k3b_variants.txt): bit-exact, and SLOWER - C3' 44.7 against 43.4-43.5 ms: the sequential half of a step (partial segment, selection) is what a step costs, and most hits are on the partial segment; kept as a measured option */
@@ -711,6 +717,7 @@ __global__ void k_compact_chains(uint32_t n_tasks, const ChainSeed* per_task, co
 template <int GN_KEEP, int SCENE>
 struct TeamWaveT {
   static constexpr bool LONG_GN = SCENE != 0;
+  static constexpr int kPreIt = (SCENE == 2 || EG3D_GN_PRECHECK_ALL) ? EG3D_GN_PRECHECK_IT : 30;  // eg3d_dev_coopgn.h
   static constexpr bool kSlotStep = EG3D_WAVE_SLOT_STEP != 0;
   static constexpr bool kSpecFollow = EG3D_SPEC_FOLLOW != 0 && SCENE != 2;
   CoopLds* L;
@@ -755,10 +762,14 @@ struct TeamWaveT {
                                            double X0[3]) const {
     // ONE lane runs the decomposition on slot 0 (64 lanes writing the same LDS words would serialise); the start
     // point is then broadcast
-    typedef __attribute__((address_space(3))) double* lds_dp;
     __syncthreads();
     double r[3] = {0, 0, 0};
+#if EG3D_DLT_GRP
+    dlt2_grp8(L->dltg, lane() < 8, P1, x1, y1, P2, x2, y2, r);  // the first group of 8 lanes
+#else
+    typedef __attribute__((address_space(3))) double* lds_dp;
     if (lane() == 0) dlt2_mem(P1, x1, y1, P2, x2, y2, (lds_dp)&L->dlt_work[0][0], r);
+#endif
     X0[0] = lane_bcast(r[0], 0);
     X0[1] = lane_bcast(r[1], 0);
     X0[2] = lane_bcast(r[2], 0);
@@ -784,6 +795,10 @@ struct TeamWaveT {
       if (lead < 64) break;
     }
     return cnt;
+  }
+  __device__ __forceinline__ uint64_t valid_mask(const Chain& c, int base, int end) const {
+    const int k = base + lane();
+    return __ballot(k < end && c.cand[k].valid != 0);
   }
   __device__ __forceinline__ int group_size(int n_items) const {
     int g = 1;
@@ -1102,14 +1117,25 @@ struct TeamWaveT {
           Obs* sel = L->tmp_a + j * n_end;
           uint32_t fl = 0;
           int m = 0;
-          for (int st = 0; st < nprev && m == 0; st++) m = stepn_walks(*this, s, prev, nprev, st, dirs, sel, n_end, fl);
+#ifdef EG3D_ONE_SECTION
+          const uint64_t tdd0 = EG3D_TICK();  // light timing build: section 11 = the walks of the step that DIES (every starting observation tried)
+#endif
+          int st_used = 0;
+          for (int st = 0; st < nprev && m == 0; st++) {
+            m = stepn_walks(*this, s, prev, nprev, st, dirs, sel, n_end, fl);
+            st_used = st;
+          }
           if (m == 0) {
+#ifdef EG3D_ONE_SECTION
+            EG3D_SEC_ADD(c.tsec, 11, EG3D_TICK() - tdd0);
+#endif
             fl_dead = fl;
             break;
           }
           if (lane() == 0) {
             L->la_m[j] = m;
             L->la_fl[j] = fl;
+            L->la_st[j] = st_used;
           }
           Deff++;
           prev = sel;
@@ -1123,9 +1149,47 @@ struct TeamWaveT {
       __syncthreads();  // la_m / la_fl
       // ---- stage 2: the Deff initial DLTs, list j on lane j
       const uint64_t tq1 = EG3D_TICK();
-      c.tsec[1] += tq1 - tq0;
+      EG3D_SEC_ADD(c.tsec, 1, tq1 - tq0);
       double X0[3] = {0, 0, 0};
       uint32_t dfl = 0;
+#if EG3D_DLT_GRP
+      // list j on the 8 lanes of group j (every lane of the group selects the two observations; the decomposition is
+      // spread over the group: dlt2_grp8); the start point and the flag then move to lane j, where request j lives
+      {
+        const int gj = lane() >> 3;
+        const bool on = gj < Deff;
+        const float* P1 = s.cam_P;
+        const float* P2 = s.cam_P;
+        float gx1 = 0.f, gy1 = 0.f, gx2 = 0.f, gy2 = 0.f;
+        if (on) {
+          const Obs* a = L->tmp_a + gj * n_end;
+          const int n = L->la_m[gj];
+          int mi = 0;
+          int32_t mv = a[0].view;
+          for (int i = 0; i < n; i++)
+            if (a[i].view < mv) {
+              mv = a[i].view;
+              mi = i;
+            }
+          const int la = n - 1;
+          if (a[mi].view == a[la].view) dfl = 16u;
+          P1 = s.cam_P + (size_t)a[mi].view * 16;
+          gx1 = a[mi].x;
+          gy1 = a[mi].y;
+          P2 = s.cam_P + (size_t)a[la].view * 16;
+          gx2 = a[la].x;
+          gy2 = a[la].y;
+        }
+        double Xg[3] = {0, 0, 0};
+        dlt2_grp8(L->dltg, on, P1, gx1, gy1, P2, gx2, gy2, Xg);
+        const int src = (lane() & 7) * 8;  // lane j < 8 takes group j's result
+        X0[0] = (double)__shfl((float)Xg[0], src);  // DLT results are float-valued
+        X0[1] = (double)__shfl((float)Xg[1], src);
+        X0[2] = (double)__shfl((float)Xg[2], src);
+        dfl = (uint32_t)__shfl((int)dfl, src);
+        if (lane() >= Deff) dfl = 0;
+      }
+#else
       if (lane() < Deff) {
         const Obs* a = L->tmp_a + lane() * n_end;
         const int n = L->la_m[lane()];
@@ -1146,22 +1210,24 @@ struct TeamWaveT {
         dlt2(s.cam_P + (size_t)a[mi].view * 16, a[mi].x, a[mi].y, s.cam_P + (size_t)a[la].view * 16, a[la].x, a[la].y, X0);
 #endif
       }
+#endif  // EG3D_DLT_GRP
       // ---- stage 3: the Deff Gauss-Newton solves as one batch (request j on lane j)
       const uint64_t tq2 = EG3D_TICK();
-      c.tsec[5] += tq2 - tq1;
+      EG3D_SEC_ADD(c.tsec, 5, tq2 - tq1);
       {
         const bool want = lane() < Deff;
         const float X0f[3] = {(float)X0[0], (float)X0[1], (float)X0[2]};  // DLT results are float-valued
         float Xr[3];
-        const bool ok = coop_gn_groups<GN_KEEP, LONG_GN>(s.cam_P, *L, want, L->tmp_a + (want ? lane() : 0) * n_end,
+        const bool ok = coop_gn_groups<GN_KEEP, LONG_GN, kPreIt>(s.cam_P, *L, want, L->tmp_a + (want ? lane() : 0) * n_end,
                                        want ? L->la_m[lane()] : 0, false, 0, 0.f, 0.f, X0f, Xr);
         // results stay in the request table: L->res_ok[j], L->x0[j]
         (void)ok;
         (void)Xr;
       }
       // ---- stage 4: accept in order
-      c.tsec[6] += EG3D_TICK() - tq2;
+      EG3D_SEC_ADD(c.tsec, 6, EG3D_TICK() - tq2);
       bool redo = false, stop = false;
+      int redo_j = 0;
       for (int j = 0; j < Deff; j++) {
         const uint32_t dflj = lane_bcast(dfl, j);
         if (L->res_ok[j]) {
@@ -1172,17 +1238,49 @@ struct TeamWaveT {
             break;
           }
           added++;
-#ifdef EG3D_SECTION_TIMING
-          c.tsec[11] += 1ull << 16;  // diagnostic: steps accepted from a look-ahead round
+#if defined(EG3D_SECTION_TIMING) && !defined(EG3D_ONE_SECTION)
+          EG3D_SEC_ADD(c.tsec, 11, 1ull << 16);  // diagnostic: steps accepted from a look-ahead round
 #endif
         } else {
-#ifdef EG3D_SECTION_TIMING
-          c.tsec[11] += 1ull << 32;  // diagnostic: look-ahead rounds that ended in a redo
+#if defined(EG3D_SECTION_TIMING) && !defined(EG3D_ONE_SECTION)
+          EG3D_SEC_ADD(c.tsec, 11, 1ull << 32);  // diagnostic: look-ahead rounds that ended in a redo
 #endif
           redo = true;  // sequential N-view step from the chain's current end (same walks, then the
-          break;        // 3-subset fallback and the later candidates)
+          redo_j = j;   // 3-subset fallback and the later candidates)
+          break;
         }
       }
+#if EG3D_REDO_SKIP
+      // The step that failed is candidate la_st[j] of the sequential N-view step from the chain's current end (the
+      // steps before it were appended, so that end IS the list it was walked from): its walks, its DLT and its
+      // all-observation solve would be repeated with the same operands and fail the same way. Go on where the
+      // sequential order goes on after that failure: the 3-subset fallback on the list, then the later candidates.
+      if (redo && !stop) {
+        const int mj = L->la_m[redo_j], stj = L->la_st[redo_j];
+        const uint32_t flj = L->la_fl[redo_j] | lane_bcast(dfl, redo_j);
+        Obs keep;
+        keep.view = 0;
+        keep.pl = keep.seg = 0;
+        keep.x = keep.y = 0.f;
+        if (lane() < mj) keep = L->tmp_a[redo_j * n_end + lane()];
+        __syncthreads();
+        if (lane() < mj) L->tmp_a[lane()] = keep;
+        __syncthreads();
+        c.flags |= flj;
+        const ChainPt& e2 = front ? chain_at(c, 0) : chain_at(c, c.len - 1);
+        float X[3];
+        const uint64_t tsq0 = EG3D_TICK();
+        int m = stepn_fallback(*this, s, c.tmp_a, mj, c.tmp_b, c.tmp_mask, X, c.flags);
+        if (m == 0) m = stepn_chain(*this, s, c, e2, dirs, X, stj + 1);
+        EG3D_SEC_ADD(c.tsec, 15, EG3D_TICK() - tsq0);
+        if (m == 0) return added;
+        if (!follow_append(c, front, c.tmp_a, m, X)) return added;
+        added++;
+        look_ahead = EG3D_LA_RESUME >= 2;
+        d_cap = EG3D_LA_RESUME;
+        continue;
+      }
+#endif
       __syncthreads();  // the lists / results are rewritten next
       if (stop) return added;
       if (!redo) {
@@ -1194,15 +1292,17 @@ struct TeamWaveT {
         continue;
       }
       seq = true;  // redo the failed step with the sequential N-view step; where the first candidate's
-      look_ahead = EG3D_LA_RESUME >= 2;  // where a first candidate's triangulation fails it tends to fail again
+      look_ahead = EG3D_LA_RESUME >= 2;  // (0: look-ahead stays off for the rest of this following call)
       d_cap = EG3D_LA_RESUME;
       }
       if (seq) {
         const ChainPt& e2 = front ? chain_at(c, 0) : chain_at(c, c.len - 1);
         float X[3];
+        const uint64_t tsq0 = EG3D_TICK();
         const int m = stepn_chain(*this, s, c, e2, dirs, X);
-#ifdef EG3D_SECTION_TIMING
-        c.tsec[11] += 1ull;  // diagnostic: sequential N-view steps
+        EG3D_SEC_ADD(c.tsec, 15, EG3D_TICK() - tsq0);
+#if defined(EG3D_SECTION_TIMING) && !defined(EG3D_ONE_SECTION)
+        EG3D_SEC_ADD(c.tsec, 11, 1ull);  // diagnostic: sequential N-view steps
 #endif
         if (m == 0) return added;
         if (!follow_append(c, front, c.tmp_a, m, X)) return added;
@@ -1216,7 +1316,7 @@ struct TeamWaveT {
     // one request (lane 0), the whole wave on its rows
     const float X0f[3] = {(float)X0[0], (float)X0[1], (float)X0[2]};  // callers pass float-valued starts
     float Xr[3];
-    const bool ok = coop_gn_groups<GN_KEEP, LONG_GN>(s.cam_P, *L, lane() == 0, a, n, false, 0, 0.f, 0.f, X0f, Xr);
+    const bool ok = coop_gn_groups<GN_KEEP, LONG_GN, kPreIt>(s.cam_P, *L, lane() == 0, a, n, false, 0, 0.f, 0.f, X0f, Xr);
     Xout[0] = lane_bcast(Xr[0], 0);
     Xout[1] = lane_bcast(Xr[1], 0);
     Xout[2] = lane_bcast(Xr[2], 0);
@@ -1225,7 +1325,7 @@ struct TeamWaveT {
   __device__ __forceinline__ bool add_array(const DevScene& s, const Obs* a, int n, const Obs& extra, const float X0[3],
                                             float Xout[3]) const {
     float Xr[3];
-    const bool ok = coop_gn_groups<GN_KEEP, LONG_GN>(s.cam_P, *L, lane() == 0, a, n, true, extra.view, extra.x, extra.y, X0, Xr);
+    const bool ok = coop_gn_groups<GN_KEEP, LONG_GN, kPreIt>(s.cam_P, *L, lane() == 0, a, n, true, extra.view, extra.x, extra.y, X0, Xr);
     Xout[0] = lane_bcast(Xr[0], 0);
     Xout[1] = lane_bcast(Xr[1], 0);
     Xout[2] = lane_bcast(Xr[2], 0);
@@ -1235,7 +1335,7 @@ struct TeamWaveT {
                                           float Xout[3]) const {
     const float X0f[3] = {p.X[0], p.X[1], p.X[2]};
     float Xr[3];
-    const bool ok = coop_gn_groups<GN_KEEP, LONG_GN>(s.cam_P, *L, lane() == 0, c.pool + p.off, (int)p.nobs, true, extra.view, extra.x,
+    const bool ok = coop_gn_groups<GN_KEEP, LONG_GN, kPreIt>(s.cam_P, *L, lane() == 0, c.pool + p.off, (int)p.nobs, true, extra.view, extra.x,
                                    extra.y, X0f, Xr);
     Xout[0] = lane_bcast(Xr[0], 0);
     Xout[1] = lane_bcast(Xr[1], 0);
@@ -1262,7 +1362,7 @@ struct TeamWaveT {
         X0[1] = pt->X[1];
         X0[2] = pt->X[2];
       }
-      const bool ok = coop_gn_groups<GN_KEEP, LONG_GN>(s.cam_P, *L, want, want ? c.pool + pt->off : nullptr, want ? (int)pt->nobs : 0, true,
+      const bool ok = coop_gn_groups<GN_KEEP, LONG_GN, kPreIt>(s.cam_P, *L, want, want ? c.pool + pt->off : nullptr, want ? (int)pt->nobs : 0, true,
                                      o.view, o.x, o.y, X0, X);
       if (want) put(j, ok, X);
     }
@@ -1758,7 +1858,7 @@ void launch_compact_chains(hipStream_t st, uint32_t n_tasks, const ChainSeed* pe
   hipLaunchKernelGGL(k_compact_chains, blocks_for(n_tasks, 256), dim3(256), 0, st, n_tasks, per_task, valid, chain_off,
                      chains);
 }
-#ifdef EG3D_SECTION_TIMING
+#ifdef EG3D_GN_COUNTERS
 int gn_dbg_read(unsigned long long* out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gn_dbg), sizeof(unsigned long long) * 128) != hipSuccess) return -1;
   if (reset) {

@@ -16,6 +16,9 @@ int eg3d_probe_arith(uint64_t n, const double* a, const double* b, const double*
 int eg3d_probe_dlt_rows(void); /* the DLT form the probe was compiled with (EG3D_DLT_ROWS) */
 int eg3d_probe_triangulate(const float* cam_P, int n_views, uint64_t n_cases, int k, const int32_t* views, const float* xy,
                            float* X, uint8_t* valid, double* dlt_X0);
+/* the same 2-view DLTs (minimum view id, last observation) on groups of 8 lanes (dlt2_grp8, eg3d_dev_coopgn.h) */
+int eg3d_probe_dlt_groups(const float* cam_P, int n_views, uint64_t n_cases, int k, const int32_t* views, const float* xy,
+                          double* dlt_X0);
 /* the shared-reciprocal division of the Gauss-Newton rows: out[0..n) = num/den, out[n..2n) = gn_div(num, gn_recip(den)),
  * out[2n..3n) = 1.0 where den is in the admitted range */
 int eg3d_probe_gn_div(uint64_t n, const double* num, const double* den, double* out3n);

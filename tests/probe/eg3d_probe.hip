@@ -60,6 +60,37 @@ __global__ void k_probe_tri(const float* cam_P, uint64_t n, int k, const int32_t
   dlt[3 * i + 2] = X0[2];
 }
 
+// the 2-view DLT on groups of 8 lanes (dlt2_grp8): item i on group (i % 8) of block (i / 8); same operand choice as
+// k_probe_tri (minimum view id, last observation)
+__global__ void __launch_bounds__(64) k_probe_dlt_grp(const float* cam_P, uint64_t n, int k, const int32_t* views, const float* xy,
+                                                      double* dlt) {
+  __shared__ DltGrpLds S;
+  const int lane = (int)threadIdx.x, g = lane >> 3;
+  const uint64_t i = (uint64_t)blockIdx.x * 8 + (uint64_t)g;
+  const bool on = i < n;
+  const float* P1 = cam_P;
+  const float* P2 = cam_P;
+  float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f;
+  if (on) {
+    int mi = 0;
+    for (int j = 0; j < k; j++)
+      if (views[i * k + j] < views[i * k + mi]) mi = j;
+    P1 = cam_P + (size_t)views[i * k + mi] * 16;
+    x1 = xy[2 * (i * k + mi)];
+    y1 = xy[2 * (i * k + mi) + 1];
+    P2 = cam_P + (size_t)views[i * k + k - 1] * 16;
+    x2 = xy[2 * (i * k + k - 1)];
+    y2 = xy[2 * (i * k + k - 1) + 1];
+  }
+  double X0[3] = {0, 0, 0};
+  dlt2_grp8(S, on, P1, x1, y1, P2, x2, y2, X0);
+  if (on && (lane & 7) == 0) {
+    dlt[3 * i] = X0[0];
+    dlt[3 * i + 1] = X0[1];
+    dlt[3 * i + 2] = X0[2];
+  }
+}
+
 #define PT(expr)                         \
   do {                                   \
     if ((expr) != hipSuccess) return -2; \
@@ -127,6 +158,29 @@ extern "C" int eg3d_probe_triangulate(const float* cam_P, int n_views, uint64_t 
   (void)hipFree(dxy);
   (void)hipFree(dX);
   (void)hipFree(dval);
+  (void)hipFree(ddlt);
+  return 0;
+}
+
+extern "C" int eg3d_probe_dlt_groups(const float* cam_P, int n_views, uint64_t n, int k, const int32_t* views, const float* xy,
+                                     double* dlt) {
+  if (!cam_P || n_views < 1 || k < 2 || k > 16 || !n) return -1;
+  int32_t* dv;
+  float *dxy, *dP;
+  double* ddlt;
+  PT(hipMalloc(&dP, (size_t)n_views * 64));
+  PT(hipMemcpy(dP, cam_P, (size_t)n_views * 64, hipMemcpyHostToDevice));
+  PT(hipMalloc(&dv, n * k * 4));
+  PT(hipMalloc(&dxy, n * k * 8));
+  PT(hipMalloc(&ddlt, n * 24));
+  PT(hipMemcpy(dv, views, n * k * 4, hipMemcpyHostToDevice));
+  PT(hipMemcpy(dxy, xy, n * k * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_probe_dlt_grp, dim3((unsigned)((n + 7) / 8)), dim3(64), 0, 0, dP, n, k, dv, dxy, ddlt);
+  PT(hipDeviceSynchronize());
+  PT(hipMemcpy(dlt, ddlt, n * 24, hipMemcpyDeviceToHost));
+  (void)hipFree(dP);
+  (void)hipFree(dv);
+  (void)hipFree(dxy);
   (void)hipFree(ddlt);
   return 0;
 }

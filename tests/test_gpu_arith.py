@@ -22,6 +22,7 @@ def ctx():
     L = C.CDLL(path)
     L.eg3d_probe_arith.argtypes = [C.c_uint64, D.f64p, D.f64p, D.f64p, D.f64p, D.f32p, D.f32p, D.f32p, D.f32p]
     L.eg3d_probe_triangulate.argtypes = [D.f32p, C.c_int, C.c_uint64, C.c_int, D.i32p, D.f32p, D.f32p, D.u8p, D.f64p]
+    L.eg3d_probe_dlt_groups.argtypes = [D.f32p, C.c_int, C.c_uint64, C.c_int, D.i32p, D.f32p, D.f64p]
     s = host.Synth(1)
     yield L, s
 
@@ -91,6 +92,14 @@ def _triangulation_check(c, s, ob):
         both_nan = np.isnan(d0).all() and np.isnan(dlt[i]).all()
         assert both_nan or np.array_equal(d0.view(np.uint64), dlt[i].view(np.uint64)), i
     assert n_deg > 0
+    # the lane-group form of the same decomposition (dlt2_grp8: what k3b_expand runs) against the one-lane form just
+    # checked against the oracle: every case, degenerate pairs included, bit for bit
+    dlt_g = np.zeros((m, 3))
+    rc = c.eg3d_probe_dlt_groups(D.np_ptr(P, C.c_float), len(P), m, 3, D.np_ptr(cv, C.c_int32), D.np_ptr(cxy, C.c_float),
+                                 D.np_ptr(dlt_g, C.c_double))
+    assert rc == 0
+    same = (dlt_g.view(np.uint64) == dlt.view(np.uint64)).all(axis=1) | (np.isnan(dlt_g).all(axis=1) & np.isnan(dlt).all(axis=1))
+    assert same.all(), np.flatnonzero(~same)[:10]
 
 
 def test_shared_reciprocal_divisions_equal_plain_divisions(ctx):
