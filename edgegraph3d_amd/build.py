@@ -187,7 +187,7 @@ RESOURCE_BOUNDS = {
     # each inline more code around the places where the chain's state is live — 23 / 157 / 61 spilled registers became
     # 87 / 332 / 123, all of them around calls, none inside a loop — and each was kept because the kernel got faster:
     # profiles/r06_experiments/follow_ab.txt)
-    "k3b_expand_t<4, 0, 0>": {"vgpr_spill_count": 100, "private_segment_fixed_size": 224, "group_segment_fixed_size": 10240},
+    "k3b_expand_t<4, 0, 0>": {"vgpr_spill_count": 120, "private_segment_fixed_size": 224, "group_segment_fixed_size": 10240},
     "k3b_expand_t<4, 0, 1>": {"vgpr_spill_count": 360, "private_segment_fixed_size": 400, "group_segment_fixed_size": 10240},
     "k3b_expand_t<4, 1, 2>": {"vgpr_spill_count": 140, "private_segment_fixed_size": 256, "group_segment_fixed_size": 10240},
     "k3a_orient": {"vgpr_spill_count": 0, "group_segment_fixed_size": 12800},

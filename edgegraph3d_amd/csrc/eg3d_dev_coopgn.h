@@ -37,6 +37,9 @@ namespace eg3d {
 #ifndef EG3D_GN_PRECHECK_IT
 #define EG3D_GN_PRECHECK_IT 2
 #endif
+#ifndef EG3D_K3B_HOIST
+#define EG3D_K3B_HOIST 0 /* k3b_expand's one-chunk rounds load a lane's observation once, before the iterations (gn_round's HOIST); 0: per iteration (round 5's measurement) */
+#endif
 #ifndef EG3D_GN_PRECHECK_ALL
 #define EG3D_GN_PRECHECK_ALL 0 /* 1 = every build of the expand kernel, not only the many-views one (A/B switch) */
 #endif
@@ -943,7 +946,7 @@ __device__ __forceinline__ bool coop_gn_groups(const float* cam_P, CoopLds& L, b
     L.res_ok[lane] = 0;
   }
   __syncthreads();
-  const bool res = coop_gn_run<KEEP, LONG_GN, false, PRE_IT>(cam_P, L, want, n_req, Xout);
+  const bool res = coop_gn_run<KEEP, LONG_GN, EG3D_K3B_HOIST != 0, PRE_IT>(cam_P, L, want, n_req, Xout);
 #if defined(EG3D_GN_COUNTERS)
   if (lane == 0) EG3D_GN_DBG(112, __builtin_readcyclecounter() - gg_begin_);
 #endif

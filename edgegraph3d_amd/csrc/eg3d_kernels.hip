@@ -688,6 +688,12 @@ __global__ void k_compact_chains(uint32_t n_tasks, const ChainSeed* per_task, co
 #ifndef EG3D_REDO_SKIP
 #define EG3D_REDO_SKIP 1 /* the redo of a look-ahead step whose triangulation failed does not walk and triangulate that candidate a second time (same walks, same DLT, same solve, same failure): it starts at the 3-subset fallback on the list the round already holds and goes on with the later starting observations (0: the whole sequential N-view step, rounds 3-5) */
 #endif
+#ifndef EG3D_PAR_CANDIDATES
+#define EG3D_PAR_CANDIDATES 1 /* look-ahead rounds: when a step's first starting observation dies, the others are walked several at a time (stepn_walks_par) instead of one pass of the wave each */
+#endif
+#ifndef EG3D_WINDOW_ROUNDS
+#define EG3D_WINDOW_ROUNDS 0 /* batches of ADD solves: a window of requests ends where a round of the solver ends (add_solves). Measured (round 6, profiles/r06_experiments/ab7_par_candidates_window_rounds.txt): bit-exact and SLOWER, C3' 38.6-38.8 -> 39.2-39.4 ms (the extra windows cost more than the rounds saved): off, kept as an option */
+#endif
 #ifndef EG3D_LOOKAHEAD
 #define EG3D_LOOKAHEAD 8 /* steps walked ahead per round (<= 8, and <= 64 / observations of the end point) */
 #endif
@@ -1048,6 +1054,105 @@ struct TeamWaveT {
     if constexpr (SCENE != 1) return 0;  // unreachable in those builds (fits is a constant there)
     return walk_side_candidates_core(s, c, pl, epi, staged, view, from, direction, lo, ci, hi, towards_start, out, walk);
   }
+  // The walk phase of the starting observations st0 .. n-1 of an N-view step, SEVERAL CANDIDATES AT ONCE (round 6). The
+  // sequential order tries them one after the other and takes the first that keeps >= 3 observations; each try is a
+  // pass of the wave in which n - 1 lanes walk — and a following ENDS with a step in which every candidate is tried
+  // and dies (4 % of the chain clocks on C3'). Here lane (g, i) of a pass is observation i of candidate st = base + g,
+  // 64 / n candidates per pass: every lane of a group advances the group's starting observation itself (the same
+  // uniform walk, redundantly), then follows its own observation; the first group in order whose walks keep >= 3
+  // wins, its survivors are compacted in observation order exactly as stepn_walks does, and only the diagnostic flags
+  // of the candidates up to the winner count (the sequential order never ran the later ones). Returns m (0: all dead).
+  __device__ __forceinline__ int stepn_walks_par(const DevScene& s, const Obs* co_all, int n, int st0, const uint32_t* dirs,
+                                                 Obs* sel, uint32_t& flags, int& st_used) const {
+    const int per = 64 / n;
+    if (per < 2) {
+      int m = 0;
+      for (int st = st0; st < n && m == 0; st++) {
+        m = stepn_walks(*this, s, co_all, n, st, dirs, sel, n, flags);
+        st_used = st;
+      }
+      return m;
+    }
+    const int g = lane() / n, i = lane() - g * n;
+    for (int base = st0; base < n; base += per) {
+      const int st = base + g;
+      const bool valid = g < per && st < n;
+      bool dead = true, bad = false, found = false, bad_i = false;
+      PlPt q;
+      q.seg = 0;
+      q.x = q.y = 0.f;
+      Obs so, r;
+      so.view = 0;
+      so.pl = so.seg = 0;
+      so.x = so.y = 0.f;
+      r = so;
+      if (valid) {
+        so = co_all[st];
+        const PlRef ps = polyline_of(s, so.view, so.pl);
+        PlPt p;
+        p.seg = so.seg;
+        p.x = so.x;
+        p.y = so.y;
+        const uint32_t w = walk_by_distance(ps, p, dirs[so.view], EG3D_FOLLOW_STEP, q);
+        bad = (w & WALK_BAD_DIR) != 0;
+        dead = (w & WALK_EXTREME) != 0;
+        if (!dead && i != st) {
+          const Obs co = co_all[i];
+          float la, lb, lc;
+          if (epiline(s.F, s.F_valid, s.n_views, so.view, co.view, q.x, q.y, la, lb, lc)) {
+            const PlRef pk = polyline_of(s, co.view, co.pl);
+            PlPt cp, rp;
+            cp.seg = co.seg;
+            cp.x = co.x;
+            cp.y = co.y;
+            const uint32_t wr = walk_by_line(pk, cp, dirs[co.view], la, lb, lc, true, EG3D_FOLLOW_MIN, EG3D_FOLLOW_MAX, rp);
+            bad_i = (wr & WALK_BAD_DIR) != 0;
+            if (wr & WALK_FOUND) {
+              found = true;
+              r.view = co.view;
+              r.pl = co.pl;
+              r.seg = rp.seg;
+              r.x = rp.x;
+              r.y = rp.y;
+            }
+          }
+        }
+      }
+      const unsigned long long fm = __ballot(found);
+      const unsigned long long gm = ((1ull << n) - 1ull) << (valid ? g * n : 0);  // this lane's group (n <= 32 here)
+      const int cnt = valid ? __popcll(fm & gm) : 0;
+      const bool alive = valid && !dead && 1 + cnt >= 3;
+      const unsigned long long am = __ballot(alive);
+      const unsigned long long bm = __ballot(valid && (bad_i || bad));
+      const int gw = am ? (__ffsll((long long)am) - 1) / n : per;  // the winning group (per: none in this pass)
+      // flags of the candidates the sequential order would have run: groups <= gw
+      {
+        const int upto = gw < per ? (gw + 1) * n : per * n;
+        const unsigned long long lanes = upto >= 64 ? ~0ull : ((1ull << upto) - 1ull);
+        if (bm & lanes) flags |= 8u;
+      }
+      if (gw < per) {
+        if (g == gw) {
+          if (i == 0) {
+            Obs o0;
+            o0.view = so.view;
+            o0.pl = so.pl;
+            o0.seg = q.seg;
+            o0.x = q.x;
+            o0.y = q.y;
+            sel[0] = o0;
+          }
+          if (found) sel[1 + __popcll(fm & gm & ((1ull << lane()) - 1ull))] = r;
+        }
+        const int m = 1 + lane_bcast(cnt, gw * n);
+        st_used = base + gw;
+        __syncthreads();
+        return m;
+      }
+    }
+    __syncthreads();
+    return 0;
+  }
   // append a followed point at the chain's front / back (the checks of follow_front / follow_back)
   __device__ __forceinline__ bool follow_append(Chain& c, bool front, const Obs* list, int m, const float X[3]) const {
     if (front ? (c.head <= 0) : (c.head + c.len >= c.cap_pts)) {
@@ -1121,10 +1226,15 @@ struct TeamWaveT {
           const uint64_t tdd0 = EG3D_TICK();  // light timing build: section 11 = the walks of the step that DIES (every starting observation tried)
 #endif
           int st_used = 0;
+#if EG3D_PAR_CANDIDATES
+          m = stepn_walks(*this, s, prev, nprev, 0, dirs, sel, n_end, fl);  // (nearly every step that lives, lives on its first candidate)
+          if (m == 0 && nprev > 1) m = stepn_walks_par(s, prev, nprev, 1, dirs, sel, fl, st_used);
+#else
           for (int st = 0; st < nprev && m == 0; st++) {
             m = stepn_walks(*this, s, prev, nprev, st, dirs, sel, n_end, fl);
             st_used = st;
           }
+#endif
           if (m == 0) {
 #ifdef EG3D_ONE_SECTION
             EG3D_SEC_ADD(c.tsec, 11, EG3D_TICK() - tdd0);
@@ -1347,14 +1457,40 @@ struct TeamWaveT {
   // otherwise each lane runs its own solve. Both produce the same bits.
   template <class Get, class Put>
   __device__ __forceinline__ void add_solves(const DevScene& s, Chain& c, int B, Get get, Put put) const {
-    for (int w0 = 0; w0 < B; w0 += EG3D_COOP_REQ) {
+    int take = EG3D_COOP_REQ;
+    for (int w0 = 0; w0 < B; w0 += take) {
       const int j = w0 + lane();
       const ChainPt* pt = nullptr;
       Obs o;
       o.view = 0;
       o.pl = o.seg = 0;
       o.x = o.y = 0.f;
-      const bool want = lane() < EG3D_COOP_REQ && j < B && get(j, pt, o);
+      bool want = lane() < EG3D_COOP_REQ && j < B && get(j, pt, o);
+      take = EG3D_COOP_REQ;
+#if EG3D_WINDOW_ROUNDS
+      // More requests follow this window: end it where a ROUND of the solver ends. The solver packs whole requests into
+      // rounds of <= 64 rows in lane order; a window of 32 requests usually ends in a partly filled round (32 requests of
+      // 9 rows: 7 + 7 + 7 + 7 + 4), which the next window's first requests could have shared — the requests of that last
+      // round are left to the next window instead (same rounds as one greedy packing of the whole batch; results do not
+      // depend on the grouping).
+      if (B - w0 > EG3D_COOP_REQ) {
+        const int rows = want ? (int)pt->nobs + 1 : 0;
+        if (!__ballot(rows > EG3D_GN_PACK_MAX)) {  // (long requests take the other path of the solver: windows as they come)
+          const int pre = wave_incl_scan(rows);
+          int start = 0;
+          for (;;) {
+            const int base = start > 0 ? lane_bcast(pre, start - 1) : 0;
+            const unsigned long long fit = __ballot(lane() >= start && lane() < EG3D_COOP_REQ && pre - base <= EG3D_COOP_ROWS);
+            const unsigned long long nofit = ~fit & ~((1ull << start) - 1ull) & ((1ull << EG3D_COOP_REQ) - 1ull);
+            const int next = nofit ? __ffsll((long long)nofit) - 1 : EG3D_COOP_REQ;
+            if (next >= EG3D_COOP_REQ || next <= start) break;  // this round reaches the window's end
+            start = next;
+          }
+          if (start > 0) take = start;
+          want = want && lane() < take;
+        }
+      }
+#endif
       float X[3] = {0.f, 0.f, 0.f};
       float X0[3] = {0.f, 0.f, 0.f};
       if (want) {
