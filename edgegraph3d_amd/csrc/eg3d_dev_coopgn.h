@@ -38,7 +38,7 @@ namespace eg3d {
 #define EG3D_GN_PRECHECK_IT 2
 #endif
 #ifndef EG3D_K3B_HOIST
-#define EG3D_K3B_HOIST 0 /* k3b_expand's one-chunk rounds load a lane's observation once, before the iterations (gn_round's HOIST); 0: per iteration (round 5's measurement) */
+#define EG3D_K3B_HOIST 1 /* k3b_expand's one-chunk rounds load a lane's observation once, before the iterations (gn_round's HOIST) instead of per iteration (0: rounds 4-5, when it measured as a loss; on the round-6 kernel: C3' 38.6 -> 38.2 ms, C2 4.23 -> 4.16, three runs each) */
 #endif
 #ifndef EG3D_GN_PRECHECK_ALL
 #define EG3D_GN_PRECHECK_ALL 0 /* 1 = every build of the expand kernel, not only the many-views one (A/B switch) */

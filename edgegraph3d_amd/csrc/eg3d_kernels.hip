@@ -2015,7 +2015,10 @@ static constexpr auto k3b_expand = k3b_expand_t<EG3D_K3B_WAVES, 0, 1>;
 #ifndef EG3D_MANY_KEEP
 #define EG3D_MANY_KEEP 1 /* chunks of a long solve whose rows stay in registers between the passes of an iteration, many-views build (gn_round<KEEP>): 0 / 1 / 2 -> C4 step 1810 / 1774 / 1823 ms at 27 / 60 / 263 spilled VGPRs (round 5; round 4 had only measured 4 chunks at 2 waves per SIMD: slower) */
 #endif
-static constexpr auto k3b_expand_many = k3b_expand_t<EG3D_K3B_WAVES, EG3D_MANY_KEEP, 2>;
+#ifndef EG3D_MANY_WAVES
+#define EG3D_MANY_WAVES EG3D_K3B_WAVES /* waves per SIMD of the many-views build (fewer = more registers for kept chunks) */
+#endif
+static constexpr auto k3b_expand_many = k3b_expand_t<EG3D_MANY_WAVES, EG3D_MANY_KEEP, 2>;
 int k3b_blocks_per_cu() {  // the largest residency of the builds sizes the slot pools
   int best = 0;
   for (int k = 0; k < 3; k++) {
