@@ -183,10 +183,10 @@ def build_rccl(force=False):
 # (experimental variants built with other switches).
 RESOURCE_BOUNDS = {
     # kernel (substring of the demangled name): {metadata field: largest accepted value}
-    # (round 6, late: the lane-group DLT, the short redo of a failed look-ahead step and the solver's convergence pre-check
-    # each inline more code around the places where the chain's state is live — 23 / 157 / 61 spilled registers became
-    # 87 / 332 / 123, all of them around calls, none inside a loop — and each was kept because the kernel got faster:
-    # profiles/r06_experiments/follow_ab.txt)
+    # (round 6, late: the lane-group DLT, the short redo of a failed look-ahead step, the parallel candidate walks and the
+    # solver's convergence pre-check each inline more code around the places where the chain's state is live — 23 / 157 /
+    # 61 spilled registers became 101 / 341 / 107, all of them around calls, none inside a loop — and each was kept
+    # because the kernel got faster: DESIGN_LOG.md round 6 item 8, profiles/r06_experiments/ab*.txt)
     "k3b_expand_t<4, 0, 0>": {"vgpr_spill_count": 120, "private_segment_fixed_size": 224, "group_segment_fixed_size": 10240},
     "k3b_expand_t<4, 0, 1>": {"vgpr_spill_count": 360, "private_segment_fixed_size": 400, "group_segment_fixed_size": 10240},
     "k3b_expand_t<4, 1, 2>": {"vgpr_spill_count": 140, "private_segment_fixed_size": 256, "group_segment_fixed_size": 10240},
